@@ -1,0 +1,207 @@
+// TEST INFRASTRUCTURE ONLY -- host-side functional emulator of the gfx950 execution model, used by
+// tests/test_emu_kernels.py to check kernel INDEXING LOGIC (LDS layouts, swizzles, MFMA fragment maps,
+// edge handling) on the CPU-only build container, where no GPU is present.  It is not a backend: the product
+// library is compiled by hipcc for gfx950 only, and nothing under videollama2_amd/ includes this file.
+//
+// Model: one workgroup at a time; every work-item is a ucontext fiber; wave = 64 consecutive threads;
+// __syncthreads and wave-collective builtins (shuffles, MFMA, LDS-DMA) are rendezvous points.
+// MFMA lane<->element maps follow /opt/skills/guides/cdna_hip_programming.md section 3.
+#pragma once
+#include <ucontext.h>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+
+namespace emu {
+struct Wave {
+    int arrived = 0;
+    unsigned gen = 0;
+    alignas(16) unsigned char scratch[64][128];   // per-lane operand deposit area
+};
+struct Thread {
+    dim3 tid;
+    int lane = 0, wave = 0, flat = 0;
+    ucontext_t ctx;
+    char* stack = nullptr;
+    bool done = false;
+};
+inline Thread* cur = nullptr;
+inline dim3 g_block, g_bdim, g_gdim;
+inline std::vector<Thread> threads;
+inline std::vector<Wave> waves;
+inline ucontext_t main_ctx;
+inline int blk_arrived = 0;
+inline unsigned blk_gen = 0;
+inline std::function<void()> body;
+inline int nthreads = 0;
+alignas(64) inline unsigned char dyn_smem[160 * 1024];
+
+inline void yield() { swapcontext(&cur->ctx, &main_ctx); }
+
+inline void block_sync() {
+    unsigned g = blk_gen;
+    if (++blk_arrived == nthreads) { blk_arrived = 0; ++blk_gen; }
+    else while (blk_gen == g) yield();
+}
+inline void wave_sync() {
+    Wave& w = waves[cur->wave];
+    unsigned g = w.gen;
+    int n = 64;
+    int wave_threads = nthreads - cur->wave * 64;
+    if (wave_threads < n) n = wave_threads;
+    if (++w.arrived == n) { w.arrived = 0; ++w.gen; }
+    else while (w.gen == g) yield();
+}
+inline void trampoline() {
+    body();
+    cur->done = true;
+    swapcontext(&cur->ctx, &main_ctx);
+}
+inline void launch(dim3 grid, dim3 block, std::function<void()> fn, size_t stack_bytes = 256 * 1024) {
+    g_gdim = grid; g_bdim = block;
+    nthreads = block.x * block.y * block.z;
+    body = fn;
+    threads.assign(nthreads, Thread());
+    for (auto& t : threads) t.stack = (char*)malloc(stack_bytes);
+    for (unsigned bz = 0; bz < grid.z; ++bz) for (unsigned by = 0; by < grid.y; ++by) for (unsigned bx = 0; bx < grid.x; ++bx) {
+        g_block = dim3(bx, by, bz);
+        waves.assign((nthreads + 63) / 64, Wave());
+        blk_arrived = 0; blk_gen = 0;
+        int f = 0;
+        for (unsigned z = 0; z < block.z; ++z) for (unsigned y = 0; y < block.y; ++y) for (unsigned x = 0; x < block.x; ++x, ++f) {
+            Thread& t = threads[f];
+            t.tid = dim3(x, y, z); t.flat = f; t.lane = f & 63; t.wave = f >> 6; t.done = false;
+            getcontext(&t.ctx);
+            t.ctx.uc_stack.ss_sp = t.stack; t.ctx.uc_stack.ss_size = stack_bytes; t.ctx.uc_link = &main_ctx;
+            makecontext(&t.ctx, (void (*)())trampoline, 0);
+        }
+        int remaining = nthreads;
+        while (remaining) {
+            for (auto& t : threads) if (!t.done) {
+                cur = &t;
+                swapcontext(&main_ctx, &t.ctx);
+                if (t.done) --remaining;
+            }
+        }
+    }
+    for (auto& t : threads) free(t.stack);
+    threads.clear();
+}
+
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+inline float bf2f(short s) { uint32_t u = ((uint32_t)(uint16_t)s) << 16; float f; memcpy(&f, &u, 4); return f; }
+
+// v_mfma_f32_32x32x16_bf16: A lane l = A[i=l&31][k=(l>>5)*8+j]; B lane l = B[k=(l>>5)*8+j][n=l&31];
+// D reg r lane l = D[(r&3)+8*(r>>2)+4*(l>>5)][l&31].
+inline f32x16 mfma_32x32x16_bf16(s16x8 a, s16x8 b, f32x16 c) {
+    Wave& w = waves[cur->wave];
+    memcpy(w.scratch[cur->lane], &a, 16); memcpy(w.scratch[cur->lane] + 16, &b, 16);
+    wave_sync();
+    int l = cur->lane;
+    for (int r = 0; r < 16; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = l & 31;
+        float acc = c[r];
+        for (int k = 0; k < 16; ++k) {
+            short av, bv;
+            memcpy(&av, w.scratch[row + 32 * (k >> 3)] + 2 * (k & 7), 2);
+            memcpy(&bv, w.scratch[col + 32 * (k >> 3)] + 16 + 2 * (k & 7), 2);
+            acc = fmaf(bf2f(av), bf2f(bv), acc);
+        }
+        c[r] = acc;
+    }
+    wave_sync();
+    return c;
+}
+// v_mfma_f32_16x16x32_bf16: A lane l = A[i=l&15][k=(l>>4)*8+j]; B = B[k=(l>>4)*8+j][n=l&15]; D reg r = D[(l>>4)*4+r][l&15].
+inline f32x4 mfma_16x16x32_bf16(s16x8 a, s16x8 b, f32x4 c) {
+    Wave& w = waves[cur->wave];
+    memcpy(w.scratch[cur->lane], &a, 16); memcpy(w.scratch[cur->lane] + 16, &b, 16);
+    wave_sync();
+    int l = cur->lane;
+    for (int r = 0; r < 4; ++r) {
+        int row = (l >> 4) * 4 + r, col = l & 15;
+        float acc = c[r];
+        for (int k = 0; k < 32; ++k) {
+            short av, bv;
+            memcpy(&av, w.scratch[row + 16 * (k >> 3)] + 2 * (k & 7), 2);
+            memcpy(&bv, w.scratch[col + 16 * (k >> 3)] + 16 + 2 * (k & 7), 2);
+            acc = fmaf(bf2f(av), bf2f(bv), acc);
+        }
+        c[r] = acc;
+    }
+    wave_sync();
+    return c;
+}
+template <class T> inline float dot2(T a, T b, float c) {   // v_dot2c_f32_bf16
+    uint32_t x, y; memcpy(&x, &a, 4); memcpy(&y, &b, 4);
+    float r = c;
+    r = fmaf(bf2f((short)(x & 0xffff)), bf2f((short)(y & 0xffff)), r);
+    r = fmaf(bf2f((short)(x >> 16)), bf2f((short)(y >> 16)), r);
+    return r;
+}
+template <class T> inline T shfl_idx(T v, int src) {
+    Wave& w = waves[cur->wave];
+    memcpy(w.scratch[cur->lane], &v, sizeof(T));
+    wave_sync();
+    T r; memcpy(&r, w.scratch[src & 63], sizeof(T));
+    wave_sync();
+    return r;
+}
+// LDS-DMA: destination = wave-uniform base (first lane's) + lane*size; source address is per lane.
+inline void global_load_lds(const void* g, void* lds, unsigned size, int offset, unsigned) {
+    Wave& w = waves[cur->wave];
+    memcpy(w.scratch[cur->lane], &lds, sizeof(void*));
+    wave_sync();
+    void* base; memcpy(&base, w.scratch[0], sizeof(void*));
+    if (base != lds) { fprintf(stderr, "EMU: global_load_lds with non-uniform LDS base\n"); abort(); }
+    wave_sync();
+    memcpy((char*)base + offset + cur->lane * size, (const char*)g + offset, size);
+}
+}  // namespace emu
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __shared__ static
+#define __launch_bounds__(...)
+#define threadIdx (emu::cur->tid)
+#define blockIdx (emu::g_block)
+#define blockDim (emu::g_bdim)
+#define gridDim (emu::g_gdim)
+#define __syncthreads() emu::block_sync()
+#define __builtin_amdgcn_s_barrier() emu::block_sync()
+#define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) emu::mfma_32x32x16_bf16(a, b, c)
+#define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) emu::mfma_16x16x32_bf16(a, b, c)
+#define __builtin_amdgcn_global_load_lds(g, l, sz, off, aux) emu::global_load_lds((const void*)(g), (void*)(l), sz, off, aux)
+#define __builtin_amdgcn_readfirstlane(x) emu::shfl_idx((x), 0)
+#define __builtin_amdgcn_fdot2_f32_bf16(a, b, c, cl) emu::dot2((a), (b), (c))
+#define __builtin_amdgcn_s_setprio(x) ((void)0)
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_s_sleep(x) ((void)0)
+#define __builtin_nontemporal_load(p) (*(p))
+#define __builtin_nontemporal_store(v, p) (*(p) = (v))
+#define __shfl_xor(v, m) emu::shfl_idx((v), emu::cur->lane ^ (m))
+#define __shfl_down(v, d) emu::shfl_idx((v), (emu::cur->lane + (d)) > 63 ? emu::cur->lane : emu::cur->lane + (d))
+#define __shfl(v, s) emu::shfl_idx((v), (s))
+#define __expf(x) expf(x)
+#define __fdividef(a, b) ((a) / (b))
+#define __frcp_rn(x) (1.0f / (x))
+#define VL2_EMU 1
+static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
+static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
+static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
+// the harness defines the dynamic LDS array that kernels declare `extern __shared__ ... vl2_smem[]`
+// (the build step rewrites `extern __shared__` -> `extern`)

@@ -1,0 +1,69 @@
+// Device-side helpers shared by every gfx950 kernel in this library (wave = 64 lanes).
+// No HIP runtime headers are included here: the translation unit (vl2_abi.hip) includes <hip/hip_runtime.h> first.
+#pragma once
+#include <stdint.h>
+
+typedef uint16_t bf16_t;                                           // raw bfloat16 bits
+typedef short bf16x8 __attribute__((ext_vector_type(8)));          // 8 bf16 = one MFMA A/B fragment = 16 B
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+#define VL2_WAVE 64
+
+__device__ __forceinline__ float bf2f(bf16_t b) { return __builtin_bit_cast(float, ((uint32_t)b) << 16); }
+__device__ __forceinline__ float bf2f_s(short b) { return __builtin_bit_cast(float, ((uint32_t)(uint16_t)b) << 16); }
+// round-to-nearest-even, NaN preserved (same rule as torch's float->bfloat16)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    uint32_t u = __builtin_bit_cast(uint32_t, f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+
+__device__ __forceinline__ void unpack8(const u32x4& v, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f[2 * i] = __builtin_bit_cast(float, v[i] << 16);
+        f[2 * i + 1] = __builtin_bit_cast(float, v[i] & 0xffff0000u);
+    }
+}
+__device__ __forceinline__ u32x4 pack8(const float* f) {
+    u32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = pack2bf(f[2 * i], f[2 * i + 1]);
+    return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
+    return v;
+}
+
+// LDS-DMA, 16 B per lane: LDS destination = wave-uniform `lds_wave_base` + lane*16, global source per lane.
+__device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float quick_gelu_f(float x) { return x / (1.0f + __expf(-1.702f * x)); }
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+// XCD-aware, bijective remap of a 1-D block id: block b runs on XCD b%8 (observed); give every XCD one
+// contiguous chunk of the logical tile order so neighbouring tiles share an L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, k = bid >> 3;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + k;
+}

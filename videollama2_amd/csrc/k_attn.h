@@ -1,0 +1,202 @@
+// Fused (flash-style) attention forward for gfx950, used for
+//   * CLIP-ViT MHSA, non-causal, B = frames, H = 16, N = 577, D = 64  (HF:models/clip/modeling_clip.py
+//     eager_attention_forward: softmax(QK^T * d^-0.5) V, softmax in fp32; the reference forces flash-attn,
+//     videollama2/model/encoder.py:24)
+//   * Mistral causal GQA prefill, H = 32, KV = 8, D = 128               (HF:models/mistral/modeling_mistral.py
+//     eager_attention_forward + repeat_kv; causal mask from the cache length)
+//
+// Transposed formulation so every softmax statistic is lane-local (guide App. B "swapped QK^T"):
+//   S^T[key][q] = K . Q^T   (A = K rows from LDS, B = Q^T from registers)  -> lane (q = lane&31) owns 32 of the
+//   64 scores of its q row per KV tile, its partner lane^32 the other 32;
+//   O^T[d][q]  += V^T . P^T (A = V^T from a transposed LDS image, B = P^T straight from the score registers: the
+//   MFMA contraction order over keys is a free permutation, so the B fragment is exactly the registers a lane
+//   already owns and the V^T fragment is read with the same permutation).
+// 4 waves x 32 q rows per workgroup, KV tile = 64 keys, K/V staged global -> registers -> LDS (next tile's loads
+// are issued before the current tile's MFMAs), online softmax in the exp2 domain.
+#pragma once
+#include "dev_common.h"
+
+struct AttnArgs {
+    const bf16_t* q; const bf16_t* k; const bf16_t* v; bf16_t* o;
+    long q_bs, q_hs; int q_rs;      // element strides: batch, head, row
+    long k_bs, k_hs; int k_rs;
+    long v_bs, v_hs; int v_rs;
+    long o_bs, o_hs; int o_rs;
+    int nq, nk, group;              // group = q heads per kv head
+    float scale_log2e;              // softmax scale * log2(e)
+    int causal_off;                 // key j visible to q row i iff j <= i + causal_off
+};
+
+template <int D> __device__ __forceinline__ int attn_k_off(int row, int chunk);
+template <> __device__ __forceinline__ int attn_k_off<128>(int row, int chunk) { return ((row << 4) + (chunk ^ (row & 15))) << 4; }
+template <> __device__ __forceinline__ int attn_k_off<64>(int row, int chunk) {
+    const int R = row >> 1, s = ((row & 1) << 3) | chunk;
+    return ((R << 4) + (s ^ (R & 15))) << 4;
+}
+// V^T image: row d = 64 keys * 2 B = 128 B = 16 chunks of 8 B (4 keys); chunk kc of row d is stored at kc ^ ((d>>1)&15)
+__device__ __forceinline__ int attn_vt_off(int d, int kc) { return (d << 7) + ((kc ^ ((d >> 1) & 15)) << 3); }
+
+template <int D, bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
+    constexpr int KCH = D / 8;                 // 16-B chunks per K row
+    constexpr int KPT = 64 * KCH / 256;        // K chunks per thread per tile
+    constexpr int VPT = 32 * KCH / 256;        // V (key-pair, chunk) items per thread per tile
+    constexpr int NKS = D / 16;                // k-steps of the QK^T MFMA chain
+    constexpr int NDB = D / 32;                // 32-row d blocks of O^T
+    __shared__ __attribute__((aligned(16))) unsigned char Ks[64 * D * 2];
+    __shared__ __attribute__((aligned(16))) unsigned char Vt[D * 128];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int h = blockIdx.y, b = blockIdx.z, hk = h / p.group;
+    const int q0 = blockIdx.x * 128;
+    const bf16_t* Q = p.q + b * p.q_bs + h * p.q_hs;
+    const bf16_t* K = p.k + b * p.k_bs + hk * p.k_hs;
+    const bf16_t* V = p.v + b * p.v_bs + hk * p.v_hs;
+
+    // Q^T fragments: lane (q, hi) holds Q[q][16*ks + 8*hi .. +7]
+    const int qrow = q0 + wave * 32 + l31;
+    const int qrow_c = qrow < p.nq ? qrow : p.nq - 1;
+    bf16x8 qf[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) qf[ks] = *(const bf16x8*)(Q + (size_t)qrow_c * p.q_rs + ks * 16 + hi * 8);
+
+    int kmax = p.nk;
+    if (CAUSAL) { const int lim = q0 + 128 + p.causal_off; kmax = lim < kmax ? lim : kmax; }
+    const int ntiles = (kmax + 63) >> 6;
+
+    u32x4 kreg[KPT], vreg[VPT][2];
+    auto load_tile = [&](int kv0) {
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            const int c = tid + 256 * i, row = c / KCH, ch = c % KCH;
+            int kr = kv0 + row; kr = kr < p.nk ? kr : p.nk - 1;
+            kreg[i] = *(const u32x4*)(K + (size_t)kr * p.k_rs + ch * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int c = tid + 256 * i, kp = c / KCH, ch = c % KCH;
+            int r0 = kv0 + 2 * kp, r1 = r0 + 1;
+            r0 = r0 < p.nk ? r0 : p.nk - 1; r1 = r1 < p.nk ? r1 : p.nk - 1;
+            vreg[i][0] = *(const u32x4*)(V + (size_t)r0 * p.v_rs + ch * 8);
+            vreg[i][1] = *(const u32x4*)(V + (size_t)r1 * p.v_rs + ch * 8);
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            const int c = tid + 256 * i, row = c / KCH, ch = c % KCH;
+            *(u32x4*)(Ks + attn_k_off<D>(row, ch)) = kreg[i];
+        }
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int c = tid + 256 * i, kp = c / KCH, ch = c % KCH;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const unsigned a = (vreg[i][0][j >> 1] >> ((j & 1) * 16)) & 0xffffu;
+                const unsigned bb = (vreg[i][1][j >> 1] >> ((j & 1) * 16)) & 0xffffu;
+                *(unsigned*)(Vt + attn_vt_off(ch * 8 + j, kp >> 1) + (kp & 1) * 4) = a | (bb << 16);
+            }
+        }
+    };
+
+    f32x16 oT[NDB];
+#pragma unroll
+    for (int i = 0; i < NDB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oT[i][r] = 0.f;
+    float m = -1e30f, l = 0.f;
+
+    load_tile(0);
+    for (int t = 0; t < ntiles; ++t) {
+        const int kv0 = t * 64;
+        __syncthreads();
+        store_tile();
+        __syncthreads();
+        if (t + 1 < ntiles) load_tile(kv0 + 64);
+
+        // S^T = K . Q^T
+        f32x16 sT[2];
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sT[kh][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const bf16x8 kf = *(const bf16x8*)(Ks + attn_k_off<D>(kh * 32 + l31, ks * 2 + hi));
+                sT[kh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sT[kh], 0, 0, 0);
+            }
+        }
+        // online softmax (exp2 domain); lane owns keys kv0 + 32kh + (r&3) + 8(r>>2) + 4hi of row qrow
+        const int wq0 = q0 + wave * 32;
+        const bool need_mask = (kv0 + 64 > p.nk) || (CAUSAL && (kv0 + 63 > wq0 + p.causal_off));
+        float mt = -1e30f;
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float s = sT[kh][r] * p.scale_log2e;
+                if (need_mask) {
+                    const int key = kv0 + kh * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    const bool ok = key < p.nk && (!CAUSAL || key <= qrow + p.causal_off);
+                    s = ok ? s : -1e30f;
+                }
+                sT[kh][r] = s;
+                mt = fmaxf(mt, s);
+            }
+        mt = fmaxf(mt, __shfl_xor(mt, 32));
+        const float m_new = fmaxf(m, mt);
+        const float alpha = exp2f(m - m_new);
+        m = m_new;
+        float rs = 0.f;
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = exp2f(sT[kh][r] - m_new);
+                sT[kh][r] = pv;
+                rs += pv;
+            }
+        rs += __shfl_xor(rs, 32);
+        l = l * alpha + rs;
+#pragma unroll
+        for (int i = 0; i < NDB; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oT[i][r] *= alpha;
+
+        // O^T += V^T . P^T
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+            for (int ks2 = 0; ks2 < 2; ++ks2) {
+                bf16x8 pf;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pf[j] = (short)f2bf(sT[kh][ks2 * 8 + j]);
+                const int kc = 8 * kh + 4 * ks2 + hi;
+#pragma unroll
+                for (int db = 0; db < NDB; ++db) {
+                    const int d = db * 32 + l31;
+                    const bf16x4 v0 = *(const bf16x4*)(Vt + attn_vt_off(d, kc));
+                    const bf16x4 v1 = *(const bf16x4*)(Vt + attn_vt_off(d, kc + 2));
+                    bf16x8 vf;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { vf[j] = v0[j]; vf[4 + j] = v1[j]; }
+                    oT[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oT[db], 0, 0, 0);
+                }
+            }
+    }
+
+    if (qrow < p.nq) {
+        const float inv = 1.0f / l;
+        bf16_t* O = p.o + b * p.o_bs + h * p.o_hs + (size_t)qrow * p.o_rs;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                u32x2 w;
+                w[0] = pack2bf(oT[db][4 * g] * inv, oT[db][4 * g + 1] * inv);
+                w[1] = pack2bf(oT[db][4 * g + 2] * inv, oT[db][4 * g + 3] * inv);
+                *(u32x2*)(O + db * 32 + 8 * g + 4 * hi) = w;
+            }
+    }
+}

@@ -1,0 +1,253 @@
+// Mistral decoder glue + single-token (decode) kernels.  HBM-bound: the per-token cost is streaming the bf16 weights.
+//   rope_kv_kernel           : rotate-half RoPE on q,k (HF:models/mistral/modeling_mistral.py apply_rotary_pos_emb /
+//                              rotate_half) from the fused qkv GEMM output, + KV-cache append (DynamicCache.update).
+//   gemv_bf16_kernel         : y = W x for one token (q/k/v/o/gate/up/down/lm_head at M=1), 16-B lane loads straight to
+//                              VGPRs, v_dot2c_f32_bf16, optional fused RMSNorm prologue, residual / SwiGLU epilogue.
+//   attn_decode_kernel (+combine): one query token against the KV cache, split over the context (flash-decoding).
+//   argmax_kernel            : greedy token (HF:generation/utils.py _sample, do_sample=False -> torch.argmax).
+//   embed_rows_kernel        : embed_tokens gather (videollama2/model/videollama2_arch.py:203-220).
+#pragma once
+#include "dev_common.h"
+
+typedef __bf16 bf16v2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float dot2_bf16(uint32_t a, uint32_t b, float c) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16v2_t, a), __builtin_bit_cast(bf16v2_t, b), c, false);
+}
+
+// qkv [S, (nh+2*nkv)*HD] -> q_out [S, nh*HD] (roped), kcache/vcache [nkv][smax][HD] rows pos0+s.
+// cos/sin: fp32 [maxpos][HD/2].  One thread per (token, head, 8-dim chunk of the first half).  HD = 128.
+__global__ __launch_bounds__(256) void rope_kv_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ q_out,
+                                                      bf16_t* __restrict__ kcache, bf16_t* __restrict__ vcache,
+                                                      const float* __restrict__ cos_t, const float* __restrict__ sin_t,
+                                                      int S, int nh, int nkv, int smax, int pos0) {
+    constexpr int HD = 128, HALF = 64;
+    const int heads = nh + 2 * nkv;
+    const size_t total = (size_t)S * heads * 8;
+    for (size_t it = (size_t)blockIdx.x * 256 + threadIdx.x; it < total; it += (size_t)gridDim.x * 256) {
+        const int ch = (int)(it & 7);
+        const int head = (int)((it >> 3) % heads);
+        const int s = (int)(it / ((size_t)heads * 8));
+        const bf16_t* src = qkv + (size_t)s * heads * HD + head * HD + ch * 8;
+        const u32x4 a = *(const u32x4*)src, b = *(const u32x4*)(src + HALF);
+        const int pos = pos0 + s;
+        if (head < nh + nkv) {
+            float x1[8], x2[8], o1[8], o2[8];
+            unpack8(a, x1); unpack8(b, x2);
+            const float* cp = cos_t + (size_t)pos * HALF + ch * 8;
+            const float* sp = sin_t + (size_t)pos * HALF + ch * 8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float c = cp[j], sn = sp[j];
+                o1[j] = x1[j] * c - x2[j] * sn;       // q*cos + rotate_half(q)*sin, first half:  -x2
+                o2[j] = x2[j] * c + x1[j] * sn;       //                              second half: +x1
+            }
+            bf16_t* dst = head < nh ? q_out + (size_t)s * nh * HD + head * HD + ch * 8
+                                    : kcache + ((size_t)(head - nh) * smax + pos) * HD + ch * 8;
+            *(u32x4*)dst = pack8(o1);
+            *(u32x4*)(dst + HALF) = pack8(o2);
+        } else {
+            bf16_t* dst = vcache + ((size_t)(head - nh - nkv) * smax + pos) * HD + ch * 8;
+            *(u32x4*)dst = a;
+            *(u32x4*)(dst + HALF) = b;
+        }
+    }
+}
+
+struct GemvArgs {
+    const bf16_t* W;        // [N, ldw]  (SWIGLU: packed blocks of 64 rows = 32 gate rows then 32 up rows)
+    const bf16_t* x;        // [K]
+    const float* norm_w;    // fused RMSNorm prologue on x (or null)
+    const bf16_t* res;      // [N_out] residual (or null)
+    void* y;                // bf16 or fp32 [N_out]
+    int N, K, ldw;
+    float eps;
+};
+
+// grid = ceil(N_out / (4*RPW)), block 256; dynamic LDS = K * 2 bytes (x as bf16)
+template <bool SWIGLU, bool OUT_F32, int RPW>
+__global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char vl2_smem[];
+    __shared__ float red[8];
+    bf16_t* xs = (bf16_t*)vl2_smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // stage x (optionally RMS-normalised: HF MistralRMSNorm, fp32 statistics, result rounded to bf16)
+    float rstd = 1.f;
+    if (p.norm_w) {
+        float ss = 0.f;
+        for (int k = tid * 8; k < p.K; k += 2048) {
+            float v[8];
+            unpack8(*(const u32x4*)(p.x + k), v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ss += v[j] * v[j];
+        }
+        ss = wave_sum(ss);
+        if (lane == 0) red[wave] = ss;
+        __syncthreads();
+        rstd = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)p.K + p.eps);
+    }
+    for (int k = tid * 8; k < p.K; k += 2048) {
+        u32x4 raw = *(const u32x4*)(p.x + k);
+        if (p.norm_w) {
+            float v[8];
+            unpack8(raw, v);
+            const f32x4 w0 = *(const f32x4*)(p.norm_w + k), w1 = *(const f32x4*)(p.norm_w + k + 4);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = v[j] * rstd * (j < 4 ? w0[j] : w1[j - 4]);
+            raw = pack8(v);
+        }
+        *(u32x4*)(xs + k) = raw;
+    }
+    __syncthreads();
+
+    const int n_out = SWIGLU ? p.N / 2 : p.N;
+    const int nvec = p.K >> 3;                       // 16-B vectors per row
+#pragma unroll 1
+    for (int r = 0; r < RPW; ++r) {
+        const int j = (blockIdx.x * 4 + wave) * RPW + r;
+        if (j >= n_out) break;
+        const int row0 = SWIGLU ? (j >> 5) * 64 + (j & 31) : j;
+        const bf16_t* w0p = p.W + (size_t)row0 * p.ldw;
+        const bf16_t* w1p = w0p + (size_t)32 * p.ldw;
+        float a0 = 0.f, a1 = 0.f;
+        for (int v0 = 0; v0 < nvec; v0 += 64 * 8) {
+            u32x4 wv[8], uv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int v = v0 + i * 64 + lane;
+                if (v < nvec) {
+                    wv[i] = __builtin_nontemporal_load((const u32x4*)(w0p + (size_t)v * 8));
+                    if (SWIGLU) uv[i] = __builtin_nontemporal_load((const u32x4*)(w1p + (size_t)v * 8));
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int v = v0 + i * 64 + lane;
+                if (v < nvec) {
+                    const u32x4 xv = *(const u32x4*)(xs + (size_t)v * 8);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        a0 = dot2_bf16(wv[i][q], xv[q], a0);
+                        if (SWIGLU) a1 = dot2_bf16(uv[i][q], xv[q], a1);
+                    }
+                }
+            }
+        }
+        a0 = wave_sum(a0);
+        if (SWIGLU) a1 = wave_sum(a1);
+        if (lane == 0) {
+            float o = SWIGLU ? silu_f(a0) * a1 : a0;
+            if (p.res) o += bf2f(p.res[j]);
+            if (OUT_F32) ((float*)p.y)[j] = o;
+            else ((bf16_t*)p.y)[j] = f2bf(o);
+        }
+    }
+}
+
+// ---- decode attention: q [nh*128] (roped) vs cache rows [0, ctx).  grid = (nsplit, nkv), block = group*64 (group<=4).
+// partial: fp32 [nh][nsplit][130] = {m (exp2 domain), l, o[128]}
+__global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kcache,
+                                                          const bf16_t* __restrict__ vcache, float* __restrict__ partial,
+                                                          int nh, int group, int smax, int ctx, int chunk, float scale_log2e) {
+    constexpr int HD = 128;
+    __shared__ float qs[4][HD];
+    __shared__ float ps[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int split = blockIdx.x, hk = blockIdx.y, nsplit = gridDim.x;
+    const int h = hk * group + wave;
+    qs[wave][lane] = bf2f(q[h * HD + lane]);
+    qs[wave][lane + 64] = bf2f(q[h * HD + lane + 64]);
+    __syncthreads();
+    const int k0 = split * chunk;
+    int k1 = k0 + chunk; k1 = k1 < ctx ? k1 : ctx;
+    const bf16_t* Kb = kcache + (size_t)hk * smax * HD;
+    const bf16_t* Vb = vcache + (size_t)hk * smax * HD;
+    float m = -1e30f, l = 0.f, o0 = 0.f, o1 = 0.f;
+    for (int kb = k0; kb < k1; kb += 64) {
+        const int key = kb + lane;
+        float s = -1e30f;
+        if (key < k1) {
+            const bf16_t* kr = Kb + (size_t)key * HD;
+            float acc = 0.f;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                float kv[8];
+                unpack8(*(const u32x4*)(kr + c * 8), kv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc += kv[j] * qs[wave][c * 8 + j];
+            }
+            s = acc * scale_log2e;
+        }
+        const float mt = wave_max(s);
+        const float m_new = fmaxf(m, mt);
+        const float alpha = exp2f(m - m_new);
+        const float pv = key < k1 ? exp2f(s - m_new) : 0.f;
+        l = l * alpha + wave_sum(pv);
+        o0 *= alpha; o1 *= alpha;
+        m = m_new;
+        __syncthreads();                 // all waves take the same trip count (same k0,k1)
+        ps[wave][lane] = pv;
+        __syncthreads();
+        const int nk = (k1 - kb) < 64 ? (k1 - kb) : 64;
+        for (int i = 0; i < nk; ++i) {
+            const float pi = ps[wave][i];
+            const uint32_t vv = *(const uint32_t*)(Vb + (size_t)(kb + i) * HD + lane * 2);
+            o0 += pi * __builtin_bit_cast(float, vv << 16);
+            o1 += pi * __builtin_bit_cast(float, vv & 0xffff0000u);
+        }
+    }
+    float* dst = partial + ((size_t)h * nsplit + split) * 130;
+    if (lane == 0) { dst[0] = m; dst[1] = l; }
+    dst[2 + lane * 2] = o0;
+    dst[3 + lane * 2] = o1;
+}
+
+// grid = nh, block 128: out[h*128 + d] = sum_i o_i[d] 2^(m_i - M) / sum_i l_i 2^(m_i - M)
+__global__ __launch_bounds__(128) void attn_decode_combine_kernel(const float* __restrict__ partial, bf16_t* __restrict__ out,
+                                                                  int nsplit) {
+    const int h = blockIdx.x, d = threadIdx.x;
+    const float* src = partial + (size_t)h * nsplit * 130;
+    float M = -1e30f;
+    for (int i = 0; i < nsplit; ++i) M = fmaxf(M, src[i * 130]);
+    float L = 0.f, o = 0.f;
+    for (int i = 0; i < nsplit; ++i) {
+        const float w = exp2f(src[i * 130] - M);
+        L += src[i * 130 + 1] * w;
+        o += src[i * 130 + 2 + d] * w;
+    }
+    out[h * 128 + d] = f2bf(o / L);
+}
+
+// first index of the maximum of logits[V] (fp32) -> *tok (int32) and tok_hist[step]; one block of 1024 threads
+__global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ logits, int V, int* __restrict__ tok,
+                                                      int* __restrict__ hist, int step) {
+    __shared__ float bv[16];
+    __shared__ int bi[16];
+    float best = -3.4e38f;
+    int idx = 0x7fffffff;
+    for (int i = threadIdx.x; i < V; i += 1024) {
+        const float v = logits[i];
+        if (v > best) { best = v; idx = i; }
+    }
+#pragma unroll
+    for (int msk = 32; msk >= 1; msk >>= 1) {
+        const float ov = __shfl_xor(best, msk);
+        const int oi = __shfl_xor(idx, msk);
+        if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { bv[threadIdx.x >> 6] = best; bi[threadIdx.x >> 6] = idx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w)
+            if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
+        *tok = idx;
+        if (hist) hist[step] = idx;
+    }
+}
+
+// out[i, :] = table[ids[i], :] (bf16 rows of D elements); ids int32 on the device; grid = n, block 128
+__global__ __launch_bounds__(128) void embed_rows_kernel(const int* __restrict__ ids, const bf16_t* __restrict__ table,
+                                                         bf16_t* __restrict__ out, int D, int ldo) {
+    const int i = blockIdx.x;
+    const bf16_t* src = table + (size_t)ids[i] * D;
+    for (int c = threadIdx.x * 8; c < D; c += 1024) *(u32x4*)(out + (size_t)i * ldo + c) = *(const u32x4*)(src + c);
+}

@@ -1,0 +1,87 @@
+// Row normalisations (HBM-bound; one wave per row, 16-B lane loads, fp32 statistics, wave-shuffle reductions).
+//   layernorm_kernel: nn.LayerNorm over the last dim, eps inside the sqrt           (HF:models/clip/modeling_clip.py
+//                     CLIPEncoderLayer.layer_norm1/2, pre_layrnorm; timm LayerNormAct2d in channels-last form for the
+//                     STC connector, videollama2/model/projector.py:153-184) with optional "+ residual" and SiLU
+//                     (the tail of timm Bottleneck: act3(conv3(x) + shortcut)).
+//   rmsnorm_kernel:   HF:models/mistral/modeling_mistral.py MistralRMSNorm.forward (fp32 upcast, rsqrt(mean x^2 + eps)).
+#pragma once
+#include "dev_common.h"
+
+struct NormArgs {
+    const bf16_t* x;      // [rows, ldx]
+    bf16_t* y;            // [rows, ldy]
+    const float* w;       // [C]
+    const float* b;       // [C] (layernorm) or null
+    const bf16_t* res;    // [rows, ldres] added AFTER the affine (or null)
+    int rows, C, ldx, ldy, ldres;
+    float eps;
+    int silu;             // apply SiLU last
+};
+
+// NV = number of 8-element vectors per lane (C <= NV*512)
+template <int NV, bool RMS>
+__global__ __launch_bounds__(256) void norm_kernel(NormArgs p) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.rows) return;
+    const bf16_t* x = p.x + (size_t)row * p.ldx;
+    float v[NV][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 8;
+        if (c < p.C) {
+            unpack8(*(const u32x4*)(x + c), v[i]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += RMS ? v[i][j] * v[i][j] : v[i][j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
+        }
+    }
+    s = wave_sum(s);
+    const float inv_c = 1.0f / (float)p.C;
+    float mean = 0.f, rstd;
+    if (RMS) {
+        rstd = rsqrtf(s * inv_c + p.eps);
+    } else {
+        mean = s * inv_c;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 8;
+            if (c < p.C) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mean; q += d * d; }
+            }
+        }
+        q = wave_sum(q);
+        rstd = rsqrtf(q * inv_c + p.eps);
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 8;
+        if (c < p.C) {
+            const f32x4 w0 = *(const f32x4*)(p.w + c), w1 = *(const f32x4*)(p.w + c + 4);
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (v[i][j] - mean) * rstd * (j < 4 ? w0[j] : w1[j - 4]);
+            if (!RMS && p.b) {
+                const f32x4 b0 = *(const f32x4*)(p.b + c), b1 = *(const f32x4*)(p.b + c + 4);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] += (j < 4 ? b0[j] : b1[j - 4]);
+            }
+            if (p.res) {
+                float r[8];
+                unpack8(*(const u32x4*)(p.res + (size_t)row * p.ldres + c), r);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] += r[j];
+            }
+            if (p.silu) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = silu_f(o[j]);
+            }
+            *(u32x4*)(p.y + (size_t)row * p.ldy + c) = pack8(o);
+        }
+    }
+}
