@@ -1,0 +1,210 @@
+#!/usr/bin/env python
+"""bench.py -- VideoLLaMA2-7B video-inference hot path on MI355X (HIP kernels via libvl2hip.so).
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+
+One "step" = one synthetic 16-frame 336^2 video through the whole hot path with inputs resident in HBM:
+  ViT (frames sharded over the N ranks) -> RCCL all-gather of visual tokens -> STC connector -> splice with
+  100 synthetic text ids -> Mistral-7B prefill (S = 1621) -> `--new-tokens` greedy decode steps.
+`value` = encoder video-frames/s (T / (t_vit + t_allgather + t_stc)), BASELINE.json's headline; prefill and decode
+throughput ride along as extra keys.  Weights: random-init bf16 of the exact VideoLLaMA2-7B architecture (no
+checkpoints on the box); data: synthetic.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_MFMA_BF16_TFLOPS = 2500.0   # dense, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+PEAK_HBM_GBS = 8000.0
+
+
+def algorithmic_tflop(T, S_text=100):
+    """SURVEY.md 8(d) formulas (2*MAC; the discarded 24th CLIP layer is not counted)."""
+    vit = T * (2 * 576 * 588 * 1024 + 23 * (577 * 2 * (4 * 1024 ** 2 + 2 * 1024 * 4096) + 4 * 577 ** 2 * 1024))
+    b1 = 2 * (576 * (1024 * 4096 * 2 + 4096 ** 2) + 576 * 4096 * 9 + 2 * 4096 * 256)
+    b = 2 * (576 * 2 * 4096 ** 2 + 576 * 4096 * 9 + 2 * 4096 * 1024)
+    to = T // 2 + 1
+    nvis = to * 169
+    stc = T * (b1 + 3 * b) + 2 * to * 169 * 4096 ** 2 * 8 + to * 4 * 2 * (169 * 2 * 4096 ** 2 + 169 * 4096 * 9 + 2 * 4096 * 1024) \
+        + 2 * nvis * 2 * 4096 ** 2
+    S = nvis + S_text
+    lin = 32 * 2 * (4096 * 4096 * 2 + 2 * 4096 * 1024 + 3 * 4096 * 14336)
+    prefill = S * lin + 32 * 4 * (S * (S + 1) // 2) * 4096 + 2 * 4096 * 32000
+    return vit / 1e12, stc / 1e12, prefill / 1e12, S
+
+
+def decode_bytes_per_token(ctx):
+    """bf16 weights streamed per token (embedding table excluded: one row) + KV read; SURVEY.md 8(d)."""
+    params = 32 * (4096 * 4096 * 2 + 2 * 4096 * 1024 + 3 * 4096 * 14336) + 32000 * 4096
+    return 2 * params + 131072 * ctx
+
+
+def cpu_baseline(threads):
+    """The CPU restatement of the reference path (oracle/vl2_oracle.py, kind 'port') timed on this box's host cores on
+    a bounded sample: CLIP tower (23 layers) on 1 frame + STC connector on 2 frames, fp32."""
+    from oracle import vl2_oracle as O
+    torch.set_num_threads(threads)
+    cfg = O.config_videollama2_7b(2)
+    g = torch.Generator().manual_seed(0)
+    sd = {}
+    for name, shape in O.state_dict_names(cfg):
+        if "vision_tower" in name or "mm_projector" in name:
+            fan = 1
+            for s in shape[1:]:
+                fan *= s
+            t = torch.randn(shape, generator=g)
+            sd[name] = t * (fan ** -0.5) if len(shape) >= 2 else (1.0 + 0.1 * t if name.endswith("weight") else 0.02 * t)
+    fr = torch.randn(1, 3, 336, 336, generator=g)
+    x = torch.randn(1, 2, 576, 1024, generator=g)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        O.clip_tower(sd, cfg, fr)
+        t1 = time.perf_counter()
+        O.stc_connector(sd, x)
+        t2 = time.perf_counter()
+    t_frame = (t1 - t0) + (t2 - t1) / 2.0
+    return dict(value=round(1.0 / t_frame, 4), unit="frames/s", cores=threads, kind="port",
+                sample=f"oracle fp32: CLIP tower 1 frame ({t1 - t0:.2f} s) + STC connector 2 frames ({t2 - t1:.2f} s), "
+                       f"torch {threads} threads; no LLM leg")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=16)
+    ap.add_argument("--new-tokens", type=int, default=32)
+    ap.add_argument("--llm-layers", type=int, default=None, help="debug only: fewer decoder layers (INVALID as a result)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)        # backend "nccl" is RCCL on ROCm
+
+    from videollama2_amd import ops
+    from videollama2_amd.config import videollama2_7b
+    from videollama2_amd.model import VideoLLaMA2Hip
+    from videollama2_amd.weights import random_state_dict
+
+    T, n_new = args.frames, args.new_tokens
+    cfg = videollama2_7b(T)
+    sd = random_state_dict(cfg, dev, seed=1234, n_llm_layers=args.llm_layers)
+    model = VideoLLaMA2Hip(cfg, sd, dev, max_seq_len=4096, n_llm_layers=args.llm_layers)
+    del sd
+    torch.cuda.empty_cache()
+
+    g = torch.Generator(device=dev).manual_seed(0)
+    frames = torch.randn((T, 3, 336, 336), generator=g, device=dev, dtype=torch.float32).to(torch.bfloat16)
+    V = cfg["llm"]["vocab_size"]
+    cg = torch.Generator().manual_seed(1)
+    ids = torch.cat([torch.tensor([1]), torch.randint(3, V, (31,), generator=cg), torch.tensor([-201]),
+                     torch.randint(3, V, (68,), generator=cg)])[None].to(dev)
+    mask = torch.ones_like(ids)
+
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+
+    def step(rec=None):
+        e = [ev() for _ in range(4)]
+        e[0].record()
+        _, _, _, emb, _ = model.prepare_inputs_labels_for_multimodal(ids, mask, None, None, [(frames, "video")])
+        e[1].record()
+        logits = model.decoder.prefill(emb[0])
+        e[2].record()
+        for s in range(n_new):                       # fixed length: stop criteria disabled for timing
+            ops.argmax(logits, model.decoder.tok)
+            logits = model.decoder.decode_step(model.decoder.tok)
+        e[3].record()
+        if rec is not None:
+            rec.append(e)
+        return emb.shape[1]
+
+    for _ in range(args.warmup):
+        S = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    rec = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        S = step(rec)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = tt.item()
+    ms_step = dt * 1e3 / args.steps
+    enc_ms = sum(e[0].elapsed_time(e[1]) for e in rec) / len(rec)
+    pre_ms = sum(e[1].elapsed_time(e[2]) for e in rec) / len(rec)
+    dec_ms = sum(e[2].elapsed_time(e[3]) for e in rec) / len(rec)
+
+    # ---- roofline of the dominant kernel (gemm_bf16_kernel, MFMA-bound): one extra profiled pass, every GEMM launch
+    #      bracketed by HIP events on the launch stream; achieved = sum(algorithmic FLOPs) / sum(kernel time)
+    roof = None
+    if rank == 0:
+        ops.PROFILE = []
+        step()
+        torch.cuda.synchronize()
+        prof = ops.PROFILE
+        ops.PROFILE = None
+        gflop = sum(p[1] for p in prof if p[0] == "gemm") / 1e9
+        gms = sum(p[2].elapsed_time(p[3]) for p in prof if p[0] == "gemm")
+        ngemm = sum(1 for p in prof if p[0] == "gemm")
+        ach = gflop / gms if gms > 0 else 0.0                  # GFLOP/ms = TFLOP/s
+        roof = dict(bound="mfma", kernel="gemm_bf16_kernel", achieved=round(ach, 2), peak=PEAK_MFMA_BF16_TFLOPS,
+                    unit="TFLOP/s", frac=round(ach / PEAK_MFMA_BF16_TFLOPS, 4), traffic=None,
+                    launches=ngemm, avg_launch_us=round(1e3 * gms / max(ngemm, 1), 2),
+                    flop_per_launch_avg=round(1e9 * gflop / max(ngemm, 1), 0))
+
+    if rank == 0:
+        vit_tf, stc_tf, pre_tf, S_alg = algorithmic_tflop(T)
+        fwd_ms = enc_ms + pre_ms
+        out = {
+            "metric": "video-frames/sec encoded (CLIP-ViT + STC), VideoLLaMA2-7B 16f@336^2; prefill/decode tokens/sec as extra keys",
+            "value": round(T / (enc_ms / 1e3), 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"VideoLLaMA2-7B, {T}-frame 336^2 video, bf16, S={S} prefill, {n_new} greedy decode tokens "
+                                   f"(BASELINE.json configs[1])", "frames": T, "prefill_tokens": S, "new_tokens": n_new,
+                       "parallelism": f"frames sharded over {world} rank(s) + RCCL all-gather; connector/LLM replicated",
+                       "llm_layers": len(model.decoder.w["layers"])},
+            "encode_ms": round(enc_ms, 3), "prefill_ms": round(pre_ms, 3), "decode_ms_per_token": round(dec_ms / n_new, 4),
+            "prefill_tokens_per_s": round(S / (pre_ms / 1e3), 1), "decode_tokens_per_s": round(n_new / (dec_ms / 1e3), 2),
+            "forward_tflop": round(vit_tf + stc_tf + pre_tf, 3),
+            "forward_mfma_frac": round((vit_tf + stc_tf + pre_tf) / (fwd_ms / 1e3) / PEAK_MFMA_BF16_TFLOPS, 4),
+            "decode_hbm_frac": round(decode_bytes_per_token(S + n_new // 2) / (dec_ms / n_new / 1e3) / 1e9 / PEAK_HBM_GBS, 4),
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
+            except Exception as exc:  # the oracle is a checker, never a dependency of the measured path
+                out["cpu_baseline"] = {"value": None, "error": repr(exc)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,112 @@
+/* libvl2hip.so -- C ABI of the MI355X-native VideoLLaMA2 video-inference hot path.
+ *
+ * The reference (DAMO-NLP-SG/VideoLLaMA2) is pure Python and has NO FFI of its own: every FLOP of its hot path runs
+ * inside third-party library kernels (HF transformers / timm / torch / flash-attn).  Each entry
+ * point below therefore cites the reference call site (file:line under /root/reference, or HF: for the installed
+ * transformers package) whose delegated library kernel it replaces.  The Python host code in videollama2_amd/ binds
+ * these with ctypes (videollama2_amd/_lib.py); INTEGRATION.md shows the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every function returns int32: 0 = ok, < 0 = VL2_E_* (argument/shape error, nothing launched), > 0 = hipError_t.
+ *   - no allocation, no synchronisation, no host<->device copies inside: every call only enqueues kernels on `stream`
+ *     (a hipStream_t passed as void*), so every call is hipGraph-capturable.  The caller owns all buffers.
+ *   - all pointers are DEVICE pointers unless stated; bf16 tensors are raw uint16 bit patterns; strides (ld*) are in
+ *     elements; every row pointer / ld must keep 16-byte alignment (8 bf16).
+ *   - thread-safe and re-entrant; the only global state is a thread-local error string.
+ */
+#ifndef VL2HIP_H
+#define VL2HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VL2_ABI_VERSION 1
+#define VL2_E_BADARG  (-1)   /* null pointer / non-positive size */
+#define VL2_E_SHAPE   (-2)   /* shape not supported by the gfx950 kernels (alignment / multiple-of constraints) */
+#define VL2_E_UNSUPP  (-3)   /* option combination not built */
+
+int32_t vl2_version(void);
+const char* vl2_last_error_string(void);      /* host pointer, thread-local, valid until the next failing call */
+
+/* activation codes for vl2_gemm_bf16 / vl2_small_linear */
+#define VL2_ACT_NONE    0
+#define VL2_ACT_QGELU   1   /* x*sigmoid(1.702x)  HF:activations.py QuickGELUActivation (CLIP MLP) */
+#define VL2_ACT_GELU    2   /* exact erf GELU     torch nn.GELU() in projector.py:125-130 build_mlp (STC readout) */
+#define VL2_ACT_SILU    3   /* nn.SiLU            projector.py:164-174 sampler, timm act_layer */
+#define VL2_ACT_SIGMOID 4   /* only vl2_small_linear */
+/* flags for vl2_gemm_bf16 */
+#define VL2_GEMM_SWIGLU  1  /* W = blocks of 64 rows {32 gate rows, 32 up rows}; C[m, j] = silu(gate_j) * up_j; C has N/2 cols.
+                               HF:models/mistral/modeling_mistral.py MistralMLP.forward */
+#define VL2_GEMM_OUT_F32 2  /* C is fp32 (validation / logits) */
+
+/* C[M,N] = epilogue(A[M,K] . W[N,K]^T):  bf16 MFMA GEMM, fp32 accumulate.  Replaces the cuBLAS / cuDNN GEMMs behind
+ *   nn.Linear in HF:models/clip/modeling_clip.py CLIPAttention/CLIPMLP, HF:models/mistral/modeling_mistral.py
+ *   MistralAttention/MistralMLP/lm_head, and the 1x1 convs / Conv3d / readout of videollama2/model/projector.py:153-187.
+ * N % 128 == 0, K % 64 == 0.  bias fp32 [N] or NULL.  res bf16 rows or NULL (added after the activation).
+ * Gathered-A form (a_idx != NULL): K = nseg*seg_k; the A row of (segment s, output row m) is A[a_idx[s*M+m]] or
+ *   zeros when the index is < 0 (zero_row: >= seg_k zero bf16) -- this is Conv3d(k=2,s=2,p=1) as a GEMM over the
+ *   8 taps (projector.py:164-174).
+ * Row remap: out_grp > 0 -> output row = m + (m/out_grp)*out_grp_pad + out_row_off; res_row_mod > 0 -> residual row =
+ *   m % res_row_mod + res_row_off (else the output row).  Used by the patch-embed GEMM to write torch.cat([cls, patches])
+ *   + position_embedding directly (HF:modeling_clip.py CLIPVisionEmbeddings.forward). */
+int32_t vl2_gemm_bf16(const void* A, const void* W, void* C, const float* bias, const void* res, int32_t M, int32_t N,
+                      int32_t K, int32_t lda, int32_t ldw, int32_t ldc, int32_t ldres, int32_t act, int32_t flags,
+                      const int32_t* a_idx, const void* zero_row, int32_t seg_k, int32_t out_grp, int32_t out_grp_pad,
+                      int32_t out_row_off, int32_t res_row_mod, int32_t res_row_off, void* stream);
+
+/* y = LayerNorm(x)*w + b [+ res] [-> SiLU]; rows x C, fp32 statistics.  HF:modeling_clip.py pre_layrnorm / layer_norm1/2;
+ * timm LayerNormAct2d in channels-last form (projector.py:153-184) incl. the Bottleneck tail act3(conv3(x)+shortcut).
+ * C % 8 == 0, C <= 4096. */
+int32_t vl2_layernorm(const void* x, void* y, const float* w, const float* b, const void* res, int32_t rows, int32_t C,
+                      int32_t ldx, int32_t ldy, int32_t ldres, float eps, int32_t silu, void* stream);
+/* HF:modeling_mistral.py MistralRMSNorm.forward. */
+int32_t vl2_rmsnorm(const void* x, void* y, const float* w, int32_t rows, int32_t C, int32_t ldx, int32_t ldy, float eps,
+                    void* stream);
+
+/* frames [T,3,H,W] (dtype 0=fp32, 1=fp16, 2=bf16; what process_video returns / mm_infer casts, videollama2/__init__.py:60)
+ * -> im2col rows [T*G*G, Kp] bf16 (k = c*P*P+ky*P+kx, zero padded to Kp).  HF:modeling_clip.py CLIPVisionEmbeddings
+ * patch_embedding (Conv2d k=P s=P, no bias). */
+int32_t vl2_patchify(const void* frames, int32_t dtype, void* out, int32_t T, int32_t H, int32_t W, int32_t P, int32_t G,
+                     int32_t Kp, void* stream);
+/* x[t*rows_per_frame, :] = cls_pos (class_embedding + position_embedding[0]). */
+int32_t vl2_fill_cls(void* x, const void* cls_pos, int32_t T, int32_t D, int32_t rows_per_frame, void* stream);
+
+/* Fused attention forward, softmax in fp32.  D = 64 or 128.  Element strides: *_bs batch, *_hs head, *_rs row.
+ * kv head of q head h = h / group.  causal: key j visible to q row i iff j <= i + causal_off.
+ * Replaces flash-attn (videollama2/model/encoder.py:24) / HF eager_attention_forward for CLIP, and HF Mistral
+ * attention (repeat_kv + causal softmax) for the prefill. */
+int32_t vl2_attn_fwd(const void* q, const void* k, const void* v, void* o, int64_t q_bs, int64_t q_hs, int32_t q_rs,
+                     int64_t k_bs, int64_t k_hs, int32_t k_rs, int64_t v_bs, int64_t v_hs, int32_t v_rs, int64_t o_bs,
+                     int64_t o_hs, int32_t o_rs, int32_t B, int32_t H, int32_t nq, int32_t nk, int32_t group, float scale,
+                     int32_t causal, int32_t causal_off, int32_t D, void* stream);
+
+/* STC connector direct kernels (channels-last activations [F, H, W, C]); timm Bottleneck.conv2 + LayerNormAct2d, SEModule. */
+int32_t vl2_dwconv3x3_ln_silu(const void* x, void* y, const float* w9c, const float* lnw, const float* lnb, int32_t F,
+                              int32_t H, int32_t W, int32_t C, float eps, void* stream);
+int32_t vl2_chan_mean(const void* x, float* mean, int32_t F, int32_t HW, int32_t C, void* stream);
+int32_t vl2_small_linear(const float* x, const void* W, const float* b, float* out, int32_t F, int32_t N, int32_t K,
+                         int32_t act, void* stream);
+int32_t vl2_se_scale(void* x, const float* gate, int32_t F, int32_t HW, int32_t C, void* stream);
+
+/* Mistral RoPE (rotate-half) on q,k of the fused qkv rows + KV-cache append at positions pos0..pos0+S-1.
+ * head_dim 128.  cos/sin fp32 [maxpos][64].  HF:modeling_mistral.py apply_rotary_pos_emb, DynamicCache.update. */
+int32_t vl2_rope_kv(const void* qkv, void* q_out, void* kcache, void* vcache, const float* cos_t, const float* sin_t,
+                    int32_t S, int32_t nh, int32_t nkv, int32_t smax, int32_t pos0, void* stream);
+
+/* y[N] = W[N,K] x[K] for one token (decode).  norm_w != NULL fuses MistralRMSNorm on x first.  flags as vl2_gemm_bf16. */
+int32_t vl2_gemv_bf16(const void* W, const void* x, const float* norm_w, const void* res, void* y, int32_t N, int32_t K,
+                      int32_t ldw, float eps, int32_t flags, void* stream);
+/* one query token vs the KV cache rows [0, ctx); partial: fp32 workspace >= nh*ceil(ctx/chunk)*130 floats. */
+int32_t vl2_attn_decode(const void* q, const void* kcache, const void* vcache, float* partial, void* out, int32_t nh,
+                        int32_t nkv, int32_t smax, int32_t ctx, int32_t chunk, float scale, void* stream);
+/* greedy argmax (first maximal index) of fp32 logits -> *tok (device int32) and hist[step] if hist != NULL.
+ * HF:generation/utils.py _sample with do_sample=False (videollama2/__init__.py:93-99). */
+int32_t vl2_argmax(const float* logits, int32_t V, int32_t* tok, int32_t* hist, int32_t step, void* stream);
+/* out[i,:] = table[ids[i],:]; ids int32 device.  embed_tokens in videollama2/model/videollama2_arch.py:203-220. */
+int32_t vl2_embed_rows(const int32_t* ids, const void* table, void* out, int32_t n, int32_t D, int32_t ldo, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,5 +1,7 @@
-// TEST INFRASTRUCTURE ONLY: compiles the product's kernel headers against tests/emu/hip_emu.h (host CPU) so
-// tests/test_emu_kernels.py can check their indexing logic without a GPU.  Built by tests/emu/build_emu.py.
+// TEST INFRASTRUCTURE ONLY: the product's kernel headers (videollama2_amd/csrc/k_*.h) compiled for the host against
+// tests/emu/hip_emu.h, exported under the SAME C ABI as libvl2hip.so (include/vl2hip.h; `stream` ignored), so the
+// CPU-only test-suite can drive the real host code (videollama2_amd/ops.py, tower.py, connector.py, decoder.py,
+// model.py) end to end through the real kernels' indexing logic.  Built by tests/emu/build_emu.py.
 #include "hip_emu.h"
 alignas(64) unsigned char vl2_smem[160 * 1024];
 #include "k_gemm.h"
@@ -8,37 +10,40 @@ alignas(64) unsigned char vl2_smem[160 * 1024];
 #include "k_attn.h"
 #include "k_stc.h"
 #include "k_decode.h"
+#include <cstdint>
+
+static char g_err[256] = "emu";
+extern "C" int32_t vl2_version(void) { return 1; }
+extern "C" const char* vl2_last_error_string(void) { return g_err; }
 
 template <int ACT, bool SW, bool F32, bool G>
 static void run_gemm(GemmArgs a) {
     emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(256), [=] { gemm_bf16_kernel<ACT, SW, F32, G>(a); });
 }
-extern "C" int emu_gemm(const void* A, const void* W, void* C, const float* bias, const void* res, const int* a_idx,
-                        const void* zero_row, int M, int N, int K, int lda, int ldw, int ldc, int ldres, int seg_k,
-                        int out_grp, int out_grp_pad, int out_row_off, int res_row_mod, int res_row_off, int act,
-                        int swiglu, int out_f32) {
+extern "C" int32_t vl2_gemm_bf16(const void* A, const void* W, void* C, const float* bias, const void* res, int32_t M,
+                                 int32_t N, int32_t K, int32_t lda, int32_t ldw, int32_t ldc, int32_t ldres, int32_t act,
+                                 int32_t flags, const int32_t* a_idx, const void* zero_row, int32_t seg_k, int32_t out_grp,
+                                 int32_t out_grp_pad, int32_t out_row_off, int32_t res_row_mod, int32_t res_row_off, void*) {
+    if (N % 128 || K % 64) return -2;
     GemmArgs a{(const bf16_t*)A, (const bf16_t*)W, C, bias, (const bf16_t*)res, a_idx, (const bf16_t*)zero_row,
                M, N, K, lda, ldw, ldc, ldres, seg_k, out_grp, out_grp_pad, out_row_off, res_row_mod, res_row_off,
                (M + 127) / 128, N / 128};
-    const bool g = a_idx != nullptr;
-    if (swiglu) { run_gemm<0, true, false, false>(a); return 0; }
-    if (g) { if (act == 3) run_gemm<3, false, false, true>(a); else run_gemm<0, false, false, true>(a); return 0; }
-    if (out_f32) { run_gemm<0, false, true, false>(a); return 0; }
+    const bool sw = flags & 1, f32 = flags & 2, g = a_idx != nullptr;
+    if (sw) { run_gemm<0, true, false, false>(a); return 0; }
+    if (g) { if (act == 3) run_gemm<3, false, false, true>(a); else if (act == 0) run_gemm<0, false, false, true>(a); else return -3; return 0; }
+    if (f32) { if (act) return -3; run_gemm<0, false, true, false>(a); return 0; }
     switch (act) {
         case 0: run_gemm<0, false, false, false>(a); break;
         case 1: run_gemm<1, false, false, false>(a); break;
         case 2: run_gemm<2, false, false, false>(a); break;
         case 3: run_gemm<3, false, false, false>(a); break;
-        default: return -1;
+        default: return -3;
     }
     return 0;
 }
-
-extern "C" int emu_norm(const void* x, void* y, const float* w, const float* b, const void* res, int rows, int C, int ldx,
-                        int ldy, int ldres, float eps, int silu, int rms) {
-    NormArgs a{(const bf16_t*)x, (bf16_t*)y, w, b, (const bf16_t*)res, rows, C, ldx, ldy, ldres, eps, silu};
-    const int nv = (C + 511) / 512;
-    dim3 g((rows + 3) / 4), blk(256);
+static int32_t run_norm(NormArgs a, bool rms) {
+    const int nv = (a.C + 511) / 512;
+    dim3 g((a.rows + 3) / 4), blk(256);
     if (rms) {
         if (nv <= 1) emu::launch(g, blk, [=] { norm_kernel<1, true>(a); });
         else if (nv <= 2) emu::launch(g, blk, [=] { norm_kernel<2, true>(a); });
@@ -50,16 +55,30 @@ extern "C" int emu_norm(const void* x, void* y, const float* w, const float* b, 
     }
     return 0;
 }
-extern "C" int emu_patchify(const void* frames, int dtype, void* out, int T, int H, int W, int P, int G, int Kp) {
+extern "C" int32_t vl2_layernorm(const void* x, void* y, const float* w, const float* b, const void* res, int32_t rows,
+                                 int32_t C, int32_t ldx, int32_t ldy, int32_t ldres, float eps, int32_t silu, void*) {
+    return run_norm(NormArgs{(const bf16_t*)x, (bf16_t*)y, w, b, (const bf16_t*)res, rows, C, ldx, ldy, ldres, eps, silu}, false);
+}
+extern "C" int32_t vl2_rmsnorm(const void* x, void* y, const float* w, int32_t rows, int32_t C, int32_t ldx, int32_t ldy,
+                               float eps, void*) {
+    return run_norm(NormArgs{(const bf16_t*)x, (bf16_t*)y, w, nullptr, nullptr, rows, C, ldx, ldy, 0, eps, 0}, true);
+}
+extern "C" int32_t vl2_patchify(const void* frames, int32_t dtype, void* out, int32_t T, int32_t H, int32_t W, int32_t P,
+                                int32_t G, int32_t Kp, void*) {
     dim3 g(G, T), blk(256);
     if (dtype == 0) emu::launch(g, blk, [=] { patchify_kernel<float>((const float*)frames, (bf16_t*)out, H, W, P, G, Kp); });
     else if (dtype == 1) emu::launch(g, blk, [=] { patchify_kernel<_Float16>((const _Float16*)frames, (bf16_t*)out, H, W, P, G, Kp); });
     else emu::launch(g, blk, [=] { patchify_kernel<bf16_t>((const bf16_t*)frames, (bf16_t*)out, H, W, P, G, Kp); });
     return 0;
 }
-extern "C" int emu_attn(const void* q, const void* k, const void* v, void* o, long q_bs, long q_hs, int q_rs, long k_bs,
-                        long k_hs, int k_rs, long v_bs, long v_hs, int v_rs, long o_bs, long o_hs, int o_rs, int B, int H,
-                        int nq, int nk, int group, float scale, int causal, int causal_off, int D) {
+extern "C" int32_t vl2_fill_cls(void* x, const void* cls_pos, int32_t T, int32_t D, int32_t rows_per_frame, void*) {
+    emu::launch(dim3(T), dim3(128), [=] { fill_cls_kernel((bf16_t*)x, (const bf16_t*)cls_pos, D, rows_per_frame); });
+    return 0;
+}
+extern "C" int32_t vl2_attn_fwd(const void* q, const void* k, const void* v, void* o, int64_t q_bs, int64_t q_hs, int32_t q_rs,
+                                int64_t k_bs, int64_t k_hs, int32_t k_rs, int64_t v_bs, int64_t v_hs, int32_t v_rs,
+                                int64_t o_bs, int64_t o_hs, int32_t o_rs, int32_t B, int32_t H, int32_t nq, int32_t nk,
+                                int32_t group, float scale, int32_t causal, int32_t causal_off, int32_t D, void*) {
     AttnArgs a{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, q_bs, q_hs, q_rs, k_bs, k_hs, k_rs,
                v_bs, v_hs, v_rs, o_bs, o_hs, o_rs, nq, nk, group, scale * 1.4426950408889634f, causal_off};
     dim3 g((nq + 127) / 128, H, B), blk(256);
@@ -67,58 +86,61 @@ extern "C" int emu_attn(const void* q, const void* k, const void* v, void* o, lo
     else if (D == 128 && causal) emu::launch(g, blk, [=] { attn_fwd_kernel<128, true>(a); });
     else if (D == 128 && !causal) emu::launch(g, blk, [=] { attn_fwd_kernel<128, false>(a); });
     else if (D == 64 && causal) emu::launch(g, blk, [=] { attn_fwd_kernel<64, true>(a); });
-    else return -1;
+    else return -2;
     return 0;
 }
-
-extern "C" int emu_dwconv_ln_silu(const void* x, void* y, const float* wt, const float* lnw, const float* lnb, int F, int H,
-                                  int W, int C, float eps) {
+extern "C" int32_t vl2_dwconv3x3_ln_silu(const void* x, void* y, const float* wt, const float* lnw, const float* lnb, int32_t F,
+                                         int32_t H, int32_t W, int32_t C, float eps, void*) {
     dim3 g(F * H * W), blk(256);
     if (C <= 2048) emu::launch(g, blk, [=] { dwconv_ln_silu_kernel<1>((const bf16_t*)x, (bf16_t*)y, wt, lnw, lnb, H, W, C, eps); });
     else emu::launch(g, blk, [=] { dwconv_ln_silu_kernel<2>((const bf16_t*)x, (bf16_t*)y, wt, lnw, lnb, H, W, C, eps); });
     return 0;
 }
-extern "C" int emu_chan_mean(const void* x, float* mean, int F, int HW, int C) {
+extern "C" int32_t vl2_chan_mean(const void* x, float* mean, int32_t F, int32_t HW, int32_t C, void*) {
     emu::launch(dim3(C / 64, F), dim3(256), [=] { chan_mean_kernel((const bf16_t*)x, mean, HW, C); });
     return 0;
 }
-extern "C" int emu_small_linear(const float* x, const void* W, const float* b, float* out, int F, int N, int K, int act) {
-    emu::launch(dim3((N + 3) / 4), dim3(256), [=] { small_linear_kernel(x, (const bf16_t*)W, b, out, F, N, K, act); });
+extern "C" int32_t vl2_small_linear(const float* x, const void* W, const float* b, float* out, int32_t F, int32_t N, int32_t K,
+                                    int32_t act, void*) {
+    const int a = act == 3 ? 1 : act == 4 ? 2 : 0;
+    emu::launch(dim3((N + 3) / 4), dim3(256), [=] { small_linear_kernel(x, (const bf16_t*)W, b, out, F, N, K, a); });
     return 0;
 }
-extern "C" int emu_se_scale(void* x, const float* gate, int F, int HW, int C) {
+extern "C" int32_t vl2_se_scale(void* x, const float* gate, int32_t F, int32_t HW, int32_t C, void*) {
     size_t nvec = (size_t)F * HW * C / 8;
     emu::launch(dim3(7), dim3(256), [=] { se_scale_kernel((bf16_t*)x, gate, HW, C, nvec); });
     return 0;
 }
-extern "C" int emu_rope_kv(const void* qkv, void* q_out, void* kc, void* vc, const float* cos_t, const float* sin_t, int S,
-                           int nh, int nkv, int smax, int pos0) {
+extern "C" int32_t vl2_rope_kv(const void* qkv, void* q_out, void* kc, void* vc, const float* cos_t, const float* sin_t,
+                               int32_t S, int32_t nh, int32_t nkv, int32_t smax, int32_t pos0, void*) {
+    if (pos0 < 0 || pos0 + S > smax) return -2;
     emu::launch(dim3(5), dim3(256), [=] { rope_kv_kernel((const bf16_t*)qkv, (bf16_t*)q_out, (bf16_t*)kc, (bf16_t*)vc, cos_t, sin_t, S, nh, nkv, smax, pos0); });
     return 0;
 }
-extern "C" int emu_gemv(const void* W, const void* x, const float* norm_w, const void* res, void* y, int N, int K, int ldw,
-                        float eps, int swiglu, int out_f32) {
+extern "C" int32_t vl2_gemv_bf16(const void* W, const void* x, const float* norm_w, const void* res, void* y, int32_t N,
+                                 int32_t K, int32_t ldw, float eps, int32_t flags, void*) {
     GemvArgs a{(const bf16_t*)W, (const bf16_t*)x, norm_w, (const bf16_t*)res, y, N, K, ldw, eps};
-    const int n_out = swiglu ? N / 2 : N;
+    const bool sw = flags & 1, f32 = flags & 2;
+    const int n_out = sw ? N / 2 : N;
     dim3 g((n_out + 7) / 8), blk(256);
-    if (swiglu) emu::launch(g, blk, [=] { gemv_bf16_kernel<true, false, 2>(a); });
-    else if (out_f32) emu::launch(g, blk, [=] { gemv_bf16_kernel<false, true, 2>(a); });
+    if (sw) emu::launch(g, blk, [=] { gemv_bf16_kernel<true, false, 2>(a); });
+    else if (f32) emu::launch(g, blk, [=] { gemv_bf16_kernel<false, true, 2>(a); });
     else emu::launch(g, blk, [=] { gemv_bf16_kernel<false, false, 2>(a); });
     return 0;
 }
-extern "C" int emu_attn_decode(const void* q, const void* kc, const void* vc, float* partial, void* out, int nh, int nkv,
-                               int smax, int ctx, int chunk, float scale) {
+extern "C" int32_t vl2_attn_decode(const void* q, const void* kc, const void* vc, float* partial, void* out, int32_t nh,
+                                   int32_t nkv, int32_t smax, int32_t ctx, int32_t chunk, float scale, void*) {
     const int group = nh / nkv, nsplit = (ctx + chunk - 1) / chunk;
     emu::launch(dim3(nsplit, nkv), dim3(group * 64), [=] {
         attn_decode_kernel((const bf16_t*)q, (const bf16_t*)kc, (const bf16_t*)vc, partial, nh, group, smax, ctx, chunk, scale * 1.4426950408889634f); });
     emu::launch(dim3(nh), dim3(128), [=] { attn_decode_combine_kernel(partial, (bf16_t*)out, nsplit); });
     return 0;
 }
-extern "C" int emu_argmax(const float* logits, int V, int* tok, int* hist, int step) {
+extern "C" int32_t vl2_argmax(const float* logits, int32_t V, int32_t* tok, int32_t* hist, int32_t step, void*) {
     emu::launch(dim3(1), dim3(1024), [=] { argmax_kernel(logits, V, tok, hist, step); });
     return 0;
 }
-extern "C" int emu_embed_rows(const int* ids, const void* table, void* out, int n, int D, int ldo) {
+extern "C" int32_t vl2_embed_rows(const int32_t* ids, const void* table, void* out, int32_t n, int32_t D, int32_t ldo, void*) {
     emu::launch(dim3(n), dim3(128), [=] { embed_rows_kernel(ids, (const bf16_t*)table, (bf16_t*)out, D, ldo); });
     return 0;
 }

@@ -1,0 +1,244 @@
+"""Per-operator parity on MI355X: every libvl2hip.so kernel, called through the C ABI (videollama2_amd.ops ->
+ctypes), against the fp32 oracle of the same op on identical bf16-rounded inputs.  Tolerances: tests/util.py."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.util import TOL_BF16_OUT, TOL_F32_OUT, rel
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    from videollama2_amd import _lib, ops as o
+    _lib.load()
+    return o
+
+
+def bf(*shape, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).bfloat16()
+
+
+@pytest.mark.parametrize("M,N,K", [(200, 256, 192), (128, 128, 64), (9232, 1024, 1024), (1621, 6144, 4096), (577, 4096, 1024)])
+def test_gemm_plain_f32(ops, M, N, K):
+    a, w = bf(M, K), bf(N, K, scale=K ** -0.5)
+    c = ops.gemm(a.to(DEV), w.to(DEV), out_f32=True)
+    assert rel(c, a.float() @ w.float().T) < TOL_F32_OUT
+
+
+@pytest.mark.parametrize("act", [0, 1, 2, 3])
+def test_gemm_bias_act_res(ops, act):
+    M, N, K = 1521, 1024, 4096
+    a, w, bias, res = bf(M, K), bf(N, K, scale=K ** -0.5), torch.randn(N), bf(M, N)
+    c = ops.gemm(a.to(DEV), w.to(DEV), bias=bias.to(DEV), res=res.to(DEV), act=act)
+    y = F.linear(a.float(), w.float(), bias)
+    y = [y, y * torch.sigmoid(1.702 * y), F.gelu(y), F.silu(y)][act] + res.float()
+    assert rel(c, y) < TOL_BF16_OUT
+
+
+def test_gemm_swiglu(ops):
+    from videollama2_amd.weights import pack_gate_up
+    M, I, K = 333, 1792, 1024
+    a, wg, wu = bf(M, K), bf(I, K, scale=K ** -0.5), bf(I, K, scale=K ** -0.5, seed=1)
+    c = ops.gemm(a.to(DEV), pack_gate_up(wg, wu).to(DEV), swiglu=True)
+    assert c.shape == (M, I)
+    assert rel(c, F.silu(a.float() @ wg.float().T) * (a.float() @ wu.float().T)) < TOL_BF16_OUT
+
+
+def test_gemm_conv3d_gather_full_size(ops):
+    """Conv3d(4096,4096,k2,s2,p1)+bias+SiLU on [4,24,24] frames as the gathered GEMM (projector.py:164-174, :208)."""
+    from videollama2_amd.connector import conv3d_k2s2p1_index
+    T, H, C = 4, 24, 512
+    x = bf(T * H * H, C)
+    w3 = bf(C, C, 2, 2, 2, scale=(8 * C) ** -0.5)
+    bias = torch.randn(C) * 0.1
+    idx, (To, Ho, Wo) = conv3d_k2s2p1_index(T, H, H, DEV)
+    wp = w3.permute(0, 2, 3, 4, 1).reshape(C, 8 * C).contiguous()
+    y = ops.gemm(x.to(DEV), wp.to(DEV), bias=bias.to(DEV), act=3, gather=(idx, torch.zeros(C, dtype=torch.bfloat16, device=DEV), C))
+    ref = F.silu(F.conv3d(x.float().view(1, T, H, H, C).permute(0, 4, 1, 2, 3), w3.float(), bias, stride=2, padding=1))
+    ref = ref[0].permute(1, 2, 3, 0).reshape(To * Ho * Wo, C)
+    assert (To, Ho, Wo) == (3, 13, 13)
+    assert rel(y, ref) < TOL_BF16_OUT
+
+
+@pytest.mark.parametrize("C,rows", [(128, 37), (1024, 9232), (4096, 1521)])
+def test_layernorm_rmsnorm(ops, C, rows):
+    x, w, b, r = bf(rows, C, scale=2.0) + 0.5, torch.randn(C), torch.randn(C), bf(rows, C)
+    x = x.bfloat16()
+    y = ops.layernorm(x.to(DEV), w.to(DEV), b.to(DEV), 1e-5, res=r.to(DEV), silu=True)
+    assert rel(y, F.silu(F.layer_norm(x.float(), (C,), w, b, 1e-5) + r.float())) < TOL_BF16_OUT
+    y = ops.layernorm(x.to(DEV), w.to(DEV), b.to(DEV), 1e-5)
+    assert rel(y, F.layer_norm(x.float(), (C,), w, b, 1e-5)) < TOL_BF16_OUT
+    y = ops.rmsnorm(x.to(DEV), w.to(DEV), 1e-5)
+    xf = x.float()
+    assert rel(y, w * xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-5)) < TOL_BF16_OUT
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+def test_patch_embed_full_size(ops, dtype):
+    """[T,3,336,336] -> cat([cls, conv(k14,s14)]) + pos  (HF CLIPVisionEmbeddings.forward)."""
+    T, D, P, S = 2, 1024, 14, 336
+    fr = torch.randn(T, 3, S, S, generator=torch.Generator().manual_seed(3)).to(dtype)
+    w = bf(D, 3, P, P, scale=588 ** -0.5)
+    pos, cls = bf(577, D, scale=0.1), bf(D, scale=0.5)
+    a = ops.patchify(fr.to(DEV), P, 640)
+    pw = torch.zeros(D, 640, dtype=torch.bfloat16)
+    pw[:, :588] = w.reshape(D, 588)
+    x = torch.zeros(T * 577, D, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(a, pw.to(DEV), res=pos.to(DEV), out=x, out_map=(576, 1, 1), res_map=(576, 1))
+    ops.fill_cls(x, (cls.float() + pos[0].float()).bfloat16().to(DEV), T, 577)
+    ref = F.conv2d(fr.bfloat16().float(), w.float(), stride=P).flatten(2).transpose(1, 2)
+    ref = torch.cat([cls.float().expand(T, 1, D), ref], 1) + pos.float()[None]
+    assert rel(x.view(T, 577, D), ref) < TOL_BF16_OUT
+
+
+def test_attn_vit_full_size(ops):
+    """B frames x 16 heads x 577 tokens x 64, non-causal, straight out of the fused qkv buffer."""
+    B, H, N, D = 2, 16, 577, 64
+    qkv = bf(B * N, 3 * H * D)
+    o = torch.zeros(B * N, H * D, dtype=torch.bfloat16, device=DEV)
+    g = qkv.to(DEV)
+    st = (N * 3 * H * D, D, 3 * H * D)
+    ops.attn_fwd(g, g[:, H * D:], g[:, 2 * H * D:], o, st, st, st, (N * H * D, D, H * D), B, H, N, N, 1, D ** -0.5, False, 0, D)
+    q, k, v = [t.view(B, N, H, D).transpose(1, 2).float() for t in qkv.view(B * N, 3, H * D).unbind(1)]
+    ref = (torch.softmax(q @ k.transpose(-1, -2) * D ** -0.5, -1) @ v).transpose(1, 2).reshape(B * N, H * D)
+    assert rel(o, ref) < TOL_BF16_OUT
+
+
+@pytest.mark.parametrize("S,nh,nkv", [(1621, 32, 8), (200, 4, 2), (64, 2, 1)])
+def test_attn_causal_gqa(ops, S, nh, nkv):
+    D, smax = 128, 2048
+    q, kc, vc = bf(S, nh * D), bf(nkv, smax, D), bf(nkv, smax, D, seed=1)
+    o = torch.zeros(S, nh * D, dtype=torch.bfloat16, device=DEV)
+    ops.attn_fwd(q.to(DEV), kc.to(DEV), vc.to(DEV), o, (0, D, nh * D), (0, smax * D, D), (0, smax * D, D), (0, D, nh * D),
+                 1, nh, S, S, nh // nkv, D ** -0.5, True, 0, D)
+    qf = q.view(S, nh, D).transpose(0, 1).float()
+    kf = kc[:, :S].float().repeat_interleave(nh // nkv, 0)
+    vf = vc[:, :S].float().repeat_interleave(nh // nkv, 0)
+    sc = (qf @ kf.transpose(1, 2)) * D ** -0.5
+    sc = sc.masked_fill(torch.triu(torch.ones(S, S, dtype=torch.bool), 1), float("-inf"))
+    ref = (torch.softmax(sc, -1) @ vf).transpose(0, 1).reshape(S, nh * D)
+    assert rel(o, ref) < TOL_BF16_OUT
+
+
+def test_attn_softmax_spike(ops):
+    """One key dominating one query row at a late tile forces the online-softmax rescale branch (guide rule 26)."""
+    B, H, N, D = 1, 1, 300, 64
+    qkv = bf(B * N, 3 * D)
+    qkv[17, :D] = 6.0
+    qkv[250, D:2 * D] = 6.0
+    g = qkv.to(DEV)
+    o = torch.zeros(N, D, dtype=torch.bfloat16, device=DEV)
+    st = (N * 3 * D, D, 3 * D)
+    ops.attn_fwd(g, g[:, D:], g[:, 2 * D:], o, st, st, st, (N * D, D, D), B, H, N, N, 1, D ** -0.5, False, 0, D)
+    q, k, v = [t.float() for t in qkv.view(N, 3, D).unbind(1)]
+    ref = torch.softmax(q @ k.T * D ** -0.5, -1) @ v
+    assert rel(o, ref) < TOL_BF16_OUT
+    assert rel(o[17], ref[17]) < 1e-2
+
+
+def test_stc_direct_kernels_full_width(ops):
+    Fr, H, C = 2, 24, 4096
+    x = bf(Fr * H * H, C)
+    wt, lnw, lnb = torch.randn(C, 1, 3, 3) * 0.3, torch.randn(C), torch.randn(C)
+    wt = wt.bfloat16().float()
+    y = ops.dwconv3x3_ln_silu(x.to(DEV), wt.view(C, 9).t().contiguous().to(DEV), lnw.to(DEV), lnb.to(DEV), Fr, H, H)
+    ref = F.conv2d(x.float().view(Fr, H, H, C).permute(0, 3, 1, 2), wt, padding=1, groups=C).permute(0, 2, 3, 1)
+    ref = F.silu(F.layer_norm(ref, (C,), lnw, lnb, 1e-5)).reshape(Fr * H * H, C)
+    assert rel(y, ref) < TOL_BF16_OUT
+    m = ops.chan_mean(x.to(DEV), Fr, H * H)
+    assert rel(m, x.float().view(Fr, H * H, C).mean(1)) < 1e-5
+    w1, b1 = bf(1024, C, scale=C ** -0.5), torch.randn(1024) * 0.1
+    w2, b2 = bf(C, 1024, scale=1 / 32), torch.randn(C) * 0.1
+    g1 = ops.small_linear(m, w1.to(DEV), b1.to(DEV), ops.ACT_SILU)
+    g2 = ops.small_linear(g1, w2.to(DEV), b2.to(DEV), ops.ACT_SIGMOID)
+    mref = x.float().view(Fr, H * H, C).mean(1)
+    gref = torch.sigmoid(F.linear(F.silu(F.linear(mref, w1.float(), b1)), w2.float(), b2))
+    assert rel(g2, gref) < 1e-4
+    xs = x.to(DEV).clone()
+    ops.se_scale_(xs, g2, Fr, H * H)
+    assert rel(xs, x.float().view(Fr, H * H, C) * gref[:, None, :]) < TOL_BF16_OUT
+
+
+def test_rope_kv(ops):
+    S, nh, nkv, HD, smax, pos0 = 77, 32, 8, 128, 256, 100
+    qkv = bf(S, (nh + 2 * nkv) * HD)
+    inv = 1.0 / (1e6 ** (torch.arange(0, HD, 2).float() / HD))
+    fr = torch.arange(smax).float()[:, None] * inv[None]
+    q_out = torch.zeros(S, nh * HD, dtype=torch.bfloat16, device=DEV)
+    kc = torch.zeros(nkv, smax, HD, dtype=torch.bfloat16, device=DEV)
+    vc = torch.zeros_like(kc)
+    ops.rope_kv(qkv.to(DEV), q_out, kc, vc, fr.cos().contiguous().to(DEV), fr.sin().contiguous().to(DEV), nh, nkv, pos0)
+    rot = lambda t: torch.cat([-t[..., HD // 2:], t[..., :HD // 2]], -1)
+    emb = torch.cat([fr, fr], -1)[pos0:pos0 + S]
+    c, s = emb.cos()[:, None], emb.sin()[:, None]
+    q = qkv[:, :nh * HD].float().view(S, nh, HD)
+    k = qkv[:, nh * HD:(nh + nkv) * HD].float().view(S, nkv, HD)
+    v = qkv[:, (nh + nkv) * HD:].view(S, nkv, HD)
+    assert rel(q_out.view(S, nh, HD), q * c + rot(q) * s) < TOL_BF16_OUT
+    assert rel(kc[:, pos0:pos0 + S].transpose(0, 1), k * c + rot(k) * s) < TOL_BF16_OUT
+    assert torch.equal(vc[:, pos0:pos0 + S].transpose(0, 1).cpu(), v)
+    assert kc[:, :pos0].abs().max().item() == 0 and kc[:, pos0 + S:].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("N,K", [(6144, 4096), (4096, 14336), (32000, 4096), (40, 256)])
+def test_gemv(ops, N, K):
+    w, x, nw, res = bf(N, K, scale=K ** -0.5), bf(K), torch.randn(K), bf(N)
+    y = ops.gemv(w.to(DEV), x.to(DEV), res=res.to(DEV))
+    assert rel(y, w.float() @ x.float() + res.float()) < TOL_BF16_OUT
+    yf = ops.gemv(w.to(DEV), x.to(DEV), norm_w=nw.to(DEV), eps=1e-5, out_f32=True)
+    xf = x.float()
+    xn = (nw * xf * torch.rsqrt(xf.pow(2).mean() + 1e-5)).bfloat16().float()
+    assert rel(yf, w.float() @ xn) < TOL_F32_OUT
+
+
+def test_gemv_swiglu(ops):
+    from videollama2_amd.weights import pack_gate_up
+    I, K = 14336, 4096
+    wg, wu, x = bf(I, K, scale=K ** -0.5), bf(I, K, scale=K ** -0.5, seed=1), bf(K)
+    y = ops.gemv(pack_gate_up(wg, wu).to(DEV), x.to(DEV), swiglu=True)
+    assert rel(y, F.silu(wg.float() @ x.float()) * (wu.float() @ x.float())) < TOL_BF16_OUT
+
+
+@pytest.mark.parametrize("ctx", [1, 63, 1700])
+def test_attn_decode(ops, ctx):
+    nh, nkv, smax, chunk = 32, 8, 2048, 256
+    q, kc, vc = bf(nh * 128), bf(nkv, smax, 128), bf(nkv, smax, 128, seed=1)
+    part = torch.zeros(nh * ((smax + chunk - 1) // chunk) * 130, device=DEV)
+    out = torch.zeros(nh * 128, dtype=torch.bfloat16, device=DEV)
+    ops.attn_decode(q.to(DEV), kc.to(DEV), vc.to(DEV), part, out, nh, nkv, ctx, chunk, 128 ** -0.5)
+    qf = q.float().view(nh, 128)
+    kf = kc[:, :ctx].float().repeat_interleave(nh // nkv, 0)
+    vf = vc[:, :ctx].float().repeat_interleave(nh // nkv, 0)
+    a = torch.softmax(torch.einsum("hd,hkd->hk", qf, kf) * 128 ** -0.5, -1)
+    assert rel(out, torch.einsum("hk,hkd->hd", a, vf).reshape(-1)) < TOL_BF16_OUT
+
+
+def test_argmax_embed(ops):
+    lg = torch.randn(32000)
+    lg[1234] = 9.0
+    lg[31999] = 9.0          # tie -> first index, like torch.argmax
+    tok = torch.zeros(1, dtype=torch.int32, device=DEV)
+    hist = torch.zeros(4, dtype=torch.int32, device=DEV)
+    ops.argmax(lg.to(DEV), tok, hist, 2)
+    assert tok.item() == 1234 and hist.tolist() == [0, 0, 1234, 0]
+    ids = torch.tensor([3, 0, 31999], dtype=torch.int32, device=DEV)
+    tab = bf(32000, 256)
+    out = torch.zeros(3, 256, dtype=torch.bfloat16, device=DEV)
+    ops.embed_rows(ids, tab.to(DEV), out)
+    assert torch.equal(out.cpu(), tab[ids.cpu().long()])
+
+
+def test_abi_rejects_bad_shapes(ops):
+    from videollama2_amd._lib import Vl2HipError
+    a, w = bf(16, 100).to(DEV), bf(128, 100).to(DEV)
+    with pytest.raises(Vl2HipError):
+        ops.gemm(a, w)                      # K % 64 != 0
+    with pytest.raises(Vl2HipError):
+        ops.gemm(bf(16, 64).to(DEV), bf(100, 64).to(DEV))   # N % 128 != 0

@@ -1,0 +1,69 @@
+"""ctypes binding of libvl2hip.so (include/vl2hip.h).  The product path has NO fallback: if the HIP library is
+missing or a call fails, this raises -- nothing here (or anywhere in videollama2_amd/) imports oracle/."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvl2hip.so")
+
+_vp, _i32, _i64, _f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
+
+# name -> argtypes (all return int32 except the two below)
+SIGNATURES = {
+    "vl2_gemm_bf16": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _i32,
+                      _i32, _i32, _i32, _i32, _vp],
+    "vl2_layernorm": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp],
+    "vl2_rmsnorm": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp],
+    "vl2_patchify": [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
+    "vl2_fill_cls": [_vp, _vp, _i32, _i32, _i32, _vp],
+    "vl2_attn_fwd": [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _i64, _i64, _i32, _i64, _i64, _i32, _i64, _i64, _i32, _i32, _i32,
+                     _i32, _i32, _i32, _f32, _i32, _i32, _i32, _vp],
+    "vl2_dwconv3x3_ln_silu": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp],
+    "vl2_chan_mean": [_vp, _vp, _i32, _i32, _i32, _vp],
+    "vl2_small_linear": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
+    "vl2_se_scale": [_vp, _vp, _i32, _i32, _i32, _vp],
+    "vl2_rope_kv": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
+    "vl2_gemv_bf16": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _i32, _vp],
+    "vl2_attn_decode": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp],
+    "vl2_argmax": [_vp, _i32, _vp, _vp, _i32, _vp],
+    "vl2_embed_rows": [_vp, _vp, _vp, _i32, _i32, _i32, _vp],
+}
+EXPORTS = ["vl2_version", "vl2_last_error_string"] + list(SIGNATURES)
+
+_lib = None
+
+
+class Vl2HipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libvl2hip.so (once).  Raises if it has not been built: there is deliberately no CPU fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise Vl2HipError(f"{LIB_PATH} not found: build it with `python -m videollama2_amd.csrc.build` "
+                          "(hipcc --offload-arch=gfx950); the HIP path has no fallback")
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.vl2_version.restype = _i32
+    lib.vl2_version.argtypes = []
+    lib.vl2_last_error_string.restype = ctypes.c_char_p
+    lib.vl2_last_error_string.argtypes = []
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = _i32
+        fn.argtypes = args
+    if lib.vl2_version() != 1:
+        raise Vl2HipError("libvl2hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    """Call an entry point; non-zero return codes become Vl2HipError with the library's message."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        msg = lib.vl2_last_error_string().decode(errors="replace")
+        raise Vl2HipError(f"{name} failed (rc={rc}): {msg}")

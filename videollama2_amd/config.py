@@ -1,0 +1,52 @@
+"""Model hyper-parameters of the hot path (no hub access on the target box, so the public VideoLLaMA2-7B values are
+hard-coded; SURVEY.md section 8 header).  The dict layout {vision, llm, num_frames} is shared with the test oracle."""
+
+
+def videollama2_7b(num_frames=16):
+    """CLIP-ViT-L/14-336 + stc_connector + Mistral-7B-Instruct-v0.2 (README.md:117-120 of the reference)."""
+    return dict(
+        vision=dict(hidden_size=1024, intermediate_size=4096, num_hidden_layers=24, num_attention_heads=16,
+                    image_size=336, patch_size=14, layer_norm_eps=1e-5, select_layer=-2),
+        llm=dict(hidden_size=4096, intermediate_size=14336, num_hidden_layers=32, num_attention_heads=32,
+                 num_key_value_heads=8, head_dim=128, vocab_size=32000, rms_norm_eps=1e-5, rope_theta=1e6),
+        num_frames=num_frames)
+
+
+def from_hf_config(hf_cfg, vision_cfg):
+    """Build the dict from a Videollama2MistralConfig + CLIPVisionConfig (videollama2_arch.py:49-68 keys)."""
+    g = lambda o, k, d=None: getattr(o, k, d)
+    rope_theta = g(hf_cfg, "rope_theta", None)
+    if rope_theta is None and g(hf_cfg, "rope_parameters", None):
+        rope_theta = hf_cfg.rope_parameters.get("rope_theta", 1e6)
+    return dict(
+        vision=dict(hidden_size=vision_cfg.hidden_size, intermediate_size=vision_cfg.intermediate_size,
+                    num_hidden_layers=vision_cfg.num_hidden_layers, num_attention_heads=vision_cfg.num_attention_heads,
+                    image_size=vision_cfg.image_size, patch_size=vision_cfg.patch_size,
+                    layer_norm_eps=vision_cfg.layer_norm_eps, select_layer=g(hf_cfg, "mm_vision_select_layer", -2)),
+        llm=dict(hidden_size=hf_cfg.hidden_size, intermediate_size=hf_cfg.intermediate_size,
+                 num_hidden_layers=hf_cfg.num_hidden_layers, num_attention_heads=hf_cfg.num_attention_heads,
+                 num_key_value_heads=hf_cfg.num_key_value_heads,
+                 head_dim=g(hf_cfg, "head_dim", None) or hf_cfg.hidden_size // hf_cfg.num_attention_heads,
+                 vocab_size=hf_cfg.vocab_size, rms_norm_eps=hf_cfg.rms_norm_eps, rope_theta=float(rope_theta or 1e6)),
+        num_frames=g(hf_cfg, "num_frames", 8))
+
+
+def check_supported(cfg):
+    """The gfx950 kernels are built for head_dim 64 (ViT) / 128 (LLM), GEMM N%128==0, K%64==0."""
+    v, l = cfg["vision"], cfg["llm"]
+    hd_v = v["hidden_size"] // v["num_attention_heads"]
+    errs = []
+    if hd_v != 64:
+        errs.append(f"vision head_dim {hd_v} != 64")
+    if l["head_dim"] != 128:
+        errs.append(f"llm head_dim {l['head_dim']} != 128")
+    if l["num_attention_heads"] // l["num_key_value_heads"] > 4:
+        errs.append("GQA group > 4")
+    for name, n in (("vision hidden", v["hidden_size"]), ("vision mlp", v["intermediate_size"]),
+                    ("llm hidden", l["hidden_size"]), ("llm mlp", l["intermediate_size"]), ("vocab", l["vocab_size"])):
+        if n % 128:
+            errs.append(f"{name} {n} % 128 != 0")
+    if l["hidden_size"] > 4096 or v["hidden_size"] > 4096:
+        errs.append("hidden size > 4096 (row-norm kernels)")
+    if errs:
+        raise ValueError("config not supported by the gfx950 kernels: " + "; ".join(errs))

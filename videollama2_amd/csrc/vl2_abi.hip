@@ -1,0 +1,242 @@
+// libvl2hip.so: extern "C" launchers (include/vl2hip.h) over the gfx950 kernels in k_*.h.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC vl2_abi.hip -o libvl2hip.so   (see build.py)
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+
+#include "../../include/vl2hip.h"
+#include "k_attn.h"
+#include "k_decode.h"
+#include "k_gemm.h"
+#include "k_norm.h"
+#include "k_stc.h"
+#include "k_vit.h"
+
+static thread_local char g_err[512] = "";
+static int32_t fail(int32_t code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+static int32_t launched(const char* what) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail((int32_t)e, "%s: %s", what, hipGetErrorString(e));
+    return 0;
+}
+#define ST(s) ((hipStream_t)(s))
+#define ALIGNED16(p) ((((uintptr_t)(p)) & 15) == 0)
+
+extern "C" int32_t vl2_version(void) { return VL2_ABI_VERSION; }
+extern "C" const char* vl2_last_error_string(void) { return g_err; }
+
+// ------------------------------------------------------------------------------------------------ GEMM
+template <int ACT, bool SW, bool F32, bool G>
+static void launch_gemm(const GemmArgs& a, hipStream_t s) {
+    static bool attr_set = false;   // 64 KiB dynamic LDS needs the opt-in once per kernel instance
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)gemm_bf16_kernel<ACT, SW, F32, G>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            GEMM_LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_bf16_kernel<ACT, SW, F32, G>), dim3(a.tiles_m * a.tiles_n), dim3(256), GEMM_LDS_BYTES, s, a);
+}
+
+extern "C" int32_t vl2_gemm_bf16(const void* A, const void* W, void* C, const float* bias, const void* res, int32_t M,
+                                 int32_t N, int32_t K, int32_t lda, int32_t ldw, int32_t ldc, int32_t ldres, int32_t act,
+                                 int32_t flags, const int32_t* a_idx, const void* zero_row, int32_t seg_k, int32_t out_grp,
+                                 int32_t out_grp_pad, int32_t out_row_off, int32_t res_row_mod, int32_t res_row_off,
+                                 void* stream) {
+    if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0) return fail(VL2_E_BADARG, "vl2_gemm_bf16: null pointer or empty shape");
+    if (N % 128 || K % 64) return fail(VL2_E_SHAPE, "vl2_gemm_bf16: need N%%128==0 and K%%64==0 (N=%d K=%d)", N, K);
+    if ((lda % 8) || (ldw % 8) || (ldc % 8) || (res && (ldres % 8)) || !ALIGNED16(A) || !ALIGNED16(W) || !ALIGNED16(C) ||
+        (res && !ALIGNED16(res)) || (bias && !ALIGNED16(bias)))
+        return fail(VL2_E_SHAPE, "vl2_gemm_bf16: pointers / leading dims must be 16-byte aligned");
+    const bool sw = flags & VL2_GEMM_SWIGLU, f32 = flags & VL2_GEMM_OUT_F32, g = a_idx != nullptr;
+    if (g && (!zero_row || seg_k <= 0 || seg_k % 64 || K % seg_k)) return fail(VL2_E_SHAPE, "vl2_gemm_bf16: bad gather segments");
+    GemmArgs a{(const bf16_t*)A, (const bf16_t*)W, C, bias, (const bf16_t*)res, a_idx, (const bf16_t*)zero_row, M, N, K,
+               lda, ldw, ldc, ldres, seg_k, out_grp, out_grp_pad, out_row_off, res_row_mod, res_row_off,
+               (M + GEMM_BM - 1) / GEMM_BM, N / GEMM_BN};
+    hipStream_t s = ST(stream);
+    if (sw) {
+        if (f32 || g || act != VL2_ACT_NONE || bias) return fail(VL2_E_UNSUPP, "vl2_gemm_bf16: SWIGLU excludes bias/act/f32/gather");
+        launch_gemm<ACT_NONE, true, false, false>(a, s);
+    } else if (g) {
+        if (f32) return fail(VL2_E_UNSUPP, "vl2_gemm_bf16: gather + f32 not built");
+        if (act == VL2_ACT_SILU) launch_gemm<ACT_SILU, false, false, true>(a, s);
+        else if (act == VL2_ACT_NONE) launch_gemm<ACT_NONE, false, false, true>(a, s);
+        else return fail(VL2_E_UNSUPP, "vl2_gemm_bf16: gather supports act none/silu");
+    } else if (f32) {
+        if (act != VL2_ACT_NONE) return fail(VL2_E_UNSUPP, "vl2_gemm_bf16: f32 output supports act none");
+        launch_gemm<ACT_NONE, false, true, false>(a, s);
+    } else {
+        switch (act) {
+            case VL2_ACT_NONE: launch_gemm<ACT_NONE, false, false, false>(a, s); break;
+            case VL2_ACT_QGELU: launch_gemm<ACT_QGELU, false, false, false>(a, s); break;
+            case VL2_ACT_GELU: launch_gemm<ACT_GELU, false, false, false>(a, s); break;
+            case VL2_ACT_SILU: launch_gemm<ACT_SILU, false, false, false>(a, s); break;
+            default: return fail(VL2_E_UNSUPP, "vl2_gemm_bf16: unknown act %d", act);
+        }
+    }
+    return launched("vl2_gemm_bf16");
+}
+
+// ------------------------------------------------------------------------------------------------ norms
+static int32_t launch_norm(const NormArgs& a, bool rms, hipStream_t s, const char* what) {
+    if (!a.x || !a.y || !a.w || a.rows <= 0 || a.C <= 0) return fail(VL2_E_BADARG, "%s: null pointer or empty shape", what);
+    if (a.C % 8 || a.C > 4096 || a.ldx % 8 || a.ldy % 8 || (a.res && a.ldres % 8))
+        return fail(VL2_E_SHAPE, "%s: need C%%8==0, C<=4096, aligned strides (C=%d)", what, a.C);
+    const int nv = (a.C + 511) / 512;
+    dim3 g((a.rows + 3) / 4), b(256);
+    if (rms) {
+        if (nv <= 1) hipLaunchKernelGGL((norm_kernel<1, true>), g, b, 0, s, a);
+        else if (nv <= 2) hipLaunchKernelGGL((norm_kernel<2, true>), g, b, 0, s, a);
+        else hipLaunchKernelGGL((norm_kernel<8, true>), g, b, 0, s, a);
+    } else {
+        if (nv <= 1) hipLaunchKernelGGL((norm_kernel<1, false>), g, b, 0, s, a);
+        else if (nv <= 2) hipLaunchKernelGGL((norm_kernel<2, false>), g, b, 0, s, a);
+        else hipLaunchKernelGGL((norm_kernel<8, false>), g, b, 0, s, a);
+    }
+    return launched(what);
+}
+extern "C" int32_t vl2_layernorm(const void* x, void* y, const float* w, const float* b, const void* res, int32_t rows,
+                                 int32_t C, int32_t ldx, int32_t ldy, int32_t ldres, float eps, int32_t silu, void* stream) {
+    NormArgs a{(const bf16_t*)x, (bf16_t*)y, w, b, (const bf16_t*)res, rows, C, ldx, ldy, ldres, eps, silu};
+    return launch_norm(a, false, ST(stream), "vl2_layernorm");
+}
+extern "C" int32_t vl2_rmsnorm(const void* x, void* y, const float* w, int32_t rows, int32_t C, int32_t ldx, int32_t ldy,
+                               float eps, void* stream) {
+    NormArgs a{(const bf16_t*)x, (bf16_t*)y, w, nullptr, nullptr, rows, C, ldx, ldy, 0, eps, 0};
+    return launch_norm(a, true, ST(stream), "vl2_rmsnorm");
+}
+
+// ------------------------------------------------------------------------------------------------ ViT front end
+extern "C" int32_t vl2_patchify(const void* frames, int32_t dtype, void* out, int32_t T, int32_t H, int32_t W, int32_t P,
+                                int32_t G, int32_t Kp, void* stream) {
+    if (!frames || !out || T <= 0) return fail(VL2_E_BADARG, "vl2_patchify: null pointer or empty shape");
+    if (G * P > H || G * P > W || Kp % 8 || Kp < 3 * P * P) return fail(VL2_E_SHAPE, "vl2_patchify: bad geometry");
+    dim3 g(G, T), b(256);
+    hipStream_t s = ST(stream);
+    if (dtype == 0) hipLaunchKernelGGL((patchify_kernel<float>), g, b, 0, s, (const float*)frames, (bf16_t*)out, H, W, P, G, Kp);
+    else if (dtype == 1) hipLaunchKernelGGL((patchify_kernel<_Float16>), g, b, 0, s, (const _Float16*)frames, (bf16_t*)out, H, W, P, G, Kp);
+    else if (dtype == 2) hipLaunchKernelGGL((patchify_kernel<bf16_t>), g, b, 0, s, (const bf16_t*)frames, (bf16_t*)out, H, W, P, G, Kp);
+    else return fail(VL2_E_UNSUPP, "vl2_patchify: dtype %d", dtype);
+    return launched("vl2_patchify");
+}
+extern "C" int32_t vl2_fill_cls(void* x, const void* cls_pos, int32_t T, int32_t D, int32_t rows_per_frame, void* stream) {
+    if (!x || !cls_pos || T <= 0 || D % 8) return fail(VL2_E_BADARG, "vl2_fill_cls: bad args");
+    hipLaunchKernelGGL(fill_cls_kernel, dim3(T), dim3(128), 0, ST(stream), (bf16_t*)x, (const bf16_t*)cls_pos, D, rows_per_frame);
+    return launched("vl2_fill_cls");
+}
+
+// ------------------------------------------------------------------------------------------------ attention
+extern "C" int32_t vl2_attn_fwd(const void* q, const void* k, const void* v, void* o, int64_t q_bs, int64_t q_hs, int32_t q_rs,
+                                int64_t k_bs, int64_t k_hs, int32_t k_rs, int64_t v_bs, int64_t v_hs, int32_t v_rs,
+                                int64_t o_bs, int64_t o_hs, int32_t o_rs, int32_t B, int32_t H, int32_t nq, int32_t nk,
+                                int32_t group, float scale, int32_t causal, int32_t causal_off, int32_t D, void* stream) {
+    if (!q || !k || !v || !o || B <= 0 || H <= 0 || nq <= 0 || nk <= 0 || group <= 0)
+        return fail(VL2_E_BADARG, "vl2_attn_fwd: null pointer or empty shape");
+    if ((q_rs | k_rs | v_rs | o_rs) % 8 || (q_bs | q_hs | k_bs | k_hs | v_bs | v_hs | o_bs | o_hs) % 4 || !ALIGNED16(q) ||
+        !ALIGNED16(k) || !ALIGNED16(v) || ((uintptr_t)o & 7))
+        return fail(VL2_E_SHAPE, "vl2_attn_fwd: strides must keep 16-byte row alignment");
+    if (causal && causal_off < 0) return fail(VL2_E_SHAPE, "vl2_attn_fwd: causal_off must be >= 0");
+    AttnArgs a{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, q_bs, q_hs, q_rs, k_bs, k_hs, k_rs,
+               v_bs, v_hs, v_rs, o_bs, o_hs, o_rs, nq, nk, group, scale * 1.4426950408889634f, causal_off};
+    dim3 g((nq + 127) / 128, H, B), b(256);
+    hipStream_t s = ST(stream);
+    if (D == 64 && !causal) hipLaunchKernelGGL((attn_fwd_kernel<64, false>), g, b, 0, s, a);
+    else if (D == 64 && causal) hipLaunchKernelGGL((attn_fwd_kernel<64, true>), g, b, 0, s, a);
+    else if (D == 128 && !causal) hipLaunchKernelGGL((attn_fwd_kernel<128, false>), g, b, 0, s, a);
+    else if (D == 128 && causal) hipLaunchKernelGGL((attn_fwd_kernel<128, true>), g, b, 0, s, a);
+    else return fail(VL2_E_SHAPE, "vl2_attn_fwd: head_dim %d not built (64, 128)", D);
+    return launched("vl2_attn_fwd");
+}
+
+// ------------------------------------------------------------------------------------------------ STC direct kernels
+extern "C" int32_t vl2_dwconv3x3_ln_silu(const void* x, void* y, const float* w9c, const float* lnw, const float* lnb, int32_t F,
+                                         int32_t H, int32_t W, int32_t C, float eps, void* stream) {
+    if (!x || !y || !w9c || !lnw || !lnb || F <= 0 || H <= 0 || W <= 0) return fail(VL2_E_BADARG, "vl2_dwconv3x3_ln_silu: bad args");
+    if (C % 8 || C > 4096) return fail(VL2_E_SHAPE, "vl2_dwconv3x3_ln_silu: need C%%8==0 and C<=4096");
+    dim3 g(F * H * W), b(256);
+    if (C <= 2048) hipLaunchKernelGGL((dwconv_ln_silu_kernel<1>), g, b, 0, ST(stream), (const bf16_t*)x, (bf16_t*)y, w9c, lnw, lnb, H, W, C, eps);
+    else hipLaunchKernelGGL((dwconv_ln_silu_kernel<2>), g, b, 0, ST(stream), (const bf16_t*)x, (bf16_t*)y, w9c, lnw, lnb, H, W, C, eps);
+    return launched("vl2_dwconv3x3_ln_silu");
+}
+extern "C" int32_t vl2_chan_mean(const void* x, float* mean, int32_t F, int32_t HW, int32_t C, void* stream) {
+    if (!x || !mean || F <= 0 || HW <= 0) return fail(VL2_E_BADARG, "vl2_chan_mean: bad args");
+    if (C % 64) return fail(VL2_E_SHAPE, "vl2_chan_mean: need C%%64==0");
+    hipLaunchKernelGGL(chan_mean_kernel, dim3(C / 64, F), dim3(256), 0, ST(stream), (const bf16_t*)x, mean, HW, C);
+    return launched("vl2_chan_mean");
+}
+extern "C" int32_t vl2_small_linear(const float* x, const void* W, const float* b, float* out, int32_t F, int32_t N, int32_t K,
+                                    int32_t act, void* stream) {
+    if (!x || !W || !out || F <= 0 || N <= 0 || K <= 0) return fail(VL2_E_BADARG, "vl2_small_linear: bad args");
+    if (K % 8) return fail(VL2_E_SHAPE, "vl2_small_linear: need K%%8==0");
+    const int a = act == VL2_ACT_SILU ? 1 : act == VL2_ACT_SIGMOID ? 2 : act == VL2_ACT_NONE ? 0 : -1;
+    if (a < 0) return fail(VL2_E_UNSUPP, "vl2_small_linear: act %d", act);
+    hipLaunchKernelGGL(small_linear_kernel, dim3((N + 3) / 4), dim3(256), 0, ST(stream), x, (const bf16_t*)W, b, out, F, N, K, a);
+    return launched("vl2_small_linear");
+}
+extern "C" int32_t vl2_se_scale(void* x, const float* gate, int32_t F, int32_t HW, int32_t C, void* stream) {
+    if (!x || !gate || F <= 0 || HW <= 0 || C % 8) return fail(VL2_E_BADARG, "vl2_se_scale: bad args");
+    const size_t nvec = (size_t)F * HW * C / 8;
+    size_t blocks = (nvec + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(se_scale_kernel, dim3((unsigned)blocks), dim3(256), 0, ST(stream), (bf16_t*)x, gate, HW, C, nvec);
+    return launched("vl2_se_scale");
+}
+
+// ------------------------------------------------------------------------------------------------ decoder glue / decode
+extern "C" int32_t vl2_rope_kv(const void* qkv, void* q_out, void* kcache, void* vcache, const float* cos_t, const float* sin_t,
+                               int32_t S, int32_t nh, int32_t nkv, int32_t smax, int32_t pos0, void* stream) {
+    if (!qkv || !q_out || !kcache || !vcache || !cos_t || !sin_t || S <= 0) return fail(VL2_E_BADARG, "vl2_rope_kv: bad args");
+    if (pos0 < 0 || pos0 + S > smax) return fail(VL2_E_SHAPE, "vl2_rope_kv: positions %d..%d exceed the cache (%d)", pos0, pos0 + S, smax);
+    const size_t total = (size_t)S * (nh + 2 * nkv) * 8;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(rope_kv_kernel, dim3((unsigned)blocks), dim3(256), 0, ST(stream), (const bf16_t*)qkv, (bf16_t*)q_out,
+                       (bf16_t*)kcache, (bf16_t*)vcache, cos_t, sin_t, S, nh, nkv, smax, pos0);
+    return launched("vl2_rope_kv");
+}
+
+template <bool SW, bool F32>
+static void launch_gemv(const GemvArgs& a, int n_out, hipStream_t s) {
+    constexpr int RPW = 2;
+    hipLaunchKernelGGL((gemv_bf16_kernel<SW, F32, RPW>), dim3((n_out + 4 * RPW - 1) / (4 * RPW)), dim3(256), (size_t)a.K * 2, s, a);
+}
+extern "C" int32_t vl2_gemv_bf16(const void* W, const void* x, const float* norm_w, const void* res, void* y, int32_t N,
+                                 int32_t K, int32_t ldw, float eps, int32_t flags, void* stream) {
+    if (!W || !x || !y || N <= 0 || K <= 0) return fail(VL2_E_BADARG, "vl2_gemv_bf16: bad args");
+    if (K % 8 || ldw % 8 || K > 28672) return fail(VL2_E_SHAPE, "vl2_gemv_bf16: need K%%8==0, K<=28672 (K=%d)", K);
+    const bool sw = flags & VL2_GEMM_SWIGLU, f32 = flags & VL2_GEMM_OUT_F32;
+    if (sw && (N % 64 || f32)) return fail(VL2_E_SHAPE, "vl2_gemv_bf16: SWIGLU needs N%%64==0 and bf16 output");
+    GemvArgs a{(const bf16_t*)W, (const bf16_t*)x, norm_w, (const bf16_t*)res, y, N, K, ldw, eps};
+    if (sw) launch_gemv<true, false>(a, N / 2, ST(stream));
+    else if (f32) launch_gemv<false, true>(a, N, ST(stream));
+    else launch_gemv<false, false>(a, N, ST(stream));
+    return launched("vl2_gemv_bf16");
+}
+extern "C" int32_t vl2_attn_decode(const void* q, const void* kcache, const void* vcache, float* partial, void* out, int32_t nh,
+                                   int32_t nkv, int32_t smax, int32_t ctx, int32_t chunk, float scale, void* stream) {
+    if (!q || !kcache || !vcache || !partial || !out || nh <= 0 || nkv <= 0 || ctx <= 0 || chunk <= 0)
+        return fail(VL2_E_BADARG, "vl2_attn_decode: bad args");
+    const int group = nh / nkv;
+    if (group * nkv != nh || group > 4 || ctx > smax) return fail(VL2_E_SHAPE, "vl2_attn_decode: need nh = nkv*group, group<=4, ctx<=smax");
+    const int nsplit = (ctx + chunk - 1) / chunk;
+    hipLaunchKernelGGL(attn_decode_kernel, dim3(nsplit, nkv), dim3(group * 64), 0, ST(stream), (const bf16_t*)q,
+                       (const bf16_t*)kcache, (const bf16_t*)vcache, partial, nh, group, smax, ctx, chunk,
+                       scale * 1.4426950408889634f);
+    hipLaunchKernelGGL(attn_decode_combine_kernel, dim3(nh), dim3(128), 0, ST(stream), partial, (bf16_t*)out, nsplit);
+    return launched("vl2_attn_decode");
+}
+extern "C" int32_t vl2_argmax(const float* logits, int32_t V, int32_t* tok, int32_t* hist, int32_t step, void* stream) {
+    if (!logits || !tok || V <= 0) return fail(VL2_E_BADARG, "vl2_argmax: bad args");
+    hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(1024), 0, ST(stream), logits, V, tok, hist, step);
+    return launched("vl2_argmax");
+}
+extern "C" int32_t vl2_embed_rows(const int32_t* ids, const void* table, void* out, int32_t n, int32_t D, int32_t ldo, void* stream) {
+    if (!ids || !table || !out || n <= 0 || D % 8 || ldo % 8) return fail(VL2_E_BADARG, "vl2_embed_rows: bad args");
+    hipLaunchKernelGGL(embed_rows_kernel, dim3(n), dim3(128), 0, ST(stream), ids, (const bf16_t*)table, (bf16_t*)out, D, ldo);
+    return launched("vl2_embed_rows");
+}

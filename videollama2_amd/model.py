@@ -1,0 +1,119 @@
+"""VideoLLaMA2Hip -- the reference's inference surface for ONE model family (CLIP-ViT + stc_connector + Mistral),
+method for method (videollama2/model/videollama2_arch.py:99-263, videollama2_mistral.py:110-144), on the HIP path:
+    encode_images_or_videos(images)                   arch.py:114-134   (+ temporal_aggregator :136-159)
+    prepare_inputs_labels_for_multimodal(...)         arch.py:161-263   (inference subset: batch 1, no labels)
+    generate(inputs, images=..., **hf_generate_kwargs) videollama2_mistral.py:110-144
+Frames may be sharded over ranks (dist.py): each rank encodes its slice with the ViT and the visual tokens are
+all-gathered (RCCL) in front of the connector."""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .config import check_supported
+from .connector import HipSTCConnector
+from .constants import MODAL_INDEX_MAP, NUM_FRAMES
+from .decoder import HipMistralDecoder
+from .dist import FrameSharder
+from .tower import HipCLIPVisionTower
+
+
+class VideoLLaMA2Hip(nn.Module):
+    def __init__(self, cfg, state_dict, device="cuda", max_seq_len=4096, image_processor=None, n_llm_layers=None,
+                 mm_projector_type="stc_connector", sharder=None):
+        super().__init__()
+        check_supported(cfg)
+        if "tc_connector" not in mm_projector_type or mm_projector_type != "stc_connector":
+            raise Exception(f"Unsupported projector type {mm_projector_type}!!!")     # arch.py:157 / projector.py:122
+        self.cfg = cfg
+        self.mm_projector_type = mm_projector_type
+        self._dev = torch.device(device)
+        self.vision_tower = HipCLIPVisionTower(cfg, state_dict, device, image_processor=image_processor)
+        self.mm_projector = HipSTCConnector(state_dict, device)
+        self.decoder = HipMistralDecoder(cfg, state_dict, device, max_seq_len, n_llm_layers)
+        self.sharder = sharder or FrameSharder()
+
+    def get_vision_tower(self):
+        return self.vision_tower
+
+    @property
+    def device(self):
+        return self._dev
+
+    def num_frames(self):
+        return self.cfg.get("num_frames", NUM_FRAMES)
+
+    # ---------------------------------------------------------------------------------- arch.py:114-134
+    @torch.no_grad()
+    def encode_images_or_videos(self, images):
+        num_frames = self.num_frames()
+        batch = []
+        for data, modal in images:
+            batch.append(data.expand(num_frames, -1, -1, -1) if modal == "image" else data)
+        batch = torch.stack(batch, dim=0)
+        assert len(batch.size()) == 5                                                   # arch.py:127
+        b, t = batch.shape[:2]
+        frames = batch.reshape(b * t, *batch.shape[2:])                                  # 'b t c h w -> (b t) c h w'
+        feats = self.sharder.encode(self.vision_tower, frames)                           # [(b t), n, h] (all ranks)
+        feats = feats.view(b, t, *feats.shape[1:])                                       # '(b t) n h -> b t n h'
+        return self.temporal_aggregator(feats)
+
+    def temporal_aggregator(self, frames_features):                                      # arch.py:136-159
+        if "tc_connector" in self.mm_projector_type:
+            return self.mm_projector(frames_features)
+        raise Exception(f"Unsupported projector type {self.mm_projector_type}!!!")
+
+    # ---------------------------------------------------------------------------------- arch.py:161-263
+    @torch.no_grad()
+    def prepare_inputs_labels_for_multimodal(self, input_ids, attention_mask, past_key_values, labels, images):
+        if images is None or input_ids.shape[1] == 1:                                    # arch.py:166-169
+            return input_ids, attention_mask, past_key_values, None, labels
+        if input_ids.shape[0] != 1 or labels is not None:
+            raise NotImplementedError("HIP path: batch 1 inference only (the reference's eval loops use batch 1)")
+        mm_features = self.encode_images_or_videos(images)
+        ids = input_ids[0].to(self._dev)
+        sentinels = torch.tensor(list(MODAL_INDEX_MAP.values()), device=self._dev)
+        is_mm = (ids[:, None] == sentinels[None, :]).any(-1)
+        mm_pos = torch.nonzero(is_mm).flatten().tolist()
+        D = self.decoder.D
+        n_vis = sum(mm_features[k].shape[0] for k in range(len(mm_pos)))
+        S = ids.numel() - len(mm_pos) + n_vis
+        emb = torch.empty((S, D), dtype=torch.bfloat16, device=self._dev)
+        ids32 = ids.clamp(min=0).to(torch.int32)
+        cur, prev = 0, 0
+        for k, p in enumerate(mm_pos + [ids.numel()]):
+            if p > prev:                                                                 # text piece -> embed_tokens
+                ops.embed_rows(ids32[prev:p].contiguous(), self.decoder.w["embed"], emb[cur:cur + (p - prev)])
+                cur += p - prev
+            if k < len(mm_pos):                                                          # visual block in place of sentinel
+                f = mm_features[k].to(torch.bfloat16)
+                emb[cur:cur + f.shape[0]].copy_(f)
+                cur += f.shape[0]
+            prev = p + 1
+        if attention_mask is not None:                                                   # arch.py:256-259
+            pad = torch.ones((1, S - input_ids.shape[1]), dtype=attention_mask.dtype, device=attention_mask.device)
+            attention_mask = torch.cat((pad, attention_mask), dim=1)
+        return None, attention_mask, past_key_values, emb.unsqueeze(0), labels
+
+    # ---------------------------------------------------------------------------------- videollama2_mistral.py:110-144
+    @torch.no_grad()
+    def generate(self, inputs=None, images=None, **kwargs):
+        kwargs.pop("position_ids", None)
+        attention_mask = kwargs.pop("attention_mask", None)
+        if "inputs_embeds" in kwargs:
+            raise NotImplementedError("`inputs_embeds` is not supported")                # videollama2_mistral.py:119-120
+        if kwargs.get("do_sample", False):
+            raise NotImplementedError("HIP path implements greedy decoding (do_sample=False, the reference default)")
+        if images is not None:
+            _, attention_mask, _, inputs_embeds, _ = self.prepare_inputs_labels_for_multimodal(
+                inputs, attention_mask, None, None, images)
+            inputs_embeds = inputs_embeds[0]
+        else:
+            ids32 = inputs[0].to(self._dev).to(torch.int32).contiguous()
+            inputs_embeds = torch.empty((ids32.numel(), self.decoder.D), dtype=torch.bfloat16, device=self._dev)
+            ops.embed_rows(ids32, self.decoder.w["embed"], inputs_embeds)
+        if attention_mask is not None and not bool(attention_mask.bool().all()):
+            raise NotImplementedError("HIP path: padded prompts (attention_mask with zeros) are not supported")
+        return self.decoder.generate(inputs_embeds, max_new_tokens=kwargs.get("max_new_tokens", 2048),
+                                     eos_token_id=kwargs.get("eos_token_id", None),
+                                     stopping_criteria=kwargs.get("stopping_criteria", None),
+                                     return_logits=kwargs.get("return_logits", False))

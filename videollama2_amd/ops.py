@@ -1,0 +1,171 @@
+"""Operator-level Python wrappers over the C ABI (include/vl2hip.h).  PyTorch-ROCm tensors are used ONLY as device
+storage: every wrapper passes raw `data_ptr()`s plus the current HIP stream to libvl2hip.so and returns torch tensors
+it allocated.  No torch math happens here and there is no fallback path."""
+import torch
+
+from . import _lib
+
+ACT_NONE, ACT_QGELU, ACT_GELU, ACT_SILU, ACT_SIGMOID = 0, 1, 2, 3, 4
+GEMM_SWIGLU, GEMM_OUT_F32 = 1, 2
+BF16 = torch.bfloat16
+PROFILE = None      # bench.py sets this to a list: every gemm launch is then bracketed by HIP events on the launch stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t, dtype, name):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise ValueError(f"{name} must be a device tensor")
+    if t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+    if t.dim() >= 2 and t.stride(-1) != 1:
+        raise ValueError(f"{name} must be contiguous in its last dim")
+
+
+def gemm(a, w, bias=None, res=None, act=ACT_NONE, swiglu=False, out_f32=False, out=None, M=None,
+         gather=None, out_map=None, res_map=None, flop_k=None):
+    """C = epilogue(a @ w.T).  a [M,K] bf16 (or row pool when `gather`), w [N,K] bf16, bias fp32 [N], res bf16 rows.
+    gather = (a_idx int32 [nseg, M], zero_row bf16 [>=seg_k], seg_k).  out_map = (grp, grp_pad, row_off),
+    res_map = (row_mod, row_off) -- see include/vl2hip.h."""
+    _chk(a, BF16, "a"); _chk(w, BF16, "w"); _chk(bias, torch.float32, "bias"); _chk(res, BF16, "res")
+    N = w.shape[0]
+    if gather is not None:
+        a_idx, zero_row, seg_k = gather
+        K = seg_k * a_idx.shape[0]
+        M = a_idx.shape[1] if M is None else M
+    else:
+        a_idx = zero_row = None
+        seg_k = 0
+        K = w.shape[1]
+        M = a.shape[0] if M is None else M
+        if a.shape[1] != K:
+            raise ValueError(f"gemm: a is [{a.shape[0]},{a.shape[1]}] but w is [{N},{K}]")
+    ncol = N // 2 if swiglu else N
+    if out is None:
+        out = torch.empty((M, ncol), dtype=torch.float32 if out_f32 else BF16, device=a.device)
+    grp, grp_pad, row_off = out_map or (0, 0, 0)
+    rmod, roff = res_map or (0, 0)
+    flags = (GEMM_SWIGLU if swiglu else 0) | (GEMM_OUT_F32 if out_f32 else 0)
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.call("vl2_gemm_bf16", _p(a), _p(w), _p(out), _p(bias), _p(res), M, N, K, a.stride(0), w.stride(0), out.stride(0),
+              res.stride(0) if res is not None else 0, act, flags, _p(a_idx), _p(zero_row), seg_k, grp, grp_pad, row_off,
+              rmod, roff, _stream())
+    if PROFILE is not None:
+        e1.record()
+        PROFILE.append(("gemm", 2.0 * M * N * (flop_k or K), e0, e1, (M, N, K)))
+    return out
+
+
+def layernorm(x, w, b, eps, res=None, silu=False, out=None):
+    _chk(x, BF16, "x"); _chk(w, torch.float32, "w"); _chk(b, torch.float32, "b"); _chk(res, BF16, "res")
+    rows, C = x.shape
+    out = torch.empty((rows, C), dtype=BF16, device=x.device) if out is None else out
+    _lib.call("vl2_layernorm", _p(x), _p(out), _p(w), _p(b), _p(res), rows, C, x.stride(0), out.stride(0),
+              res.stride(0) if res is not None else 0, float(eps), int(silu), _stream())
+    return out
+
+
+def rmsnorm(x, w, eps, out=None):
+    _chk(x, BF16, "x"); _chk(w, torch.float32, "w")
+    rows, C = x.shape
+    out = torch.empty((rows, C), dtype=BF16, device=x.device) if out is None else out
+    _lib.call("vl2_rmsnorm", _p(x), _p(out), _p(w), rows, C, x.stride(0), out.stride(0), float(eps), _stream())
+    return out
+
+
+_DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+
+
+def patchify(frames, patch, kp):
+    """frames [T,3,H,W] fp32/fp16/bf16 -> [T*G*G, kp] bf16 im2col rows."""
+    if frames.dtype not in _DTYPE_CODE:
+        raise TypeError(f"frames dtype {frames.dtype} not supported")
+    frames = frames.contiguous()
+    T, C, H, W = frames.shape
+    G = H // patch
+    out = torch.empty((T * G * G, kp), dtype=BF16, device=frames.device)
+    _lib.call("vl2_patchify", _p(frames), _DTYPE_CODE[frames.dtype], _p(out), T, H, W, patch, G, kp, _stream())
+    return out
+
+
+def fill_cls(x, cls_pos, T, rows_per_frame):
+    _lib.call("vl2_fill_cls", _p(x), _p(cls_pos), T, x.shape[1], rows_per_frame, _stream())
+
+
+def attn_fwd(q, k, v, o, q_str, k_str, v_str, o_str, B, H, nq, nk, group, scale, causal, causal_off, D):
+    """Strided fused attention; *_str = (batch_stride, head_stride, row_stride) in elements; q/k/v/o may be views
+    into one fused buffer (pass tensors whose data_ptr is the first element of head 0, batch 0)."""
+    _lib.call("vl2_attn_fwd", _p(q), _p(k), _p(v), _p(o), *q_str, *k_str, *v_str, *o_str, B, H, nq, nk, group, float(scale),
+              int(causal), causal_off, D, _stream())
+    return o
+
+
+def dwconv3x3_ln_silu(x, w9c, lnw, lnb, F, H, W, eps=1e-5):
+    _chk(x, BF16, "x")
+    C = x.shape[-1]
+    y = torch.empty_like(x)
+    _lib.call("vl2_dwconv3x3_ln_silu", _p(x), _p(y), _p(w9c), _p(lnw), _p(lnb), F, H, W, C, float(eps), _stream())
+    return y
+
+
+def chan_mean(x, F, HW):
+    C = x.shape[-1]
+    m = torch.empty((F, C), dtype=torch.float32, device=x.device)
+    _lib.call("vl2_chan_mean", _p(x), _p(m), F, HW, C, _stream())
+    return m
+
+
+def small_linear(x, w, b, act):
+    _chk(x, torch.float32, "x"); _chk(w, BF16, "w")
+    F, K = x.shape
+    N = w.shape[0]
+    out = torch.empty((F, N), dtype=torch.float32, device=x.device)
+    _lib.call("vl2_small_linear", _p(x), _p(w), _p(b), _p(out), F, N, K, act, _stream())
+    return out
+
+
+def se_scale_(x, gate, F, HW):
+    _lib.call("vl2_se_scale", _p(x), _p(gate), F, HW, x.shape[-1], _stream())
+    return x
+
+
+def rope_kv(qkv, q_out, kcache, vcache, cos_t, sin_t, nh, nkv, pos0):
+    S = qkv.shape[0]
+    smax = kcache.shape[1]
+    _lib.call("vl2_rope_kv", _p(qkv), _p(q_out), _p(kcache), _p(vcache), _p(cos_t), _p(sin_t), S, nh, nkv, smax, pos0, _stream())
+
+
+def gemv(w, x, norm_w=None, eps=1e-5, res=None, swiglu=False, out_f32=False, out=None):
+    _chk(w, BF16, "w"); _chk(x, BF16, "x")
+    N, K = w.shape
+    n_out = N // 2 if swiglu else N
+    if out is None:
+        out = torch.empty((n_out,), dtype=torch.float32 if out_f32 else BF16, device=w.device)
+    flags = (GEMM_SWIGLU if swiglu else 0) | (GEMM_OUT_F32 if out_f32 else 0)
+    _lib.call("vl2_gemv_bf16", _p(w), _p(x), _p(norm_w), _p(res), _p(out), N, K, w.stride(0), float(eps), flags, _stream())
+    return out
+
+
+def attn_decode(q, kcache, vcache, partial, out, nh, nkv, ctx, chunk, scale):
+    _lib.call("vl2_attn_decode", _p(q), _p(kcache), _p(vcache), _p(partial), _p(out), nh, nkv, kcache.shape[1], ctx, chunk,
+              float(scale), _stream())
+    return out
+
+
+def argmax(logits, tok, hist=None, step=0):
+    _lib.call("vl2_argmax", _p(logits), logits.numel(), _p(tok), _p(hist), step, _stream())
+
+
+def embed_rows(ids_i32, table, out):
+    _lib.call("vl2_embed_rows", _p(ids_i32), _p(table), _p(out), ids_i32.numel(), table.shape[1], out.stride(0), _stream())
+    return out

@@ -1,0 +1,100 @@
+"""HipCLIPVisionTower -- drop-in for videollama2/model/encoder.py:12-81 `CLIPVisionTower` (the object
+`build_vision_tower(cfg)` returns, encoder.py:154-164): same call contract `tower(frames[(b t),3,H,W]) ->
+[(b t), num_patches, hidden]` in the input dtype, same attributes (`hidden_size`, `num_patches`,
+`num_patches_per_side`, `image_size`, `dtype`, `device`, `config`, `image_processor`), `@torch.no_grad()`.
+All arithmetic runs in libvl2hip.so (gfx950); torch only owns the buffers."""
+import types
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .weights import pack_tower
+
+
+class HipCLIPVisionTower(nn.Module):
+    def __init__(self, cfg, state_dict, device="cuda", select_feature="patch", image_processor=None,
+                 prefix="model.vision_tower.vision_tower."):
+        super().__init__()
+        v = cfg["vision"]
+        self.cfg = cfg
+        self.select_layer = v["select_layer"]
+        self.select_feature = select_feature
+        if select_feature not in ("patch", "cls_patch"):
+            raise ValueError(f"Unexpected select feature: {select_feature}")      # encoder.py:38
+        self.image_processor = image_processor
+        self._dev = torch.device(device)
+        self.w = pack_tower(state_dict, cfg, self._dev, prefix)
+        self.config = types.SimpleNamespace(**v)
+        self.is_loaded = True
+
+    # ---- attributes the reference reads (encoder.py:55-81, videollama2_arch.py:66, model/__init__.py:186)
+    @property
+    def dtype(self):
+        return torch.bfloat16
+
+    @property
+    def device(self):
+        return self._dev
+
+    @property
+    def hidden_size(self):
+        return self.config.hidden_size
+
+    @property
+    def num_patches_per_side(self):
+        return self.config.image_size // self.config.patch_size
+
+    @property
+    def num_patches(self):
+        return self.num_patches_per_side ** 2
+
+    @property
+    def image_size(self):
+        return self.config.image_size
+
+    @torch.no_grad()
+    def forward_hidden(self, images):
+        """Returns hidden_states[select_layer] INCLUDING the CLS row: bf16 [T*(N+1), D] (flat token-major)."""
+        v = self.cfg["vision"]
+        if images.dim() != 4 or images.shape[1] != 3:
+            raise ValueError(f"expected frames [T,3,H,W], got {tuple(images.shape)}")
+        T, _, H, W = images.shape
+        if H != v["image_size"] or W != v["image_size"]:                          # HF:modeling_clip.py:203-207
+            raise ValueError(f"Input image size ({H}*{W}) doesn't match model ({v['image_size']}*{v['image_size']}).")
+        images = images.to(self._dev)
+        w = self.w
+        D, P = v["hidden_size"], v["patch_size"]
+        G = H // P
+        N1 = G * G + 1
+        nh = v["num_attention_heads"]
+        hd = D // nh
+        eps = v["layer_norm_eps"]
+        a = ops.patchify(images, P, w["kp"])
+        x = torch.empty((T * N1, D), dtype=torch.bfloat16, device=self._dev)
+        ops.gemm(a, w["patch_w"], res=w["pos"], out=x, out_map=(G * G, 1, 1), res_map=(G * G, 1), flop_k=3 * P * P)
+        ops.fill_cls(x, w["cls_pos"], T, N1)
+        x = ops.layernorm(x, w["pre_w"], w["pre_b"], eps)
+        o = torch.empty((T * N1, D), dtype=torch.bfloat16, device=self._dev)
+        for lw in w["layers"]:
+            h = ops.layernorm(x, lw["ln1_w"], lw["ln1_b"], eps)
+            qkv = ops.gemm(h, lw["wqkv"], bias=lw["bqkv"])                         # [T*N1, 3D] = q | k | v
+            st = (N1 * 3 * D, hd, 3 * D)
+            ops.attn_fwd(qkv, qkv[:, D:], qkv[:, 2 * D:], o, st, st, st, (N1 * D, hd, D), T, nh, N1, N1, 1,
+                         hd ** -0.5, False, 0, hd)
+            x = ops.gemm(o, lw["wo"], bias=lw["bo"], res=x)
+            h = ops.layernorm(x, lw["ln2_w"], lw["ln2_b"], eps)
+            h = ops.gemm(h, lw["w1"], bias=lw["b1"], act=ops.ACT_QGELU)
+            x = ops.gemm(h, lw["w2"], bias=lw["b2"], res=x)
+        return x, T, N1
+
+    @torch.no_grad()
+    def forward(self, images):
+        if type(images) is list:                                                   # encoder.py:43-48
+            return [self.forward(im.unsqueeze(0)) for im in images]
+        in_dtype = images.dtype
+        x, T, N1 = self.forward_hidden(images)
+        x = x.view(T, N1, -1)
+        if self.select_feature == "patch":                                         # encoder.py:33-34
+            x = x[:, 1:]
+        return x.contiguous().to(in_dtype)                                         # encoder.py:51 `.to(images.dtype)`

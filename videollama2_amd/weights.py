@@ -1,0 +1,181 @@
+"""HF state-dict -> kernel layouts, done once at load time (bf16 matrices in nn.Linear [N,K] layout, fp32 vectors).
+
+Accepts both transformers-5.x key names (`...vision_tower.vision_tower.embeddings...`) and the 4.40-era names real
+VideoLLaMA2 checkpoints carry (`...vision_tower.vision_tower.vision_model.embeddings...`); SURVEY.md 7.3-7."""
+import torch
+
+BF16 = torch.bfloat16
+
+
+def normalise_keys(sd):
+    return {k.replace("vision_tower.vision_tower.vision_model.", "vision_tower.vision_tower."): v for k, v in sd.items()}
+
+
+def _bf(t, dev):
+    return t.detach().to(device=dev, dtype=BF16).contiguous()
+
+
+def _f32(t, dev):
+    # parameters are stored in bf16 by the reference's bf16 path; bf16 -> fp32 is exact
+    return t.detach().to(dtype=BF16).to(device=dev, dtype=torch.float32).contiguous()
+
+
+def pack_tower(sd, cfg, dev, prefix="model.vision_tower.vision_tower."):
+    """CLIPVisionModel weights (HF:models/clip/modeling_clip.py).  Only the layers feeding hidden_states[select_layer]."""
+    sd = normalise_keys(sd)
+    v = cfg["vision"]
+    D, P = v["hidden_size"], v["patch_size"]
+    L, sel = v["num_hidden_layers"], v["select_layer"]
+    n_run = (L + 1 + sel) if sel < 0 else sel
+    kreal = 3 * P * P
+    kp = (kreal + 63) // 64 * 64
+    pw = torch.zeros((D, kp), dtype=BF16, device=dev)
+    pw[:, :kreal] = _bf(sd[prefix + "embeddings.patch_embedding.weight"].reshape(D, kreal), dev)
+    pos = _bf(sd[prefix + "embeddings.position_embedding.weight"], dev)
+    cls = _bf(sd[prefix + "embeddings.class_embedding"], dev)
+    out = dict(kp=kp, n_run=n_run, patch_w=pw, pos=pos,
+               cls_pos=(cls.float() + pos[0].float()).to(BF16).contiguous(),
+               pre_w=_f32(sd[prefix + "pre_layrnorm.weight"], dev), pre_b=_f32(sd[prefix + "pre_layrnorm.bias"], dev),
+               layers=[])
+    for i in range(n_run):
+        p = f"{prefix}encoder.layers.{i}."
+        a = p + "self_attn."
+        out["layers"].append(dict(
+            ln1_w=_f32(sd[p + "layer_norm1.weight"], dev), ln1_b=_f32(sd[p + "layer_norm1.bias"], dev),
+            wqkv=_bf(torch.cat([sd[a + "q_proj.weight"], sd[a + "k_proj.weight"], sd[a + "v_proj.weight"]], 0), dev),
+            bqkv=_f32(torch.cat([sd[a + "q_proj.bias"], sd[a + "k_proj.bias"], sd[a + "v_proj.bias"]], 0), dev),
+            wo=_bf(sd[a + "out_proj.weight"], dev), bo=_f32(sd[a + "out_proj.bias"], dev),
+            ln2_w=_f32(sd[p + "layer_norm2.weight"], dev), ln2_b=_f32(sd[p + "layer_norm2.bias"], dev),
+            w1=_bf(sd[p + "mlp.fc1.weight"], dev), b1=_f32(sd[p + "mlp.fc1.bias"], dev),
+            w2=_bf(sd[p + "mlp.fc2.weight"], dev), b2=_f32(sd[p + "mlp.fc2.bias"], dev)))
+    return out
+
+
+def _pack_bottleneck(sd, p, dev):
+    C = sd[p + "conv1.conv.weight"].shape[0]
+    blk = dict(
+        conv1_w=_bf(sd[p + "conv1.conv.weight"].reshape(C, -1), dev),
+        bn1_w=_f32(sd[p + "conv1.bn.weight"], dev), bn1_b=_f32(sd[p + "conv1.bn.bias"], dev),
+        dw_w=_f32(sd[p + "conv2.conv.weight"].reshape(C, 9).t(), dev),             # [9][C] tap-major
+        bn2_w=_f32(sd[p + "conv2.bn.weight"], dev), bn2_b=_f32(sd[p + "conv2.bn.bias"], dev),
+        fc1_w=_bf(sd[p + "se.fc1.weight"].reshape(-1, C), dev), fc1_b=_f32(sd[p + "se.fc1.bias"], dev),
+        fc2_w=_bf(sd[p + "se.fc2.weight"].reshape(C, -1), dev), fc2_b=_f32(sd[p + "se.fc2.bias"], dev),
+        conv3_w=_bf(sd[p + "conv3.conv.weight"].reshape(C, C), dev),
+        bn3_w=_f32(sd[p + "conv3.bn.weight"], dev), bn3_b=_f32(sd[p + "conv3.bn.bias"], dev))
+    if (p + "downsample.conv.weight") in sd:
+        blk.update(ds_w=_bf(sd[p + "downsample.conv.weight"].reshape(C, -1), dev),
+                   dsbn_w=_f32(sd[p + "downsample.bn.weight"], dev), dsbn_b=_f32(sd[p + "downsample.bn.bias"], dev))
+    return blk
+
+
+def pack_connector(sd, dev, prefix="model.mm_projector."):
+    """STCConnector weights (videollama2/model/projector.py:135-187); key names of timm RegStage."""
+    w3 = sd[prefix + "sampler.0.weight"]                       # [Cout, Cin, 2, 2, 2]
+    cout, cin = w3.shape[:2]
+    return dict(
+        s1=[_pack_bottleneck(sd, f"{prefix}s1.b{b}.", dev) for b in range(1, 5)],
+        s2=[_pack_bottleneck(sd, f"{prefix}s2.b{b}.", dev) for b in range(1, 5)],
+        samp_w=_bf(w3.permute(0, 2, 3, 4, 1).reshape(cout, 8 * cin), dev),   # K order = (kt, kh, kw, cin)
+        samp_b=_f32(sd[prefix + "sampler.0.bias"], dev), cin=cin,
+        ro0_w=_bf(sd[prefix + "readout.0.weight"], dev), ro0_b=_f32(sd[prefix + "readout.0.bias"], dev),
+        ro2_w=_bf(sd[prefix + "readout.2.weight"], dev), ro2_b=_f32(sd[prefix + "readout.2.bias"], dev),
+        zero_row=torch.zeros(cin, dtype=BF16, device=dev))
+
+
+def pack_gate_up(gate, up):
+    """[I,D] x2 -> [2I, D] in blocks of 64 rows {32 gate rows, 32 up rows} (VL2_GEMM_SWIGLU layout)."""
+    I, D = gate.shape
+    return torch.stack([gate.reshape(I // 32, 32, D), up.reshape(I // 32, 32, D)], 1).reshape(2 * I, D).contiguous()
+
+
+def pack_decoder(sd, cfg, dev, n_layers=None):
+    """MistralForCausalLM weights (HF:models/mistral/modeling_mistral.py)."""
+    l = cfg["llm"]
+    n_layers = l["num_hidden_layers"] if n_layers is None else n_layers
+    out = dict(embed=_bf(sd["model.embed_tokens.weight"], dev), norm_w=_f32(sd["model.norm.weight"], dev),
+               lm_head=_bf(sd["lm_head.weight"], dev), layers=[])
+    for i in range(n_layers):
+        p = f"model.layers.{i}."
+        a = p + "self_attn."
+        out["layers"].append(dict(
+            ln1_w=_f32(sd[p + "input_layernorm.weight"], dev), ln2_w=_f32(sd[p + "post_attention_layernorm.weight"], dev),
+            wqkv=_bf(torch.cat([sd[a + "q_proj.weight"], sd[a + "k_proj.weight"], sd[a + "v_proj.weight"]], 0), dev),
+            wo=_bf(sd[a + "o_proj.weight"], dev),
+            wgu=_bf(pack_gate_up(sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"]), dev),
+            wd=_bf(sd[p + "mlp.down_proj.weight"], dev)))
+    return out
+
+
+def state_dict_names(cfg):
+    """(name, shape) of every parameter the hot path reads, transformers-5.x key naming (what
+    `Videollama2MistralForCausalLM(config).state_dict()` yields for CLIP + stc_connector + Mistral)."""
+    v, l = cfg["vision"], cfg["llm"]
+    Dv, Iv, P = v["hidden_size"], v["intermediate_size"], v["patch_size"]
+    npos = (v["image_size"] // P) ** 2 + 1
+    D, I = l["hidden_size"], l["intermediate_size"]
+    hd, nh, nkv = l["head_dim"], l["num_attention_heads"], l["num_key_value_heads"]
+    vt, mp = "model.vision_tower.vision_tower.", "model.mm_projector."
+    out = [(vt + "embeddings.class_embedding", (Dv,)), (vt + "embeddings.patch_embedding.weight", (Dv, 3, P, P)),
+           (vt + "embeddings.position_embedding.weight", (npos, Dv)),
+           (vt + "pre_layrnorm.weight", (Dv,)), (vt + "pre_layrnorm.bias", (Dv,))]
+    for i in range(v["num_hidden_layers"]):
+        p = f"{vt}encoder.layers.{i}."
+        for n in ("k_proj", "v_proj", "q_proj", "out_proj"):
+            out += [(p + f"self_attn.{n}.weight", (Dv, Dv)), (p + f"self_attn.{n}.bias", (Dv,))]
+        out += [(p + "layer_norm1.weight", (Dv,)), (p + "layer_norm1.bias", (Dv,)),
+                (p + "mlp.fc1.weight", (Iv, Dv)), (p + "mlp.fc1.bias", (Iv,)),
+                (p + "mlp.fc2.weight", (Dv, Iv)), (p + "mlp.fc2.bias", (Dv,)),
+                (p + "layer_norm2.weight", (Dv,)), (p + "layer_norm2.bias", (Dv,))]
+    for stage, cin in (("s1", Dv), ("s2", D)):
+        for b in range(1, 5):
+            ci = cin if b == 1 else D
+            rd = int(round(ci * 0.25))
+            p = f"{mp}{stage}.b{b}."
+            out += [(p + "conv1.conv.weight", (D, ci, 1, 1)), (p + "conv1.bn.weight", (D,)), (p + "conv1.bn.bias", (D,)),
+                    (p + "conv2.conv.weight", (D, 1, 3, 3)), (p + "conv2.bn.weight", (D,)), (p + "conv2.bn.bias", (D,)),
+                    (p + "se.fc1.weight", (rd, D, 1, 1)), (p + "se.fc1.bias", (rd,)),
+                    (p + "se.fc2.weight", (D, rd, 1, 1)), (p + "se.fc2.bias", (D,)),
+                    (p + "conv3.conv.weight", (D, D, 1, 1)), (p + "conv3.bn.weight", (D,)), (p + "conv3.bn.bias", (D,))]
+            if ci != D:
+                out += [(p + "downsample.conv.weight", (D, ci, 1, 1)), (p + "downsample.bn.weight", (D,)),
+                        (p + "downsample.bn.bias", (D,))]
+    out += [(mp + "sampler.0.weight", (D, D, 2, 2, 2)), (mp + "sampler.0.bias", (D,)),
+            (mp + "readout.0.weight", (D, D)), (mp + "readout.0.bias", (D,)),
+            (mp + "readout.2.weight", (D, D)), (mp + "readout.2.bias", (D,)),
+            ("model.embed_tokens.weight", (l["vocab_size"], D))]
+    for i in range(l["num_hidden_layers"]):
+        p = f"model.layers.{i}."
+        out += [(p + "self_attn.q_proj.weight", (nh * hd, D)), (p + "self_attn.k_proj.weight", (nkv * hd, D)),
+                (p + "self_attn.v_proj.weight", (nkv * hd, D)), (p + "self_attn.o_proj.weight", (D, nh * hd)),
+                (p + "mlp.gate_proj.weight", (I, D)), (p + "mlp.up_proj.weight", (I, D)),
+                (p + "mlp.down_proj.weight", (D, I)),
+                (p + "input_layernorm.weight", (D,)), (p + "post_attention_layernorm.weight", (D,))]
+    out += [("model.norm.weight", (D,)), ("lm_head.weight", (l["vocab_size"], D))]
+    return out
+
+
+def random_state_dict(cfg, device, seed=1234, n_llm_layers=None):
+    """Synthetic random-init weights created ON THE DEVICE (no checkpoints / hub on the target box): matrices
+    ~ N(0, 1/fan_in), norm weights ~ 1 + 0.1 N, biases ~ 0.02 N.  bf16.  Used by bench.py and smoke()."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    sd = {}
+    for name, shape in state_dict_names(cfg):
+        if n_llm_layers is not None and name.startswith("model.layers."):
+            if int(name.split(".")[2]) >= n_llm_layers:
+                continue
+        x = torch.randn(shape, generator=g, device=device, dtype=torch.float32)
+        leaf = name.split(".")[-1]
+        is_norm = any(t in name for t in ("layernorm", "layer_norm", "layrnorm", ".bn.")) or name == "model.norm.weight"
+        if leaf == "weight" and is_norm:
+            x = 1.0 + 0.1 * x
+        elif leaf == "bias":
+            x = 0.02 * x
+        elif len(shape) >= 2:
+            fan_in = 1
+            for s in shape[1:]:
+                fan_in *= s
+            x = x * (fan_in ** -0.5)
+        else:
+            x = 0.5 * x
+        sd[name] = x.to(BF16)
+    return sd
