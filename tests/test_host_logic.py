@@ -1,0 +1,142 @@
+"""CPU tests of the host-side mirror of the reference interface (no kernels involved) and of the C-ABI library's
+export table (loads libvl2hip.so; no compute calls without a GPU)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_builds_loads_and_exports_every_declared_symbol():
+    import __graft_entry__ as ge
+    ge.build()
+    from videollama2_amd import _lib
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    header = open(os.path.join(ROOT, "include", "vl2hip.h")).read()
+    declared = set(re.findall(r"\b(vl2_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert _lib.load().vl2_version() == 1
+
+
+def test_abi_argument_validation_without_gpu():
+    from videollama2_amd import _lib
+    with pytest.raises(_lib.Vl2HipError, match="null pointer"):
+        _lib.call("vl2_gemm_bf16", None, None, None, None, None, 1, 128, 64, 64, 64, 128, 0, 0, 0, None, None, 0, 0, 0, 0, 0, 0, None)
+    with pytest.raises(_lib.Vl2HipError, match="N%128"):
+        _lib.call("vl2_gemm_bf16", 16, 16, 16, None, None, 4, 100, 64, 64, 64, 104, 0, 0, 0, None, None, 0, 0, 0, 0, 0, 0, None)
+    with pytest.raises(_lib.Vl2HipError, match="head_dim"):
+        _lib.call("vl2_attn_fwd", 16, 16, 16, 16, 0, 96, 96, 0, 96, 96, 0, 96, 96, 0, 96, 96, 1, 1, 4, 4, 1, 1.0, 0, 0, 96, None)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "videollama2_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip")):
+                txt = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", txt, re.M), f"{f} imports the oracle"
+                assert "tests.emu" not in txt and "hip_emu" not in txt, f"{f} references the emulator"
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from videollama2_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.Vl2HipError, match="no fallback"):
+        _lib.load()
+
+
+def test_frame_sample_and_process_video_match_reference_goldens(golden_small):
+    from videollama2_amd.mm_utils import frame_sample, process_video
+    from videollama2_amd.tower import default_image_processor
+    g = golden_small
+    for (d, n), ids in g["frame_sample"].items():
+        assert np.array_equal(frame_sample(d, "uniform", num_frames=n), ids.numpy())
+    assert frame_sample(90, "fps", fps=30).tolist() == [15, 45, 75]
+    proc = default_image_processor(g["cfg"]["vision"]["image_size"])
+    T = g["cfg"]["num_frames"]
+    out = process_video(g["frames_u8"].numpy(), proc, aspect_ratio=None, num_frames=T)
+    assert out.dtype == torch.float32 and torch.allclose(out, g["frames"], atol=1e-6)
+    odd = g["odd_u8"].numpy()
+    out = process_video([f for f in odd], proc, aspect_ratio=None, num_frames=T)         # bicubic resize + crop + pad frame
+    assert torch.allclose(out, g["odd_frames"], atol=1e-6)
+    out = process_video(odd, proc, aspect_ratio="pad", num_frames=T)
+    assert torch.allclose(out, g["odd_frames_pad"], atol=1e-6)
+    with pytest.raises(ValueError, match="Unsupported video path type"):
+        process_video(123, proc)
+
+
+def test_tokenizer_multimodal_token_and_stopping_criteria():
+    from videollama2_amd.mm_utils import KeywordsStoppingCriteria, tokenizer_multimodal_token
+
+    class Tok:
+        bos_token_id = 1
+
+        def __call__(self, text, add_special_tokens=True):
+            ids = [10 + (ord(c) % 50) for c in text]
+            return type("E", (), {"input_ids": ([1] + ids) if add_special_tokens else ids})()
+
+        def batch_decode(self, ids, skip_special_tokens=True):
+            return ["".join(chr(97 + int(t) % 26) for t in row) for row in ids]
+
+    tok = Tok()
+    ids = tokenizer_multimodal_token("ab<video>\ncd", tok, "<video>", return_tensors="pt")
+    assert ids.tolist() == tok("ab", False).input_ids + [-201] + tok("\ncd", False).input_ids
+    assert tokenizer_multimodal_token("xyz", tok, "") == tok("xyz", False).input_ids
+    crit = KeywordsStoppingCriteria(["q"], tok, torch.zeros(1, 3, dtype=torch.long))
+    kw = crit.keyword_ids[0]
+    assert crit(torch.cat([torch.tensor([5, 6, 7, 8]), kw])[None], None)
+    assert not crit(torch.tensor([[5, 6, 7, 8, 9]]), None) or "q" in tok.batch_decode(torch.tensor([[5, 6, 7, 8, 9]]))[0]
+
+
+def test_conv3d_gather_table_equals_conv3d():
+    """The gathered-GEMM formulation of Conv3d(k=2,s=2,p=1) (projector.py:164-174) on the host, in fp64."""
+    from videollama2_amd.connector import conv3d_k2s2p1_index
+    for T, H in ((16, 24), (5, 7), (2, 4)):
+        C, Co = 6, 5
+        x = torch.randn(T * H * H, C, dtype=torch.float64)
+        w = torch.randn(Co, C, 2, 2, 2, dtype=torch.float64)
+        idx, (To, Ho, Wo) = conv3d_k2s2p1_index(T, H, H, "cpu")
+        wp = w.permute(0, 2, 3, 4, 1).reshape(Co, 8 * C)
+        rows = torch.cat([torch.where((idx[s] >= 0)[:, None], x[idx[s].clamp(min=0).long()], torch.zeros(1, C, dtype=torch.float64))
+                          for s in range(8)], 1)
+        ref = F.conv3d(x.view(1, T, H, H, C).permute(0, 4, 1, 2, 3), w, stride=2, padding=1)[0].permute(1, 2, 3, 0)
+        assert (To, Ho, Wo) == tuple(ref.shape[:3]) == (T // 2 + 1, H // 2 + 1, H // 2 + 1)
+        assert torch.allclose(rows @ wp.T, ref.reshape(-1, Co), atol=1e-10)
+
+
+def test_gate_up_packing_roundtrip():
+    from videollama2_amd.weights import pack_gate_up
+    g, u = torch.arange(64 * 4.).view(64, 4), -torch.arange(64 * 4.).view(64, 4)
+    p = pack_gate_up(g, u)
+    assert torch.equal(p[:32], g[:32]) and torch.equal(p[32:64], u[:32]) and torch.equal(p[64:96], g[32:])
+
+
+def test_weight_key_normalisation_accepts_4_40_names():
+    from videollama2_amd.weights import normalise_keys
+    sd = {"model.vision_tower.vision_tower.vision_model.embeddings.class_embedding": 1, "lm_head.weight": 2}
+    assert "model.vision_tower.vision_tower.embeddings.class_embedding" in normalise_keys(sd)
+
+
+def test_frame_sharder_split():
+    from videollama2_amd.dist import FrameSharder
+    assert FrameSharder.split(32, 8) == [(i * 4, 4) for i in range(8)]
+    assert FrameSharder.split(10, 4) == [(0, 3), (3, 3), (6, 2), (8, 2)]
+    assert FrameSharder.split(1, 2) == [(0, 1), (1, 0)]
+    assert sum(c for _, c in FrameSharder.split(16, 3)) == 16
+
+
+def test_config_checks():
+    from videollama2_amd.config import check_supported, videollama2_7b
+    check_supported(videollama2_7b(16))
+    bad = videollama2_7b(16)
+    bad["llm"]["head_dim"] = 96
+    with pytest.raises(ValueError, match="head_dim"):
+        check_supported(bad)

@@ -12,6 +12,18 @@ from . import ops
 from .weights import pack_tower
 
 
+def default_image_processor(image_size=336):
+    """The CLIPImageProcessor the reference gets from `CLIPImageProcessor.from_pretrained(tower)` (encoder.py:21), built
+    from the public openai/clip-vit-large-patch14-336 preprocessor values (no hub access): shortest-edge resize
+    (bicubic) -> centre crop -> 1/255 -> mean/std normalise."""
+    from transformers import CLIPImageProcessor
+    return CLIPImageProcessor(do_resize=True, size={"shortest_edge": image_size}, resample=3, do_center_crop=True,
+                              crop_size={"height": image_size, "width": image_size}, do_rescale=True,
+                              rescale_factor=1 / 255, do_normalize=True, do_convert_rgb=True,
+                              image_mean=[0.48145466, 0.4578275, 0.40821073],
+                              image_std=[0.26862954, 0.26130258, 0.27577711])
+
+
 class HipCLIPVisionTower(nn.Module):
     def __init__(self, cfg, state_dict, device="cuda", select_feature="patch", image_processor=None,
                  prefix="model.vision_tower.vision_tower."):
