@@ -198,7 +198,7 @@ def main():
         }
         if not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
+                out["cpu_baseline"] = cpu_baseline(min(os.cpu_count() or 1, 32))   # eager torch oversubscribes badly beyond ~32 threads
             except Exception as exc:  # the oracle is a checker, never a dependency of the measured path
                 out["cpu_baseline"] = {"value": None, "error": repr(exc)}
         print(json.dumps(out), flush=True)

@@ -88,3 +88,22 @@ def test_emu_small_config_end_to_end_vs_reference_goldens(emu, golden_small):
         m.generate(ids, images=None, inputs_embeds=torch.zeros(1))
     with pytest.raises(ValueError, match="doesn't match model"):
         m.vision_tower(torch.zeros(1, 3, 28, 28))
+
+
+def test_emu_drop_in_accelerate_reference_model(emu, golden_small):
+    """The seam test: a live reference model (build container only) re-routed by install.accelerate(); the reference's own
+    `encode_images_or_videos` and `generate` entry points then run on the HIP host path (emulated kernels here)."""
+    from oracle import ref_harness as RH
+    if not RH.reference_available():
+        pytest.skip("reference tree only exists in the build container")
+    from videollama2_amd.install import accelerate
+    g = golden_small
+    model, _ = RH.build_reference_model(g["cfg"])
+    RH.reseed_weights(model, g["seed"])
+    accelerate(model, device="cpu", max_seq_len=64)
+    feats = model.encode_images_or_videos([(g["frames"], "video")])          # reference method, HIP modules underneath
+    assert rel(feats, g["mm_features"]) < 2.5e-2
+    ids = g["input_ids"][None]
+    out = model.generate(ids, attention_mask=torch.ones_like(ids), images=[(g["frames"], "video")], do_sample=False,
+                         max_new_tokens=2, use_cache=True, pad_token_id=0, eos_token_id=None)
+    assert out[0].tolist() == g["new_tokens"][:2].tolist()

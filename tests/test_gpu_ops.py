@@ -163,7 +163,7 @@ def test_stc_direct_kernels_full_width(ops):
     assert rel(g2, gref) < 1e-4
     xs = x.to(DEV).clone()
     ops.se_scale_(xs, g2, Fr, H * H)
-    assert rel(xs, x.float().view(Fr, H * H, C) * gref[:, None, :]) < TOL_BF16_OUT
+    assert rel(xs.view(Fr, H * H, C), x.float().view(Fr, H * H, C) * gref[:, None, :]) < TOL_BF16_OUT
 
 
 def test_rope_kv(ops):
