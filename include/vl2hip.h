@@ -27,6 +27,11 @@ extern "C" {
 #define VL2_E_UNSUPP  (-3)   /* option combination not built */
 
 int32_t vl2_version(void);
+/* Tuning knobs (process-global, for A/B benchmarking; defaults are the shipped heuristics).
+ *   key 1 = GEMM tile variant: 0 auto (128x256x32 when N%256==0 and N>=2048, else 128x128x64), 1 force 128x128x64,
+ *           2 force 128x256x32 where N%256==0. */
+#define VL2_TUNE_GEMM_VARIANT 1
+int32_t vl2_set_tuning(int32_t key, int32_t value);
 const char* vl2_last_error_string(void);      /* host pointer, thread-local, valid until the next failing call */
 
 /* activation codes for vl2_gemm_bf16 / vl2_small_linear */
@@ -97,7 +102,8 @@ int32_t vl2_rope_kv(const void* qkv, void* q_out, void* kcache, void* vcache, co
 /* y[N] = W[N,K] x[K] for one token (decode).  norm_w != NULL fuses MistralRMSNorm on x first.  flags as vl2_gemm_bf16. */
 int32_t vl2_gemv_bf16(const void* W, const void* x, const float* norm_w, const void* res, void* y, int32_t N, int32_t K,
                       int32_t ldw, float eps, int32_t flags, void* stream);
-/* one query token vs the KV cache rows [0, ctx); partial: fp32 workspace >= nh*ceil(ctx/chunk)*130 floats. */
+/* one query token vs the KV cache rows [0, ctx); partial: fp32 workspace >= nh*ceil(ctx/64)*130 floats (`chunk` is
+ * accepted for ABI stability and ignored: the context is split in 64-key slices). */
 int32_t vl2_attn_decode(const void* q, const void* kcache, const void* vcache, float* partial, void* out, int32_t nh,
                         int32_t nkv, int32_t smax, int32_t ctx, int32_t chunk, float scale, void* stream);
 /* greedy argmax (first maximal index) of fp32 logits -> *tok (device int32) and hist[step] if hist != NULL.

@@ -1,0 +1,99 @@
+#!/usr/bin/env python
+"""Micro-benchmark of the hot kernels at the exact VideoLLaMA2-7B (T=16) shapes, through the C ABI.  A/B of the GEMM
+tile variants in ONE process, interleaved rounds (guide rule 24).  Usage: python scripts/kernel_bench.py [--quick]"""
+import os
+import sys
+import json
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from videollama2_amd import ops  # noqa: E402
+
+dev = "cuda"
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3      # us
+
+
+def rnd(*shape, scale=1.0):
+    return (torch.randn(*shape, device=dev) * scale).to(torch.bfloat16)
+
+
+SHAPES = [  # name, M, N, K, kwargs
+    ("vit_qkv", 9232, 3072, 1024, dict(bias=True)),
+    ("vit_wo", 9232, 1024, 1024, dict(bias=True, res=True)),
+    ("vit_fc1", 9232, 4096, 1024, dict(bias=True, act=1)),
+    ("vit_fc2", 9232, 1024, 4096, dict(bias=True, res=True)),
+    ("stc_s1_conv", 9216, 4096, 4096, dict()),
+    ("stc_s1_b1", 9216, 4096, 1024, dict()),
+    ("stc_s2_conv", 1521, 4096, 4096, dict()),
+    ("llm_qkv", 1621, 6144, 4096, dict()),
+    ("llm_wo", 1621, 4096, 4096, dict(res=True)),
+    ("llm_gateup", 1621, 28672, 4096, dict(swiglu=True)),
+    ("llm_down", 1621, 4096, 14336, dict(res=True)),
+]
+
+
+def main():
+    out = {}
+    rounds = 2 if "--quick" in sys.argv else 3
+    for name, M, N, K, kw in SHAPES:
+        a, w = rnd(M, K), rnd(N, K, scale=K ** -0.5)
+        ncol = N // 2 if kw.get("swiglu") else N
+        bias = torch.randn(N, device=dev) if kw.get("bias") else None
+        res = rnd(M, ncol) if kw.get("res") else None
+        c = torch.empty(M, ncol, dtype=torch.bfloat16, device=dev)
+        best = {}
+        for r in range(rounds):
+            for v in (1, 2):
+                if v == 2 and N % 256:
+                    continue
+                ops.set_gemm_variant(v)
+                us = timeit(lambda: ops.gemm(a, w, bias=bias, res=res, act=kw.get("act", 0), swiglu=kw.get("swiglu", False), out=c))
+                best[v] = min(best.get(v, 1e9), us)
+        ops.set_gemm_variant(0)
+        fl = 2.0 * M * N * K
+        out[name] = {f"v{v}": dict(us=round(us, 1), tflops=round(fl / us / 1e6, 1)) for v, us in best.items()}
+        print(name, M, N, K, out[name], flush=True)
+    # attention
+    B, H, Nn, D = 16, 16, 577, 64
+    qkv = rnd(B * Nn, 3 * H * D)
+    o = torch.empty(B * Nn, H * D, dtype=torch.bfloat16, device=dev)
+    st = (Nn * 3 * H * D, D, 3 * H * D)
+    us = timeit(lambda: ops.attn_fwd(qkv, qkv[:, H * D:], qkv[:, 2 * H * D:], o, st, st, st, (Nn * H * D, D, H * D), B, H, Nn, Nn, 1, D ** -0.5, False, 0, D))
+    out["attn_vit"] = dict(us=round(us, 1), tflops=round(4.0 * B * H * Nn * Nn * D / us / 1e6, 1))
+    S, nh, nkv, D, smax = 1621, 32, 8, 128, 4096
+    q, kc, vc = rnd(S, nh * D), rnd(nkv, smax, D), rnd(nkv, smax, D)
+    o = torch.empty(S, nh * D, dtype=torch.bfloat16, device=dev)
+    us = timeit(lambda: ops.attn_fwd(q, kc, vc, o, (0, D, nh * D), (0, smax * D, D), (0, smax * D, D), (0, D, nh * D), 1, nh, S, S, nh // nkv, D ** -0.5, True, 0, D))
+    out["attn_prefill"] = dict(us=round(us, 1), tflops=round(4.0 * nh * (S * (S + 1) / 2) * D / us / 1e6, 1))
+    part = torch.empty(nh * 64 * 130, device=dev)
+    od = torch.empty(nh * D, dtype=torch.bfloat16, device=dev)
+    q1 = rnd(nh * D)
+    us = timeit(lambda: ops.attn_decode(q1, kc, vc, part, od, nh, nkv, 1650, 64, D ** -0.5), iters=50)
+    out["attn_decode_ctx1650"] = dict(us=round(us, 1), gbs=round(2 * 1650 * nkv * D * 2 / us / 1e3, 1))
+    # decode gemv
+    for name, N, K, kw in (("gemv_qkv", 6144, 4096, dict(norm=True)), ("gemv_wo", 4096, 4096, dict()), ("gemv_gateup", 28672, 4096, dict(swiglu=True, norm=True)),
+                           ("gemv_down", 4096, 14336, dict()), ("gemv_lmhead", 32000, 4096, dict(norm=True, f32=True))):
+        w, x = rnd(N, K, scale=K ** -0.5), rnd(K)
+        nw = torch.randn(K, device=dev) if kw.get("norm") else None
+        us = timeit(lambda: ops.gemv(w, x, norm_w=nw, swiglu=kw.get("swiglu", False), out_f32=kw.get("f32", False)), iters=50)
+        out[name] = dict(us=round(us, 1), gbs=round(N * K * 2 / us / 1e3, 1))
+    for k in ("attn_vit", "attn_prefill", "attn_decode_ctx1650", "gemv_qkv", "gemv_wo", "gemv_gateup", "gemv_down", "gemv_lmhead"):
+        print(k, out[k], flush=True)
+    print("JSON", json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -16,8 +16,15 @@ static char g_err[256] = "emu";
 extern "C" int32_t vl2_version(void) { return 1; }
 extern "C" const char* vl2_last_error_string(void) { return g_err; }
 
+static int g_gemm_variant = 0;
+extern "C" int32_t vl2_set_tuning(int32_t key, int32_t value) { if (key == 1) { g_gemm_variant = value; return 0; } return -1; }
 template <int ACT, bool SW, bool F32, bool G>
 static void run_gemm(GemmArgs a) {
+    if ((a.N % 256 == 0) && (g_gemm_variant == 2 || (g_gemm_variant == 0 && a.N >= 2048))) {
+        a.tiles_m = (a.M + 127) / 128; a.tiles_n = a.N / 256;
+        emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(256), [=] { gemm2_bf16_kernel<ACT, SW, F32, G>(a); });
+        return;
+    }
     emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(256), [=] { gemm_bf16_kernel<ACT, SW, F32, G>(a); });
 }
 extern "C" int32_t vl2_gemm_bf16(const void* A, const void* W, void* C, const float* bias, const void* res, int32_t M,
@@ -130,9 +137,9 @@ extern "C" int32_t vl2_gemv_bf16(const void* W, const void* x, const float* norm
 }
 extern "C" int32_t vl2_attn_decode(const void* q, const void* kc, const void* vc, float* partial, void* out, int32_t nh,
                                    int32_t nkv, int32_t smax, int32_t ctx, int32_t chunk, float scale, void*) {
-    const int group = nh / nkv, nsplit = (ctx + chunk - 1) / chunk;
-    emu::launch(dim3(nsplit, nkv), dim3(group * 64), [=] {
-        attn_decode_kernel((const bf16_t*)q, (const bf16_t*)kc, (const bf16_t*)vc, partial, nh, group, smax, ctx, chunk, scale * 1.4426950408889634f); });
+    const int group = nh / nkv, nsplit = (ctx + 63) / 64;
+    emu::launch(dim3(nsplit, nkv), dim3(256), [=] {
+        attn_decode_kernel((const bf16_t*)q, (const bf16_t*)kc, (const bf16_t*)vc, partial, nh, group, smax, ctx, scale * 1.4426950408889634f); });
     emu::launch(dim3(nh), dim3(128), [=] { attn_decode_combine_kernel(partial, (bf16_t*)out, nsplit); });
     return 0;
 }

@@ -150,6 +150,15 @@ template <class T> inline float dot2(T a, T b, float c) {   // v_dot2c_f32_bf16
     r = fmaf(bf2f((short)(x >> 16)), bf2f((short)(y >> 16)), r);
     return r;
 }
+inline bool wave_all(bool pred) {
+    Wave& w = waves[cur->wave];
+    w.scratch[cur->lane][0] = pred ? 1 : 0;
+    wave_sync();
+    bool r = true;
+    for (int i = 0; i < 64; ++i) r = r && w.scratch[i][0];
+    wave_sync();
+    return r;
+}
 template <class T> inline T shfl_idx(T v, int src) {
     Wave& w = waves[cur->wave];
     memcpy(w.scratch[cur->lane], &v, sizeof(T));
@@ -192,6 +201,7 @@ inline void global_load_lds(const void* g, void* lds, unsigned size, int offset,
 #define __builtin_amdgcn_s_sleep(x) ((void)0)
 #define __builtin_nontemporal_load(p) (*(p))
 #define __builtin_nontemporal_store(v, p) (*(p) = (v))
+#define __all(p) emu::wave_all(p)
 #define __shfl_xor(v, m) emu::shfl_idx((v), emu::cur->lane ^ (m))
 #define __shfl_down(v, d) emu::shfl_idx((v), (emu::cur->lane + (d)) > 63 ? emu::cur->lane : emu::cur->lane + (d))
 #define __shfl(v, s) emu::shfl_idx((v), (s))

@@ -10,6 +10,7 @@ _vp, _i32, _i64, _f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.
 
 # name -> argtypes (all return int32 except the two below)
 SIGNATURES = {
+    "vl2_set_tuning": [_i32, _i32],
     "vl2_gemm_bf16": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _i32,
                       _i32, _i32, _i32, _i32, _vp],
     "vl2_layernorm": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp],

@@ -15,14 +15,14 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ float bf2f(bf16_t b) { return __builtin_bit_cast(float, ((uint32_t)b) << 16); }
 __device__ __forceinline__ float bf2f_s(short b) { return __builtin_bit_cast(float, ((uint32_t)(uint16_t)b) << 16); }
-// round-to-nearest-even, NaN preserved (same rule as torch's float->bfloat16)
-__device__ __forceinline__ bf16_t f2bf(float f) {
-    uint32_t u = __builtin_bit_cast(uint32_t, f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+// float -> bf16, round-to-nearest-even (torch semantics); on gfx950 this is v_cvt_pk_bf16_f32
+typedef __bf16 bf16v2_hw __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16v2_hw));
 }
-__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
 
 __device__ __forceinline__ void unpack8(const u32x4& v, float* f) {
 #pragma unroll

@@ -49,7 +49,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5, l31 = lane & 31;
     const int h = blockIdx.y, b = blockIdx.z, hk = h / p.group;
-    const int q0 = blockIdx.x * 128;
+    // causal: the last q blocks own the most KV tiles -> dispatch them first (longest-processing-time order)
+    const int q0 = (CAUSAL ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x) * 128;
     const bf16_t* Q = p.q + b * p.q_bs + h * p.q_hs;
     const bf16_t* K = p.k + b * p.k_bs + hk * p.k_hs;
     const bf16_t* V = p.v + b * p.v_bs + hk * p.v_hs;
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
     for (int i = 0; i < NDB; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oT[i][r] = 0.f;
-    float m = -1e30f, l = 0.f;
+    float m = -1e30f, l = 0.f;      // m: running max in the exp2 domain (first tile always rescales: mt - m is huge)
 
     load_tile(0);
     for (int t = 0; t < ntiles; ++t) {
@@ -127,51 +128,60 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
                 sT[kh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sT[kh], 0, 0, 0);
             }
         }
-        // online softmax (exp2 domain); lane owns keys kv0 + 32kh + (r&3) + 8(r>>2) + 4hi of row qrow
+        // online softmax (exp2 domain: p = 2^(s*c - m), c = scale*log2 e folded into one FMA per score).
+        // lane owns keys kv0 + 32kh + (r&3) + 8(r>>2) + 4hi of row qrow.
         const int wq0 = q0 + wave * 32;
         const bool need_mask = (kv0 + 64 > p.nk) || (CAUSAL && (kv0 + 63 > wq0 + p.causal_off));
-        float mt = -1e30f;
+        const float c = p.scale_log2e;
+        float mt = -3.0e38f;
+        if (need_mask) {
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kv0 + kh * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    const bool ok = key < p.nk && (!CAUSAL || key <= qrow + p.causal_off);
+                    sT[kh][r] = ok ? sT[kh][r] : -1e30f;           // raw domain; c > 0
+                }
+        }
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float s = sT[kh][r] * p.scale_log2e;
-                if (need_mask) {
-                    const int key = kv0 + kh * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    const bool ok = key < p.nk && (!CAUSAL || key <= qrow + p.causal_off);
-                    s = ok ? s : -1e30f;
-                }
-                sT[kh][r] = s;
-                mt = fmaxf(mt, s);
-            }
-        mt = fmaxf(mt, __shfl_xor(mt, 32));
-        const float m_new = fmaxf(m, mt);
-        const float alpha = exp2f(m - m_new);
-        m = m_new;
+            for (int r = 0; r < 16; ++r) mt = fmaxf(mt, sT[kh][r]);
+        mt = fmaxf(mt, __shfl_xor(mt, 32)) * c;
+        // deferred rescale (guide T13): keep the old running max while the tile max exceeds it by < 2^THR; P is then
+        // bounded by 2^THR (fp32 accumulators, bf16 P: fine).  THR = 0 would rescale every tile.
+        constexpr float THR = 6.0f;
+        if (!__all(mt - m <= THR)) {
+            const float m_new = fmaxf(m, mt);
+            const float alpha = exp2f(m - m_new);
+            m = m_new;
+            l *= alpha;
+#pragma unroll
+            for (int i = 0; i < NDB; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oT[i][r] *= alpha;
+        }
         float rs = 0.f;
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float pv = exp2f(sT[kh][r] - m_new);
+                const float pv = exp2f(fmaf(sT[kh][r], c, -m));
                 sT[kh][r] = pv;
                 rs += pv;
             }
-        rs += __shfl_xor(rs, 32);
-        l = l * alpha + rs;
-#pragma unroll
-        for (int i = 0; i < NDB; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) oT[i][r] *= alpha;
+        l += rs + __shfl_xor(rs, 32);
 
         // O^T += V^T . P^T
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
             for (int ks2 = 0; ks2 < 2; ++ks2) {
-                bf16x8 pf;
+                u32x4 pw;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) pf[j] = (short)f2bf(sT[kh][ks2 * 8 + j]);
+                for (int j = 0; j < 4; ++j) pw[j] = pack2bf(sT[kh][ks2 * 8 + 2 * j], sT[kh][ks2 * 8 + 2 * j + 1]);
+                const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
                 const int kc = 8 * kh + 4 * ks2 + hi;
 #pragma unroll
                 for (int db = 0; db < NDB; ++db) {

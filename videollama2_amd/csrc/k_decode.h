@@ -143,62 +143,91 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvArgs p) {
     }
 }
 
-// ---- decode attention: q [nh*128] (roped) vs cache rows [0, ctx).  grid = (nsplit, nkv), block = group*64 (group<=4).
+// ---- decode attention (flash-decoding): q [nh*128] (roped) vs cache rows [0, ctx).
+// grid = (nsplit, nkv) with nsplit = ceil(ctx/64): one workgroup per (64-key slice, kv head), 4 waves x 16 keys.
+// A lane is (key = lane&15, head-in-group = lane>>4): the K row is read once and scored against all `group` q heads;
+// V rows are requested up front (they do not depend on the scores) so the kernel is ONE memory round trip.
 // partial: fp32 [nh][nsplit][130] = {m (exp2 domain), l, o[128]}
 __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kcache,
                                                           const bf16_t* __restrict__ vcache, float* __restrict__ partial,
-                                                          int nh, int group, int smax, int ctx, int chunk, float scale_log2e) {
+                                                          int nh, int group, int smax, int ctx, float scale_log2e) {
     constexpr int HD = 128;
-    __shared__ float qs[4][HD];
-    __shared__ float ps[4][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ __attribute__((aligned(16))) float qs[4][HD];
+    __shared__ __attribute__((aligned(16))) float pk[64][4];       // p[key][head]
+    __shared__ float wred[2][4][4];                                 // [max|sum][wave][head]
+    __shared__ __attribute__((aligned(16))) float oacc[4][4][HD];   // [wave][head][d]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kl = lane & 15, hh = lane >> 4;
     const int split = blockIdx.x, hk = blockIdx.y, nsplit = gridDim.x;
-    const int h = hk * group + wave;
-    qs[wave][lane] = bf2f(q[h * HD + lane]);
-    qs[wave][lane + 64] = bf2f(q[h * HD + lane + 64]);
-    __syncthreads();
-    const int k0 = split * chunk;
-    int k1 = k0 + chunk; k1 = k1 < ctx ? k1 : ctx;
+    const int k0 = split * 64;
     const bf16_t* Kb = kcache + (size_t)hk * smax * HD;
     const bf16_t* Vb = vcache + (size_t)hk * smax * HD;
-    float m = -1e30f, l = 0.f, o0 = 0.f, o1 = 0.f;
-    for (int kb = k0; kb < k1; kb += 64) {
-        const int key = kb + lane;
-        float s = -1e30f;
-        if (key < k1) {
-            const bf16_t* kr = Kb + (size_t)key * HD;
-            float acc = 0.f;
+
+    // V rows of this wave's 16 keys: lane owns dims 2*lane, 2*lane+1 (256 B per key per wave, coalesced)
+    uint32_t vv[16];
 #pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                float kv[8];
-                unpack8(*(const u32x4*)(kr + c * 8), kv);
+    for (int i = 0; i < 16; ++i) {
+        int key = k0 + wave * 16 + i;
+        key = key < ctx ? key : ctx - 1;
+        vv[i] = *(const uint32_t*)(Vb + (size_t)key * HD + lane * 2);
+    }
+    // K row of (this lane's key)
+    const int key = k0 + wave * 16 + kl;
+    const bool valid = key < ctx;
+    const bf16_t* kr = Kb + (size_t)(valid ? key : ctx - 1) * HD;
+    u32x4 kreg[16];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc += kv[j] * qs[wave][c * 8 + j];
-            }
-            s = acc * scale_log2e;
-        }
-        const float mt = wave_max(s);
-        const float m_new = fmaxf(m, mt);
-        const float alpha = exp2f(m - m_new);
-        const float pv = key < k1 ? exp2f(s - m_new) : 0.f;
-        l = l * alpha + wave_sum(pv);
-        o0 *= alpha; o1 *= alpha;
-        m = m_new;
-        __syncthreads();                 // all waves take the same trip count (same k0,k1)
-        ps[wave][lane] = pv;
-        __syncthreads();
-        const int nk = (k1 - kb) < 64 ? (k1 - kb) : 64;
-        for (int i = 0; i < nk; ++i) {
-            const float pi = ps[wave][i];
-            const uint32_t vv = *(const uint32_t*)(Vb + (size_t)(kb + i) * HD + lane * 2);
-            o0 += pi * __builtin_bit_cast(float, vv << 16);
-            o1 += pi * __builtin_bit_cast(float, vv & 0xffff0000u);
+    for (int c = 0; c < 16; ++c) kreg[c] = *(const u32x4*)(kr + c * 8);
+    for (int t = tid; t < group * HD; t += 256) qs[t / HD][t % HD] = bf2f(q[(size_t)(hk * group) * HD + t]);
+    __syncthreads();
+
+    const int hq = hh < group ? hh : group - 1;
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        float kv[8];
+        unpack8(kreg[c], kv);
+        const f32x4 q0 = *(const f32x4*)&qs[hq][c * 8], q1 = *(const f32x4*)&qs[hq][c * 8 + 4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc += kv[j] * q0[j] + kv[4 + j] * q1[j];
+    }
+    const float s = valid ? acc * scale_log2e : -1e30f;
+    float mx = s;
+#pragma unroll
+    for (int msk = 8; msk >= 1; msk >>= 1) mx = fmaxf(mx, __shfl_xor(mx, msk));     // over the 16 keys of (wave, head)
+    if (kl == 0) wred[0][wave][hh] = mx;
+    __syncthreads();
+    const float m = fmaxf(fmaxf(wred[0][0][hh], wred[0][1][hh]), fmaxf(wred[0][2][hh], wred[0][3][hh]));
+    const float pv = valid ? exp2f(s - m) : 0.f;
+    float sm = pv;
+#pragma unroll
+    for (int msk = 8; msk >= 1; msk >>= 1) sm += __shfl_xor(sm, msk);
+    if (kl == 0) wred[1][wave][hh] = sm;
+    pk[wave * 16 + kl][hh] = pv;
+    __syncthreads();
+
+    float o[4][2];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) o[h][0] = o[h][1] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const f32x4 p4 = *(const f32x4*)pk[wave * 16 + i];
+        const float v0 = __builtin_bit_cast(float, vv[i] << 16), v1 = __builtin_bit_cast(float, vv[i] & 0xffff0000u);
+#pragma unroll
+        for (int h = 0; h < 4; ++h) { o[h][0] += p4[h] * v0; o[h][1] += p4[h] * v1; }
+    }
+#pragma unroll
+    for (int h = 0; h < 4; ++h) { oacc[wave][h][lane * 2] = o[h][0]; oacc[wave][h][lane * 2 + 1] = o[h][1]; }
+    __syncthreads();
+    for (int t = tid; t < group * HD; t += 256) {
+        const int h = t / HD, d = t % HD;
+        float* dst = partial + ((size_t)(hk * group + h) * nsplit + split) * 130;
+        dst[2 + d] = oacc[0][h][d] + oacc[1][h][d] + oacc[2][h][d] + oacc[3][h][d];
+        if (d == 0) {
+            dst[0] = fmaxf(fmaxf(wred[0][0][h], wred[0][1][h]), fmaxf(wred[0][2][h], wred[0][3][h]));
+            dst[1] = wred[1][0][h] + wred[1][1][h] + wred[1][2][h] + wred[1][3][h];
         }
     }
-    float* dst = partial + ((size_t)h * nsplit + split) * 130;
-    if (lane == 0) { dst[0] = m; dst[1] = l; }
-    dst[2 + lane * 2] = o0;
-    dst[3 + lane * 2] = o1;
 }
 
 // grid = nh, block 128: out[h*128 + d] = sum_i o_i[d] 2^(m_i - M) / sum_i l_i 2^(m_i - M)

@@ -43,6 +43,66 @@ __device__ __forceinline__ int gemm_lds_off(int row, int chunk) {   // byte offs
     return ((R << 4) + (s ^ (R & 15))) << 4;
 }
 
+// One wave-private fp32 patch ep[32][68] (64 GEMM columns) -> global rows: fused bias / activation / SwiGLU / residual /
+// row remap, 16-B stores.  m_base = first row of the patch, n_base = first (un-halved) GEMM column of the patch.
+template <int ACT, bool SWIGLU, bool OUT_F32>
+__device__ __forceinline__ void gemm_store_patch(const GemmArgs& p, const float* ep, int m_base, int n_base, int lane) {
+        constexpr int LPR = SWIGLU ? 4 : 8;            // lanes per row
+        constexpr int RPP = 64 / LPR;                  // rows per pass
+#pragma unroll
+        for (int pass = 0; pass < 32 / RPP; ++pass) {
+            const int row = pass * RPP + lane / LPR;
+            const int cg = (lane % LPR) * 8;
+            const int m = m_base + row;
+            if (m < p.M) {
+                float v[8];
+                const int nfull = n_base + cg;             // column in the (un-halved) GEMM N space
+                if (SWIGLU) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float g = ep[row * 68 + cg + j], u = ep[row * 68 + 32 + cg + j];
+                        v[j] = silu_f(g) * u;
+                    }
+                } else {
+                    const f32x4 x0 = *(const f32x4*)(ep + row * 68 + cg), x1 = *(const f32x4*)(ep + row * 68 + cg + 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { v[j] = x0[j]; v[4 + j] = x1[j]; }
+                    if (p.bias) {
+                        const f32x4 b0 = *(const f32x4*)(p.bias + nfull), b1 = *(const f32x4*)(p.bias + nfull + 4);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { v[j] += b0[j]; v[4 + j] += b1[j]; }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        if (ACT == ACT_QGELU) v[j] = quick_gelu_f(v[j]);
+                        if (ACT == ACT_GELU) v[j] = gelu_erf_f(v[j]);
+                        if (ACT == ACT_SILU) v[j] = silu_f(v[j]);
+                    }
+                }
+                const int n = SWIGLU ? (n_base >> 1) + cg : nfull;
+                const int orow = p.out_grp > 0 ? m + (m / p.out_grp) * p.out_grp_pad + p.out_row_off : m;
+                if (p.res) {
+                    const int rrow = p.res_row_mod > 0 ? (m % p.res_row_mod) + p.res_row_off : orow;
+                    const u32x4 rv = *(const u32x4*)(p.res + (size_t)rrow * p.ldres + n);
+                    float rf[8];
+                    unpack8(rv, rf);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] += rf[j];
+                }
+                if (OUT_F32) {
+                    float* c = (float*)p.C + (size_t)orow * p.ldc + n;
+                    f32x4 o0, o1;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { o0[j] = v[j]; o1[j] = v[4 + j]; }
+                    *(f32x4*)c = o0;
+                    *(f32x4*)(c + 4) = o1;
+                } else {
+                    *(u32x4*)((bf16_t*)p.C + (size_t)orow * p.ldc + n) = pack8(v);
+                }
+            }
+        }
+}
+
 template <int ACT, bool SWIGLU, bool OUT_F32, bool GATHER>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char vl2_smem[];
@@ -140,60 +200,130 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
                 ep[row * 68 + ni * 32 + (lane & 31)] = acc[mi][ni][r];
             }
         __syncthreads();
-        constexpr int LPR = SWIGLU ? 4 : 8;            // lanes per row
-        constexpr int RPP = 64 / LPR;                  // rows per pass
+        gemm_store_patch<ACT, SWIGLU, OUT_F32>(p, ep, m0 + wm * 64 + mi * 32, n0 + wn * 64, lane);
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// gemm2: 128 x 256 block tile, BK = 32, 4 waves (2x2), wave tile 64 x 128 = 2x4 v_mfma_f32_32x32x16_bf16 (128 acc VGPRs),
+// double-buffered 2 x (8 KiB A + 16 KiB W) = 48 KiB LDS -> THREE workgroups per CU (<= 168 VGPRs).
+// Why: at 128x128 the L2 -> LDS operand stream is 15.3 B/kFLOP, i.e. ~17 TB/s chip-wide at 1.1 PF/s -- half of the
+// ~34 TB/s aggregate L2 bandwidth -- and a wave reads 1 KiB of LDS per MFMA.  128x256 cuts the operand stream to 3/4 and
+// the LDS reads to 0.75 KiB per MFMA at the same 16-MFMAs-per-barrier cadence; 3 resident workgroups hide the barrier.
+// LDS image: 64-B tile rows, 4 per 256-B bank row; chunk c of row r is stored at c ^ ((r>>2)&3) (conflict-free b128 reads).
+#define GEMM2_BM 128
+#define GEMM2_BN 256
+#define GEMM2_BK 32
+#define GEMM2_LDS_BYTES 49152
+
+__device__ __forceinline__ int gemm2_lds_off(int row, int chunk) {
+    return (((row >> 2) << 4) + ((row & 3) << 2) + (chunk ^ ((row >> 2) & 3))) << 4;
+}
+
+template <int ACT, bool SWIGLU, bool OUT_F32, bool GATHER>
+__global__ __launch_bounds__(256, 3) void gemm2_bf16_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char vl2_smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int t = xcd_remap(blockIdx.x, gridDim.x);
+    const int grp_sz = 8 * p.tiles_n;
+    const int first_m = (t / grp_sz) * 8;
+    const int gm = (p.tiles_m - first_m) < 8 ? (p.tiles_m - first_m) : 8;
+    const int tm = first_m + (t % grp_sz) % gm, tn = (t % grp_sz) / gm;
+    const int m0 = tm * GEMM2_BM, n0 = tn * GEMM2_BN;
+
+    // staging: A tile 128 rows x 4 chunks = 2 LDS-DMA per thread; W tile 256 rows x 4 chunks = 4 per thread.
+    // 32-bit element offsets from the (uniform) base pointers keep the address state in few VGPRs.
+    const int slot0 = (wave << 6) + lane;                          // i-th LDS-DMA covers slot0 + 256*i  (64 rows per i)
+    const int srow = 4 * (slot0 >> 4) + ((slot0 & 15) >> 2);
+    const int schk = (slot0 & 3) ^ ((slot0 >> 4) & 3);             // (R & 3) is the same for every i (R advances by 16)
+    int a_row[2];
+    unsigned a_off[2];
 #pragma unroll
-        for (int pass = 0; pass < 32 / RPP; ++pass) {
-            const int row = pass * RPP + lane / LPR;
-            const int cg = (lane % LPR) * 8;
-            const int m = m0 + wm * 64 + mi * 32 + row;
-            if (m < p.M) {
-                float v[8];
-                const int nfull = n0 + wn * 64 + cg;   // column in the (un-halved) GEMM N space
-                if (SWIGLU) {
+    for (int i = 0; i < 2; ++i) {
+        int am = m0 + srow + 64 * i;
+        am = am < p.M ? am : p.M - 1;
+        a_row[i] = am;
+        a_off[i] = (unsigned)am * (unsigned)p.lda + schk * 8;
+    }
+    const unsigned b_off = (unsigned)(n0 + srow) * (unsigned)p.ldw + schk * 8;
+    const unsigned b_step = 64u * (unsigned)p.ldw;
+
+    auto stage = [&](int buf, int kt) {
+        unsigned char* As = vl2_smem + buf * 24576;
+        unsigned char* Bs = As + 8192;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float g = ep[row * 68 + cg + j], u = ep[row * 68 + 32 + cg + j];
-                        v[j] = silu_f(g) * u;
-                    }
-                } else {
-                    const f32x4 x0 = *(const f32x4*)(ep + row * 68 + cg), x1 = *(const f32x4*)(ep + row * 68 + cg + 4);
+        for (int i = 0; i < 2; ++i) {
+            const bf16_t* src;
+            if (GATHER) {
+                const int k = kt * GEMM2_BK;
+                const int seg = k / p.seg_k, koff = k - seg * p.seg_k;
+                const int r = p.a_idx[(size_t)seg * p.M + a_row[i]];
+                src = (r < 0 ? p.zero_row : p.A + (size_t)r * p.lda) + koff + schk * 8;
+            } else {
+                src = p.A + a_off[i] + kt * GEMM2_BK;
+            }
+            glds16(src, As + ((i * 4 + wave) << 10));
+        }
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { v[j] = x0[j]; v[4 + j] = x1[j]; }
-                    if (p.bias) {
-                        const f32x4 b0 = *(const f32x4*)(p.bias + nfull), b1 = *(const f32x4*)(p.bias + nfull + 4);
+        for (int i = 0; i < 4; ++i) glds16(p.W + b_off + i * b_step + kt * GEMM2_BK, Bs + ((i * 4 + wave) << 10));
+    };
+
+    f32x16 acc[2][4];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) { v[j] += b0[j]; v[4 + j] += b1[j]; }
-                    }
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        if (ACT == ACT_QGELU) v[j] = quick_gelu_f(v[j]);
-                        if (ACT == ACT_GELU) v[j] = gelu_erf_f(v[j]);
-                        if (ACT == ACT_SILU) v[j] = silu_f(v[j]);
-                    }
-                }
-                const int n = SWIGLU ? ((n0 + wn * 64) >> 1) + cg : nfull;
-                const int orow = p.out_grp > 0 ? m + (m / p.out_grp) * p.out_grp_pad + p.out_row_off : m;
-                if (p.res) {
-                    const int rrow = p.res_row_mod > 0 ? (m % p.res_row_mod) + p.res_row_off : orow;
-                    const u32x4 rv = *(const u32x4*)(p.res + (size_t)rrow * p.ldres + n);
-                    float rf[8];
-                    unpack8(rv, rf);
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] += rf[j];
-                }
-                if (OUT_F32) {
-                    float* c = (float*)p.C + (size_t)orow * p.ldc + n;
-                    f32x4 o0, o1;
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nt = p.K / GEMM2_BK;
+    const int frow = lane & 31, fchk = lane >> 5;
+    stage(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nt; ++kt) {
+        if (kt + 1 < nt) stage((kt + 1) & 1, kt + 1);
+        const unsigned char* As = vl2_smem + (kt & 1) * 24576;
+        const unsigned char* Bs = As + 8192;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { o0[j] = v[j]; o1[j] = v[4 + j]; }
-                    *(f32x4*)c = o0;
-                    *(f32x4*)(c + 4) = o1;
-                } else {
-                    *(u32x4*)((bf16_t*)p.C + (size_t)orow * p.ldc + n) = pack8(v);
-                }
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = *(const bf16x8*)(As + gemm2_lds_off(wm * 64 + i * 32 + frow, ks * 2 + fchk));
+#pragma unroll
+            for (int jh = 0; jh < 2; ++jh) {                      // two W fragments live at a time (register budget 168)
+                bf16x8 bfr[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    bfr[j] = *(const bf16x8*)(Bs + gemm2_lds_off(wn * 128 + (jh * 2 + j) * 32 + frow, ks * 2 + fchk));
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][jh * 2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][jh * 2 + j], 0, 0, 0);
             }
         }
         __syncthreads();
     }
+
+    // epilogue: four 32 x 64 patches per wave (2 row blocks x 2 column halves), same store path as gemm_bf16_kernel
+    float* ep = (float*)vl2_smem + wave * (32 * 68);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh) {
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    ep[row * 68 + ni * 32 + (lane & 31)] = acc[mi][nh * 2 + ni][r];
+                }
+            __syncthreads();
+            gemm_store_patch<ACT, SWIGLU, OUT_F32>(p, ep, m0 + wm * 64 + mi * 32, n0 + wn * 128 + nh * 64, lane);
+            __syncthreads();
+        }
 }

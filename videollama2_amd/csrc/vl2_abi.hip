@@ -31,9 +31,24 @@ static int32_t launched(const char* what) {
 extern "C" int32_t vl2_version(void) { return VL2_ABI_VERSION; }
 extern "C" const char* vl2_last_error_string(void) { return g_err; }
 
+static int g_gemm_variant = 0;
+extern "C" int32_t vl2_set_tuning(int32_t key, int32_t value) {
+    if (key == VL2_TUNE_GEMM_VARIANT && value >= 0 && value <= 2) { g_gemm_variant = value; return 0; }
+    return fail(VL2_E_BADARG, "vl2_set_tuning: unknown key/value %d/%d", key, value);
+}
+
 // ------------------------------------------------------------------------------------------------ GEMM
 template <int ACT, bool SW, bool F32, bool G>
-static void launch_gemm(const GemmArgs& a, hipStream_t s) {
+static void launch_gemm(const GemmArgs& a0, hipStream_t s) {
+    const bool v2 = (a0.N % GEMM2_BN == 0) && (g_gemm_variant == 2 || (g_gemm_variant == 0 && a0.N >= 2048));
+    if (v2) {
+        GemmArgs a = a0;
+        a.tiles_m = (a.M + GEMM2_BM - 1) / GEMM2_BM;
+        a.tiles_n = a.N / GEMM2_BN;
+        hipLaunchKernelGGL((gemm2_bf16_kernel<ACT, SW, F32, G>), dim3(a.tiles_m * a.tiles_n), dim3(256), GEMM2_LDS_BYTES, s, a);
+        return;
+    }
+    const GemmArgs& a = a0;
     static bool attr_set = false;   // 64 KiB dynamic LDS needs the opt-in once per kernel instance
     if (!attr_set) {
         hipFuncSetAttribute((const void*)gemm_bf16_kernel<ACT, SW, F32, G>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -223,9 +238,10 @@ extern "C" int32_t vl2_attn_decode(const void* q, const void* kcache, const void
         return fail(VL2_E_BADARG, "vl2_attn_decode: bad args");
     const int group = nh / nkv;
     if (group * nkv != nh || group > 4 || ctx > smax) return fail(VL2_E_SHAPE, "vl2_attn_decode: need nh = nkv*group, group<=4, ctx<=smax");
-    const int nsplit = (ctx + chunk - 1) / chunk;
-    hipLaunchKernelGGL(attn_decode_kernel, dim3(nsplit, nkv), dim3(group * 64), 0, ST(stream), (const bf16_t*)q,
-                       (const bf16_t*)kcache, (const bf16_t*)vcache, partial, nh, group, smax, ctx, chunk,
+    (void)chunk;                                    // slice size is fixed at 64 keys per workgroup
+    const int nsplit = (ctx + 63) / 64;
+    hipLaunchKernelGGL(attn_decode_kernel, dim3(nsplit, nkv), dim3(256), 0, ST(stream), (const bf16_t*)q,
+                       (const bf16_t*)kcache, (const bf16_t*)vcache, partial, nh, group, smax, ctx,
                        scale * 1.4426950408889634f);
     hipLaunchKernelGGL(attn_decode_combine_kernel, dim3(nh), dim3(128), 0, ST(stream), partial, (bf16_t*)out, nsplit);
     return launched("vl2_attn_decode");

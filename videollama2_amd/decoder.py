@@ -29,7 +29,7 @@ class HipMistralDecoder(nn.Module):
         bf = dict(dtype=torch.bfloat16, device=self._dev)
         self.kcache = [torch.zeros((self.nkv, max_seq_len, self.hd), **bf) for _ in range(self.n_layers)]
         self.vcache = [torch.zeros((self.nkv, max_seq_len, self.hd), **bf) for _ in range(self.n_layers)]
-        self.decode_chunk = 256
+        self.decode_chunk = 64
         nsplit_max = (max_seq_len + self.decode_chunk - 1) // self.decode_chunk
         self.partial = torch.empty((self.nh * nsplit_max * 130,), dtype=torch.float32, device=self._dev)
         self.tok = torch.zeros((1,), dtype=torch.int32, device=self._dev)

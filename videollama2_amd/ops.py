@@ -30,6 +30,11 @@ def _chk(t, dtype, name):
         raise ValueError(f"{name} must be contiguous in its last dim")
 
 
+def set_gemm_variant(v):
+    """0 auto, 1 force 128x128x64, 2 force 128x256x32 (A/B benchmarking knob, include/vl2hip.h)."""
+    _lib.call("vl2_set_tuning", 1, int(v))
+
+
 def gemm(a, w, bias=None, res=None, act=ACT_NONE, swiglu=False, out_f32=False, out=None, M=None,
          gather=None, out_map=None, res_map=None, flop_k=None):
     """C = epilogue(a @ w.T).  a [M,K] bf16 (or row pool when `gather`), w [N,K] bf16, bias fp32 [N], res bf16 rows.
