@@ -20,10 +20,12 @@ static int g_gemm_variant = 0;
 extern "C" int32_t vl2_set_tuning(int32_t key, int32_t value) { if (key == 1) { g_gemm_variant = value; return 0; } return -1; }
 template <int ACT, bool SW, bool F32, bool G>
 static void run_gemm(GemmArgs a) {
-    if ((a.N % 256 == 0) && (g_gemm_variant == 2 || (g_gemm_variant == 0 && a.N >= 2048))) {
-        a.tiles_m = (a.M + 127) / 128; a.tiles_n = a.N / 256;
-        emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(256), [=] { gemm2_bf16_kernel<ACT, SW, F32, G>(a); });
-        return;
+    if constexpr (!G) {
+        if (g_gemm_variant == 4 && a.N % 256 == 0) {
+            a.tiles_m = (a.M + 127) / 128; a.tiles_n = a.N / 256;
+            emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(512), [=] { gemm3_bf16_kernel<ACT, SW, F32>(a); });
+            return;
+        }
     }
     emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(256), [=] { gemm_bf16_kernel<ACT, SW, F32, G>(a); });
 }

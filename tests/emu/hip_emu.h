@@ -197,6 +197,7 @@ inline void global_load_lds(const void* g, void* lds, unsigned size, int offset,
 #define __builtin_amdgcn_readfirstlane(x) emu::shfl_idx((x), 0)
 #define __builtin_amdgcn_fdot2_f32_bf16(a, b, c, cl) emu::dot2((a), (b), (c))
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
+#define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_s_sleep(x) ((void)0)
 #define __builtin_nontemporal_load(p) (*(p))

@@ -206,124 +206,134 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// gemm2: 128 x 256 block tile, BK = 32, 4 waves (2x2), wave tile 64 x 128 = 2x4 v_mfma_f32_32x32x16_bf16 (128 acc VGPRs),
-// double-buffered 2 x (8 KiB A + 16 KiB W) = 48 KiB LDS -> THREE workgroups per CU (<= 168 VGPRs).
-// Why: at 128x128 the L2 -> LDS operand stream is 15.3 B/kFLOP, i.e. ~17 TB/s chip-wide at 1.1 PF/s -- half of the
-// ~34 TB/s aggregate L2 bandwidth -- and a wave reads 1 KiB of LDS per MFMA.  128x256 cuts the operand stream to 3/4 and
-// the LDS reads to 0.75 KiB per MFMA at the same 16-MFMAs-per-barrier cadence; 3 resident workgroups hide the barrier.
-// LDS image: 64-B tile rows, 4 per 256-B bank row; chunk c of row r is stored at c ^ ((r>>2)&3) (conflict-free b128 reads).
-#define GEMM2_BM 128
-#define GEMM2_BN 256
-#define GEMM2_BK 32
-#define GEMM2_LDS_BYTES 49152
+// gemm3 "ping-pong": 128 (M) x 256 (N) block tile, BK = 64, 8 waves = two groups of 4 (waves 0-3 / 4-7; waves w and
+// w+4 share a SIMD).  Group g owns the 128 x 128 half-tile A x W_g (wave tile 64 x 64, as gemm_bf16_kernel).
+// Why: PMC on the 128x128 kernel (profiles/r01_gemm_pmc.md) shows each wave spends ~52 % of its cycles stalled on MFMA
+// issue behind its SIMD partner and ~27 % parked at waitcnt/barrier: with two identical in-order waves per SIMD, a wave
+// stuck behind the partner's MFMA cannot issue its own ds_reads / LDS-DMA either.  Here the two waves of a SIMD run in
+// anti-phase: in every phase one group issues ONLY MFMAs (16 per wave, operands already in registers) while the other
+// issues ONLY memory work (all 16 ds_read_b128 of its next K-tile into registers + its share of the LDS-DMA for the
+// tile after next), phases separated by a raw s_barrier; roles swap every phase.
+//   group g:  LOAD(t) at phase 2t+g,  MFMA(t) at phase 2t+g+1.
+// LDS: 3 stages x (A 16 KiB | W_0 16 KiB | W_1 16 KiB) = 144 KiB, one workgroup per CU.  The stage of tile t is read in
+// phases 2t and 2t+1 and refilled with tile t+3 from phase 2t+2 on; every LDS-DMA has >= 3 phases of flight time and
+// is retired with a COUNTED vmcnt (never 0 in the main loop: the newest 6 stay in flight) followed by the phase barrier.
+#define GEMM3_BM 128
+#define GEMM3_BN 256
+#define GEMM3_BK 64
+#define GEMM3_STAGE 49152
+#define GEMM3_LDS_BYTES (3 * GEMM3_STAGE)
 
-__device__ __forceinline__ int gemm2_lds_off(int row, int chunk) {
-    return (((row >> 2) << 4) + ((row & 3) << 2) + (chunk ^ ((row >> 2) & 3))) << 4;
-}
+// s_waitcnt with only vmcnt active (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14)
+#define VL2_WAIT_VMCNT(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (7 << 4) | (15 << 8) | (((n) >> 4) << 14))
+#define VL2_WAIT_LGKMCNT0() __builtin_amdgcn_s_waitcnt(15 | (7 << 4) | (0 << 8) | (3 << 14))
 
-template <int ACT, bool SWIGLU, bool OUT_F32, bool GATHER>
-__global__ __launch_bounds__(256, 3) void gemm2_bf16_kernel(GemmArgs p) {
+template <int ACT, bool SWIGLU, bool OUT_F32>
+__global__ __launch_bounds__(512, 2) void gemm3_bf16_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char vl2_smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    // which waves share a SIMD is not architecturally defined (speed only); measured: waves w and w+4 (scripts/ubench)
+    const int grp = wave >> 2, w4 = wave & 3;
+    const int wm = w4 >> 1, wn = w4 & 1;
 
-    const int t = xcd_remap(blockIdx.x, gridDim.x);
+    const int t0 = xcd_remap(blockIdx.x, gridDim.x);
     const int grp_sz = 8 * p.tiles_n;
-    const int first_m = (t / grp_sz) * 8;
+    const int first_m = (t0 / grp_sz) * 8;
     const int gm = (p.tiles_m - first_m) < 8 ? (p.tiles_m - first_m) : 8;
-    const int tm = first_m + (t % grp_sz) % gm, tn = (t % grp_sz) / gm;
-    const int m0 = tm * GEMM2_BM, n0 = tn * GEMM2_BN;
+    const int tm = first_m + (t0 % grp_sz) % gm, tn = (t0 % grp_sz) / gm;
+    const int m0 = tm * GEMM3_BM, n0 = tn * GEMM3_BN;
 
-    // staging: A tile 128 rows x 4 chunks = 2 LDS-DMA per thread; W tile 256 rows x 4 chunks = 4 per thread.
-    // 32-bit element offsets from the (uniform) base pointers keep the address state in few VGPRs.
-    const int slot0 = (wave << 6) + lane;                          // i-th LDS-DMA covers slot0 + 256*i  (64 rows per i)
-    const int srow = 4 * (slot0 >> 4) + ((slot0 & 15) >> 2);
-    const int schk = (slot0 & 3) ^ ((slot0 >> 4) & 3);             // (R & 3) is the same for every i (R advances by 16)
-    int a_row[2];
-    unsigned a_off[2];
+    // LDS-DMA parts of one K-tile issued by THIS wave: 4 x W_grp (its own half, 128 rows) + 2 x A (rows 64*grp..+63).
+    // Slot -> (row, chunk) is the gemm_bf16_kernel image (two 128-B tile rows per 256-B bank row, slot ^ (R & 15)).
+    unsigned w_off[4], a_off[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int slot = ((i * 4 + w4) << 6) + lane;
+        const int R = slot >> 4, s = (slot & 15) ^ (R & 15);
+        w_off[i] = (unsigned)(n0 + grp * 128 + 2 * R + (s >> 3)) * (unsigned)p.ldw + (s & 7) * 8;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        int am = m0 + srow + 64 * i;
+        const int slot = (((grp * 2 + i) * 4 + w4) << 6) + lane;          // A image slots [grp*512, grp*512+512)
+        const int R = slot >> 4, s = (slot & 15) ^ (R & 15);
+        int am = m0 + 2 * R + (s >> 3);
         am = am < p.M ? am : p.M - 1;
-        a_row[i] = am;
-        a_off[i] = (unsigned)am * (unsigned)p.lda + schk * 8;
+        a_off[i] = (unsigned)am * (unsigned)p.lda + (s & 7) * 8;
     }
-    const unsigned b_off = (unsigned)(n0 + srow) * (unsigned)p.ldw + schk * 8;
-    const unsigned b_step = 64u * (unsigned)p.ldw;
-
-    auto stage = [&](int buf, int kt) {
-        unsigned char* As = vl2_smem + buf * 24576;
-        unsigned char* Bs = As + 8192;
+    auto issue_dma = [&](int kt) {
+        unsigned char* st = vl2_smem + (kt % 3) * GEMM3_STAGE;
+        unsigned char* Ws = st + 16384 + grp * 16384;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const bf16_t* src;
-            if (GATHER) {
-                const int k = kt * GEMM2_BK;
-                const int seg = k / p.seg_k, koff = k - seg * p.seg_k;
-                const int r = p.a_idx[(size_t)seg * p.M + a_row[i]];
-                src = (r < 0 ? p.zero_row : p.A + (size_t)r * p.lda) + koff + schk * 8;
-            } else {
-                src = p.A + a_off[i] + kt * GEMM2_BK;
-            }
-            glds16(src, As + ((i * 4 + wave) << 10));
-        }
+        for (int i = 0; i < 4; ++i) glds16(p.W + w_off[i] + kt * GEMM3_BK, Ws + ((i * 4 + w4) << 10));
 #pragma unroll
-        for (int i = 0; i < 4; ++i) glds16(p.W + b_off + i * b_step + kt * GEMM2_BK, Bs + ((i * 4 + wave) << 10));
+        for (int i = 0; i < 2; ++i) glds16(p.A + a_off[i] + kt * GEMM3_BK, st + (((grp * 2 + i) * 4 + w4) << 10));
     };
 
-    f32x16 acc[2][4];
+    f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    bf16x8 fa[4][2], fb[4][2];           // the whole K-tile of this wave's fragments (64 VGPRs)
 
-    const int nt = p.K / GEMM2_BK;
+    const int nt = p.K / GEMM3_BK;
     const int frow = lane & 31, fchk = lane >> 5;
-    stage(0, 0);
-    __syncthreads();
-    for (int kt = 0; kt < nt; ++kt) {
-        if (kt + 1 < nt) stage((kt + 1) & 1, kt + 1);
-        const unsigned char* As = vl2_smem + (kt & 1) * 24576;
-        const unsigned char* Bs = As + 8192;
+    issue_dma(0);
+    if (nt > 1) issue_dma(1);
+    if (nt > 1) VL2_WAIT_VMCNT(6); else VL2_WAIT_VMCNT(0);
+    __builtin_amdgcn_s_barrier();
+
+    // Both groups run the SAME straight-line loop body {LOAD(t); barrier; MFMA(t); barrier}; group 1 is shifted by one
+    // phase with a leading barrier (group 0 gets the matching trailing one), so the groups are always in opposite roles.
+    if (grp == 1) __builtin_amdgcn_s_barrier();
+    for (int t = 0; t < nt; ++t) {
+        // ---------------- LOAD(t): memory work only
+        const bool more = t + 2 < nt;
+        if (more) issue_dma(t + 2);
+        const unsigned char* st = vl2_smem + (t % 3) * GEMM3_STAGE;
+        const unsigned char* Ws = st + 16384 + grp * 16384;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 af[2];
+        for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) af[i] = *(const bf16x8*)(As + gemm2_lds_off(wm * 64 + i * 32 + frow, ks * 2 + fchk));
+            for (int i = 0; i < 2; ++i) {
+                fa[ks][i] = *(const bf16x8*)(st + gemm_lds_off(wm * 64 + i * 32 + frow, ks * 2 + fchk));
+                fb[ks][i] = *(const bf16x8*)(Ws + gemm_lds_off(wn * 64 + i * 32 + frow, ks * 2 + fchk));
+            }
+        // retire everything but the DMA just issued: tile t+1 (issued one LOAD ago) must have landed before the barrier
+        // that opens the phase in which either group reads it; the ds_reads must be done before this stage is refilled
+        if (more) VL2_WAIT_VMCNT(6); else VL2_WAIT_VMCNT(0);
+        VL2_WAIT_LGKMCNT0();
+        __builtin_amdgcn_s_barrier();
+        // ---------------- MFMA(t): matrix work only
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int jh = 0; jh < 2; ++jh) {                      // two W fragments live at a time (register budget 168)
-                bf16x8 bfr[2];
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    bfr[j] = *(const bf16x8*)(Bs + gemm2_lds_off(wn * 128 + (jh * 2 + j) * 32 + frow, ks * 2 + fchk));
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][jh * 2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][jh * 2 + j], 0, 0, 0);
-            }
-        }
-        __syncthreads();
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
     }
+    if (grp == 0) __builtin_amdgcn_s_barrier();
 
-    // epilogue: four 32 x 64 patches per wave (2 row blocks x 2 column halves), same store path as gemm_bf16_kernel
+    // ---- epilogue (all DMA retired, every wave past its last phase): same patch path as gemm_bf16_kernel
     float* ep = (float*)vl2_smem + wave * (32 * 68);
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
-        for (int nh = 0; nh < 2; ++nh) {
+        for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    ep[row * 68 + ni * 32 + (lane & 31)] = acc[mi][nh * 2 + ni][r];
-                }
-            __syncthreads();
-            gemm_store_patch<ACT, SWIGLU, OUT_F32>(p, ep, m0 + wm * 64 + mi * 32, n0 + wn * 128 + nh * 64, lane);
-            __syncthreads();
-        }
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                ep[row * 68 + ni * 32 + (lane & 31)] = acc[mi][ni][r];
+            }
+        __syncthreads();
+        gemm_store_patch<ACT, SWIGLU, OUT_F32>(p, ep, m0 + wm * 64 + mi * 32, n0 + grp * 128 + wn * 64, lane);
+        __syncthreads();
+    }
 }

@@ -33,20 +33,27 @@ extern "C" const char* vl2_last_error_string(void) { return g_err; }
 
 static int g_gemm_variant = 0;
 extern "C" int32_t vl2_set_tuning(int32_t key, int32_t value) {
-    if (key == VL2_TUNE_GEMM_VARIANT && value >= 0 && value <= 2) { g_gemm_variant = value; return 0; }
+    if (key == VL2_TUNE_GEMM_VARIANT && (value == 0 || value == 1 || value == 4)) { g_gemm_variant = value; return 0; }
     return fail(VL2_E_BADARG, "vl2_set_tuning: unknown key/value %d/%d", key, value);
 }
 
 // ------------------------------------------------------------------------------------------------ GEMM
 template <int ACT, bool SW, bool F32, bool G>
 static void launch_gemm(const GemmArgs& a0, hipStream_t s) {
-    const bool v2 = (a0.N % GEMM2_BN == 0) && (g_gemm_variant == 2 || (g_gemm_variant == 0 && a0.N >= 2048));
-    if (v2) {
-        GemmArgs a = a0;
-        a.tiles_m = (a.M + GEMM2_BM - 1) / GEMM2_BM;
-        a.tiles_n = a.N / GEMM2_BN;
-        hipLaunchKernelGGL((gemm2_bf16_kernel<ACT, SW, F32, G>), dim3(a.tiles_m * a.tiles_n), dim3(256), GEMM2_LDS_BYTES, s, a);
-        return;
+    if constexpr (!G) {
+        if (g_gemm_variant == 4 && a0.N % GEMM3_BN == 0) {
+            static bool attr3 = false;   // 144 KiB dynamic LDS needs the opt-in once per kernel instance
+            if (!attr3) {
+                hipFuncSetAttribute((const void*)gemm3_bf16_kernel<ACT, SW, F32>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    GEMM3_LDS_BYTES);
+                attr3 = true;
+            }
+            GemmArgs a = a0;
+            a.tiles_m = (a.M + GEMM3_BM - 1) / GEMM3_BM;
+            a.tiles_n = a.N / GEMM3_BN;
+            hipLaunchKernelGGL((gemm3_bf16_kernel<ACT, SW, F32>), dim3(a.tiles_m * a.tiles_n), dim3(512), GEMM3_LDS_BYTES, s, a);
+            return;
+        }
     }
     const GemmArgs& a = a0;
     static bool attr_set = false;   // 64 KiB dynamic LDS needs the opt-in once per kernel instance
