@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--new-tokens", type=int, default=32)
     ap.add_argument("--llm-layers", type=int, default=None, help="debug only: fewer decoder layers (INVALID as a result)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="eager decode loop instead of hipGraph replay")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -119,22 +120,33 @@ def main():
     mask = torch.ones_like(ids)
 
     ev = lambda: torch.cuda.Event(enable_timing=True)
+    graph = None
 
     def step(rec=None):
         e = [ev() for _ in range(4)]
         e[0].record()
         _, _, _, emb, _ = model.prepare_inputs_labels_for_multimodal(ids, mask, None, None, [(frames, "video")])
         e[1].record()
-        logits = model.decoder.prefill(emb[0])
+        dec = model.decoder
+        dec.prefill(emb[0])                          # logits of the last position -> dec.logits
         e[2].record()
-        for s in range(n_new):                       # fixed length: stop criteria disabled for timing
-            ops.argmax(logits, model.decoder.tok)
-            logits = model.decoder.decode_step(model.decoder.tok)
+        if graph is not None:                        # one captured hipGraph per token: argmax + the whole decode step
+            dec.state.copy_(torch.tensor([dec.pos - 1, 0], dtype=torch.int32), non_blocking=True)
+            for s in range(n_new):                   # fixed length: stop criteria disabled for timing
+                graph.replay()
+            dec.pos += n_new
+        else:
+            for s in range(n_new):
+                ops.argmax(dec.logits, dec.tok)
+                dec.decode_step()
         e[3].record()
         if rec is not None:
             rec.append(e)
         return emb.shape[1]
 
+    S = step()                                       # eager pass (also performs every first-launch initialisation)
+    if not args.no_graph:
+        graph = model.decoder.capture_graph()
     for _ in range(args.warmup):
         S = step()
     torch.cuda.synchronize()
@@ -188,7 +200,8 @@ def main():
             "config": {"workload": f"VideoLLaMA2-7B, {T}-frame 336^2 video, bf16, S={S} prefill, {n_new} greedy decode tokens "
                                    f"(BASELINE.json configs[1])", "frames": T, "prefill_tokens": S, "new_tokens": n_new,
                        "parallelism": f"frames sharded over {world} rank(s) + RCCL all-gather; connector/LLM replicated",
-                       "llm_layers": len(model.decoder.w["layers"])},
+                       "llm_layers": len(model.decoder.w["layers"]),
+                       "decode": "eager launches" if graph is None else "hipGraph replay (argmax + 32-layer step per token)"},
             "encode_ms": round(enc_ms, 3), "prefill_ms": round(pre_ms, 3), "decode_ms_per_token": round(dec_ms / n_new, 4),
             "prefill_tokens_per_s": round(S / (pre_ms / 1e3), 1), "decode_tokens_per_s": round(n_new / (dec_ms / 1e3), 2),
             "forward_tflop": round(vit_tf + stc_tf + pre_tf, 3),

@@ -102,13 +102,19 @@ int32_t vl2_rope_kv(const void* qkv, void* q_out, void* kcache, void* vcache, co
 /* y[N] = W[N,K] x[K] for one token (decode).  norm_w != NULL fuses MistralRMSNorm on x first.  flags as vl2_gemm_bf16. */
 int32_t vl2_gemv_bf16(const void* W, const void* x, const float* norm_w, const void* res, void* y, int32_t N, int32_t K,
                       int32_t ldw, float eps, int32_t flags, void* stream);
-/* one query token vs the KV cache rows [0, ctx); partial: fp32 workspace >= nh*ceil(ctx/64)*130 floats (`chunk` is
- * accepted for ABI stability and ignored: the context is split in 64-key slices). */
-int32_t vl2_attn_decode(const void* q, const void* kcache, const void* vcache, float* partial, void* out, int32_t nh,
-                        int32_t nkv, int32_t smax, int32_t ctx, int32_t chunk, float scale, void* stream);
+/* Decode attention for ONE new token at position pos, fused with RoPE and the KV-cache append:
+ *   qkv [(nh+2*nkv)*128] = un-roped fused q|k|v projection of the token; the kernel ropes q, ropes k and appends k,v to
+ *   cache row pos (HF apply_rotary_pos_emb + DynamicCache.update), then softmax(q K^T / sqrt(d)) V over rows [0, pos]
+ *   split in 64-key slices (flash-decoding), and combines the slices into out [nh*128] bf16.
+ *   pos_dev != NULL: the position is read from device memory (*pos_dev) so a captured hipGraph replays as it moves; the
+ *   launch then covers positions < ctx_cap.  partial: fp32 workspace >= nh*ceil(cap/64)*130 floats (cap = ctx_cap or pos+1). */
+int32_t vl2_attn_decode(const void* qkv, void* kcache, void* vcache, const float* cos_t, const float* sin_t, float* partial,
+                        void* out, int32_t nh, int32_t nkv, int32_t smax, int32_t pos, const int32_t* pos_dev,
+                        int32_t ctx_cap, float scale, void* stream);
 /* greedy argmax (first maximal index) of fp32 logits -> *tok (device int32) and hist[step] if hist != NULL.
- * HF:generation/utils.py _sample with do_sample=False (videollama2/__init__.py:93-99). */
-int32_t vl2_argmax(const float* logits, int32_t V, int32_t* tok, int32_t* hist, int32_t step, void* stream);
+ * state != NULL (device int32[2] = {position, step}): hist index = state[1], then both counters advance by one, so the
+ * whole decode step is replayable from a hipGraph.  HF:generation/utils.py _sample with do_sample=False. */
+int32_t vl2_argmax(const float* logits, int32_t V, int32_t* tok, int32_t* hist, int32_t step, int32_t* state, void* stream);
 /* out[i,:] = table[ids[i],:]; ids int32 device.  embed_tokens in videollama2/model/videollama2_arch.py:203-220. */
 int32_t vl2_embed_rows(const int32_t* ids, const void* table, void* out, int32_t n, int32_t D, int32_t ldo, void* stream);
 

@@ -87,8 +87,11 @@ def main():
     out["attn_prefill"] = dict(us=round(us, 1), tflops=round(4.0 * nh * (S * (S + 1) / 2) * D / us / 1e6, 1))
     part = torch.empty(nh * 64 * 130, device=dev)
     od = torch.empty(nh * D, dtype=torch.bfloat16, device=dev)
-    q1 = rnd(nh * D)
-    us = timeit(lambda: ops.attn_decode(q1, kc, vc, part, od, nh, nkv, 1650, 64, D ** -0.5), iters=50)
+    qkv1 = rnd((nh + 2 * nkv) * D)
+    inv = 1.0 / (1e6 ** (torch.arange(0, D, 2).float() / D))
+    fr = torch.arange(smax).float()[:, None] * inv[None]
+    cos_t, sin_t = fr.cos().contiguous().to(dev), fr.sin().contiguous().to(dev)
+    us = timeit(lambda: ops.attn_decode(qkv1, kc, vc, cos_t, sin_t, part, od, nh, nkv, 1650, D ** -0.5), iters=50)
     out["attn_decode_ctx1650"] = dict(us=round(us, 1), gbs=round(2 * 1650 * nkv * D * 2 / us / 1e3, 1))
     # decode gemv
     for name, N, K, kw in (("gemv_qkv", 6144, 4096, dict(norm=True)), ("gemv_wo", 4096, 4096, dict()), ("gemv_gateup", 28672, 4096, dict(swiglu=True, norm=True)),

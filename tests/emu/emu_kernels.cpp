@@ -137,16 +137,18 @@ extern "C" int32_t vl2_gemv_bf16(const void* W, const void* x, const float* norm
     else emu::launch(g, blk, [=] { gemv_bf16_kernel<false, false, 2>(a); });
     return 0;
 }
-extern "C" int32_t vl2_attn_decode(const void* q, const void* kc, const void* vc, float* partial, void* out, int32_t nh,
-                                   int32_t nkv, int32_t smax, int32_t ctx, int32_t chunk, float scale, void*) {
-    const int group = nh / nkv, nsplit = (ctx + 63) / 64;
+extern "C" int32_t vl2_attn_decode(const void* qkv, void* kc, void* vc, const float* cos_t, const float* sin_t, float* partial,
+                                   void* out, int32_t nh, int32_t nkv, int32_t smax, int32_t pos, const int32_t* pos_dev,
+                                   int32_t ctx_cap, float scale, void*) {
+    const int group = nh / nkv, cap = pos_dev ? ctx_cap : pos + 1, nsplit = (cap + 63) / 64;
+    if (cap <= 0 || cap > smax) return -2;
     emu::launch(dim3(nsplit, nkv), dim3(256), [=] {
-        attn_decode_kernel((const bf16_t*)q, (const bf16_t*)kc, (const bf16_t*)vc, partial, nh, group, smax, ctx, scale * 1.4426950408889634f); });
-    emu::launch(dim3(nh), dim3(128), [=] { attn_decode_combine_kernel(partial, (bf16_t*)out, nsplit); });
+        attn_decode_kernel((const bf16_t*)qkv, (bf16_t*)kc, (bf16_t*)vc, cos_t, sin_t, partial, nh, group, nkv, smax, pos, pos_dev, scale * 1.4426950408889634f); });
+    emu::launch(dim3(nh), dim3(128), [=] { attn_decode_combine_kernel(partial, (bf16_t*)out, nsplit, pos, pos_dev); });
     return 0;
 }
-extern "C" int32_t vl2_argmax(const float* logits, int32_t V, int32_t* tok, int32_t* hist, int32_t step, void*) {
-    emu::launch(dim3(1), dim3(1024), [=] { argmax_kernel(logits, V, tok, hist, step); });
+extern "C" int32_t vl2_argmax(const float* logits, int32_t V, int32_t* tok, int32_t* hist, int32_t step, int32_t* state, void*) {
+    emu::launch(dim3(1), dim3(1024), [=] { argmax_kernel(logits, V, tok, hist, step, state); });
     return 0;
 }
 extern "C" int32_t vl2_embed_rows(const int32_t* ids, const void* table, void* out, int32_t n, int32_t D, int32_t ldo, void*) {

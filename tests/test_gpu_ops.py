@@ -206,18 +206,35 @@ def test_gemv_swiglu(ops):
     assert rel(y, F.silu(wg.float() @ x.float()) * (wu.float() @ x.float())) < TOL_BF16_OUT
 
 
-@pytest.mark.parametrize("ctx", [1, 63, 1700])
-def test_attn_decode(ops, ctx):
-    nh, nkv, smax, chunk = 32, 8, 2048, 256
-    q, kc, vc = bf(nh * 128), bf(nkv, smax, 128), bf(nkv, smax, 128, seed=1)
-    part = torch.zeros(nh * ((smax + chunk - 1) // chunk) * 130, device=DEV)
-    out = torch.zeros(nh * 128, dtype=torch.bfloat16, device=DEV)
-    ops.attn_decode(q.to(DEV), kc.to(DEV), vc.to(DEV), part, out, nh, nkv, ctx, chunk, 128 ** -0.5)
-    qf = q.float().view(nh, 128)
-    kf = kc[:, :ctx].float().repeat_interleave(nh // nkv, 0)
-    vf = vc[:, :ctx].float().repeat_interleave(nh // nkv, 0)
-    a = torch.softmax(torch.einsum("hd,hkd->hk", qf, kf) * 128 ** -0.5, -1)
-    assert rel(out, torch.einsum("hk,hkd->hd", a, vf).reshape(-1)) < TOL_BF16_OUT
+@pytest.mark.parametrize("pos", [0, 62, 63, 64, 1699])
+def test_attn_decode_fused_rope_append(ops, pos):
+    """One new token at position `pos`: RoPE(q,k) + cache append + attention over rows [0, pos], vs the fp32 oracle."""
+    nh, nkv, smax, HD = 32, 8, 2048, 128
+    qkv, kc, vc = bf((nh + 2 * nkv) * HD), bf(nkv, smax, HD), bf(nkv, smax, HD, seed=1)
+    inv = 1.0 / (1e6 ** (torch.arange(0, HD, 2).float() / HD))
+    fr = torch.arange(smax).float()[:, None] * inv[None]
+    cos_t, sin_t = fr.cos().contiguous(), fr.sin().contiguous()
+    kcd, vcd = kc.to(DEV), vc.to(DEV)
+    part = torch.zeros(nh * ((smax + 63) // 64) * 130, device=DEV)
+    out = torch.zeros(nh * HD, dtype=torch.bfloat16, device=DEV)
+    pos_dev = torch.tensor([pos], dtype=torch.int32, device=DEV)
+    for dyn in (False, True):
+        kcd.copy_(kc); vcd.copy_(vc)
+        ops.attn_decode(qkv.to(DEV), kcd, vcd, cos_t.to(DEV), sin_t.to(DEV), part, out, nh, nkv, pos, HD ** -0.5,
+                        pos_dev=pos_dev if dyn else None, ctx_cap=smax if dyn else 0)
+        rot = lambda t: torch.cat([-t[..., HD // 2:], t[..., :HD // 2]], -1)
+        emb = torch.cat([fr[pos], fr[pos]])
+        q = qkv[:nh * HD].float().view(nh, HD)
+        kn = qkv[nh * HD:(nh + nkv) * HD].float().view(nkv, HD)
+        vn = qkv[(nh + nkv) * HD:].view(nkv, HD)
+        qr = (q * emb.cos() + rot(q) * emb.sin()).bfloat16().float()
+        kr = (kn * emb.cos() + rot(kn) * emb.sin()).bfloat16()
+        assert torch.equal(kcd[:, pos].cpu(), kr) and torch.equal(vcd[:, pos].cpu(), vn)           # appended rows
+        assert torch.equal(kcd[:, :pos].cpu(), kc[:, :pos]) and torch.equal(kcd[:, pos + 1:].cpu(), kc[:, pos + 1:])
+        kf = torch.cat([kc[:, :pos], kr[:, None]], 1).float().repeat_interleave(nh // nkv, 0)
+        vf = torch.cat([vc[:, :pos], vn[:, None]], 1).float().repeat_interleave(nh // nkv, 0)
+        a = torch.softmax(torch.einsum("hd,hkd->hk", qr, kf) * HD ** -0.5, -1)
+        assert rel(out, torch.einsum("hk,hkd->hd", a, vf).reshape(-1)) < TOL_BF16_OUT
 
 
 def test_argmax_embed(ops):
@@ -228,6 +245,9 @@ def test_argmax_embed(ops):
     hist = torch.zeros(4, dtype=torch.int32, device=DEV)
     ops.argmax(lg.to(DEV), tok, hist, 2)
     assert tok.item() == 1234 and hist.tolist() == [0, 0, 1234, 0]
+    state = torch.tensor([10, 1], dtype=torch.int32, device=DEV)           # device-side {position, step} (graph replay form)
+    ops.argmax(lg.to(DEV), tok, hist, 0, state)
+    assert hist.tolist() == [0, 1234, 1234, 0] and state.tolist() == [11, 2]
     ids = torch.tensor([3, 0, 31999], dtype=torch.int32, device=DEV)
     tab = bf(32000, 256)
     out = torch.zeros(3, 256, dtype=torch.bfloat16, device=DEV)

@@ -157,3 +157,15 @@ def test_full_width_mistral_layers_prefill_and_decode():
         print("[parity] greedy path diverged on a near-tie:", out[0].tolist(), toks)
         top2 = lg[0].topk(2).values
         assert out[0, 0].item() == toks[0] or (top2[0] - top2[1]).item() < 0.05
+
+
+def test_hipgraph_decode_matches_eager(small):
+    """The captured {argmax + decode step} hipGraph must reproduce the eager loop token for token and logit for logit."""
+    g, cfg, sd, model = small
+    emb = g["inputs_embeds"].to(DEV)
+    eager, le = model.decoder.generate(emb, max_new_tokens=8, return_logits=True)
+    graph, lg = model.decoder.generate(emb, max_new_tokens=8, return_logits=True, use_graph=True)
+    assert eager.tolist() == graph.tolist()
+    assert torch.equal(le, lg)
+    graph2 = model.decoder.generate(emb, max_new_tokens=5, use_graph=True)       # replay the same graph on a fresh request
+    assert graph2[0].tolist() == eager[0, :5].tolist()

@@ -3,7 +3,7 @@
 //                              rotate_half) from the fused qkv GEMM output, + KV-cache append (DynamicCache.update).
 //   gemv_bf16_kernel         : y = W x for one token (q/k/v/o/gate/up/down/lm_head at M=1), 16-B lane loads straight to
 //                              VGPRs, v_dot2c_f32_bf16, optional fused RMSNorm prologue, residual / SwiGLU epilogue.
-//   attn_decode_kernel (+combine): one query token against the KV cache, split over the context (flash-decoding).
+//   attn_decode_kernel (+combine): RoPE + KV append + one query token against the KV cache, split over the context.
 //   argmax_kernel            : greedy token (HF:generation/utils.py _sample, do_sample=False -> torch.argmax).
 //   embed_rows_kernel        : embed_tokens gather (videollama2/model/videollama2_arch.py:203-220).
 #pragma once
@@ -143,15 +143,20 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvArgs p) {
     }
 }
 
-// ---- decode attention (flash-decoding): q [nh*128] (roped) vs cache rows [0, ctx).
-// grid = (nsplit, nkv) with nsplit = ceil(ctx/64): one workgroup per (64-key slice, kv head), 4 waves x 16 keys.
-// A lane is (key = lane&15, head-in-group = lane>>4): the K row is read once and scored against all `group` q heads;
+// ---- decode attention (flash-decoding) fused with RoPE and the KV-cache append of the new token.
+// qkv [(nh+2*nkv)*128] = the un-roped fused projection of the ONE new token at position pos (pos = *pos_dev when pos_dev
+// is non-null, so a captured hipGraph replays with a moving position).  grid = (nsplit_cap, nkv), 256 threads:
+// one workgroup per (64-key slice, kv head), 4 waves x 16 keys; slices at or beyond ctx = pos+1 exit at once.
+// A lane is (key = lane&15, head-in-group = lane>>4): a K row is read once and scored against all `group` q heads;
 // V rows are requested up front (they do not depend on the scores) so the kernel is ONE memory round trip.
-// partial: fp32 [nh][nsplit][130] = {m (exp2 domain), l, o[128]}
-__global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kcache,
-                                                          const bf16_t* __restrict__ vcache, float* __restrict__ partial,
-                                                          int nh, int group, int smax, int ctx, float scale_log2e) {
-    constexpr int HD = 128;
+// The workgroup whose slice contains pos ropes k_new, appends k_new / v_new to the cache (DynamicCache.update) first.
+// partial: fp32 [nh][nsplit_cap][130] = {m (exp2 domain), l, o[128]}
+__global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ kcache,
+                                                          bf16_t* __restrict__ vcache, const float* __restrict__ cos_t,
+                                                          const float* __restrict__ sin_t, float* __restrict__ partial,
+                                                          int nh, int group, int nkv, int smax, int pos_arg,
+                                                          const int* __restrict__ pos_dev, float scale_log2e) {
+    constexpr int HD = 128, HALF = 64;
     __shared__ __attribute__((aligned(16))) float qs[4][HD];
     __shared__ __attribute__((aligned(16))) float pk[64][4];       // p[key][head]
     __shared__ float wred[2][4][4];                                 // [max|sum][wave][head]
@@ -159,9 +164,34 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kl = lane & 15, hh = lane >> 4;
     const int split = blockIdx.x, hk = blockIdx.y, nsplit = gridDim.x;
+    const int pos = pos_dev ? *pos_dev : pos_arg;
+    const int ctx = pos + 1;
     const int k0 = split * 64;
-    const bf16_t* Kb = kcache + (size_t)hk * smax * HD;
-    const bf16_t* Vb = vcache + (size_t)hk * smax * HD;
+    if (k0 >= ctx) return;
+    bf16_t* Kb = kcache + (size_t)hk * smax * HD;
+    bf16_t* Vb = vcache + (size_t)hk * smax * HD;
+    const float* cp = cos_t + (size_t)pos * HALF;
+    const float* sp = sin_t + (size_t)pos * HALF;
+
+    // roped q of the `group` heads of this kv head -> LDS (rounded through bf16 like the unfused path)
+    for (int t = tid; t < group * HALF; t += 256) {
+        const int h = t / HALF, d = t % HALF;
+        const bf16_t* qh = qkv + (size_t)(hk * group + h) * HD;
+        const float x1 = bf2f(qh[d]), x2 = bf2f(qh[d + HALF]), c = cp[d], sn = sp[d];
+        qs[h][d] = bf2f(f2bf(x1 * c - x2 * sn));
+        qs[h][d + HALF] = bf2f(f2bf(x2 * c + x1 * sn));
+    }
+    // the slice that owns the new position appends roped k_new and v_new to the cache before anyone reads row `pos`
+    if (pos >= k0 && pos < k0 + 64 && tid < HALF) {
+        const bf16_t* kn = qkv + (size_t)(nh + hk) * HD;
+        const bf16_t* vn = qkv + (size_t)(nh + nkv + hk) * HD;
+        const float x1 = bf2f(kn[tid]), x2 = bf2f(kn[tid + HALF]), c = cp[tid], sn = sp[tid];
+        Kb[(size_t)pos * HD + tid] = f2bf(x1 * c - x2 * sn);
+        Kb[(size_t)pos * HD + tid + HALF] = f2bf(x2 * c + x1 * sn);
+        Vb[(size_t)pos * HD + tid] = vn[tid];
+        Vb[(size_t)pos * HD + tid + HALF] = vn[tid + HALF];
+    }
+    __syncthreads();       // workgroup-scope release/acquire: the appended rows are visible to this workgroup's loads
 
     // V rows of this wave's 16 keys: lane owns dims 2*lane, 2*lane+1 (256 B per key per wave, coalesced)
     uint32_t vv[16];
@@ -171,15 +201,12 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
         key = key < ctx ? key : ctx - 1;
         vv[i] = *(const uint32_t*)(Vb + (size_t)key * HD + lane * 2);
     }
-    // K row of (this lane's key)
     const int key = k0 + wave * 16 + kl;
     const bool valid = key < ctx;
     const bf16_t* kr = Kb + (size_t)(valid ? key : ctx - 1) * HD;
     u32x4 kreg[16];
 #pragma unroll
     for (int c = 0; c < 16; ++c) kreg[c] = *(const u32x4*)(kr + c * 8);
-    for (int t = tid; t < group * HD; t += 256) qs[t / HD][t % HD] = bf2f(q[(size_t)(hk * group) * HD + t]);
-    __syncthreads();
 
     const int hq = hh < group ? hh : group - 1;
     float acc = 0.f;
@@ -230,25 +257,45 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
     }
 }
 
-// grid = nh, block 128: out[h*128 + d] = sum_i o_i[d] 2^(m_i - M) / sum_i l_i 2^(m_i - M)
+// grid = nh, block 128: out[h*128 + d] = sum_i o_i[d] 2^(m_i - M) / sum_i l_i 2^(m_i - M) over the ceil(ctx/64) live slices.
+// Wave 0 turns the (m_i, l_i) pairs into weights with two shuffle reductions; then every thread sums its column with
+// independent, coalesced loads (no dependent chain over the slices).
 __global__ __launch_bounds__(128) void attn_decode_combine_kernel(const float* __restrict__ partial, bf16_t* __restrict__ out,
-                                                                  int nsplit) {
+                                                                  int nsplit_cap, int pos_arg, const int* __restrict__ pos_dev) {
+    __shared__ float wgt[64];
+    __shared__ float inv_l;
     const int h = blockIdx.x, d = threadIdx.x;
-    const float* src = partial + (size_t)h * nsplit * 130;
-    float M = -1e30f;
-    for (int i = 0; i < nsplit; ++i) M = fmaxf(M, src[i * 130]);
-    float L = 0.f, o = 0.f;
-    for (int i = 0; i < nsplit; ++i) {
-        const float w = exp2f(src[i * 130] - M);
-        L += src[i * 130 + 1] * w;
-        o += src[i * 130 + 2 + d] * w;
+    const int pos = pos_dev ? *pos_dev : pos_arg;
+    const int nsplit = (pos + 64) >> 6;                       // <= 64 (max context 4096)
+    const float* src = partial + (size_t)h * nsplit_cap * 130;
+    if (d < 64) {
+        const bool live = d < nsplit;
+        const float m = live ? src[d * 130] : -1e30f;
+        const float l = live ? src[d * 130 + 1] : 0.f;
+        const float M = wave_max(m);
+        const float w = live ? exp2f(m - M) : 0.f;
+        const float L = wave_sum(l * w);
+        wgt[d] = w;
+        if (d == 0) inv_l = 1.0f / L;
     }
-    out[h * 128 + d] = f2bf(o / L);
+    __syncthreads();
+    float o = 0.f;
+    int i = 0;
+    for (; i + 8 <= nsplit; i += 8) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = src[(i + j) * 130 + 2 + d];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o += v[j] * wgt[i + j];
+    }
+    for (; i < nsplit; ++i) o += src[i * 130 + 2 + d] * wgt[i];
+    out[h * 128 + d] = f2bf(o * inv_l);
 }
 
-// first index of the maximum of logits[V] (fp32) -> *tok (int32) and tok_hist[step]; one block of 1024 threads
+// first index of the maximum of logits[V] (fp32) -> *tok (int32) and hist[step]; one block of 1024 threads.
+// state != null (hipGraph-replayable decode): step = state[1]; afterwards state[0] (position) and state[1] advance by one.
 __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ logits, int V, int* __restrict__ tok,
-                                                      int* __restrict__ hist, int step) {
+                                                      int* __restrict__ hist, int step, int* __restrict__ state) {
     __shared__ float bv[16];
     __shared__ int bi[16];
     float best = -3.4e38f;
@@ -269,7 +316,13 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ 
         for (int w = 1; w < 16; ++w)
             if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
         *tok = idx;
-        if (hist) hist[step] = idx;
+        if (state) {
+            if (hist) hist[state[1]] = idx;
+            state[0] += 1;
+            state[1] += 1;
+        } else if (hist) {
+            hist[step] = idx;
+        }
     }
 }
 

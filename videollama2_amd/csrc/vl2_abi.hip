@@ -239,23 +239,25 @@ extern "C" int32_t vl2_gemv_bf16(const void* W, const void* x, const float* norm
     else launch_gemv<false, false>(a, N, ST(stream));
     return launched("vl2_gemv_bf16");
 }
-extern "C" int32_t vl2_attn_decode(const void* q, const void* kcache, const void* vcache, float* partial, void* out, int32_t nh,
-                                   int32_t nkv, int32_t smax, int32_t ctx, int32_t chunk, float scale, void* stream) {
-    if (!q || !kcache || !vcache || !partial || !out || nh <= 0 || nkv <= 0 || ctx <= 0 || chunk <= 0)
+extern "C" int32_t vl2_attn_decode(const void* qkv, void* kcache, void* vcache, const float* cos_t, const float* sin_t,
+                                   float* partial, void* out, int32_t nh, int32_t nkv, int32_t smax, int32_t pos,
+                                   const int32_t* pos_dev, int32_t ctx_cap, float scale, void* stream) {
+    if (!qkv || !kcache || !vcache || !cos_t || !sin_t || !partial || !out || nh <= 0 || nkv <= 0)
         return fail(VL2_E_BADARG, "vl2_attn_decode: bad args");
     const int group = nh / nkv;
-    if (group * nkv != nh || group > 4 || ctx > smax) return fail(VL2_E_SHAPE, "vl2_attn_decode: need nh = nkv*group, group<=4, ctx<=smax");
-    (void)chunk;                                    // slice size is fixed at 64 keys per workgroup
-    const int nsplit = (ctx + 63) / 64;
-    hipLaunchKernelGGL(attn_decode_kernel, dim3(nsplit, nkv), dim3(256), 0, ST(stream), (const bf16_t*)q,
-                       (const bf16_t*)kcache, (const bf16_t*)vcache, partial, nh, group, smax, ctx,
-                       scale * 1.4426950408889634f);
-    hipLaunchKernelGGL(attn_decode_combine_kernel, dim3(nh), dim3(128), 0, ST(stream), partial, (bf16_t*)out, nsplit);
+    if (group * nkv != nh || group > 4) return fail(VL2_E_SHAPE, "vl2_attn_decode: need nh = nkv*group, group<=4");
+    const int cap = pos_dev ? ctx_cap : pos + 1;                 // positions the launch must be able to cover
+    if (cap <= 0 || cap > smax || (!pos_dev && pos < 0)) return fail(VL2_E_SHAPE, "vl2_attn_decode: position %d outside the cache (%d)", cap - 1, smax);
+    const int nsplit = (cap + 63) / 64;
+    hipLaunchKernelGGL(attn_decode_kernel, dim3(nsplit, nkv), dim3(256), 0, ST(stream), (const bf16_t*)qkv, (bf16_t*)kcache,
+                       (bf16_t*)vcache, cos_t, sin_t, partial, nh, group, nkv, smax, pos, pos_dev, scale * 1.4426950408889634f);
+    hipLaunchKernelGGL(attn_decode_combine_kernel, dim3(nh), dim3(128), 0, ST(stream), partial, (bf16_t*)out, nsplit, pos, pos_dev);
     return launched("vl2_attn_decode");
 }
-extern "C" int32_t vl2_argmax(const float* logits, int32_t V, int32_t* tok, int32_t* hist, int32_t step, void* stream) {
+extern "C" int32_t vl2_argmax(const float* logits, int32_t V, int32_t* tok, int32_t* hist, int32_t step, int32_t* state,
+                              void* stream) {
     if (!logits || !tok || V <= 0) return fail(VL2_E_BADARG, "vl2_argmax: bad args");
-    hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(1024), 0, ST(stream), logits, V, tok, hist, step);
+    hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(1024), 0, ST(stream), logits, V, tok, hist, step, state);
     return launched("vl2_argmax");
 }
 extern "C" int32_t vl2_embed_rows(const int32_t* ids, const void* table, void* out, int32_t n, int32_t D, int32_t ldo, void* stream) {

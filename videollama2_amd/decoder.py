@@ -29,10 +29,19 @@ class HipMistralDecoder(nn.Module):
         bf = dict(dtype=torch.bfloat16, device=self._dev)
         self.kcache = [torch.zeros((self.nkv, max_seq_len, self.hd), **bf) for _ in range(self.n_layers)]
         self.vcache = [torch.zeros((self.nkv, max_seq_len, self.hd), **bf) for _ in range(self.n_layers)]
-        self.decode_chunk = 64
-        nsplit_max = (max_seq_len + self.decode_chunk - 1) // self.decode_chunk
+        nsplit_max = (max_seq_len + 63) // 64
         self.partial = torch.empty((self.nh * nsplit_max * 130,), dtype=torch.float32, device=self._dev)
+        # decode-step state lives on the device so that one captured hipGraph replays for every token:
+        #   tok = current token id, state = {position of the token being fed, step index}, hist = generated ids
         self.tok = torch.zeros((1,), dtype=torch.int32, device=self._dev)
+        self.state = torch.zeros((2,), dtype=torch.int32, device=self._dev)
+        self.hist = torch.zeros((max_seq_len,), dtype=torch.int32, device=self._dev)
+        I = l["intermediate_size"]
+        self._b = dict(x0=torch.empty((1, self.D), **bf), qkv=torch.empty(((self.nh + 2 * self.nkv) * self.hd,), **bf),
+                       o=torch.empty((self.nh * self.hd,), **bf), x1=torch.empty((self.D,), **bf),
+                       a=torch.empty((I,), **bf))
+        self.logits = torch.empty((self.V,), dtype=torch.float32, device=self._dev)
+        self.graph = None
         self.pos = 0
 
     # ------------------------------------------------------------------ prefill (M = S tokens, MFMA GEMMs)
@@ -63,58 +72,100 @@ class HipMistralDecoder(nn.Module):
         if return_all_logits:
             h = ops.rmsnorm(x, self.w["norm_w"], self.eps)
             return ops.gemm(h, self.w["lm_head"], out_f32=True)
-        return ops.gemv(self.w["lm_head"], x[S - 1], norm_w=self.w["norm_w"], eps=self.eps, out_f32=True)
+        return ops.gemv(self.w["lm_head"], x[S - 1], norm_w=self.w["norm_w"], eps=self.eps, out_f32=True, out=self.logits)
 
     # ------------------------------------------------------------------ decode (M = 1, HBM-bound GEMVs)
+    def _decode_kernels(self, dyn):
+        """Enqueue one decode step for the token in self.tok: embed -> 32 x {qkv GEMV (+RMSNorm), RoPE+append+attention,
+        o GEMV (+res), gate/up GEMV (+RMSNorm, SwiGLU), down GEMV (+res)} -> lm_head GEMV (+final RMSNorm) into self.logits.
+        dyn=True reads the position from self.state[0] on the device (hipGraph-replayable); no allocation either way."""
+        b, nh, nkv, hd = self._b, self.nh, self.nkv, self.hd
+        pos_dev = self.state[0:1] if dyn else None
+        ops.embed_rows(self.tok, self.w["embed"], b["x0"])
+        x = b["x0"][0]
+        for li, lw in enumerate(self.w["layers"]):
+            ops.gemv(lw["wqkv"], x, norm_w=lw["ln1_w"], eps=self.eps, out=b["qkv"])
+            ops.attn_decode(b["qkv"], self.kcache[li], self.vcache[li], self.cos_t, self.sin_t, self.partial, b["o"], nh, nkv,
+                            self.pos, hd ** -0.5, pos_dev=pos_dev, ctx_cap=self.max_seq_len)
+            ops.gemv(lw["wo"], b["o"], res=x, out=b["x1"])                       # x1 = x + attn
+            ops.gemv(lw["wgu"], b["x1"], norm_w=lw["ln2_w"], eps=self.eps, swiglu=True, out=b["a"])
+            ops.gemv(lw["wd"], b["a"], res=b["x1"], out=x)                      # x = x1 + mlp (x's old value is dead)
+        ops.gemv(self.w["lm_head"], x, norm_w=self.w["norm_w"], eps=self.eps, out_f32=True, out=self.logits)
+
     @torch.no_grad()
-    def decode_step(self, tok_dev):
-        """One token (device int32 [1]) at position self.pos -> fp32 logits [V]."""
+    def decode_step(self, tok_dev=None):
+        """Eager step: feed the token in self.tok (or tok_dev) at position self.pos -> fp32 logits [V] (self.logits)."""
         if self.pos >= self.max_seq_len:
             raise ValueError("KV cache exhausted")
-        nh, nkv, hd = self.nh, self.nkv, self.hd
-        x = torch.empty((1, self.D), dtype=torch.bfloat16, device=self._dev)
-        ops.embed_rows(tok_dev, self.w["embed"], x)
-        x = x[0]
-        q = torch.empty((1, nh * hd), dtype=torch.bfloat16, device=self._dev)
-        o = torch.empty((nh * hd,), dtype=torch.bfloat16, device=self._dev)
-        for li, lw in enumerate(self.w["layers"]):
-            qkv = ops.gemv(lw["wqkv"], x, norm_w=lw["ln1_w"], eps=self.eps)
-            ops.rope_kv(qkv.view(1, -1), q, self.kcache[li], self.vcache[li], self.cos_t, self.sin_t, nh, nkv, self.pos)
-            ops.attn_decode(q, self.kcache[li], self.vcache[li], self.partial, o, nh, nkv, self.pos + 1, self.decode_chunk,
-                            hd ** -0.5)
-            x = ops.gemv(lw["wo"], o, res=x)
-            a = ops.gemv(lw["wgu"], x, norm_w=lw["ln2_w"], eps=self.eps, swiglu=True)
-            x = ops.gemv(lw["wd"], a, res=x)
+        if tok_dev is not None and tok_dev.data_ptr() != self.tok.data_ptr():
+            self.tok.copy_(tok_dev)
+        self._decode_kernels(dyn=False)
         self.pos += 1
-        return ops.gemv(self.w["lm_head"], x, norm_w=self.w["norm_w"], eps=self.eps, out_f32=True)
+        return self.logits
+
+    @torch.no_grad()
+    def capture_graph(self):
+        """Capture {argmax -> decode step} once as a hipGraph (torch.cuda.CUDAGraph records the launches libvl2hip.so
+        enqueues on the capture stream).  Replays read token / position / step from device memory."""
+        if self.graph is not None:
+            return self.graph
+        saved = (self.state.clone(), self.tok.clone(), self.logits.clone(), self.hist[:2].clone())
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                       # warm-up outside capture (first-launch attribute calls etc.)
+            self.state.copy_(torch.tensor([max(self.pos - 1, 0), 0], dtype=torch.int32))
+            ops.argmax(self.logits, self.tok, self.hist, 0, self.state)
+            self._decode_kernels(dyn=True)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            ops.argmax(self.logits, self.tok, self.hist, 0, self.state)
+            self._decode_kernels(dyn=True)
+        self.state.copy_(saved[0]); self.tok.copy_(saved[1]); self.logits.copy_(saved[2]); self.hist[:2].copy_(saved[3])
+        torch.cuda.synchronize()
+        self.graph = g
+        return g
 
     @torch.no_grad()
     def generate(self, inputs_embeds, max_new_tokens=2048, eos_token_id=None, stopping_criteria=None,
-                 return_logits=False):
+                 return_logits=False, use_graph=False):
         """Greedy decode (HF GenerationMixin._sample, do_sample=False): returns LongTensor [1, n_new] of NEW tokens.
         Stops at `eos_token_id` (int or list), when `stopping_criteria(output_ids, None)` is truthy
-        (KeywordsStoppingCriteria semantics, videollama2/mm_utils.py:341-345), or at max_new_tokens / cache end."""
+        (KeywordsStoppingCriteria semantics, videollama2/mm_utils.py:341-345), or at max_new_tokens / cache end.
+        use_graph=True replays one captured hipGraph per token (argmax + the whole decode step)."""
         eos = set()
         if eos_token_id is not None:
             eos = set(eos_token_id) if isinstance(eos_token_id, (list, tuple, set)) else {int(eos_token_id)}
         logits = self.prefill(inputs_embeds)
-        hist = torch.zeros((max(max_new_tokens, 1),), dtype=torch.int32, device=self._dev)
+        if logits.data_ptr() != self.logits.data_ptr():
+            self.logits.copy_(logits)
+        max_new_tokens = min(max_new_tokens, self.max_seq_len - self.pos + 1)
+        crit = None
+        if stopping_criteria is not None:
+            crit = stopping_criteria if isinstance(stopping_criteria, (list, tuple)) else [stopping_criteria]
         toks, all_logits = [], []
+        if use_graph:
+            g = self.capture_graph()
+            self.state.copy_(torch.tensor([self.pos - 1, 0], dtype=torch.int32))
         for step in range(max_new_tokens):
             if return_logits:
-                all_logits.append(logits.clone())
-            ops.argmax(logits, self.tok, hist, step)
+                all_logits.append(self.logits.clone())
+            last = step + 1 == max_new_tokens or self.pos >= self.max_seq_len
+            if use_graph and not last:
+                g.replay()                           # argmax(step) + forward of the new token -> logits(step+1)
+                self.pos += 1
+            else:
+                ops.argmax(self.logits, self.tok, self.hist, step)
             t = int(self.tok.item())                 # one 4-byte D2H per token (the reference syncs per token too)
             toks.append(t)
-            if t in eos:
+            if t in eos or last:
                 break
-            if stopping_criteria is not None:
+            if crit is not None:
                 ids = torch.tensor([toks], dtype=torch.long, device=self._dev)
-                crit = stopping_criteria if isinstance(stopping_criteria, (list, tuple)) else [stopping_criteria]
                 if any(bool(c(ids, None)) for c in crit):
                     break
-            if step + 1 == max_new_tokens or self.pos >= self.max_seq_len:
-                break
-            logits = self.decode_step(self.tok)
+            if not use_graph:
+                self.decode_step()
         out = torch.tensor([toks], dtype=torch.long, device=self._dev)
         return (out, torch.stack(all_logits)) if return_logits else out

@@ -161,14 +161,16 @@ def gemv(w, x, norm_w=None, eps=1e-5, res=None, swiglu=False, out_f32=False, out
     return out
 
 
-def attn_decode(q, kcache, vcache, partial, out, nh, nkv, ctx, chunk, scale):
-    _lib.call("vl2_attn_decode", _p(q), _p(kcache), _p(vcache), _p(partial), _p(out), nh, nkv, kcache.shape[1], ctx, chunk,
-              float(scale), _stream())
+def attn_decode(qkv, kcache, vcache, cos_t, sin_t, partial, out, nh, nkv, pos, scale, pos_dev=None, ctx_cap=0):
+    """RoPE + KV append + flash-decoding attention of one new token (un-roped fused qkv row) at position `pos`
+    (or *pos_dev, for hipGraph replay; then ctx_cap bounds the positions the launch covers)."""
+    _lib.call("vl2_attn_decode", _p(qkv), _p(kcache), _p(vcache), _p(cos_t), _p(sin_t), _p(partial), _p(out), nh, nkv,
+              kcache.shape[1], int(pos), _p(pos_dev), int(ctx_cap), float(scale), _stream())
     return out
 
 
-def argmax(logits, tok, hist=None, step=0):
-    _lib.call("vl2_argmax", _p(logits), logits.numel(), _p(tok), _p(hist), step, _stream())
+def argmax(logits, tok, hist=None, step=0, state=None):
+    _lib.call("vl2_argmax", _p(logits), logits.numel(), _p(tok), _p(hist), step, _p(state), _stream())
 
 
 def embed_rows(ids_i32, table, out):
