@@ -205,135 +205,135 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
     }
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// gemm3 "ping-pong": 128 (M) x 256 (N) block tile, BK = 64, 8 waves = two groups of 4 (waves 0-3 / 4-7; waves w and
-// w+4 share a SIMD).  Group g owns the 128 x 128 half-tile A x W_g (wave tile 64 x 64, as gemm_bf16_kernel).
-// Why: PMC on the 128x128 kernel (profiles/r01_gemm_pmc.md) shows each wave spends ~52 % of its cycles stalled on MFMA
-// issue behind its SIMD partner and ~27 % parked at waitcnt/barrier: with two identical in-order waves per SIMD, a wave
-// stuck behind the partner's MFMA cannot issue its own ds_reads / LDS-DMA either.  Here the two waves of a SIMD run in
-// anti-phase: in every phase one group issues ONLY MFMAs (16 per wave, operands already in registers) while the other
-// issues ONLY memory work (all 16 ds_read_b128 of its next K-tile into registers + its share of the LDS-DMA for the
-// tile after next), phases separated by a raw s_barrier; roles swap every phase.
-//   group g:  LOAD(t) at phase 2t+g,  MFMA(t) at phase 2t+g+1.
-// LDS: 3 stages x (A 16 KiB | W_0 16 KiB | W_1 16 KiB) = 144 KiB, one workgroup per CU.  The stage of tile t is read in
-// phases 2t and 2t+1 and refilled with tile t+3 from phase 2t+2 on; every LDS-DMA has >= 3 phases of flight time and
-// is retired with a COUNTED vmcnt (never 0 in the main loop: the newest 6 stay in flight) followed by the phase barrier.
-#define GEMM3_BM 128
-#define GEMM3_BN 256
-#define GEMM3_BK 64
-#define GEMM3_STAGE 49152
-#define GEMM3_LDS_BYTES (3 * GEMM3_STAGE)
-
-// s_waitcnt with only vmcnt active (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14)
+// s_waitcnt with only vmcnt / only lgkmcnt active (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14)
 #define VL2_WAIT_VMCNT(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (7 << 4) | (15 << 8) | (((n) >> 4) << 14))
 #define VL2_WAIT_LGKMCNT0() __builtin_amdgcn_s_waitcnt(15 | (7 << 4) | (0 << 8) | (3 << 14))
 
+// ------------------------------------------------------------------------------------------------------------------
+// gemm4 "ping-pong": 256 x 256 block tile, K streamed in 32-deep slabs through a 4-stage LDS ring.
+// PMC on the 128x128 kernel shows each wave ~52 % of its cycles stalled on MFMA issue behind its SIMD partner and ~27 %
+// parked at waitcnt/barrier: with two identical in-order waves per SIMD, a wave stuck behind the partner's MFMA cannot issue
+// its own ds_reads / LDS-DMA either.  Here the two waves of a SIMD run in anti-phase: in every phase one group issues ONLY
+// MFMAs (operands already in registers) while the other issues ONLY memory work, phases separated by a raw s_barrier.
+// Halves the L2 -> LDS operand stream per FLOP relative to the 128-wide kernels (7.6 B/kFLOP), which is what bounds them
+// (profiles/r01_gemm_experiments.md).  8 waves = two groups of 4 (waves w, w+4 share a SIMD); group g owns rows
+// [128g, 128g+128) x all 256 columns, wave tile 64 x 128 = 2 x 4 MFMA 32x32x16 accumulators (128 VGPRs).
+// A phase = one K-slab of 32: the MFMA group issues 16 MFMAs from 12 register fragments while the other group reads its
+// next 12 fragments and issues its 4 LDS-DMA (its 128 rows of A and of W) for the slab three ahead.
+//   group g: LOAD(t) at phase 2t+g, MFMA(t) one phase later.  Stage (t+3)%4 last held slab t-1 (read in phases 2t-2,
+//   2t-1), so DMA(t+3) may be issued from phase 2t on; it is retired by a COUNTED vmcnt(8) two LOAD phases later (the
+//   two newer slabs stay in flight), i.e. every LDS-DMA has ~5 phases of flight time.
+// LDS image per operand slab: 256 rows x 64 B, 4 rows per 256-B bank row, chunk c of row r stored at c ^ ((r>>2)&3).
+#define GEMM4_BM 256
+#define GEMM4_BN 256
+#define GEMM4_BK 32
+#define GEMM4_STAGE 32768
+#define GEMM4_LDS_BYTES (4 * GEMM4_STAGE)
+// phase boundary: the compiler may not move MFMAs (register-only, so not ordered by the barrier itself) across it
+#define VL2_PHASE_BARRIER() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+
+__device__ __forceinline__ int gemm4_lds_off(int row, int chunk) {
+    return (((row >> 2) << 4) + ((row & 3) << 2) + (chunk ^ ((row >> 2) & 3))) << 4;
+}
+
 template <int ACT, bool SWIGLU, bool OUT_F32>
-__global__ __launch_bounds__(512, 2) void gemm3_bf16_kernel(GemmArgs p) {
+__global__ __launch_bounds__(512, 2) void gemm4_bf16_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char vl2_smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // which waves share a SIMD is not architecturally defined (speed only); measured: waves w and w+4 (scripts/ubench)
     const int grp = wave >> 2, w4 = wave & 3;
     const int wm = w4 >> 1, wn = w4 & 1;
 
     const int t0 = xcd_remap(blockIdx.x, gridDim.x);
-    const int grp_sz = 8 * p.tiles_n;
-    const int first_m = (t0 / grp_sz) * 8;
-    const int gm = (p.tiles_m - first_m) < 8 ? (p.tiles_m - first_m) : 8;
+    const int grp_sz = 4 * p.tiles_n;                              // 4 tile-rows (1024 rows of A) per raster group
+    const int first_m = (t0 / grp_sz) * 4;
+    const int gm = (p.tiles_m - first_m) < 4 ? (p.tiles_m - first_m) : 4;
     const int tm = first_m + (t0 % grp_sz) % gm, tn = (t0 % grp_sz) / gm;
-    const int m0 = tm * GEMM3_BM, n0 = tn * GEMM3_BN;
+    const int m0 = tm * GEMM4_BM, n0 = tn * GEMM4_BN;
 
-    // LDS-DMA parts of one K-tile issued by THIS wave: 4 x W_grp (its own half, 128 rows) + 2 x A (rows 64*grp..+63).
-    // Slot -> (row, chunk) is the gemm_bf16_kernel image (two 128-B tile rows per 256-B bank row, slot ^ (R & 15)).
-    unsigned w_off[4], a_off[2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int slot = ((i * 4 + w4) << 6) + lane;
-        const int R = slot >> 4, s = (slot & 15) ^ (R & 15);
-        w_off[i] = (unsigned)(n0 + grp * 128 + 2 * R + (s >> 3)) * (unsigned)p.ldw + (s & 7) * 8;
-    }
+    // this wave's LDS-DMA parts of a slab: 2 x A rows [128*grp, +128) and 2 x W rows [128*grp, +128)
+    unsigned a_off[2], w_off[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int slot = (((grp * 2 + i) * 4 + w4) << 6) + lane;          // A image slots [grp*512, grp*512+512)
-        const int R = slot >> 4, s = (slot & 15) ^ (R & 15);
-        int am = m0 + 2 * R + (s >> 3);
+        const int slot = grp * 512 + ((i * 4 + w4) << 6) + lane;
+        const int R = slot >> 4, sp = slot & 15;
+        const int row = 4 * R + (sp >> 2), chk = (sp & 3) ^ (R & 3);
+        int am = m0 + row;
         am = am < p.M ? am : p.M - 1;
-        a_off[i] = (unsigned)am * (unsigned)p.lda + (s & 7) * 8;
+        a_off[i] = (unsigned)am * (unsigned)p.lda + chk * 8;
+        w_off[i] = (unsigned)(n0 + row) * (unsigned)p.ldw + chk * 8;
     }
-    auto issue_dma = [&](int kt) {
-        unsigned char* st = vl2_smem + (kt % 3) * GEMM3_STAGE;
-        unsigned char* Ws = st + 16384 + grp * 16384;
+    auto issue_dma = [&](int t) {
+        unsigned char* st = vl2_smem + (t & 3) * GEMM4_STAGE;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) glds16(p.W + w_off[i] + kt * GEMM3_BK, Ws + ((i * 4 + w4) << 10));
+        for (int i = 0; i < 2; ++i) glds16(p.A + a_off[i] + t * GEMM4_BK, st + ((grp * 8 + i * 4 + w4) << 10));
 #pragma unroll
-        for (int i = 0; i < 2; ++i) glds16(p.A + a_off[i] + kt * GEMM3_BK, st + (((grp * 2 + i) * 4 + w4) << 10));
+        for (int i = 0; i < 2; ++i) glds16(p.W + w_off[i] + t * GEMM4_BK, st + 16384 + ((grp * 8 + i * 4 + w4) << 10));
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][4];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    bf16x8 fa[4][2], fb[4][2];           // the whole K-tile of this wave's fragments (64 VGPRs)
+    bf16x8 fa[2][2], fb[2][4];                     // [ks][tile]
 
-    const int nt = p.K / GEMM3_BK;
+    const int nt = p.K / GEMM4_BK;
     const int frow = lane & 31, fchk = lane >> 5;
+    const int arow = grp * 128 + wm * 64 + frow, brow = wn * 128 + frow;
     issue_dma(0);
     if (nt > 1) issue_dma(1);
-    if (nt > 1) VL2_WAIT_VMCNT(6); else VL2_WAIT_VMCNT(0);
-    __builtin_amdgcn_s_barrier();
+    if (nt > 2) issue_dma(2);
+    if (nt > 2) VL2_WAIT_VMCNT(8); else if (nt > 1) VL2_WAIT_VMCNT(4); else VL2_WAIT_VMCNT(0);
+    VL2_PHASE_BARRIER();
 
-    // Both groups run the SAME straight-line loop body {LOAD(t); barrier; MFMA(t); barrier}; group 1 is shifted by one
-    // phase with a leading barrier (group 0 gets the matching trailing one), so the groups are always in opposite roles.
-    if (grp == 1) __builtin_amdgcn_s_barrier();
+    if (grp == 1) VL2_PHASE_BARRIER();
     for (int t = 0; t < nt; ++t) {
         // ---------------- LOAD(t): memory work only
-        const bool more = t + 2 < nt;
-        if (more) issue_dma(t + 2);
-        const unsigned char* st = vl2_smem + (t % 3) * GEMM3_STAGE;
-        const unsigned char* Ws = st + 16384 + grp * 16384;
+        if (t + 3 < nt) issue_dma(t + 3);
+        const unsigned char* As = vl2_smem + (t & 3) * GEMM4_STAGE;
+        const unsigned char* Bs = As + 16384;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
+        for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                fa[ks][i] = *(const bf16x8*)(st + gemm_lds_off(wm * 64 + i * 32 + frow, ks * 2 + fchk));
-                fb[ks][i] = *(const bf16x8*)(Ws + gemm_lds_off(wn * 64 + i * 32 + frow, ks * 2 + fchk));
-            }
-        // retire everything but the DMA just issued: tile t+1 (issued one LOAD ago) must have landed before the barrier
-        // that opens the phase in which either group reads it; the ds_reads must be done before this stage is refilled
-        if (more) VL2_WAIT_VMCNT(6); else VL2_WAIT_VMCNT(0);
+            for (int i = 0; i < 2; ++i) fa[ks][i] = *(const bf16x8*)(As + gemm4_lds_off(arow + i * 32, ks * 2 + fchk));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[ks][j] = *(const bf16x8*)(Bs + gemm4_lds_off(brow + j * 32, ks * 2 + fchk));
+        }
+        // slab t+1 must have landed before the barrier below; the (up to) two newer slabs stay in flight
+        const int newer = nt - 2 - t;              // slabs issued after t+1
+        if (newer >= 2) VL2_WAIT_VMCNT(8); else if (newer == 1) VL2_WAIT_VMCNT(4); else VL2_WAIT_VMCNT(0);
         VL2_WAIT_LGKMCNT0();
-        __builtin_amdgcn_s_barrier();
+        VL2_PHASE_BARRIER();
         // ---------------- MFMA(t): matrix work only
-        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_s_barrier();
+        VL2_PHASE_BARRIER();
     }
-    if (grp == 0) __builtin_amdgcn_s_barrier();
+    if (grp == 0) VL2_PHASE_BARRIER();
 
-    // ---- epilogue (all DMA retired, every wave past its last phase): same patch path as gemm_bf16_kernel
+    // ---- epilogue: four 32 x 64 patches per wave (2 row blocks x 2 column halves)
     float* ep = (float*)vl2_smem + wave * (32 * 68);
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
+    for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int nh = 0; nh < 2; ++nh) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                ep[row * 68 + ni * 32 + (lane & 31)] = acc[mi][ni][r];
-            }
-        __syncthreads();
-        gemm_store_patch<ACT, SWIGLU, OUT_F32>(p, ep, m0 + wm * 64 + mi * 32, n0 + grp * 128 + wn * 64, lane);
-        __syncthreads();
-    }
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    ep[row * 68 + ni * 32 + (lane & 31)] = acc[mi][nh * 2 + ni][r];
+                }
+            __syncthreads();
+            gemm_store_patch<ACT, SWIGLU, OUT_F32>(p, ep, m0 + grp * 128 + wm * 64 + mi * 32, n0 + wn * 128 + nh * 64, lane);
+            __syncthreads();
+        }
 }

@@ -33,7 +33,7 @@ extern "C" const char* vl2_last_error_string(void) { return g_err; }
 
 static int g_gemm_variant = 0;
 extern "C" int32_t vl2_set_tuning(int32_t key, int32_t value) {
-    if (key == VL2_TUNE_GEMM_VARIANT && (value == 0 || value == 1 || value == 4)) { g_gemm_variant = value; return 0; }
+    if (key == VL2_TUNE_GEMM_VARIANT && (value == 0 || value == 1 || value == 8)) { g_gemm_variant = value; return 0; }
     return fail(VL2_E_BADARG, "vl2_set_tuning: unknown key/value %d/%d", key, value);
 }
 
@@ -41,17 +41,17 @@ extern "C" int32_t vl2_set_tuning(int32_t key, int32_t value) {
 template <int ACT, bool SW, bool F32, bool G>
 static void launch_gemm(const GemmArgs& a0, hipStream_t s) {
     if constexpr (!G) {
-        if (g_gemm_variant == 4 && a0.N % GEMM3_BN == 0) {
-            static bool attr3 = false;   // 144 KiB dynamic LDS needs the opt-in once per kernel instance
-            if (!attr3) {
-                hipFuncSetAttribute((const void*)gemm3_bf16_kernel<ACT, SW, F32>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    GEMM3_LDS_BYTES);
-                attr3 = true;
+        if (g_gemm_variant == 8 && a0.N % GEMM4_BN == 0) {
+            static bool attr4 = false;
+            if (!attr4) {
+                hipFuncSetAttribute((const void*)gemm4_bf16_kernel<ACT, SW, F32>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    GEMM4_LDS_BYTES);
+                attr4 = true;
             }
             GemmArgs a = a0;
-            a.tiles_m = (a.M + GEMM3_BM - 1) / GEMM3_BM;
-            a.tiles_n = a.N / GEMM3_BN;
-            hipLaunchKernelGGL((gemm3_bf16_kernel<ACT, SW, F32>), dim3(a.tiles_m * a.tiles_n), dim3(512), GEMM3_LDS_BYTES, s, a);
+            a.tiles_m = (a.M + GEMM4_BM - 1) / GEMM4_BM;
+            a.tiles_n = a.N / GEMM4_BN;
+            hipLaunchKernelGGL((gemm4_bf16_kernel<ACT, SW, F32>), dim3(a.tiles_m * a.tiles_n), dim3(512), GEMM4_LDS_BYTES, s, a);
             return;
         }
     }

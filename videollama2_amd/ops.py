@@ -31,7 +31,7 @@ def _chk(t, dtype, name):
 
 
 def set_gemm_variant(v):
-    """0/1 = 128x128x64 kernel (default), 4 = experimental 128x256x64 ping-pong kernel (A/B knob, include/vl2hip.h)."""
+    """0/1 = 128x128x64 kernel (default), 8 = experimental 256x256x32 ping-pong kernel (A/B knob, include/vl2hip.h)."""
     _lib.call("vl2_set_tuning", 1, int(v))
 
 
