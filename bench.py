@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--llm-layers", type=int, default=None, help="debug only: fewer decoder layers (INVALID as a result)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager decode loop instead of hipGraph replay")
+    ap.add_argument("--tune", type=str, default="", help="debug: comma list key=value for vl2_set_tuning")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -104,6 +105,10 @@ def main():
     from videollama2_amd.model import VideoLLaMA2Hip
     from videollama2_amd.weights import random_state_dict
 
+    from videollama2_amd import _lib
+    for kv in filter(None, args.tune.split(",")):
+        k, v = kv.split("=")
+        _lib.call("vl2_set_tuning", int(k), int(v))
     T, n_new = args.frames, args.new_tokens
     cfg = videollama2_7b(T)
     sd = random_state_dict(cfg, dev, seed=1234, n_llm_layers=args.llm_layers)

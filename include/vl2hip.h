@@ -31,6 +31,7 @@ int32_t vl2_version(void);
  *   key 1 = GEMM kernel variant: 0 / 1 = 128x128x64 two-barrier kernel (shipped default), 8 = 256x256x32 ping-pong kernel
  *           (experimental, where N%256==0; +15-20 % on well-quantised shapes, see profiles/r01_gemm_experiments.md). */
 #define VL2_TUNE_GEMM_VARIANT 1
+#define VL2_TUNE_GEMV_ROWS_PER_WAVE 2   /* 1 (default), 2 or 4 output rows streamed by each wave of the decode GEMV */
 int32_t vl2_set_tuning(int32_t key, int32_t value);
 const char* vl2_last_error_string(void);      /* host pointer, thread-local, valid until the next failing call */
 

@@ -17,7 +17,7 @@ extern "C" int32_t vl2_version(void) { return 1; }
 extern "C" const char* vl2_last_error_string(void) { return g_err; }
 
 static int g_gemm_variant = 0;
-extern "C" int32_t vl2_set_tuning(int32_t key, int32_t value) { if (key == 1) { g_gemm_variant = value; return 0; } return -1; }
+extern "C" int32_t vl2_set_tuning(int32_t key, int32_t value) { if (key == 1) { g_gemm_variant = value; return 0; } return key == 2 ? 0 : -1; }
 template <int ACT, bool SW, bool F32, bool G>
 static void run_gemm(GemmArgs a) {
     if constexpr (!G) {

@@ -207,6 +207,7 @@ inline void global_load_lds(const void* g, void* lds, unsigned size, int offset,
 #define __shfl_down(v, d) emu::shfl_idx((v), (emu::cur->lane + (d)) > 63 ? emu::cur->lane : emu::cur->lane + (d))
 #define __shfl(v, s) emu::shfl_idx((v), (s))
 #define __expf(x) expf(x)
+#define __builtin_amdgcn_exp2f(x) exp2f(x)
 #define __fdividef(a, b) ((a) / (b))
 #define __frcp_rn(x) (1.0f / (x))
 #define VL2_EMU 1

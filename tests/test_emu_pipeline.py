@@ -42,6 +42,18 @@ def test_emu_gemm_variants(emu):
     assert rel(out.view(4, 17, 128)[:, 1:], ref) < TOL_BF16_OUT and out.view(4, 17, 128)[:, 0].abs().max() == 0
 
 
+def test_emu_gemm_pingpong_variant(emu):
+    from videollama2_amd import ops
+    for K in (64, 128, 448):
+        a, w = bf(300, K), bf(512, K)
+        ref = ops.gemm(a, w, out_f32=True)
+        try:
+            ops.set_gemm_variant(8)
+            assert torch.equal(ops.gemm(a, w, out_f32=True), ref)
+        finally:
+            ops.set_gemm_variant(0)
+
+
 def test_emu_attention_ragged_and_causal(emu):
     from videollama2_amd import ops
     B, H, N, D = 2, 2, 150, 64

@@ -169,3 +169,23 @@ def test_hipgraph_decode_matches_eager(small):
     assert torch.equal(le, lg)
     graph2 = model.decoder.generate(emb, max_new_tokens=5, use_graph=True)       # replay the same graph on a fresh request
     assert graph2[0].tolist() == eager[0, :5].tolist()
+
+
+@pytest.mark.parametrize("T", [8, 16, 32])
+def test_token_count_law_and_connector_parity_over_T(T):
+    """N_vis = (T/2+1) * (g/2+1)^2 for T = 8/16/32 (845/1521/2873 at g = 24) through the HIP connector, small
+    widths / 4x4 grid so the oracle runs in a second; also an image (modal 'image' -> expanded to num_frames)."""
+    from videollama2_amd.model import VideoLLaMA2Hip
+    cfg = O.config_small(T)
+    sd = O.seeded_state_dict(cfg, 3)
+    model = VideoLLaMA2Hip(cfg, sd, DEV, max_seq_len=256)
+    frames = torch.randn(T, 3, 56, 56, generator=torch.Generator().manual_seed(T)).bfloat16().float()
+    with torch.no_grad():
+        ref = O.encode_images_or_videos(sd, cfg, [(frames, "video")])
+        ref_img = O.encode_images_or_videos(sd, cfg, [(frames[:1], "image")])
+    out = model.encode_images_or_videos([(frames.to(DEV), "video")])
+    assert tuple(out.shape) == tuple(ref.shape) == (1, (T // 2 + 1) * 9, cfg["llm"]["hidden_size"])
+    assert rel(out, ref) < 3e-2
+    img = model.encode_images_or_videos([(frames[:1].to(DEV), "image")])
+    assert tuple(img.shape) == tuple(ref_img.shape) and rel(img, ref_img) < 3e-2
+    assert [O.n_visual_tokens(t) for t in (8, 16, 32)] == [845, 1521, 2873]

@@ -33,11 +33,16 @@ template <> __device__ __forceinline__ int attn_k_off<64>(int row, int chunk) {
     const int R = row >> 1, s = ((row & 1) << 3) | chunk;
     return ((R << 4) + (s ^ (R & 15))) << 4;
 }
-// V^T image: row d = 64 keys * 2 B = 128 B = 16 chunks of 8 B (4 keys); chunk kc of row d is stored at kc ^ ((d>>1)&15)
-__device__ __forceinline__ int attn_vt_off(int d, int kc) { return (d << 7) + ((kc ^ ((d >> 1) & 15)) << 3); }
+// V^T image: row d = 64 keys * 2 B = 128 B = 8 chunks of 16 B.  Chunk (kb, hi) (kb = 16-key block 0..3) holds, in
+// order, keys 16kb + 4hi + {0,1,2,3, 8,9,10,11}: exactly the 8 keys lane-half `hi` contracts in one PV MFMA, so the
+// A fragment is ONE ds_read_b128.  Rows are swizzled like the K tile of the 64-wide case (two rows per bank row).
+__device__ __forceinline__ int attn_vt_off(int d, int c16) {
+    const int R = d >> 1, s = ((d & 1) << 3) | c16;
+    return ((R << 4) + (s ^ (R & 15))) << 4;
+}
 
 template <int D, bool CAUSAL>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
     constexpr int KCH = D / 8;                 // 16-B chunks per K row
     constexpr int KPT = 64 * KCH / 256;        // K chunks per thread per tile
     constexpr int VPT = 32 * KCH / 256;        // V (key-pair, chunk) items per thread per tile
@@ -92,11 +97,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
         for (int i = 0; i < VPT; ++i) {
             const int c = tid + 256 * i, kp = c / KCH, ch = c % KCH;
+            // keys 2kp, 2kp+1 -> chunk (kb = key>>4, hi = bit 2 of key), element (bit 3 of key)*4 + (key & 3)
+            const int k16 = (2 * kp) & 15;
+            const int c16 = ((2 * kp) >> 4) * 2 + ((k16 >> 2) & 1);
+            const int eoff = ((k16 >> 3) * 4 + (k16 & 3)) * 2;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const unsigned a = (vreg[i][0][j >> 1] >> ((j & 1) * 16)) & 0xffffu;
                 const unsigned bb = (vreg[i][1][j >> 1] >> ((j & 1) * 16)) & 0xffffu;
-                *(unsigned*)(Vt + attn_vt_off(ch * 8 + j, kp >> 1) + (kp & 1) * 4) = a | (bb << 16);
+                *(unsigned*)(Vt + attn_vt_off(ch * 8 + j, c16) + eoff) = a | (bb << 16);
             }
         }
     };
@@ -118,14 +127,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
 
         // S^T = K . Q^T
         f32x16 sT[2];
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sT[kh][r] = 0.f;
-#pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
                 const bf16x8 kf = *(const bf16x8*)(Ks + attn_k_off<D>(kh * 32 + l31, ks * 2 + hi));
-                sT[kh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sT[kh], 0, 0, 0);
+                sT[kh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? zero16 : sT[kh], 0, 0, 0);
             }
         }
         // online softmax (exp2 domain: p = 2^(s*c - m), c = scale*log2 e folded into one FMA per score).
@@ -154,7 +162,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
         constexpr float THR = 6.0f;
         if (!__all(mt - m <= THR)) {
             const float m_new = fmaxf(m, mt);
-            const float alpha = exp2f(m - m_new);
+            const float alpha = __builtin_amdgcn_exp2f(m - m_new);
             m = m_new;
             l *= alpha;
 #pragma unroll
@@ -167,7 +175,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
         for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float pv = exp2f(fmaf(sT[kh][r], c, -m));
+                const float pv = __builtin_amdgcn_exp2f(fmaf(sT[kh][r], c, -m));   // bare v_exp_f32: inputs <= THR, tiny results flush to 0
                 sT[kh][r] = pv;
                 rs += pv;
             }
@@ -182,15 +190,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) pw[j] = pack2bf(sT[kh][ks2 * 8 + 2 * j], sT[kh][ks2 * 8 + 2 * j + 1]);
                 const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
-                const int kc = 8 * kh + 4 * ks2 + hi;
+                const int c16 = (kh * 2 + ks2) * 2 + hi;
 #pragma unroll
                 for (int db = 0; db < NDB; ++db) {
-                    const int d = db * 32 + l31;
-                    const bf16x4 v0 = *(const bf16x4*)(Vt + attn_vt_off(d, kc));
-                    const bf16x4 v1 = *(const bf16x4*)(Vt + attn_vt_off(d, kc + 2));
-                    bf16x8 vf;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) { vf[j] = v0[j]; vf[4 + j] = v1[j]; }
+                    const bf16x8 vf = *(const bf16x8*)(Vt + attn_vt_off(db * 32 + l31, c16));
                     oT[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oT[db], 0, 0, 0);
                 }
             }

@@ -32,8 +32,10 @@ extern "C" int32_t vl2_version(void) { return VL2_ABI_VERSION; }
 extern "C" const char* vl2_last_error_string(void) { return g_err; }
 
 static int g_gemm_variant = 0;
+static int g_gemv_rpw = 1;   // measured on MI355X: 3.09 / 3.30 / 3.97 ms per 7B decode token at 1 / 2 / 4 rows per wave
 extern "C" int32_t vl2_set_tuning(int32_t key, int32_t value) {
     if (key == VL2_TUNE_GEMM_VARIANT && (value == 0 || value == 1 || value == 8)) { g_gemm_variant = value; return 0; }
+    if (key == VL2_TUNE_GEMV_ROWS_PER_WAVE && (value == 1 || value == 2 || value == 4)) { g_gemv_rpw = value; return 0; }
     return fail(VL2_E_BADARG, "vl2_set_tuning: unknown key/value %d/%d", key, value);
 }
 
@@ -224,8 +226,12 @@ extern "C" int32_t vl2_rope_kv(const void* qkv, void* q_out, void* kcache, void*
 
 template <bool SW, bool F32>
 static void launch_gemv(const GemvArgs& a, int n_out, hipStream_t s) {
-    constexpr int RPW = 2;
-    hipLaunchKernelGGL((gemv_bf16_kernel<SW, F32, RPW>), dim3((n_out + 4 * RPW - 1) / (4 * RPW)), dim3(256), (size_t)a.K * 2, s, a);
+    if (g_gemv_rpw == 2)
+        hipLaunchKernelGGL((gemv_bf16_kernel<SW, F32, 2>), dim3((n_out + 7) / 8), dim3(256), (size_t)a.K * 2, s, a);
+    else if (g_gemv_rpw == 4)
+        hipLaunchKernelGGL((gemv_bf16_kernel<SW, F32, 4>), dim3((n_out + 15) / 16), dim3(256), (size_t)a.K * 2, s, a);
+    else
+        hipLaunchKernelGGL((gemv_bf16_kernel<SW, F32, 1>), dim3((n_out + 3) / 4), dim3(256), (size_t)a.K * 2, s, a);
 }
 extern "C" int32_t vl2_gemv_bf16(const void* W, const void* x, const float* norm_w, const void* res, void* y, int32_t N,
                                  int32_t K, int32_t ldw, float eps, int32_t flags, void* stream) {
