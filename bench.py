@@ -4,9 +4,11 @@
     python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
 
 One "step" = one synthetic 16-frame 336^2 video through the whole hot path with inputs resident in HBM:
-  ViT (frames sharded over the N ranks) -> RCCL all-gather of visual tokens -> STC connector -> splice with
-  100 synthetic text ids -> Mistral-7B prefill (S = 1621) -> `--new-tokens` greedy decode steps.
-`value` = encoder video-frames/s (T / (t_vit + t_allgather + t_stc)), BASELINE.json's headline; prefill and decode
+  frames sharded over the N ranks: ViT + STC stage s1 per rank, one-frame halo, Conv3d/s2/readout on the rank's output
+  frames, RCCL all-gather of the visual tokens (videollama2_amd/dist.py; N = 1 runs the same kernels unsharded)
+  -> splice with 100 synthetic text ids -> Mistral-7B prefill (S = 1621) -> `--new-tokens` greedy decode steps
+  (prefill/decode replicated on every rank: one sequence, no tensor parallelism in the reference either).
+`value` = encoder video-frames/s (T / t_encode, t_encode = ViT + collectives + STC), BASELINE.json's headline; prefill and decode
 throughput ride along as extra keys.  Weights: random-init bf16 of the exact VideoLLaMA2-7B architecture (no
 checkpoints on the box); data: synthetic.  Rank 0 prints ONE JSON line.
 """
@@ -204,7 +206,8 @@ def main():
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"VideoLLaMA2-7B, {T}-frame 336^2 video, bf16, S={S} prefill, {n_new} greedy decode tokens "
                                    f"(BASELINE.json configs[1])", "frames": T, "prefill_tokens": S, "new_tokens": n_new,
-                       "parallelism": f"frames sharded over {world} rank(s) + RCCL all-gather; connector/LLM replicated",
+                       "parallelism": (f"frames sharded over {world} ranks (ViT + STC s1/conv3d/s2 per rank, halo + RCCL all-gather of visual tokens); "
+                                       f"LLM replicated" if world > 1 else "single GPU"),
                        "llm_layers": len(model.decoder.w["layers"]),
                        "decode": "eager launches" if graph is None else "hipGraph replay (argmax + 32-layer step per token)"},
             "encode_ms": round(enc_ms, 3), "prefill_ms": round(pre_ms, 3), "decode_ms_per_token": round(dec_ms / n_new, 4),

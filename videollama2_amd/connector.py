@@ -9,12 +9,16 @@ from . import ops
 from .weights import pack_connector
 
 
-def conv3d_k2s2p1_index(T, H, W, device):
+def conv3d_k2s2p1_index(T, H, W, device, to_range=None, frame_lo=0, n_local=None):
     """Gather table for Conv3d(kernel 2, stride 2, padding 1) (projector.py:164-174): output (to,ho,wo) tap (kt,kh,kw)
-    reads input (2*to-1+kt, 2*ho-1+kh, 2*wo-1+kw) or zero outside.  Returns (int32 [8, To*Ho*Wo], (To,Ho,Wo))."""
+    reads input (2*to-1+kt, 2*ho-1+kh, 2*wo-1+kw) or zero outside the [T,H,W] volume.
+    Sharded form: only the output frames `to_range = (to0, to1)` are produced, from a local row pool that holds the
+    `n_local` input frames starting at global frame `frame_lo`.  Returns (int32 [8, n_to*Ho*Wo], (n_to, Ho, Wo))."""
     o = lambda n: (n + 2 - 2) // 2 + 1
     To, Ho, Wo = o(T), o(H), o(W)
-    to = torch.arange(To).view(To, 1, 1)
+    to0, to1 = to_range if to_range is not None else (0, To)
+    n_local = T if n_local is None else n_local
+    to = torch.arange(to0, to1).view(-1, 1, 1)
     ho = torch.arange(Ho).view(1, Ho, 1)
     wo = torch.arange(Wo).view(1, 1, Wo)
     segs = []
@@ -23,9 +27,12 @@ def conv3d_k2s2p1_index(T, H, W, device):
             for kw in range(2):
                 t, h, w = 2 * to - 1 + kt, 2 * ho - 1 + kh, 2 * wo - 1 + kw
                 ok = (t >= 0) & (t < T) & (h >= 0) & (h < H) & (w >= 0) & (w < W)
-                idx = (t * H + h) * W + w
+                tl = t - frame_lo
+                if bool((ok & ((tl < 0) | (tl >= n_local))).any()):
+                    raise ValueError("conv3d shard: an input frame needed by this output range is not in the local pool")
+                idx = (tl * H + h) * W + w
                 segs.append(torch.where(ok, idx, torch.full_like(idx, -1)).reshape(-1))
-    return torch.stack(segs, 0).to(torch.int32).contiguous().to(device), (To, Ho, Wo)
+    return torch.stack(segs, 0).to(torch.int32).contiguous().to(device), (to1 - to0, Ho, Wo)
 
 
 class HipSTCConnector(nn.Module):
@@ -48,6 +55,32 @@ class HipSTCConnector(nn.Module):
         sc = ops.layernorm(ops.gemm(x, b["ds_w"]), b["dsbn_w"], b["dsbn_b"], 1e-5) if "ds_w" in b else x
         return ops.layernorm(h, b["bn3_w"], b["bn3_b"], 1e-5, res=sc, silu=True)
 
+    # ---- stages (also used one by one by the frame-sharded path in dist.py)
+    def run_s1(self, rows, F, hw):
+        """rows [F*hw*hw, 1024] bf16 -> s1 output [F*hw*hw, C] (per-frame: shards over frames)."""
+        for blk in self.w["s1"]:
+            rows = self._bottleneck(rows, blk, F, hw, hw)
+        return rows
+
+    def run_sampler(self, pool, T, hw, to_range=None, frame_lo=0, n_local=None):
+        """Conv3d(k2,s2,p1)+bias+SiLU as the gathered GEMM over a row pool of s1 frames -> ([n_to*Ho*Wo, C], (n_to,Ho,Wo))."""
+        key = (T, hw, to_range, frame_lo, n_local)
+        if key not in self._idx_cache:
+            self._idx_cache[key] = conv3d_k2s2p1_index(T, hw, hw, self._dev, to_range, frame_lo, n_local)
+        idx, dims = self._idx_cache[key]
+        h = ops.gemm(pool, self.w["samp_w"], bias=self.w["samp_b"], act=ops.ACT_SILU,
+                     gather=(idx, self.w["zero_row"], self.w["cin"]))
+        return h, dims
+
+    def run_s2_readout(self, h, To, Ho, Wo, return_s2=False):
+        """s2 (per output frame) + readout MLP (per token) -> [To*Ho*Wo, D_out]."""
+        for blk in self.w["s2"]:
+            h = self._bottleneck(h, blk, To, Ho, Wo)
+        s2 = h
+        h = ops.gemm(h, self.w["ro0_w"], bias=self.w["ro0_b"], act=ops.ACT_GELU)
+        h = ops.gemm(h, self.w["ro2_w"], bias=self.w["ro2_b"])
+        return (h, s2) if return_s2 else h
+
     @torch.no_grad()
     def forward(self, x, return_stages=False):
         if x.dim() == 5:                                              # [b, t, h, w, d]  (projector.py:200-201)
@@ -59,22 +92,9 @@ class HipSTCConnector(nn.Module):
         x = x.to(device=self._dev, dtype=torch.bfloat16).contiguous()
         outs, stages = [], {}
         for bi in range(b):
-            h = x[bi].reshape(t * l, d)
-            for blk in self.w["s1"]:
-                h = self._bottleneck(h, blk, t, hw, hw)
-            key = (t, hw)
-            if key not in self._idx_cache:
-                self._idx_cache[key] = conv3d_k2s2p1_index(t, hw, hw, self._dev)
-            idx, (To, Ho, Wo) = self._idx_cache[key]
-            s1 = h
-            h = ops.gemm(h, self.w["samp_w"], bias=self.w["samp_b"], act=ops.ACT_SILU,
-                         gather=(idx, self.w["zero_row"], self.w["cin"]))
-            samp = h
-            for blk in self.w["s2"]:
-                h = self._bottleneck(h, blk, To, Ho, Wo)
-            s2 = h
-            h = ops.gemm(h, self.w["ro0_w"], bias=self.w["ro0_b"], act=ops.ACT_GELU)
-            h = ops.gemm(h, self.w["ro2_w"], bias=self.w["ro2_b"])
+            s1 = self.run_s1(x[bi].reshape(t * l, d), t, hw)
+            samp, (To, Ho, Wo) = self.run_sampler(s1, t, hw)
+            h, s2 = self.run_s2_readout(samp, To, Ho, Wo, return_s2=True)
             outs.append(h)
             if return_stages:
                 stages = dict(s1=s1.view(t, hw, hw, -1), sampler=samp.view(To, Ho, Wo, -1), s2=s2.view(To, Ho, Wo, -1))

@@ -51,3 +51,62 @@ class FrameSharder:
         if all(p[1] == maxc for p in parts):
             return recv
         return torch.cat([recv[r * maxc:r * maxc + p[1]] for r, p in enumerate(parts)], 0)
+
+
+    # ---------------------------------------------------------------------------------------------------------------
+    def can_shard_connector(self, T):
+        """The sharded-connector cut needs an even, equal number of frames per rank (Conv3d pairs frames 2k-1, 2k)."""
+        w = self.world
+        return w > 1 and T % w == 0 and (T // w) % 2 == 0
+
+    def encode_video(self, tower, connector, frames):
+        """frames [T,3,H,W] -> visual tokens [1, N_vis, D] on every rank.
+
+        world 1, or a frame count that does not split evenly: the north-star cut -- ViT on the local frames, ONE
+        all-gather of [T/R, 576, 1024] tokens, connector replicated (`encode` above + connector).
+        Otherwise the "better cut" of SURVEY.md 8(e): everything per-frame stays sharded -- ViT and STC stage s1 on the
+        local frames, a one-frame halo (the last s1 frame goes to the next rank: Conv3d output `to` reads frames
+        2to-1 and 2to), Conv3d + s2 + readout on this rank's output frames, then ONE all-gather of the final visual
+        tokens (1.4 MB per rank at T=16).  Same arithmetic, same row order, bit-identical output."""
+        T = frames.shape[0]
+        if not self.can_shard_connector(T):
+            feats = self.encode(tower, frames)
+            return connector(feats.view(1, *feats.shape))
+        world, rank = self.world, self.rank
+        fpr = T // world
+        f0 = rank * fpr
+        local = tower(frames[f0:f0 + fpr])                                   # [fpr, n, 1024]
+        n = local.shape[1]
+        hw = int(n ** 0.5)
+        in_dtype = local.dtype
+        rows = local.to(torch.bfloat16).reshape(fpr * n, -1).contiguous()
+        s1 = connector.run_s1(rows, fpr, hw)                                 # [fpr*n, C]
+        C = s1.shape[1]
+        # halo: frame f0-1 comes from rank-1; our last frame goes to rank+1
+        pool = torch.empty(((fpr + 1) * n, C), dtype=s1.dtype, device=s1.device)
+        pool[n:].copy_(s1)
+        reqs = []
+        if rank + 1 < world:
+            reqs.append(dist.P2POp(dist.isend, s1[(fpr - 1) * n:].contiguous(), self._peer(rank + 1), self.group))
+        if rank > 0:
+            reqs.append(dist.P2POp(dist.irecv, pool[:n], self._peer(rank - 1), self.group))
+        else:
+            pool[:n].zero_()                                                # frame -1 is padding (never gathered: index -1)
+        for r in (dist.batch_isend_irecv(reqs) if reqs else []):
+            r.wait()
+        # output frames of this rank: to in [f0/2, f0/2 + fpr/2), the last rank also owns to = T/2
+        to0 = f0 // 2
+        to1 = to0 + fpr // 2 + (1 if rank == world - 1 else 0)
+        samp, (nto, Ho, Wo) = connector.run_sampler(pool, T, hw, to_range=(to0, to1), frame_lo=f0 - 1, n_local=fpr + 1)
+        tok = connector.run_s2_readout(samp, nto, Ho, Wo)                   # [nto*Ho*Wo, D]
+        per = Ho * Wo
+        max_rows = (fpr // 2 + 1) * per
+        send = torch.zeros((max_rows, tok.shape[1]), dtype=tok.dtype, device=tok.device)
+        send[:tok.shape[0]].copy_(tok)
+        recv = torch.empty((world * max_rows, tok.shape[1]), dtype=tok.dtype, device=tok.device)
+        dist.all_gather_into_tensor(recv, send, group=self.group)
+        parts = [recv[r * max_rows:r * max_rows + (fpr // 2 + (1 if r == world - 1 else 0)) * per] for r in range(world)]
+        return torch.cat(parts, 0).unsqueeze(0).to(in_dtype)
+
+    def _peer(self, group_rank):
+        return dist.get_global_rank(self.group, group_rank) if self.group is not None else group_rank

@@ -53,7 +53,9 @@ class VideoLLaMA2Hip(nn.Module):
         assert len(batch.size()) == 5                                                   # arch.py:127
         b, t = batch.shape[:2]
         frames = batch.reshape(b * t, *batch.shape[2:])                                  # 'b t c h w -> (b t) c h w'
-        feats = self.sharder.encode(self.vision_tower, frames)                           # [(b t), n, h] (all ranks)
+        if b == 1 and self.sharder.world > 1:                                            # frame-parallel over the ranks
+            return self.sharder.encode_video(self.vision_tower, self.mm_projector, frames)
+        feats = self.vision_tower(frames)                                                # [(b t), n, h]
         feats = feats.view(b, t, *feats.shape[1:])                                       # '(b t) n h -> b t n h'
         return self.temporal_aggregator(feats)
 
