@@ -28,11 +28,17 @@ extern "C" {
 
 int32_t vl2_version(void);
 /* Tuning knobs (process-global, for A/B benchmarking; defaults are the shipped heuristics).
- *   key 1 = GEMM kernel variant: 0 / 1 = 128x128x64 two-barrier kernel (shipped default), 8 = 256x256x32 ping-pong kernel
+ *   key 1 = GEMM kernel variant: 0 / 1 = 128x128x64 two-barrier kernel (shipped default), 2 = its stream-K form (experimental; needs
+ *           vl2_set_workspace), 8 = 256x256x32 ping-pong kernel
  *           (experimental, where N%256==0; +15-20 % on well-quantised shapes, see profiles/r01_gemm_experiments.md). */
 #define VL2_TUNE_GEMM_VARIANT 1
 #define VL2_TUNE_GEMV_ROWS_PER_WAVE 2   /* 1 (default), 2 or 4 output rows streamed by each wave of the decode GEMV */
 int32_t vl2_set_tuning(int32_t key, int32_t value);
+/* Optional caller-owned device workspace (>= vl2_workspace_bytes(), 16-byte aligned; NULL detaches).  With a workspace
+ * attached, tuning variant 2 runs GEMMs as stream-K (512 persistent workgroups, partial tiles exchanged through the
+ * workspace inside the launch with agent-scope release/acquire).  The library still allocates nothing.  One workspace per process: GEMMs sharing it must be ordered on one stream. */
+int64_t vl2_workspace_bytes(void);
+int32_t vl2_set_workspace(void* ws, int64_t bytes);
 const char* vl2_last_error_string(void);      /* host pointer, thread-local, valid until the next failing call */
 
 /* activation codes for vl2_gemm_bf16 / vl2_small_linear */

@@ -30,7 +30,7 @@ def rnd(*shape, scale=1.0):
     return (torch.randn(*shape, device=dev) * scale).to(torch.bfloat16)
 
 
-VARIANTS = (1, 8)
+VARIANTS = (1, 2)
 SHAPES = [  # name, M, N, K, kwargs
     ("sq_8192x4096x4096", 8192, 4096, 4096, dict()),
     ("sq_8192", 8192, 8192, 8192, dict()),
@@ -50,6 +50,7 @@ SHAPES = [  # name, M, N, K, kwargs
 
 def main():
     out = {}
+    ops.attach_workspace(dev)
     rounds = 2 if "--quick" in sys.argv else 3
     for name, M, N, K, kw in SHAPES:
         a, w = rnd(M, K), rnd(N, K, scale=K ** -0.5)
@@ -68,9 +69,9 @@ def main():
                 if v == 1:
                     ref = c.clone()
                 elif r == 0:
-                    same = torch.equal(ref, c)
-                    if not same:
-                        print(f"   !! variant {v} differs from v1 on {name}: max|d| = {(ref.float() - c.float()).abs().max().item():.4g}")
+                    d = (ref.float() - c.float()).abs().max().item()
+                    if d > 0.05 * ref.float().abs().max().item():
+                        print(f"   !! variant {v} differs from v1 on {name}: max|d| = {d:.4g}")
         ops.set_gemm_variant(0)
         fl = 2.0 * M * N * K
         out[name] = {f"v{v}": dict(us=round(us, 1), tflops=round(fl / us / 1e6, 1)) for v, us in best.items()}

@@ -13,6 +13,7 @@ def emulated_backend():
     lib = ctypes.CDLL(build())
     lib.vl2_version.restype = ctypes.c_int32
     lib.vl2_last_error_string.restype = ctypes.c_char_p
+    lib.vl2_workspace_bytes.restype = ctypes.c_int64
     for name, args in _lib.SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = ctypes.c_int32

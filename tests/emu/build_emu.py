@@ -1,6 +1,6 @@
 """TEST INFRASTRUCTURE ONLY: builds tests/emu/_emu_kernels.so (host CPU) from the product's kernel headers +
 tests/emu/hip_emu.h.  The only source rewrite is `extern __shared__` -> `extern` (dynamic LDS array is
-provided by the harness)."""
+provided by the harness) and the one inline-asm drain `s_waitcnt vmcnt(0)` -> no-op."""
 import os
 import shutil
 import subprocess
@@ -21,6 +21,7 @@ def build(force=False):
     try:
         for s in srcs:
             txt = open(s).read().replace("extern __shared__", "extern")
+            txt = txt.replace('asm volatile("s_waitcnt vmcnt(0)" ::: "memory")', "((void)0)")
             open(os.path.join(tmp, os.path.basename(s)), "w").write(txt)
         cxx = CLANG if os.path.exists(CLANG) else "clang++"
         cmd = [cxx, "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-Wno-everything", "-I", tmp, "-I", HERE,

@@ -11,10 +11,14 @@ alignas(64) unsigned char vl2_smem[160 * 1024];
 #include "k_stc.h"
 #include "k_decode.h"
 #include <cstdint>
+#include <algorithm>
+#include <vector>
 
 static char g_err[256] = "emu";
 extern "C" int32_t vl2_version(void) { return 1; }
 extern "C" const char* vl2_last_error_string(void) { return g_err; }
+extern "C" int64_t vl2_workspace_bytes(void) { return 0; }
+extern "C" int32_t vl2_set_workspace(void*, int64_t) { return 0; }
 
 static int g_gemm_variant = 0;
 extern "C" int32_t vl2_set_tuning(int32_t key, int32_t value) { if (key == 1) { g_gemm_variant = value; return 0; } return key == 2 ? 0 : -1; }
@@ -24,6 +28,27 @@ static void run_gemm(GemmArgs a) {
         if (g_gemm_variant == 8 && a.N % 256 == 0) {
             a.tiles_m = (a.M + 255) / 256; a.tiles_n = a.N / 256;
             emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(512), [=] { gemm4_bf16_kernel<ACT, SW, F32>(a); });
+            return;
+        }
+    }
+    if constexpr (!G) {
+        if (g_gemm_variant == 2) {                              // stream-K: a small persistent grid so every path is exercised
+            static std::vector<float> ws;
+            static std::vector<int> flags;
+            const int Gsk = 12, nt = a.K / 64, total = a.tiles_m * a.tiles_n * nt;
+            ws.assign((size_t)Gsk * 64 * 256, 0.f);
+            flags.assign(Gsk + 1, 0);
+            a.sk_ws = ws.data(); a.sk_flags = flags.data(); a.sk_per = (total + Gsk - 1) / Gsk;
+            // run contributors (higher logical ids) first: the emulator executes workgroups one after the other
+            std::vector<std::pair<int, unsigned>> ord;
+            for (unsigned b = 0; b < (unsigned)Gsk; ++b) {
+                const int q = Gsk >> 3, r = Gsk & 7, xcd = b & 7, k = b >> 3;
+                ord.push_back({(xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k, b});
+            }
+            std::sort(ord.rbegin(), ord.rend());
+            for (auto& o : ord) emu::block_order.push_back(o.second);
+            emu::launch(dim3(Gsk), dim3(256), [=] { gemm_sk_bf16_kernel<ACT, SW, F32>(a); });
+            if (flags[Gsk]) fprintf(stderr, "EMU: stream-K spin timeout\n");
             return;
         }
     }

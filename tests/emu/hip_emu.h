@@ -66,13 +66,16 @@ inline void trampoline() {
     cur->done = true;
     swapcontext(&cur->ctx, &main_ctx);
 }
+// optional explicit workgroup order (1-D grids): used to run stream-K contributors before the workgroups that wait on them
+inline std::vector<unsigned> block_order;
 inline void launch(dim3 grid, dim3 block, std::function<void()> fn, size_t stack_bytes = 256 * 1024) {
     g_gdim = grid; g_bdim = block;
     nthreads = block.x * block.y * block.z;
     body = fn;
     threads.assign(nthreads, Thread());
     for (auto& t : threads) t.stack = (char*)malloc(stack_bytes);
-    for (unsigned bz = 0; bz < grid.z; ++bz) for (unsigned by = 0; by < grid.y; ++by) for (unsigned bx = 0; bx < grid.x; ++bx) {
+    for (unsigned bz = 0; bz < grid.z; ++bz) for (unsigned by = 0; by < grid.y; ++by) for (unsigned bi = 0; bi < grid.x; ++bi) {
+        const unsigned bx = block_order.size() == grid.x ? block_order[bi] : bi;
         g_block = dim3(bx, by, bz);
         waves.assign((nthreads + 63) / 64, Wave());
         blk_arrived = 0; blk_gen = 0;
@@ -95,6 +98,7 @@ inline void launch(dim3 grid, dim3 block, std::function<void()> fn, size_t stack
     }
     for (auto& t : threads) free(t.stack);
     threads.clear();
+    block_order.clear();
 }
 
 typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -197,6 +201,10 @@ inline void global_load_lds(const void* g, void* lds, unsigned size, int offset,
 #define __builtin_amdgcn_readfirstlane(x) emu::shfl_idx((x), 0)
 #define __builtin_amdgcn_fdot2_f32_bf16(a, b, c, cl) emu::dot2((a), (b), (c))
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
+#define __builtin_amdgcn_fence(order, scope) ((void)0)
+#define __hip_atomic_load(p, order, scope) (*(p))
+#define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
+#define __HIP_MEMORY_SCOPE_AGENT 0
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_s_sleep(x) ((void)0)

@@ -57,6 +57,24 @@ def test_gemm_pingpong_variant_is_bit_identical(ops, M, N, K):
         ops.set_gemm_variant(0)
 
 
+def test_gemm_stream_k_variant(ops):
+    """Stream-K form (tuning knob 2): partial tiles cross workgroups through the caller-owned workspace with an
+    agent-scope release/acquire hand-off; repeated launches screen for stale reads.  fp32 sums in a different order."""
+    M, N, K = 1621, 4096, 4096
+    a, w, res = bf(M, K), bf(N, K, scale=K ** -0.5), bf(M, N)
+    ad, wd, rd = a.to(DEV), w.to(DEV), res.to(DEV)
+    ref = ops.gemm(ad, wd, res=rd).float()
+    ops.attach_workspace(DEV)
+    try:
+        ops.set_gemm_variant(2)
+        for _ in range(5):
+            out = ops.gemm(ad, wd, res=rd).float()
+            assert (out - ref).abs().max().item() <= 0.04 * ref.abs().max().item()
+            assert rel(out, ref) < 2e-3
+    finally:
+        ops.set_gemm_variant(0)
+
+
 def test_gemm_swiglu(ops):
     from videollama2_amd.weights import pack_gate_up
     M, I, K = 333, 1792, 1024

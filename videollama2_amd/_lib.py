@@ -11,6 +11,7 @@ _vp, _i32, _i64, _f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.
 # name -> argtypes (all return int32 except the two below)
 SIGNATURES = {
     "vl2_set_tuning": [_i32, _i32],
+    "vl2_set_workspace": [_vp, _i64],
     "vl2_gemm_bf16": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _i32,
                       _i32, _i32, _i32, _i32, _vp],
     "vl2_layernorm": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp],
@@ -29,7 +30,7 @@ SIGNATURES = {
     "vl2_argmax": [_vp, _i32, _vp, _vp, _i32, _vp, _vp],
     "vl2_embed_rows": [_vp, _vp, _vp, _i32, _i32, _i32, _vp],
 }
-EXPORTS = ["vl2_version", "vl2_last_error_string"] + list(SIGNATURES)
+EXPORTS = ["vl2_version", "vl2_last_error_string", "vl2_workspace_bytes"] + list(SIGNATURES)
 
 _lib = None
 
@@ -51,6 +52,8 @@ def load():
     lib.vl2_version.argtypes = []
     lib.vl2_last_error_string.restype = ctypes.c_char_p
     lib.vl2_last_error_string.argtypes = []
+    lib.vl2_workspace_bytes.restype = _i64
+    lib.vl2_workspace_bytes.argtypes = []
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = _i32

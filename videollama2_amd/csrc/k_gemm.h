@@ -28,6 +28,11 @@ struct GemmArgs {
     int out_grp, out_grp_pad, out_row_off;   // out_row = m + (m / out_grp) * out_grp_pad + out_row_off   (out_grp > 0)
     int res_row_mod, res_row_off;            // res_row = res_row_mod > 0 ? m % res_row_mod + res_row_off : out_row
     int tiles_m, tiles_n;
+    // stream-K form (gemm_sk_bf16_kernel): fp32 partial-tile workspace [grid][64][256], one flag per workgroup (zeroed by
+    // the launcher before every launch), K-tile iterations per workgroup
+    float* sk_ws;
+    int* sk_flags;
+    int sk_per;
 };
 
 enum { ACT_NONE = 0, ACT_QGELU = 1, ACT_GELU = 2, ACT_SILU = 3 };
@@ -202,6 +207,155 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
         __syncthreads();
         gemm_store_patch<ACT, SWIGLU, OUT_F32>(p, ep, m0 + wm * 64 + mi * 32, n0 + wn * 64, lane);
         __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// gemm_sk: stream-K form of gemm_bf16_kernel for grids that quantise badly on 256 CUs x 2 workgroups (e.g. the 416 / 584 /
+// 624 tiles of the M=1621 prefill and N=1024 ViT GEMMs).  A fixed grid of persistent workgroups splits the flattened
+// (tile, K-tile) iteration space evenly; a workgroup's range is contiguous, so it holds at most one tile TAIL (at the start
+// of its range -> it stores its fp32 accumulators and raises a flag at once) and at most one tile HEAD (at the end of its
+// range -> it adds the partials of the following workgroups, then runs the normal epilogue).  Hand-off = the release /
+// acquire recipe of the guide (G16): plain 16-B stores, every wave drains vmcnt, barrier, one lane: agent-scope release
+// fence + drain + relaxed agent flag store; consumer: one lane polls relaxed, agent-scope acquire, barrier, plain loads.
+// The waiter always waits on HIGHER logical workgroup ids whose contribution is the FIRST thing they compute, so there is
+// no wait chain; every spin is bounded (a timeout leaves the tile unreduced and sets flag slot [grid]).
+#define VL2_DRAIN_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+
+template <int ACT, bool SWIGLU, bool OUT_F32>
+__global__ __launch_bounds__(256, 2) void gemm_sk_bf16_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char vl2_smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int G = gridDim.x;
+    const int bid = xcd_remap(blockIdx.x, G);                      // logical id: every XCD owns a contiguous iteration range
+    const int nt = p.K / GEMM_BK;
+    const int total = p.tiles_m * p.tiles_n * nt;
+    int it = bid * p.sk_per;
+    int it_end = it + p.sk_per;
+    it_end = it_end < total ? it_end : total;
+    const int frow = lane & 31, fchk = lane >> 5;
+    float* ep = (float*)vl2_smem + wave * (32 * 68);
+
+    while (it < it_end) {
+        const int tile = it / nt, k0 = it - tile * nt;
+        int k1 = k0 + (it_end - it);
+        k1 = k1 < nt ? k1 : nt;
+        const int grp_sz = 8 * p.tiles_n;
+        const int first_m = (tile / grp_sz) * 8;
+        const int gm = (p.tiles_m - first_m) < 8 ? (p.tiles_m - first_m) : 8;
+        const int tm = first_m + (tile % grp_sz) % gm, tn = (tile % grp_sz) / gm;
+        const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
+
+        unsigned a_off[4], b_off[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int slot = ((i * 4 + wave) << 6) + lane;
+            const int R = slot >> 4, sx = (slot & 15) ^ (R & 15);
+            int am = m0 + 2 * R + (sx >> 3);
+            am = am < p.M ? am : p.M - 1;
+            a_off[i] = (unsigned)am * (unsigned)p.lda + (sx & 7) * 8;
+            b_off[i] = (unsigned)(n0 + 2 * R + (sx >> 3)) * (unsigned)p.ldw + (sx & 7) * 8;
+        }
+        auto stage = [&](int buf, int kt) {
+            unsigned char* As = vl2_smem + buf * 32768;
+            unsigned char* Bs = As + 16384;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) glds16(p.A + a_off[i] + kt * GEMM_BK, As + ((i * 4 + wave) << 10));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) glds16(p.W + b_off[i] + kt * GEMM_BK, Bs + ((i * 4 + wave) << 10));
+        };
+
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        stage(0, k0);
+        __syncthreads();
+        for (int kt = k0; kt < k1; ++kt) {
+            const int buf = (kt - k0) & 1;
+            if (kt + 1 < k1) stage(buf ^ 1, kt + 1);
+            const unsigned char* As = vl2_smem + buf * 32768;
+            const unsigned char* Bs = As + 16384;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                bf16x8 af[2], bfr[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    af[i] = *(const bf16x8*)(As + gemm_lds_off(wm * 64 + i * 32 + frow, ks * 2 + fchk));
+                    bfr[i] = *(const bf16x8*)(Bs + gemm_lds_off(wn * 64 + i * 32 + frow, ks * 2 + fchk));
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            }
+            __syncthreads();
+        }
+
+        if (k0 != 0) {
+            // ---- tile tail: publish the partial accumulators (thread-private layout: element e of thread tid at [e][tid])
+            float* ws = p.sk_ws + (size_t)bid * (64 * 256);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) ws[((i * 2 + j) * 16 + r) * 256 + tid] = acc[i][j][r];
+            VL2_DRAIN_VMEM();
+            __syncthreads();
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                VL2_DRAIN_VMEM();
+                __hip_atomic_store(p.sk_flags + bid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else {
+            if (k1 != nt) {
+                // ---- tile head: add the partials of the workgroups that own the rest of this tile's K range
+                int rem = nt - k1, c = bid + 1;
+                while (rem > 0) {
+                    if (tid == 0) {
+                        int spins = 0;
+                        while (__hip_atomic_load(p.sk_flags + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+                            __builtin_amdgcn_s_sleep(8);
+                            if (++spins > (1 << 22)) { __hip_atomic_store(p.sk_flags + G, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    }
+                    __syncthreads();
+                    const float* ws = p.sk_ws + (size_t)c * (64 * 256);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) acc[i][j][r] += ws[((i * 2 + j) * 16 + r) * 256 + tid];
+                    rem -= p.sk_per < rem ? p.sk_per : rem;
+                    ++c;
+                }
+            }
+            // ---- epilogue (as gemm_bf16_kernel)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        ep[row * 68 + ni * 32 + (lane & 31)] = acc[mi][ni][r];
+                    }
+                __syncthreads();
+                gemm_store_patch<ACT, SWIGLU, OUT_F32>(p, ep, m0 + wm * 64 + mi * 32, n0 + wn * 64, lane);
+                __syncthreads();
+            }
+        }
+        it += k1 - k0;
     }
 }
 

@@ -32,14 +32,30 @@ extern "C" int32_t vl2_version(void) { return VL2_ABI_VERSION; }
 extern "C" const char* vl2_last_error_string(void) { return g_err; }
 
 static int g_gemm_variant = 0;
+static void* g_ws = nullptr;          // caller-owned device workspace (vl2_set_workspace)
+static int64_t g_ws_bytes = 0;
+#define SK_GRID 512                  // persistent stream-K workgroups: 2 per CU
+#define SK_WS_BYTES ((int64_t)SK_GRID * 64 * 256 * 4 + (SK_GRID + 1) * 4)
 static int g_gemv_rpw = 1;   // measured on MI355X: 3.09 / 3.30 / 3.97 ms per 7B decode token at 1 / 2 / 4 rows per wave
 extern "C" int32_t vl2_set_tuning(int32_t key, int32_t value) {
-    if (key == VL2_TUNE_GEMM_VARIANT && (value == 0 || value == 1 || value == 8)) { g_gemm_variant = value; return 0; }
+    if (key == VL2_TUNE_GEMM_VARIANT && (value == 0 || value == 1 || value == 2 || value == 8)) { g_gemm_variant = value; return 0; }
     if (key == VL2_TUNE_GEMV_ROWS_PER_WAVE && (value == 1 || value == 2 || value == 4)) { g_gemv_rpw = value; return 0; }
     return fail(VL2_E_BADARG, "vl2_set_tuning: unknown key/value %d/%d", key, value);
 }
 
+extern "C" int64_t vl2_workspace_bytes(void) { return SK_WS_BYTES; }
+extern "C" int32_t vl2_set_workspace(void* ws, int64_t bytes) {
+    if (ws && (bytes < SK_WS_BYTES || !ALIGNED16(ws))) return fail(VL2_E_BADARG, "vl2_set_workspace: need >= %lld bytes, 16-byte aligned", (long long)SK_WS_BYTES);
+    g_ws = ws;
+    g_ws_bytes = ws ? bytes : 0;
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------ GEMM
+// stream-K form: measured 0.5-0.6x of the plain grid on this workload's shapes (per-tile prologue/epilogue of the persistent
+// workgroups, ~15 us of partial-tile exchange, worse L2 locality of strided tile ownership) -> only on explicit request.
+static bool want_stream_k(const GemmArgs&) { return g_ws && g_gemm_variant == 2; }
+
 template <int ACT, bool SW, bool F32, bool G>
 static void launch_gemm(const GemmArgs& a0, hipStream_t s) {
     if constexpr (!G) {
@@ -54,6 +70,24 @@ static void launch_gemm(const GemmArgs& a0, hipStream_t s) {
             a.tiles_m = (a.M + GEMM4_BM - 1) / GEMM4_BM;
             a.tiles_n = a.N / GEMM4_BN;
             hipLaunchKernelGGL((gemm4_bf16_kernel<ACT, SW, F32>), dim3(a.tiles_m * a.tiles_n), dim3(512), GEMM4_LDS_BYTES, s, a);
+            return;
+        }
+    }
+    if constexpr (!G) {
+        if (want_stream_k(a0)) {
+            static bool attr_sk = false;
+            if (!attr_sk) {
+                hipFuncSetAttribute((const void*)gemm_sk_bf16_kernel<ACT, SW, F32>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    GEMM_LDS_BYTES);
+                attr_sk = true;
+            }
+            GemmArgs a = a0;
+            const int total = a.tiles_m * a.tiles_n * (a.K / GEMM_BK);
+            a.sk_ws = (float*)g_ws;
+            a.sk_flags = (int*)((char*)g_ws + (int64_t)SK_GRID * 64 * 256 * 4);
+            a.sk_per = (total + SK_GRID - 1) / SK_GRID;
+            hipMemsetAsync(a.sk_flags, 0, (SK_GRID + 1) * 4, s);               // flags re-armed before EVERY launch (guide G16)
+            hipLaunchKernelGGL((gemm_sk_bf16_kernel<ACT, SW, F32>), dim3(SK_GRID), dim3(256), GEMM_LDS_BYTES, s, a);
             return;
         }
     }

@@ -30,8 +30,22 @@ def _chk(t, dtype, name):
         raise ValueError(f"{name} must be contiguous in its last dim")
 
 
+_WORKSPACE = {}
+
+
+def attach_workspace(device):
+    """Allocate (once per device) and attach the stream-K workspace; the library itself never allocates."""
+    key = str(device)
+    if key not in _WORKSPACE:
+        n = int(_lib.load().vl2_workspace_bytes())
+        _WORKSPACE[key] = torch.zeros((n + 15) // 16 * 16, dtype=torch.uint8, device=device)
+    ws = _WORKSPACE[key]
+    _lib.call("vl2_set_workspace", _p(ws), ws.numel())
+    return ws
+
+
 def set_gemm_variant(v):
-    """0/1 = 128x128x64 kernel (default), 8 = experimental 256x256x32 ping-pong kernel (A/B knob, include/vl2hip.h)."""
+    """0 auto, 1 plain tiled kernel, 2 stream-K, 8 experimental 256x256x32 ping-pong kernel (A/B knob, include/vl2hip.h)."""
     _lib.call("vl2_set_tuning", 1, int(v))
 
 
