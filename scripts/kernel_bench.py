@@ -30,7 +30,7 @@ def rnd(*shape, scale=1.0):
     return (torch.randn(*shape, device=dev) * scale).to(torch.bfloat16)
 
 
-VARIANTS = (1, 2)
+VARIANTS = (1, 8)
 SHAPES = [  # name, M, N, K, kwargs
     ("sq_8192x4096x4096", 8192, 4096, 4096, dict()),
     ("sq_8192", 8192, 8192, 8192, dict()),

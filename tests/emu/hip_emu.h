@@ -147,6 +147,7 @@ inline f32x4 mfma_16x16x32_bf16(s16x8 a, s16x8 b, f32x4 c) {
     wave_sync();
     return c;
 }
+struct Rsrc { const char* p; };
 template <class T> inline float dot2(T a, T b, float c) {   // v_dot2c_f32_bf16
     uint32_t x, y; memcpy(&x, &a, 4); memcpy(&y, &b, 4);
     float r = c;
@@ -198,6 +199,8 @@ inline void global_load_lds(const void* g, void* lds, unsigned size, int offset,
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) emu::mfma_32x32x16_bf16(a, b, c)
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) emu::mfma_16x16x32_bf16(a, b, c)
 #define __builtin_amdgcn_global_load_lds(g, l, sz, off, aux) emu::global_load_lds((const void*)(g), (void*)(l), sz, off, aux)
+#define __builtin_amdgcn_make_buffer_rsrc(p, stride, bytes, flags) emu::Rsrc{(const char*)(p)}
+#define __builtin_amdgcn_raw_ptr_buffer_load_lds(r, l, sz, voff, soff, off, aux) emu::global_load_lds((r).p + (voff) + (soff) + (off), (void*)(l), sz, 0, 0)
 #define __builtin_amdgcn_readfirstlane(x) emu::shfl_idx((x), 0)
 #define __builtin_amdgcn_fdot2_f32_bf16(a, b, c, cl) emu::dot2((a), (b), (c))
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
@@ -206,6 +209,7 @@ inline void global_load_lds(const void* g, void* lds, unsigned size, int offset,
 #define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
 #define __HIP_MEMORY_SCOPE_AGENT 0
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
+#define __builtin_readcyclecounter() 0LL
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_s_sleep(x) ((void)0)
 #define __builtin_nontemporal_load(p) (*(p))

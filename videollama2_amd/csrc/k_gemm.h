@@ -123,43 +123,6 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
     const int tm = first_m + (t % grp_sz) % gm, tn = (t % grp_sz) / gm;
     const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
 
-    // per-thread staging coordinates (4 x 16 B for A, 4 x 16 B for W per K-tile)
-    int st_row[4], st_chk[4];
-    const bf16_t* a_src[4];
-    const bf16_t* b_src[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int slot = ((i * 4 + wave) << 6) + lane;
-        const int R = slot >> 4, sp = slot & 15, s = sp ^ (R & 15);
-        st_row[i] = 2 * R + (s >> 3);
-        st_chk[i] = s & 7;
-        int am = m0 + st_row[i];
-        am = am < p.M ? am : p.M - 1;
-        a_src[i] = GATHER ? nullptr : p.A + (size_t)am * p.lda + st_chk[i] * 8;
-        st_row[i] = am;
-        b_src[i] = p.W + (size_t)(n0 + 2 * R + (s >> 3)) * p.ldw + st_chk[i] * 8;
-    }
-
-    auto stage = [&](int buf, int kt) {
-        unsigned char* As = vl2_smem + buf * 32768;
-        unsigned char* Bs = As + 16384;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const bf16_t* src;
-            if (GATHER) {
-                const int k = kt * GEMM_BK;
-                const int seg = k / p.seg_k, koff = k - seg * p.seg_k;
-                const int r = p.a_idx[(size_t)seg * p.M + st_row[i]];
-                src = (r < 0 ? p.zero_row : p.A + (size_t)r * p.lda) + koff + st_chk[i] * 8;
-            } else {
-                src = a_src[i] + kt * GEMM_BK;
-            }
-            glds16(src, As + ((i * 4 + wave) << 10));
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) glds16(b_src[i] + kt * GEMM_BK, Bs + ((i * 4 + wave) << 10));
-    };
-
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -170,27 +133,124 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
 
     const int nt = p.K / GEMM_BK;
     const int frow = lane & 31, fchk = lane >> 5;
-    stage(0, 0);
-    __syncthreads();
-    for (int kt = 0; kt < nt; ++kt) {
-        if (kt + 1 < nt) stage((kt + 1) & 1, kt + 1);
-        const unsigned char* As = vl2_smem + (kt & 1) * 32768;
-        const unsigned char* Bs = As + 16384;
+
+    if constexpr (!GATHER) {
+        // ---- main loop, issue-lean form.  Measured (profiles/r01_gemm_experiments.md): with two waves per SIMD the kernel is
+        // bound by instruction ISSUE, not by the MFMA pipe or LDS -- so the loop carries no per-iteration VALU:
+        //   * LDS-DMA as `buffer_load_dwordx4 ... offen lds`: loop-invariant 32-bit VGPR byte offsets, the K position in
+        //     the SGPR soffset, the LDS slot in M0 (one s_add + one VMEM instruction per 1 KiB piece);
+        //   * fragment ds_read_b128 addresses = 8 loop-invariant VGPR bases + immediate offsets (K loop unrolled by the
+        //     two LDS buffers so the buffer offset is an immediate).
+        const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x7fffffff, 0x00020000);
+        const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0x7fffffff, 0x00020000);
+        unsigned a_vo[4];                           // per-thread byte offsets of the 4 A pieces (rows clamp at M-1)
+        unsigned w_vo;                              // W piece 0; piece i is 32 rows further: + i * 64 * ldw bytes (uniform)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int slot = ((i * 4 + wave) << 6) + lane;
+            const int R = slot >> 4, sx = (slot & 15) ^ (R & 15);
+            int am = m0 + 2 * R + (sx >> 3);
+            am = am < p.M ? am : p.M - 1;
+            a_vo[i] = ((unsigned)am * (unsigned)p.lda + (sx & 7) * 8) * 2;
+            if (i == 0) w_vo = ((unsigned)(n0 + 2 * R + (sx >> 3)) * (unsigned)p.ldw + (sx & 7) * 8) * 2;
+        }
+        const unsigned w_step = 64u * (unsigned)p.ldw;                    // bytes between W pieces (32 rows)
+        unsigned a_rd[4], b_rd[4];                   // ds_read bases per k-step (tile i = 1 is +4096 B)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            bf16x8 af[2], bfr[2];
+            a_rd[ks] = gemm_lds_off(wm * 64 + frow, ks * 2 + fchk);
+            b_rd[ks] = 16384 + gemm_lds_off(wn * 64 + frow, ks * 2 + fchk);
+        }
+        auto stage = [&](unsigned lds_buf, int kt) {
+            const unsigned kb = (unsigned)kt * (GEMM_BK * 2);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                af[i] = *(const bf16x8*)(As + gemm_lds_off(wm * 64 + i * 32 + frow, ks * 2 + fchk));
-                bfr[i] = *(const bf16x8*)(Bs + gemm_lds_off(wn * 64 + i * 32 + frow, ks * 2 + fchk));
+            for (int i = 0; i < 4; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(vl2_smem + lds_buf + ((i * 4 + wave) << 10)),
+                                                         16, a_vo[i], kb, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(vl2_smem + lds_buf + 16384 + ((i * 4 + wave) << 10)),
+                                                         16, w_vo, kb + i * w_step, 0, 0);
+        };
+        auto compute = [&](unsigned lds_buf) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                bf16x8 af[2], bfr[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    af[i] = *(const bf16x8*)(vl2_smem + a_rd[ks] + (lds_buf + i * 4096));
+                    bfr[i] = *(const bf16x8*)(vl2_smem + b_rd[ks] + (lds_buf + i * 4096));
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            }
+        };
+        stage(0, 0);
+        __syncthreads();
+        int kt = 0;
+        for (; kt + 2 <= nt; kt += 2) {              // two K-tiles per trip (one per LDS buffer), no exit inside the body
+            stage(32768, kt + 1);
+            compute(0);
+            __syncthreads();
+            if (kt + 2 < nt) stage(0, kt + 2);
+            compute(32768);
+            __syncthreads();
+        }
+        if (kt < nt) {                               // odd K-tile count: the last tile sits in buffer 0
+            compute(0);
+            __syncthreads();
+        }
+    } else {
+        // ---- gathered-A form (Conv3d taps): the A row of (K segment, m) comes from an index table
+        int st_row[4], st_chk[4];
+        const bf16_t* b_src[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int slot = ((i * 4 + wave) << 6) + lane;
+            const int R = slot >> 4, sp = slot & 15, sx = sp ^ (R & 15);
+            st_chk[i] = sx & 7;
+            int am = m0 + 2 * R + (sx >> 3);
+            st_row[i] = am < p.M ? am : p.M - 1;
+            b_src[i] = p.W + (size_t)(n0 + 2 * R + (sx >> 3)) * p.ldw + st_chk[i] * 8;
+        }
+        auto stage = [&](int buf, int kt) {
+            unsigned char* As = vl2_smem + buf * 32768;
+            unsigned char* Bs = As + 16384;
+            const int k = kt * GEMM_BK;
+            const int seg = k / p.seg_k, koff = k - seg * p.seg_k;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = p.a_idx[(size_t)seg * p.M + st_row[i]];
+                glds16((r < 0 ? p.zero_row : p.A + (size_t)r * p.lda) + koff + st_chk[i] * 8, As + ((i * 4 + wave) << 10));
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-        }
+            for (int i = 0; i < 4; ++i) glds16(b_src[i] + kt * GEMM_BK, Bs + ((i * 4 + wave) << 10));
+        };
+        stage(0, 0);
         __syncthreads();
+        for (int kt = 0; kt < nt; ++kt) {
+            if (kt + 1 < nt) stage((kt + 1) & 1, kt + 1);
+            const unsigned char* As = vl2_smem + (kt & 1) * 32768;
+            const unsigned char* Bs = As + 16384;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                bf16x8 af[2], bfr[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    af[i] = *(const bf16x8*)(As + gemm_lds_off(wm * 64 + i * 32 + frow, ks * 2 + fchk));
+                    bfr[i] = *(const bf16x8*)(Bs + gemm_lds_off(wn * 64 + i * 32 + frow, ks * 2 + fchk));
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            }
+            __syncthreads();
+        }
     }
 
     // ---- epilogue: acc (col = lane&31, rows (r&3)+8(r>>2)+4(lane>>5)) -> fp32 LDS patch [32][68] per wave -> rows
@@ -405,8 +465,11 @@ __global__ __launch_bounds__(512, 2) void gemm4_bf16_kernel(GemmArgs p) {
     const int tm = first_m + (t0 % grp_sz) % gm, tn = (t0 % grp_sz) / gm;
     const int m0 = tm * GEMM4_BM, n0 = tn * GEMM4_BN;
 
-    // this wave's LDS-DMA parts of a slab: 2 x A rows [128*grp, +128) and 2 x W rows [128*grp, +128)
-    unsigned a_off[2], w_off[2];
+    // this wave's LDS-DMA parts of a slab: 2 x A rows [128*grp, +128) and 2 x W rows [128*grp, +128), issue-lean form:
+    // `buffer_load_dwordx4 ... offen lds` with loop-invariant VGPR byte offsets, K position in the SGPR soffset
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x7fffffff, 0x00020000);
+    const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0x7fffffff, 0x00020000);
+    unsigned a_vo[2], w_vo[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int slot = grp * 512 + ((i * 4 + w4) << 6) + lane;
@@ -414,15 +477,19 @@ __global__ __launch_bounds__(512, 2) void gemm4_bf16_kernel(GemmArgs p) {
         const int row = 4 * R + (sp >> 2), chk = (sp & 3) ^ (R & 3);
         int am = m0 + row;
         am = am < p.M ? am : p.M - 1;
-        a_off[i] = (unsigned)am * (unsigned)p.lda + chk * 8;
-        w_off[i] = (unsigned)(n0 + row) * (unsigned)p.ldw + chk * 8;
+        a_vo[i] = ((unsigned)am * (unsigned)p.lda + chk * 8) * 2;
+        w_vo[i] = ((unsigned)(n0 + row) * (unsigned)p.ldw + chk * 8) * 2;
     }
     auto issue_dma = [&](int t) {
-        unsigned char* st = vl2_smem + (t & 3) * GEMM4_STAGE;
+        const unsigned st = (unsigned)(t & 3) * GEMM4_STAGE, kb = (unsigned)t * (GEMM4_BK * 2);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) glds16(p.A + a_off[i] + t * GEMM4_BK, st + ((grp * 8 + i * 4 + w4) << 10));
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(vl2_smem + st + ((grp * 8 + i * 4 + w4) << 10)),
+                                                     16, a_vo[i], kb, 0, 0);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) glds16(p.W + w_off[i] + t * GEMM4_BK, st + 16384 + ((grp * 8 + i * 4 + w4) << 10));
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(vl2_smem + st + 16384 + ((grp * 8 + i * 4 + w4) << 10)),
+                                                     16, w_vo[i], kb, 0, 0);
     };
 
     f32x16 acc[2][4];
@@ -437,6 +504,12 @@ __global__ __launch_bounds__(512, 2) void gemm4_bf16_kernel(GemmArgs p) {
     const int nt = p.K / GEMM4_BK;
     const int frow = lane & 31, fchk = lane >> 5;
     const int arow = grp * 128 + wm * 64 + frow, brow = wn * 128 + frow;
+    unsigned a_rd[2], b_rd[2];                     // fragment read bases per k-step; tile i / j is +2048 B (32 rows)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        a_rd[ks] = gemm4_lds_off(arow, ks * 2 + fchk);
+        b_rd[ks] = 16384 + gemm4_lds_off(brow, ks * 2 + fchk);
+    }
     issue_dma(0);
     if (nt > 1) issue_dma(1);
     if (nt > 2) issue_dma(2);
@@ -447,14 +520,14 @@ __global__ __launch_bounds__(512, 2) void gemm4_bf16_kernel(GemmArgs p) {
     for (int t = 0; t < nt; ++t) {
         // ---------------- LOAD(t): memory work only
         if (t + 3 < nt) issue_dma(t + 3);
-        const unsigned char* As = vl2_smem + (t & 3) * GEMM4_STAGE;
-        const unsigned char* Bs = As + 16384;
+        const unsigned st = (unsigned)(t & 3) * GEMM4_STAGE;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
+            const unsigned ab = a_rd[ks] + st, bb = b_rd[ks] + st;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) fa[ks][i] = *(const bf16x8*)(As + gemm4_lds_off(arow + i * 32, ks * 2 + fchk));
+            for (int i = 0; i < 2; ++i) fa[ks][i] = *(const bf16x8*)(vl2_smem + ab + i * 2048);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) fb[ks][j] = *(const bf16x8*)(Bs + gemm4_lds_off(brow + j * 32, ks * 2 + fchk));
+            for (int j = 0; j < 4; ++j) fb[ks][j] = *(const bf16x8*)(vl2_smem + bb + j * 2048);
         }
         // slab t+1 must have landed before the barrier below; the (up to) two newer slabs stay in flight
         const int newer = nt - 2 - t;              // slabs issued after t+1

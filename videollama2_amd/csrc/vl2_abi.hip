@@ -56,10 +56,22 @@ extern "C" int32_t vl2_set_workspace(void* ws, int64_t bytes) {
 // workgroups, ~15 us of partial-tile exchange, worse L2 locality of strided tile ownership) -> only on explicit request.
 static bool want_stream_k(const GemmArgs&) { return g_ws && g_gemm_variant == 2; }
 
+// Tile-shape choice (auto): expected efficiency = how full the last round of resident workgroups is x rows wasted by the
+// M edge x the kernel's measured rate on well-quantised shapes (128x128 two-barrier kernel 1.0, 256x256 ping-pong 1.2:
+// profiles/r01_gemm_experiments.md).  Fitted to the measured shapes of the T=16 workload (ViT wo/fc2/qkv and the LLM qkv
+// projection take the 256x256 kernel, everything else the 128x128 one).
+static bool prefer_pingpong(const GemmArgs& a) {
+    const double t1 = (double)((a.M + 127) / 128) * (a.N / 128) / 512.0;          // rounds of 2 WG/CU
+    const double t4 = (double)((a.M + 255) / 256) * (a.N / 256) / 256.0;          // rounds of 1 WG/CU
+    const double e1 = t1 / (double)(long)(t1 + 0.999999) * ((double)a.M / (((a.M + 127) / 128) * 128.0));
+    const double e4 = t4 / (double)(long)(t4 + 0.999999) * ((double)a.M / (((a.M + 255) / 256) * 256.0)) * 1.2;
+    return a.K >= 512 && e4 > 1.03 * e1;
+}
+
 template <int ACT, bool SW, bool F32, bool G>
 static void launch_gemm(const GemmArgs& a0, hipStream_t s) {
     if constexpr (!G) {
-        if (g_gemm_variant == 8 && a0.N % GEMM4_BN == 0) {
+        if (a0.N % GEMM4_BN == 0 && (g_gemm_variant == 8 || (g_gemm_variant == 0 && prefer_pingpong(a0)))) {
             static bool attr4 = false;
             if (!attr4) {
                 hipFuncSetAttribute((const void*)gemm4_bf16_kernel<ACT, SW, F32>, hipFuncAttributeMaxDynamicSharedMemorySize,
