@@ -30,7 +30,7 @@ def rnd(*shape, scale=1.0):
     return (torch.randn(*shape, device=dev) * scale).to(torch.bfloat16)
 
 
-VARIANTS = (1, 8)
+VARIANTS = (1, 4, 8)
 SHAPES = [  # name, M, N, K, kwargs
     ("sq_8192x4096x4096", 8192, 4096, 4096, dict()),
     ("sq_8192", 8192, 8192, 8192, dict()),
@@ -61,7 +61,7 @@ def main():
         best = {}
         for r in range(rounds):
             for v in VARIANTS:
-                if v == 8 and N % 256:
+                if v in (4, 8) and N % 256:
                     continue
                 ops.set_gemm_variant(v)
                 us = timeit(lambda: ops.gemm(a, w, bias=bias, res=res, act=kw.get("act", 0), swiglu=kw.get("swiglu", False), out=c))

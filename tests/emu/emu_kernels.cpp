@@ -25,6 +25,11 @@ extern "C" int32_t vl2_set_tuning(int32_t key, int32_t value) { if (key == 1) { 
 template <int ACT, bool SW, bool F32, bool G>
 static void run_gemm(GemmArgs a) {
     if constexpr (!G) {
+        if (g_gemm_variant == 4 && a.N % 256 == 0) {
+            a.tiles_m = (a.M + 127) / 128; a.tiles_n = a.N / 256;
+            emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(512), [=] { gemm3_bf16_kernel<ACT, SW, F32>(a); });
+            return;
+        }
         if (g_gemm_variant == 8 && a.N % 256 == 0) {
             a.tiles_m = (a.M + 255) / 256; a.tiles_n = a.N / 256;
             emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(512), [=] { gemm4_bf16_kernel<ACT, SW, F32>(a); });

@@ -48,8 +48,9 @@ def test_emu_gemm_pingpong_variant(emu):
         a, w = bf(300, K), bf(512, K)
         ref = ops.gemm(a, w, out_f32=True)
         try:
-            ops.set_gemm_variant(8)
-            assert torch.equal(ops.gemm(a, w, out_f32=True), ref)
+            for v in (4, 8):
+                ops.set_gemm_variant(v)
+                assert torch.equal(ops.gemm(a, w, out_f32=True), ref)
         finally:
             ops.set_gemm_variant(0)
 

@@ -564,3 +564,126 @@ __global__ __launch_bounds__(512, 2) void gemm4_bf16_kernel(GemmArgs p) {
             __syncthreads();
         }
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// gemm3: 128 (M) x 256 (N) ping-pong kernel (see gemm4) for GEMMs whose M granularity matters (the M = 1621 prefill):
+// the two wave groups SHARE the 128-row A tile and own one 128-column half of W each (wave tile 64 x 64).
+// K-tile 64, 3-stage ring of (A 16 KiB | W_0 16 KiB | W_1 16 KiB) = 144 KiB, LOAD phase = 16 ds_read_b128 + 6 LDS-DMA
+// (issue-lean form: SGPR K offset, immediate read offsets), counted vmcnt(6), raw s_barrier.
+#define GEMM3_BM 128
+#define GEMM3_BN 256
+#define GEMM3_STAGE 49152
+#define GEMM3_LDS_BYTES (3 * GEMM3_STAGE)
+
+template <int ACT, bool SWIGLU, bool OUT_F32>
+__global__ __launch_bounds__(512, 2) void gemm3_bf16_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char vl2_smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, w4 = wave & 3;                      // waves w and w+4 share a SIMD (measured)
+    const int wm = w4 >> 1, wn = w4 & 1;
+
+    const int t0 = xcd_remap(blockIdx.x, gridDim.x);
+    const int grp_sz = 8 * p.tiles_n;
+    const int first_m = (t0 / grp_sz) * 8;
+    const int gm = (p.tiles_m - first_m) < 8 ? (p.tiles_m - first_m) : 8;
+    const int tm = first_m + (t0 % grp_sz) % gm, tn = (t0 % grp_sz) / gm;
+    const int m0 = tm * GEMM3_BM, n0 = tn * GEMM3_BN;
+
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x7fffffff, 0x00020000);
+    const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0x7fffffff, 0x00020000);
+    // this wave's LDS-DMA pieces of a K-tile: 4 x W_grp (its own 128 rows; piece i is 32 rows further) + 2 x A rows [64*grp, +64)
+    unsigned w_vo, a_vo[2];
+    {
+        const int slot = (w4 << 6) + lane;
+        const int R = slot >> 4, sx = (slot & 15) ^ (R & 15);
+        w_vo = ((unsigned)(n0 + grp * 128 + 2 * R + (sx >> 3)) * (unsigned)p.ldw + (sx & 7) * 8) * 2;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int slot = (((grp * 2 + i) * 4 + w4) << 6) + lane;
+        const int R = slot >> 4, sx = (slot & 15) ^ (R & 15);
+        int am = m0 + 2 * R + (sx >> 3);
+        am = am < p.M ? am : p.M - 1;
+        a_vo[i] = ((unsigned)am * (unsigned)p.lda + (sx & 7) * 8) * 2;
+    }
+    const unsigned w_step = 64u * (unsigned)p.ldw;
+    auto issue_dma = [&](int kt) {
+        const unsigned st = (unsigned)(kt % 3) * GEMM3_STAGE, kb = (unsigned)kt * (GEMM_BK * 2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(vl2_smem + st + 16384 + grp * 16384 + ((i * 4 + w4) << 10)),
+                                                     16, w_vo, kb + i * w_step, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(vl2_smem + st + (((grp * 2 + i) * 4 + w4) << 10)),
+                                                     16, a_vo[i], kb, 0, 0);
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    bf16x8 fa[4][2], fb[4][2];
+
+    const int nt = p.K / GEMM_BK;
+    const int frow = lane & 31, fchk = lane >> 5;
+    unsigned a_rd[4], b_rd[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        a_rd[ks] = gemm_lds_off(wm * 64 + frow, ks * 2 + fchk);
+        b_rd[ks] = 16384 + grp * 16384 + gemm_lds_off(wn * 64 + frow, ks * 2 + fchk);
+    }
+    issue_dma(0);
+    if (nt > 1) issue_dma(1);
+    if (nt > 1) VL2_WAIT_VMCNT(6); else VL2_WAIT_VMCNT(0);
+    VL2_PHASE_BARRIER();
+
+    if (grp == 1) VL2_PHASE_BARRIER();
+    for (int t = 0; t < nt; ++t) {
+        // ---------------- LOAD(t)
+        const bool more = t + 2 < nt;
+        if (more) issue_dma(t + 2);
+        const unsigned st = (unsigned)(t % 3) * GEMM3_STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const unsigned ab = a_rd[ks] + st, bb = b_rd[ks] + st;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                fa[ks][i] = *(const bf16x8*)(vl2_smem + ab + i * 4096);
+                fb[ks][i] = *(const bf16x8*)(vl2_smem + bb + i * 4096);
+            }
+        }
+        if (more) VL2_WAIT_VMCNT(6); else VL2_WAIT_VMCNT(0);      // tile t+1 landed; the 6 just issued stay in flight
+        VL2_WAIT_LGKMCNT0();
+        VL2_PHASE_BARRIER();
+        // ---------------- MFMA(t)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
+        VL2_PHASE_BARRIER();
+    }
+    if (grp == 0) VL2_PHASE_BARRIER();
+
+    float* ep = (float*)vl2_smem + wave * (32 * 68);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                ep[row * 68 + ni * 32 + (lane & 31)] = acc[mi][ni][r];
+            }
+        __syncthreads();
+        gemm_store_patch<ACT, SWIGLU, OUT_F32>(p, ep, m0 + wm * 64 + mi * 32, n0 + grp * 128 + wn * 64, lane);
+        __syncthreads();
+    }
+}

@@ -38,7 +38,7 @@ static int64_t g_ws_bytes = 0;
 #define SK_WS_BYTES ((int64_t)SK_GRID * 64 * 256 * 4 + (SK_GRID + 1) * 4)
 static int g_gemv_rpw = 1;   // measured on MI355X: 3.09 / 3.30 / 3.97 ms per 7B decode token at 1 / 2 / 4 rows per wave
 extern "C" int32_t vl2_set_tuning(int32_t key, int32_t value) {
-    if (key == VL2_TUNE_GEMM_VARIANT && (value == 0 || value == 1 || value == 2 || value == 8)) { g_gemm_variant = value; return 0; }
+    if (key == VL2_TUNE_GEMM_VARIANT && (value == 0 || value == 1 || value == 2 || value == 4 || value == 8)) { g_gemm_variant = value; return 0; }
     if (key == VL2_TUNE_GEMV_ROWS_PER_WAVE && (value == 1 || value == 2 || value == 4)) { g_gemv_rpw = value; return 0; }
     return fail(VL2_E_BADARG, "vl2_set_tuning: unknown key/value %d/%d", key, value);
 }
@@ -57,21 +57,41 @@ extern "C" int32_t vl2_set_workspace(void* ws, int64_t bytes) {
 static bool want_stream_k(const GemmArgs&) { return g_ws && g_gemm_variant == 2; }
 
 // Tile-shape choice (auto): expected efficiency = how full the last round of resident workgroups is x rows wasted by the
-// M edge x the kernel's measured rate on well-quantised shapes (128x128 two-barrier kernel 1.0, 256x256 ping-pong 1.2:
-// profiles/r01_gemm_experiments.md).  Fitted to the measured shapes of the T=16 workload (ViT wo/fc2/qkv and the LLM qkv
-// projection take the 256x256 kernel, everything else the 128x128 one).
-static bool prefer_pingpong(const GemmArgs& a) {
-    const double t1 = (double)((a.M + 127) / 128) * (a.N / 128) / 512.0;          // rounds of 2 WG/CU
-    const double t4 = (double)((a.M + 255) / 256) * (a.N / 256) / 256.0;          // rounds of 1 WG/CU
-    const double e1 = t1 / (double)(long)(t1 + 0.999999) * ((double)a.M / (((a.M + 127) / 128) * 128.0));
-    const double e4 = t4 / (double)(long)(t4 + 0.999999) * ((double)a.M / (((a.M + 255) / 256) * 256.0)) * 1.2;
-    return a.K >= 512 && e4 > 1.03 * e1;
+// M edge x the kernel's measured rate on well-quantised shapes (128x128 two-barrier kernel 1.0, 128x256 ping-pong 1.07,
+// 256x256 ping-pong 1.2: profiles/r01_gemm_experiments.md).  Fitted to the measured shapes of the T=16 workload: the LLM
+// o/gate-up/down projections and the STC 4096x4096 convs take 128x256, ViT qkv/wo/fc2 and the LLM qkv take 256x256,
+// short-K GEMMs (ViT fc1, STC b1) stay on 128x128.  Returns 1, 4 (gemm3) or 8 (gemm4).
+static int choose_gemm_kernel(const GemmArgs& a) {
+    if (a.N % 256) return 1;
+    const auto fill = [](double rounds) { return rounds / (double)(long)(rounds + 0.999999); };
+    const double m128 = (double)a.M / (((a.M + 127) / 128) * 128.0), m256 = (double)a.M / (((a.M + 255) / 256) * 256.0);
+    const double e1 = fill((double)((a.M + 127) / 128) * (a.N / 128) / 512.0) * m128;           // 2 WG/CU
+    const double e3 = fill((double)((a.M + 127) / 128) * (a.N / 256) / 256.0) * m128 * 1.07;    // 1 WG/CU
+    const double e4 = fill((double)((a.M + 255) / 256) * (a.N / 256) / 256.0) * m256 * 1.2;     // 1 WG/CU
+    int best = 1;
+    double eb = 1.03 * e1;
+    if (a.K >= 2048 && e3 > eb) { best = 4; eb = e3; }
+    if (a.K >= 512 && e4 > eb) { best = 8; eb = e4; }
+    return best;
 }
 
 template <int ACT, bool SW, bool F32, bool G>
 static void launch_gemm(const GemmArgs& a0, hipStream_t s) {
     if constexpr (!G) {
-        if (a0.N % GEMM4_BN == 0 && (g_gemm_variant == 8 || (g_gemm_variant == 0 && prefer_pingpong(a0)))) {
+        const int kern = g_gemm_variant == 0 ? choose_gemm_kernel(a0) : g_gemm_variant;
+        if (kern == 4 && a0.N % GEMM3_BN == 0) {
+            static bool attr3 = false;
+            if (!attr3) {
+                hipFuncSetAttribute((const void*)gemm3_bf16_kernel<ACT, SW, F32>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM3_LDS_BYTES);
+                attr3 = true;
+            }
+            GemmArgs a = a0;
+            a.tiles_m = (a.M + GEMM3_BM - 1) / GEMM3_BM;
+            a.tiles_n = a.N / GEMM3_BN;
+            hipLaunchKernelGGL((gemm3_bf16_kernel<ACT, SW, F32>), dim3(a.tiles_m * a.tiles_n), dim3(512), GEMM3_LDS_BYTES, s, a);
+            return;
+        }
+        if (kern == 8 && a0.N % GEMM4_BN == 0) {
             static bool attr4 = false;
             if (!attr4) {
                 hipFuncSetAttribute((const void*)gemm4_bf16_kernel<ACT, SW, F32>, hipFuncAttributeMaxDynamicSharedMemorySize,

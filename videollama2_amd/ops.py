@@ -45,7 +45,7 @@ def attach_workspace(device):
 
 
 def set_gemm_variant(v):
-    """0 auto, 1 plain tiled kernel, 2 stream-K, 8 experimental 256x256x32 ping-pong kernel (A/B knob, include/vl2hip.h)."""
+    """0 auto (per-shape choice), 1 128x128x64, 2 stream-K, 4 128x256x64 ping-pong, 8 256x256x32 ping-pong (include/vl2hip.h)."""
     _lib.call("vl2_set_tuning", 1, int(v))
 
 
