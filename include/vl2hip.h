@@ -57,8 +57,8 @@ const char* vl2_last_error_string(void);      /* host pointer, thread-local, val
  *   MistralAttention/MistralMLP/lm_head, and the 1x1 convs / Conv3d / readout of videollama2/model/projector.py:153-187.
  * N % 128 == 0, K % 64 == 0.  bias fp32 [N] or NULL.  res bf16 rows or NULL (added after the activation).
  * Gathered-A form (a_idx != NULL): K = nseg*seg_k; the A row of (segment s, output row m) is A[a_idx[s*M+m]] or
- *   zeros when the index is < 0 (zero_row: >= seg_k zero bf16) -- this is Conv3d(k=2,s=2,p=1) as a GEMM over the
- *   8 taps (projector.py:164-174).
+ *   zeros when the index is < 0 (an out-of-range buffer offset, which gfx950 reads as zeros; `zero_row` is accepted for
+ *   ABI stability and unused) -- this is Conv3d(k=2,s=2,p=1) as a GEMM over the 8 taps (projector.py:164-174).
  * Row remap: out_grp > 0 -> output row = m + (m/out_grp)*out_grp_pad + out_row_off; res_row_mod > 0 -> residual row =
  *   m % res_row_mod + res_row_off (else the output row).  Used by the patch-embed GEMM to write torch.cat([cls, patches])
  *   + position_embedding directly (HF:modeling_clip.py CLIPVisionEmbeddings.forward). */

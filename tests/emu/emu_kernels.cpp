@@ -68,6 +68,10 @@ extern "C" int32_t vl2_gemm_bf16(const void* A, const void* W, void* C, const fl
                M, N, K, lda, ldw, ldc, ldres, seg_k, out_grp, out_grp_pad, out_row_off, res_row_mod, res_row_off,
                (M + 127) / 128, N / 128};
     const bool sw = flags & 1, f32 = flags & 2, g = a_idx != nullptr;
+    if (out_grp > 0 || res_row_mod > 0) {
+        emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(256), [=] { gemm_bf16_kernel<0, false, false, false, true>(a); });
+        return 0;
+    }
     if (sw) { run_gemm<0, true, false, false>(a); return 0; }
     if (g) { if (act == 3) run_gemm<3, false, false, true>(a); else if (act == 0) run_gemm<0, false, false, true>(a); else return -3; return 0; }
     if (f32) { if (act) return -3; run_gemm<0, false, true, false>(a); return 0; }

@@ -182,6 +182,11 @@ inline void global_load_lds(const void* g, void* lds, unsigned size, int offset,
     wave_sync();
     memcpy((char*)base + offset + cur->lane * size, (const char*)g + offset, size);
 }
+// raw buffer load to LDS: an offset at or beyond num_records (0x7fffffff here) reads zeros (hardware range check)
+inline void buffer_load_lds(Rsrc r, void* lds, unsigned size, unsigned voff, unsigned soff) {
+    static const char zeros[16] = {0};
+    global_load_lds(voff >= 0x7fffffffu ? zeros : r.p + voff + soff, lds, size, 0, 0);
+}
 }  // namespace emu
 
 #define __global__
@@ -200,7 +205,7 @@ inline void global_load_lds(const void* g, void* lds, unsigned size, int offset,
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) emu::mfma_16x16x32_bf16(a, b, c)
 #define __builtin_amdgcn_global_load_lds(g, l, sz, off, aux) emu::global_load_lds((const void*)(g), (void*)(l), sz, off, aux)
 #define __builtin_amdgcn_make_buffer_rsrc(p, stride, bytes, flags) emu::Rsrc{(const char*)(p)}
-#define __builtin_amdgcn_raw_ptr_buffer_load_lds(r, l, sz, voff, soff, off, aux) emu::global_load_lds((r).p + (voff) + (soff) + (off), (void*)(l), sz, 0, 0)
+#define __builtin_amdgcn_raw_ptr_buffer_load_lds(r, l, sz, voff, soff, off, aux) emu::buffer_load_lds((r), (void*)(l), sz, (unsigned)(voff), (unsigned)(soff))
 #define __builtin_amdgcn_readfirstlane(x) emu::shfl_idx((x), 0)
 #define __builtin_amdgcn_fdot2_f32_bf16(a, b, c, cl) emu::dot2((a), (b), (c))
 #define __builtin_amdgcn_s_setprio(x) ((void)0)

@@ -50,7 +50,8 @@ __device__ __forceinline__ int gemm_lds_off(int row, int chunk) {   // byte offs
 
 // One wave-private fp32 patch ep[32][68] (64 GEMM columns) -> global rows: fused bias / activation / SwiGLU / residual /
 // row remap, 16-B stores.  m_base = first row of the patch, n_base = first (un-halved) GEMM column of the patch.
-template <int ACT, bool SWIGLU, bool OUT_F32>
+// REMAP = the row-remap / residual-row-modulo form (runtime integer divisions) -- only the patch-embed GEMM needs it
+template <int ACT, bool SWIGLU, bool OUT_F32, bool REMAP = false>
 __device__ __forceinline__ void gemm_store_patch(const GemmArgs& p, const float* ep, int m_base, int n_base, int lane) {
         constexpr int LPR = SWIGLU ? 4 : 8;            // lanes per row
         constexpr int RPP = 64 / LPR;                  // rows per pass
@@ -85,9 +86,9 @@ __device__ __forceinline__ void gemm_store_patch(const GemmArgs& p, const float*
                     }
                 }
                 const int n = SWIGLU ? (n_base >> 1) + cg : nfull;
-                const int orow = p.out_grp > 0 ? m + (m / p.out_grp) * p.out_grp_pad + p.out_row_off : m;
+                const int orow = (REMAP && p.out_grp > 0) ? m + (m / p.out_grp) * p.out_grp_pad + p.out_row_off : m;
                 if (p.res) {
-                    const int rrow = p.res_row_mod > 0 ? (m % p.res_row_mod) + p.res_row_off : orow;
+                    const int rrow = (REMAP && p.res_row_mod > 0) ? (m % p.res_row_mod) + p.res_row_off : orow;
                     const u32x4 rv = *(const u32x4*)(p.res + (size_t)rrow * p.ldres + n);
                     float rf[8];
                     unpack8(rv, rf);
@@ -108,7 +109,7 @@ __device__ __forceinline__ void gemm_store_patch(const GemmArgs& p, const float*
         }
 }
 
-template <int ACT, bool SWIGLU, bool OUT_F32, bool GATHER>
+template <int ACT, bool SWIGLU, bool OUT_F32, bool GATHER, bool REMAP = false>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char vl2_smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -204,44 +205,58 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
             __syncthreads();
         }
     } else {
-        // ---- gathered-A form (Conv3d taps): the A row of (K segment, m) comes from an index table
-        int st_row[4], st_chk[4];
-        const bf16_t* b_src[4];
+        // ---- gathered-A form (Conv3d taps): the A row of (K segment, m) comes from an index table.  Same issue-lean loop;
+        // the 4 per-thread A offsets are reloaded when the staged K-tile enters a new segment (every seg_k/64 tiles), and a
+        // missing tap (index < 0) is an out-of-range buffer offset, which the hardware reads as zeros (no zero page needed).
+        const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x7fffffff, 0x00020000);
+        const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0x7fffffff, 0x00020000);
+        int g_row[4];
+        unsigned g_chk[4], a_vo[4], w_vo = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int slot = ((i * 4 + wave) << 6) + lane;
-            const int R = slot >> 4, sp = slot & 15, sx = sp ^ (R & 15);
-            st_chk[i] = sx & 7;
+            const int R = slot >> 4, sx = (slot & 15) ^ (R & 15);
             int am = m0 + 2 * R + (sx >> 3);
-            st_row[i] = am < p.M ? am : p.M - 1;
-            b_src[i] = p.W + (size_t)(n0 + 2 * R + (sx >> 3)) * p.ldw + st_chk[i] * 8;
+            g_row[i] = am < p.M ? am : p.M - 1;
+            g_chk[i] = (sx & 7) * 16;
+            a_vo[i] = 0x80000000u;
+            if (i == 0) w_vo = ((unsigned)(n0 + 2 * R + (sx >> 3)) * (unsigned)p.ldw + (sx & 7) * 8) * 2;
         }
-        auto stage = [&](int buf, int kt) {
-            unsigned char* As = vl2_smem + buf * 32768;
-            unsigned char* Bs = As + 16384;
-            const int k = kt * GEMM_BK;
-            const int seg = k / p.seg_k, koff = k - seg * p.seg_k;
+        const unsigned w_step = 64u * (unsigned)p.ldw;
+        const int tps = p.seg_k / GEMM_BK;            // K-tiles per segment
+        unsigned a_rd[4], b_rd[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = p.a_idx[(size_t)seg * p.M + st_row[i]];
-                glds16((r < 0 ? p.zero_row : p.A + (size_t)r * p.lda) + koff + st_chk[i] * 8, As + ((i * 4 + wave) << 10));
+        for (int ks = 0; ks < 4; ++ks) {
+            a_rd[ks] = gemm_lds_off(wm * 64 + frow, ks * 2 + fchk);
+            b_rd[ks] = 16384 + gemm_lds_off(wn * 64 + frow, ks * 2 + fchk);
+        }
+        auto stage = [&](unsigned lds_buf, int kt) {
+            const int seg = kt / tps, kl = kt - seg * tps;
+            if (kl == 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = p.a_idx[(size_t)seg * p.M + g_row[i]];
+                    a_vo[i] = r < 0 ? 0x80000000u : (unsigned)r * (unsigned)p.lda * 2u + g_chk[i];
+                }
             }
+            const unsigned ka = (unsigned)kl * (GEMM_BK * 2), kw = (unsigned)kt * (GEMM_BK * 2);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) glds16(b_src[i] + kt * GEMM_BK, Bs + ((i * 4 + wave) << 10));
+            for (int i = 0; i < 4; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(vl2_smem + lds_buf + ((i * 4 + wave) << 10)),
+                                                         16, a_vo[i], ka, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(vl2_smem + lds_buf + 16384 + ((i * 4 + wave) << 10)),
+                                                         16, w_vo, kw + i * w_step, 0, 0);
         };
-        stage(0, 0);
-        __syncthreads();
-        for (int kt = 0; kt < nt; ++kt) {
-            if (kt + 1 < nt) stage((kt + 1) & 1, kt + 1);
-            const unsigned char* As = vl2_smem + (kt & 1) * 32768;
-            const unsigned char* Bs = As + 16384;
+        auto compute = [&](unsigned lds_buf) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 bf16x8 af[2], bfr[2];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    af[i] = *(const bf16x8*)(As + gemm_lds_off(wm * 64 + i * 32 + frow, ks * 2 + fchk));
-                    bfr[i] = *(const bf16x8*)(Bs + gemm_lds_off(wn * 64 + i * 32 + frow, ks * 2 + fchk));
+                    af[i] = *(const bf16x8*)(vl2_smem + a_rd[ks] + (lds_buf + i * 4096));
+                    bfr[i] = *(const bf16x8*)(vl2_smem + b_rd[ks] + (lds_buf + i * 4096));
                 }
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
@@ -249,6 +264,20 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
                     for (int j = 0; j < 2; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
             }
+        };
+        stage(0, 0);
+        __syncthreads();
+        int kt = 0;
+        for (; kt + 2 <= nt; kt += 2) {
+            stage(32768, kt + 1);
+            compute(0);
+            __syncthreads();
+            if (kt + 2 < nt) stage(0, kt + 2);
+            compute(32768);
+            __syncthreads();
+        }
+        if (kt < nt) {
+            compute(0);
             __syncthreads();
         }
     }
@@ -265,7 +294,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
                 ep[row * 68 + ni * 32 + (lane & 31)] = acc[mi][ni][r];
             }
         __syncthreads();
-        gemm_store_patch<ACT, SWIGLU, OUT_F32>(p, ep, m0 + wm * 64 + mi * 32, n0 + wn * 64, lane);
+        gemm_store_patch<ACT, SWIGLU, OUT_F32, REMAP>(p, ep, m0 + wm * 64 + mi * 32, n0 + wn * 64, lane);
         __syncthreads();
     }
 }

@@ -144,11 +144,21 @@ extern "C" int32_t vl2_gemm_bf16(const void* A, const void* W, void* C, const fl
         (res && !ALIGNED16(res)) || (bias && !ALIGNED16(bias)))
         return fail(VL2_E_SHAPE, "vl2_gemm_bf16: pointers / leading dims must be 16-byte aligned");
     const bool sw = flags & VL2_GEMM_SWIGLU, f32 = flags & VL2_GEMM_OUT_F32, g = a_idx != nullptr;
-    if (g && (!zero_row || seg_k <= 0 || seg_k % 64 || K % seg_k)) return fail(VL2_E_SHAPE, "vl2_gemm_bf16: bad gather segments");
+    if (g && (seg_k <= 0 || seg_k % 64 || K % seg_k)) return fail(VL2_E_SHAPE, "vl2_gemm_bf16: bad gather segments");
     GemmArgs a{(const bf16_t*)A, (const bf16_t*)W, C, bias, (const bf16_t*)res, a_idx, (const bf16_t*)zero_row, M, N, K,
                lda, ldw, ldc, ldres, seg_k, out_grp, out_grp_pad, out_row_off, res_row_mod, res_row_off,
                (M + GEMM_BM - 1) / GEMM_BM, N / GEMM_BN};
     hipStream_t s = ST(stream);
+    if (out_grp > 0 || res_row_mod > 0) {                      // row-remap epilogue (patch-embed): dedicated instantiation
+        if (sw || g || f32 || act != VL2_ACT_NONE) return fail(VL2_E_UNSUPP, "vl2_gemm_bf16: row remap supports plain bf16 output only");
+        static bool attr_r = false;
+        if (!attr_r) {
+            hipFuncSetAttribute((const void*)gemm_bf16_kernel<ACT_NONE, false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+            attr_r = true;
+        }
+        hipLaunchKernelGGL((gemm_bf16_kernel<ACT_NONE, false, false, false, true>), dim3(a.tiles_m * a.tiles_n), dim3(256), GEMM_LDS_BYTES, s, a);
+        return launched("vl2_gemm_bf16");
+    }
     if (sw) {
         if (f32 || g || act != VL2_ACT_NONE || bias) return fail(VL2_E_UNSUPP, "vl2_gemm_bf16: SWIGLU excludes bias/act/f32/gather");
         launch_gemm<ACT_NONE, true, false, false>(a, s);
