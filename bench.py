@@ -191,8 +191,15 @@ def main():
         gms = sum(p[2].elapsed_time(p[3]) for p in prof if p[0] == "gemm")
         ngemm = sum(1 for p in prof if p[0] == "gemm")
         ach = gflop / gms if gms > 0 else 0.0                  # GFLOP/ms = TFLOP/s
+        # HBM-side bytes per launch come from a separate rocprofv3 --pmc run (scripts/gpu_traffic.sh; PMC cannot be
+        # collected inside this process); only quoted for the workload it was collected on (T=16, 241 GEMM launches).
+        traffic, tpath = None, os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_gemm_traffic.json")
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            if T == 16 and tj.get("launches_per_step") == ngemm:
+                traffic = tj["hbm_bytes_per_launch"]
         roof = dict(bound="mfma", kernel="gemm_bf16_kernel", achieved=round(ach, 2), peak=PEAK_MFMA_BF16_TFLOPS,
-                    unit="TFLOP/s", frac=round(ach / PEAK_MFMA_BF16_TFLOPS, 4), traffic=None,
+                    unit="TFLOP/s", frac=round(ach / PEAK_MFMA_BF16_TFLOPS, 4), traffic=traffic,
                     launches=ngemm, avg_launch_us=round(1e3 * gms / max(ngemm, 1), 2),
                     flop_per_launch_avg=round(1e9 * gflop / max(ngemm, 1), 0))
 
