@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--llm-layers", type=int, default=None, help="debug only: fewer decoder layers (INVALID as a result)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager decode loop instead of hipGraph replay")
+    ap.add_argument("--vit-streams", type=int, default=None, help="ViT frames as N chunks on N HIP streams (default: the tower's own, 3)")
     ap.add_argument("--tune", type=str, default="", help="debug: comma list key=value for vl2_set_tuning")
     args = ap.parse_args()
 
@@ -117,6 +118,8 @@ def main():
     model = VideoLLaMA2Hip(cfg, sd, dev, max_seq_len=4096, n_llm_layers=args.llm_layers)
     del sd
     torch.cuda.empty_cache()
+    if args.vit_streams is not None:
+        model.vision_tower.streams = args.vit_streams
 
     g = torch.Generator(device=dev).manual_seed(0)
     frames = torch.randn((T, 3, 336, 336), generator=g, device=dev, dtype=torch.float32).to(torch.bfloat16)

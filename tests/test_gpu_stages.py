@@ -189,3 +189,22 @@ def test_token_count_law_and_connector_parity_over_T(T):
     img = model.encode_images_or_videos([(frames[:1].to(DEV), "image")])
     assert tuple(img.shape) == tuple(ref_img.shape) and rel(img, ref_img) < 3e-2
     assert [O.n_visual_tokens(t) for t in (8, 16, 32)] == [845, 1521, 2873]
+
+
+def test_vit_frame_chunks_on_streams_match_single_stream():
+    """tower.streams > 1 runs the frames as interleaved chunks on separate HIP streams: same kernels on row subsets
+    (every GEMM kernel accumulates K in the same order), so the result must be identical, not merely close."""
+    from videollama2_amd.tower import HipCLIPVisionTower
+    cfg = O.config_videollama2_7b(12)
+    cfg["vision"]["num_hidden_layers"] = 3
+    sd = O.seeded_state_dict(cfg, 11, only=lambda n: "vision_tower" in n)
+    tower = HipCLIPVisionTower(cfg, sd, DEV)
+    frames = torch.randn(12, 3, 336, 336, generator=torch.Generator().manual_seed(3)).bfloat16().to(DEV)
+    tower.streams = 1
+    one = tower(frames)
+    for ns in (2, 3):
+        tower.streams = ns
+        for _ in range(2):                       # second pass reuses the side streams and cached buffers
+            many = tower(frames)
+            torch.cuda.synchronize()
+            assert torch.equal(one, many), f"{ns} streams: max |d| = {(one.float() - many.float()).abs().max().item():.3e}"

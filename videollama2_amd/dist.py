@@ -73,40 +73,84 @@ class FrameSharder:
             feats = self.encode(tower, frames)
             return connector(feats.view(1, *feats.shape))
         world, rank = self.world, self.rank
-        fpr = T // world
-        f0 = rank * fpr
-        local = tower(frames[f0:f0 + fpr])                                   # [fpr, n, 1024]
-        n = local.shape[1]
-        hw = int(n ** 0.5)
-        in_dtype = local.dtype
-        rows = local.to(torch.bfloat16).reshape(fpr * n, -1).contiguous()
-        s1 = connector.run_s1(rows, fpr, hw)                                 # [fpr*n, C]
-        C = s1.shape[1]
+        s1, n, in_dtype = self.local_s1(tower, connector, frames, rank, world)
         # halo: frame f0-1 comes from rank-1; our last frame goes to rank+1
-        pool = torch.empty(((fpr + 1) * n, C), dtype=s1.dtype, device=s1.device)
-        pool[n:].copy_(s1)
+        halo = torch.empty((n, s1.shape[1]), dtype=s1.dtype, device=s1.device)
         reqs = []
         if rank + 1 < world:
-            reqs.append(dist.P2POp(dist.isend, s1[(fpr - 1) * n:].contiguous(), self._peer(rank + 1), self.group))
+            reqs.append(dist.P2POp(dist.isend, s1[s1.shape[0] - n:].contiguous(), self._peer(rank + 1), self.group))
         if rank > 0:
-            reqs.append(dist.P2POp(dist.irecv, pool[:n], self._peer(rank - 1), self.group))
-        else:
-            pool[:n].zero_()                                                # frame -1 is padding (never gathered: index -1)
+            reqs.append(dist.P2POp(dist.irecv, halo, self._peer(rank - 1), self.group))
         for r in (dist.batch_isend_irecv(reqs) if reqs else []):
             r.wait()
-        # output frames of this rank: to in [f0/2, f0/2 + fpr/2), the last rank also owns to = T/2
-        to0 = f0 // 2
-        to1 = to0 + fpr // 2 + (1 if rank == world - 1 else 0)
-        samp, (nto, Ho, Wo) = connector.run_sampler(pool, T, hw, to_range=(to0, to1), frame_lo=f0 - 1, n_local=fpr + 1)
-        tok = connector.run_s2_readout(samp, nto, Ho, Wo)                   # [nto*Ho*Wo, D]
-        per = Ho * Wo
-        max_rows = (fpr // 2 + 1) * per
+        tok = self.local_tokens(connector, s1, halo if rank > 0 else None, T, rank, world)
+        per = tok.shape[0] // (T // world // 2 + (1 if rank == world - 1 else 0))
+        max_rows = (T // world // 2 + 1) * per
         send = torch.zeros((max_rows, tok.shape[1]), dtype=tok.dtype, device=tok.device)
         send[:tok.shape[0]].copy_(tok)
         recv = torch.empty((world * max_rows, tok.shape[1]), dtype=tok.dtype, device=tok.device)
         dist.all_gather_into_tensor(recv, send, group=self.group)
+        return self._assemble(recv, T, world, per, max_rows).to(in_dtype)
+
+    # ---- the rank-local pieces of the sharded-connector cut (no communication inside: also driven rank by rank in ONE
+    #      process by `encode_video_all_ranks_locally`, which is how the cut is validated and timed on a 1-GPU box)
+    @staticmethod
+    def local_s1(tower, connector, frames, rank, world):
+        """ViT + STC stage s1 on this rank's frames -> (s1 rows [fpr*n, C], n tokens per frame, dtype of the tower output)."""
+        fpr = frames.shape[0] // world
+        local = tower(frames[rank * fpr:(rank + 1) * fpr])                   # [fpr, n, 1024]
+        n = local.shape[1]
+        rows = local.to(torch.bfloat16).reshape(fpr * n, -1).contiguous()
+        return connector.run_s1(rows, fpr, int(n ** 0.5)), n, local.dtype
+
+    @staticmethod
+    def local_tokens(connector, s1, halo, T, rank, world):
+        """Conv3d + s2 + readout on this rank's output frames.  `halo` = s1 rows of frame f0-1 (None on rank 0: that
+        frame is the Conv3d's zero padding and is never gathered).  Output frames: to in [f0/2, f0/2 + fpr/2); the
+        last rank also owns to = T/2."""
+        fpr = T // world
+        n = s1.shape[0] // fpr
+        hw = int(n ** 0.5)
+        f0 = rank * fpr
+        pool = torch.empty(((fpr + 1) * n, s1.shape[1]), dtype=s1.dtype, device=s1.device)
+        pool[n:].copy_(s1)
+        if halo is None:
+            pool[:n].zero_()
+        else:
+            pool[:n].copy_(halo)
+        to0 = f0 // 2
+        to1 = to0 + fpr // 2 + (1 if rank == world - 1 else 0)
+        samp, (nto, Ho, Wo) = connector.run_sampler(pool, T, hw, to_range=(to0, to1), frame_lo=f0 - 1, n_local=fpr + 1)
+        return connector.run_s2_readout(samp, nto, Ho, Wo)                   # [nto*Ho*Wo, D]
+
+    @staticmethod
+    def _assemble(recv, T, world, per, max_rows):
+        fpr = T // world
         parts = [recv[r * max_rows:r * max_rows + (fpr // 2 + (1 if r == world - 1 else 0)) * per] for r in range(world)]
-        return torch.cat(parts, 0).unsqueeze(0).to(in_dtype)
+        return torch.cat(parts, 0).unsqueeze(0)
+
+    @classmethod
+    def encode_video_all_ranks_locally(cls, tower, connector, frames, world, timer=None):
+        """Every rank's share of the sharded-connector cut executed one after the other in THIS process (halos passed by
+        reference, concatenation instead of the all-gather).  Returns what `encode_video` returns on every rank; with
+        `timer` (a callable returning a timestamp object after recording on the current stream) also the per-rank
+        (vit+s1, conv3d+s2+readout) stamps."""
+        T = frames.shape[0]
+        assert T % world == 0 and (T // world) % 2 == 0
+        s1s, stamps = [], []
+        for r in range(world):
+            t0 = timer() if timer else None
+            s1, n, in_dtype = cls.local_s1(tower, connector, frames, r, world)
+            s1s.append(s1)
+            stamps.append([t0, timer() if timer else None])
+        toks = []
+        for r in range(world):
+            t0 = timer() if timer else None
+            halo = s1s[r - 1][s1s[r - 1].shape[0] - n:] if r > 0 else None
+            toks.append(cls.local_tokens(connector, s1s[r], halo, T, r, world))
+            stamps[r] += [t0, timer() if timer else None]
+        out = torch.cat(toks, 0).unsqueeze(0).to(in_dtype)
+        return (out, stamps) if timer else out
 
     def _peer(self, group_rank):
         return dist.get_global_rank(self.group, group_rank) if self.group is not None else group_rank

@@ -39,6 +39,11 @@ class HipCLIPVisionTower(nn.Module):
         self.w = pack_tower(state_dict, cfg, self._dev, prefix)
         self.config = types.SimpleNamespace(**v)
         self.is_loaded = True
+        # frames as chunks on this many HIP streams.  Measured on MI355X (encode ms, 1 / 2 / 3 / 4 streams): T=16 14.15 /
+        # 14.01 / 13.76-13.88 / 16.15, T=8 8.70 / - / 8.85, T=32 25.25 / - / 25.36: within noise of nothing (the chip is
+        # power-limited, idle CUs in a GEMM's last round already return their power to the busy ones) -> default 1.
+        self.streams = 1
+        self._side = None
 
     # ---- attributes the reference reads (encoder.py:55-81, videollama2_arch.py:66, model/__init__.py:186)
     @property
@@ -67,7 +72,30 @@ class HipCLIPVisionTower(nn.Module):
 
     @torch.no_grad()
     def forward_hidden(self, images):
-        """Returns hidden_states[select_layer] INCLUDING the CLS row: bf16 [T*(N+1), D] (flat token-major)."""
+        """Returns hidden_states[select_layer] INCLUDING the CLS row: bf16 [T*(N+1), D] (flat token-major).
+        With `self.streams` > 1 the (independent) frames run as that many interleaved chunks on separate HIP streams,
+        so one chunk's partial last round of GEMM tiles overlaps the other chunk's kernels."""
+        ns = min(int(self.streams), images.shape[0] // 4 if images.dim() == 4 else 1)    # >= 4 frames per chunk
+        if ns <= 1:
+            return self._hidden(images)
+        v = self.cfg["vision"]
+        T = images.shape[0]
+        N1 = (images.shape[2] // v["patch_size"]) ** 2 + 1
+        images = images.to(self._dev)
+        out = torch.empty((T * N1, v["hidden_size"]), dtype=torch.bfloat16, device=self._dev)
+        cur = torch.cuda.current_stream(self._dev)
+        if self._side is None or len(self._side) != ns:
+            self._side = [torch.cuda.Stream(self._dev) for _ in range(ns)]
+        bounds = [T * i // ns for i in range(ns + 1)]
+        for i, st in enumerate(self._side):
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                self._hidden(images[bounds[i]:bounds[i + 1]], out[bounds[i] * N1:bounds[i + 1] * N1])
+        for st in self._side:
+            cur.wait_stream(st)
+        return out, T, N1
+
+    def _hidden(self, images, out=None):
         v = self.cfg["vision"]
         if images.dim() != 4 or images.shape[1] != 3:
             raise ValueError(f"expected frames [T,3,H,W], got {tuple(images.shape)}")
@@ -88,7 +116,7 @@ class HipCLIPVisionTower(nn.Module):
         ops.fill_cls(x, w["cls_pos"], T, N1)
         x = ops.layernorm(x, w["pre_w"], w["pre_b"], eps)
         o = torch.empty((T * N1, D), dtype=torch.bfloat16, device=self._dev)
-        for lw in w["layers"]:
+        for li, lw in enumerate(w["layers"]):
             h = ops.layernorm(x, lw["ln1_w"], lw["ln1_b"], eps)
             qkv = ops.gemm(h, lw["wqkv"], bias=lw["bqkv"])                         # [T*N1, 3D] = q | k | v
             st = (N1 * 3 * D, hd, 3 * D)
@@ -97,7 +125,7 @@ class HipCLIPVisionTower(nn.Module):
             x = ops.gemm(o, lw["wo"], bias=lw["bo"], res=x)
             h = ops.layernorm(x, lw["ln2_w"], lw["ln2_b"], eps)
             h = ops.gemm(h, lw["w1"], bias=lw["b1"], act=ops.ACT_QGELU)
-            x = ops.gemm(h, lw["w2"], bias=lw["b2"], res=x)
+            x = ops.gemm(h, lw["w2"], bias=lw["b2"], res=x, out=out if li == len(w["layers"]) - 1 else None)
         return x, T, N1
 
     @torch.no_grad()
