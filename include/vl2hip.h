@@ -33,10 +33,18 @@ int32_t vl2_version(void);
  *           vl2_set_workspace), 4 = 128x256x64 ping-pong always, 8 = 256x256x32 ping-pong always (4, 8: where N%256==0).  See profiles/r01_gemm_experiments.md. */
 #define VL2_TUNE_GEMM_VARIANT 1
 #define VL2_TUNE_GEMV_ROWS_PER_WAVE 2   /* 1 (default), 2 or 4 output rows streamed by each wave of the decode GEMV */
+#define VL2_TUNE_SPLITK 3               /* 0 (default): never; 1: small-grid GEMMs split K when a workspace is attached */
 int32_t vl2_set_tuning(int32_t key, int32_t value);
 /* Optional caller-owned device workspace (>= vl2_workspace_bytes(), 16-byte aligned; NULL detaches).  With a workspace
  * attached, tuning variant 2 runs GEMMs as stream-K (512 persistent workgroups, partial tiles exchanged through the
- * workspace inside the launch with agent-scope release/acquire).  The library still allocates nothing.  One workspace per process: GEMMs sharing it must be ordered on one stream. */
+ * workspace inside the launch with agent-scope release/acquire), and -- with VL2_TUNE_SPLITK = 1 -- GEMMs whose plain
+ * 128x128 grid has <= 192 tiles and K >= 2048 (small M: the per-rank shapes of the frame-sharded encoder; Conv3d with
+ * K = 32768) split K over up to 1024 workgroups: fp32 partial tiles go through the workspace, the last arriver of a tile
+ * sums them in split order (deterministic for a given shape) and runs the epilogue.  Off by default because it makes a
+ * row's result depend on M (the fp32 summation order changes with the split), i.e. a frame-sharded run would no longer
+ * reproduce the single-GPU run bit for bit.  The workspace MUST be zero-filled when attached (tile counters live in it and
+ * are re-armed by the kernels).  The library still allocates nothing.  One workspace per process: GEMMs sharing it
+ * must be ordered on one stream. */
 int64_t vl2_workspace_bytes(void);
 int32_t vl2_set_workspace(void* ws, int64_t bytes);
 const char* vl2_last_error_string(void);      /* host pointer, thread-local, valid until the next failing call */

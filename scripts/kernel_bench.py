@@ -48,9 +48,22 @@ SHAPES = [  # name, M, N, K, kwargs
 ]
 
 
+SMALL = [  # per-rank shapes of the frame-sharded encoder at 8 ranks (2 / 4 frames per rank)
+    ("vit_qkv_2f", 1154, 3072, 1024, dict(bias=True)), ("vit_wo_2f", 1154, 1024, 1024, dict(bias=True, res=True)),
+    ("vit_fc1_2f", 1154, 4096, 1024, dict(bias=True, act=1)), ("vit_fc2_2f", 1154, 1024, 4096, dict(bias=True, res=True)),
+    ("vit_qkv_4f", 2308, 3072, 1024, dict(bias=True)), ("vit_fc2_4f", 2308, 1024, 4096, dict(bias=True, res=True)),
+    ("stc_s1_2f", 1152, 4096, 4096, dict()), ("stc_s1_b1_2f", 1152, 4096, 1024, dict()), ("stc_s1_4f", 2304, 4096, 4096, dict()),
+    ("stc_s2_1to", 169, 4096, 4096, dict()), ("stc_s2_2to", 338, 4096, 4096, dict()),
+    ("conv3d_as_plain_2to", 338, 4096, 32768, dict(bias=True, act=3)),
+]
+
+
 def main():
+    global SHAPES, VARIANTS
     out = {}
     ops.attach_workspace(dev)
+    if "--small" in sys.argv:
+        SHAPES, VARIANTS = SMALL, (0, 1, 4, 8)      # 0 = auto (split-K where eligible); 1/4/8 with split-K off
     rounds = 2 if "--quick" in sys.argv else 3
     for name, M, N, K, kw in SHAPES:
         a, w = rnd(M, K), rnd(N, K, scale=K ** -0.5)
@@ -64,18 +77,22 @@ def main():
                 if v in (4, 8) and N % 256:
                     continue
                 ops.set_gemm_variant(v)
+                ops.set_splitk(v == 0)
                 us = timeit(lambda: ops.gemm(a, w, bias=bias, res=res, act=kw.get("act", 0), swiglu=kw.get("swiglu", False), out=c))
                 best[v] = min(best.get(v, 1e9), us)
                 if v == 1:
                     ref = c.clone()
-                elif r == 0:
+                elif r == 0 and v != 0:
                     d = (ref.float() - c.float()).abs().max().item()
                     if d > 0.05 * ref.float().abs().max().item():
                         print(f"   !! variant {v} differs from v1 on {name}: max|d| = {d:.4g}")
         ops.set_gemm_variant(0)
+        ops.set_splitk(False)
         fl = 2.0 * M * N * K
         out[name] = {f"v{v}": dict(us=round(us, 1), tflops=round(fl / us / 1e6, 1)) for v, us in best.items()}
         print(name, M, N, K, out[name], flush=True)
+    if "--small" in sys.argv:
+        return
     # attention
     B, H, Nn, D = 16, 16, 577, 64
     qkv = rnd(B * Nn, 3 * H * D)

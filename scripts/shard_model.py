@@ -1,0 +1,80 @@
+#!/usr/bin/env python
+"""Frame-sharded encoder on a ONE-GPU box: every rank's share of the sharded-connector cut (videollama2_amd/dist.py)
+executed rank by rank on this GPU (`FrameSharder.encode_video_all_ranks_locally`), timed with HIP events, and checked
+bit-for-bit against the unsharded encoder.  Gives the per-rank critical path a real R-GPU run has (all ranks run these
+pieces concurrently on their own GPUs); the two collectives are modelled from message size and the xGMI link rate
+(MI355X_MICROARCH.md: 7 links x ~153 GB/s per GPU) plus a fixed launch/sync cost, and are stated separately.
+
+    python scripts/shard_model.py [--frames 16 32] [--worlds 2 4 8] [--reps 5]
+"""
+import argparse, json, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from videollama2_amd.config import videollama2_7b
+from videollama2_amd.connector import HipSTCConnector
+from videollama2_amd.dist import FrameSharder
+from videollama2_amd.tower import HipCLIPVisionTower
+from videollama2_amd.weights import random_state_dict
+
+LINK_GBS, COLL_FIXED_US = 153.0, 30.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, nargs="+", default=[16, 32])
+    ap.add_argument("--worlds", type=int, nargs="+", default=[2, 4, 8])
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--splitk", action="store_true", help="opt-in split-K for the small per-rank grids (not bit-identical to 1 GPU)")
+    args = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    cfg = videollama2_7b(16)
+    sd = random_state_dict(cfg, dev, seed=1234, n_llm_layers=0)
+    tower = HipCLIPVisionTower(cfg, sd, dev)
+    conn = HipSTCConnector(sd, dev)
+    del sd
+    from videollama2_amd import ops
+
+    def stamp():
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    rows = []
+    for T in args.frames:
+        frames = torch.randn((T, 3, 336, 336), generator=torch.Generator(device=dev).manual_seed(0), device=dev).bfloat16()
+        feats = tower(frames)
+        ref = conn(feats.view(1, *feats.shape))
+        torch.cuda.synchronize()
+        t1 = []
+        for _ in range(args.reps + 1):
+            a = stamp(); feats = tower(frames); conn(feats.view(1, *feats.shape)); b = stamp()
+            torch.cuda.synchronize(); t1.append(a.elapsed_time(b))
+        one = min(t1[1:])
+        for R in args.worlds:
+            if T % R or (T // R) % 2:
+                continue
+            best = None
+            ops.set_splitk(args.splitk)
+            for it in range(args.reps + 1):
+                out, st = FrameSharder.encode_video_all_ranks_locally(tower, conn, frames, R, timer=stamp)
+                torch.cuda.synchronize()
+                per = [s[0].elapsed_time(s[1]) + s[2].elapsed_time(s[3]) for s in st]
+                if it and (best is None or max(per) < max(best)):
+                    best = per
+            ops.set_splitk(False)
+            same = bool(torch.equal(out, ref))
+            relerr = ((out.float() - ref.float()).norm() / ref.float().norm()).item()
+            n, C = 576, 4096
+            halo_us = COLL_FIXED_US + n * C * 2 / (LINK_GBS * 1e3)                     # one s1 frame to the next rank
+            per_out = (T // R // 2 + 1) * 169 * C * 2
+            ag_us = COLL_FIXED_US + per_out / (LINK_GBS * 1e3)                        # each peer's shard arrives on its own link
+            crit = max(best) + (halo_us + ag_us) / 1e3
+            rows.append(dict(T=T, world=R, splitk=args.splitk, identical_to_unsharded=same, rel_l2_vs_unsharded=float(f"{relerr:.3e}"), one_gpu_ms=round(one, 3),
+                             per_rank_ms=[round(x, 3) for x in best], modelled_collectives_us=round(halo_us + ag_us, 1),
+                             critical_path_ms=round(crit, 3), speedup=round(one / crit, 2)))
+            print(json.dumps(rows[-1]), flush=True)
+    return rows
+
+
+if __name__ == "__main__":
+    main()

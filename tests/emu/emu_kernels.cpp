@@ -21,7 +21,7 @@ extern "C" int64_t vl2_workspace_bytes(void) { return 0; }
 extern "C" int32_t vl2_set_workspace(void*, int64_t) { return 0; }
 
 static int g_gemm_variant = 0;
-extern "C" int32_t vl2_set_tuning(int32_t key, int32_t value) { if (key == 1) { g_gemm_variant = value; return 0; } return key == 2 ? 0 : -1; }
+extern "C" int32_t vl2_set_tuning(int32_t key, int32_t value) { if (key == 1) { g_gemm_variant = value; return 0; } return (key == 2 || key == 3) ? 0 : -1; }
 template <int ACT, bool SW, bool F32, bool G>
 static void run_gemm(GemmArgs a) {
     if constexpr (!G) {
@@ -54,6 +54,19 @@ static void run_gemm(GemmArgs a) {
             for (auto& o : ord) emu::block_order.push_back(o.second);
             emu::launch(dim3(Gsk), dim3(256), [=] { gemm_sk_bf16_kernel<ACT, SW, F32>(a); });
             if (flags[Gsk]) fprintf(stderr, "EMU: stream-K spin timeout\n");
+            return;
+        }
+    }
+    if (g_gemm_variant == 16) {                                 // split-K form of the 128x128 kernel (plain and gathered)
+        const int nt = a.K / 64;
+        const int split = nt % 4 == 0 && nt >= 8 ? 4 : nt % 3 == 0 && nt >= 6 ? 3 : nt % 2 == 0 ? 2 : 1;
+        if (split > 1) {
+            static std::vector<float> ws;
+            static std::vector<int> cnt;
+            ws.assign((size_t)a.tiles_m * a.tiles_n * split * 64 * 256, 0.f);
+            cnt.resize(a.tiles_m * a.tiles_n, 0);                // NOT re-zeroed between launches: the kernel re-arms them
+            a.sk_ws = ws.data(); a.sk_flags = cnt.data();
+            emu::launch(dim3(a.tiles_m * a.tiles_n, split), dim3(256), [=] { gemm_bf16_kernel<ACT, SW, F32, G, false, true>(a); });
             return;
         }
     }

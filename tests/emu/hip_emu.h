@@ -212,6 +212,7 @@ inline void buffer_load_lds(Rsrc r, void* lds, unsigned size, unsigned voff, uns
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 #define __hip_atomic_load(p, order, scope) (*(p))
 #define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
+#define __hip_atomic_fetch_add(p, v, order, scope) emu_fetch_add((p), (v))
 #define __HIP_MEMORY_SCOPE_AGENT 0
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 #define __builtin_readcyclecounter() 0LL
@@ -229,6 +230,7 @@ inline void buffer_load_lds(Rsrc r, void* lds, unsigned size, unsigned voff, uns
 #define __frcp_rn(x) (1.0f / (x))
 #define VL2_EMU 1
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+static inline int emu_fetch_add(int* p, int v) { int o = *p; *p = o + v; return o; }
 static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
 static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }

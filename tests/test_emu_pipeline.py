@@ -55,6 +55,29 @@ def test_emu_gemm_pingpong_variant(emu):
             ops.set_gemm_variant(0)
 
 
+def test_emu_gemm_splitk_plain_and_gathered(emu):
+    """Split-K form of the 128x128 kernel (emulator knob 16): partial tiles through the workspace, last arriver reduces in
+    split order and re-arms the tile counter (second launch reuses the counters without a host reset)."""
+    from videollama2_amd import ops
+    from videollama2_amd.connector import conv3d_k2s2p1_index
+    a, w, bias, res = bf(200, 768), bf(256, 768), torch.randn(256), bf(200, 256)
+    ref = ops.gemm(a, w, bias=bias, res=res, act=ops.ACT_SILU)
+    ref32 = ops.gemm(a, w, out_f32=True)
+    T, H, C = 4, 4, 128
+    pool, w3, b3 = bf(T * H * H, C), bf(128, 8 * C, scale=0.05), torch.randn(128)
+    idx, _ = conv3d_k2s2p1_index(T, H, H, "cpu")
+    zero = torch.zeros(C, dtype=torch.bfloat16)
+    refg = ops.gemm(pool, w3, bias=b3, act=ops.ACT_SILU, gather=(idx, zero, C))
+    try:
+        ops.set_gemm_variant(16)
+        for _ in range(2):
+            assert rel(ops.gemm(a, w, bias=bias, res=res, act=ops.ACT_SILU), ref.float()) < 2e-3
+            assert rel(ops.gemm(a, w, out_f32=True), ref32) < 1e-5
+            assert rel(ops.gemm(pool, w3, bias=b3, act=ops.ACT_SILU, gather=(idx, zero, C)), refg.float()) < 2e-3
+    finally:
+        ops.set_gemm_variant(0)
+
+
 def test_emu_attention_ragged_and_causal(emu):
     from videollama2_amd import ops
     B, H, N, D = 2, 2, 150, 64

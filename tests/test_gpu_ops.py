@@ -77,6 +77,40 @@ def test_gemm_stream_k_variant(ops):
         ops.set_gemm_variant(0)
 
 
+def test_gemm_splitk_small_grids(ops):
+    """Opt-in: small-grid GEMMs split K once a workspace is attached (include/vl2hip.h VL2_TUNE_SPLITK): the per-rank shapes of the
+    frame-sharded encoder and a long-K gathered Conv3d.  Same products, fp32 partial sums in a different order; the tile
+    counters are re-armed by the kernel, so repeated launches need no host reset and must be bit-stable."""
+    from videollama2_amd.connector import conv3d_k2s2p1_index
+    ops.attach_workspace(DEV)
+    cases = [(1154, 1024, 4096, dict(bias=True, res=True)), (338, 4096, 4096, dict()), (169, 4096, 4096, dict(act=ops.ACT_GELU, bias=True)),
+             (507, 4096, 2048, dict(bias=True, res=True))]
+    for M, N, K, kw in cases:
+        a, w = bf(M, K).to(DEV), bf(N, K, scale=K ** -0.5).to(DEV)
+        bias = torch.randn(N, device=DEV) if kw.get("bias") else None
+        res = bf(M, N).to(DEV) if kw.get("res") else None
+        ref = ops.gemm(a, w, bias=bias, res=res, act=kw.get("act", 0)).float()
+        try:
+            ops.set_splitk(True)
+            first = ops.gemm(a, w, bias=bias, res=res, act=kw.get("act", 0))
+            assert rel(first, ref) < 2e-3 and (first.float() - ref).abs().max().item() <= 0.02 * ref.abs().max().item()
+            for _ in range(4):
+                assert torch.equal(ops.gemm(a, w, bias=bias, res=res, act=kw.get("act", 0)), first)
+        finally:
+            ops.set_splitk(False)
+    T, H, C = 4, 24, 1024                                       # 2 output frames... K = 8192: 128 K-tiles, 3 x 8 tiles
+    x, wp, b = bf(T * H * H, C).to(DEV), bf(C, 8 * C, scale=(8 * C) ** -0.5).to(DEV), torch.randn(C, device=DEV)
+    idx, (To, Ho, Wo) = conv3d_k2s2p1_index(T, H, H, DEV, to_range=(1, 3))
+    zero = torch.zeros(C, dtype=torch.bfloat16, device=DEV)
+    ref = ops.gemm(x, wp, bias=b, act=3, gather=(idx, zero, C)).float()
+    try:
+        ops.set_splitk(True)
+        out = ops.gemm(x, wp, bias=b, act=3, gather=(idx, zero, C))
+    finally:
+        ops.set_splitk(False)
+    assert out.shape == (2 * Ho * Wo, C) and rel(out, ref) < 2e-3
+
+
 def test_gemm_swiglu(ops):
     from videollama2_amd.weights import pack_gate_up
     M, I, K = 333, 1792, 1024

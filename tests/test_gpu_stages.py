@@ -208,3 +208,28 @@ def test_vit_frame_chunks_on_streams_match_single_stream():
             many = tower(frames)
             torch.cuda.synchronize()
             assert torch.equal(one, many), f"{ns} streams: max |d| = {(one.float() - many.float()).abs().max().item():.3e}"
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_connector_cut_rank_by_rank_equals_unsharded(world):
+    """Full-width STC + a 2-layer tower, T=8: the rank-local pieces of dist.py's sharded-connector cut, run for every rank
+    in this process (halo handed over by reference), must reproduce the unsharded encoder (bit for bit while no GEMM splits K)."""
+    from videollama2_amd.connector import HipSTCConnector
+    from videollama2_amd.dist import FrameSharder
+    from videollama2_amd.tower import HipCLIPVisionTower
+    cfg = O.config_videollama2_7b(8)
+    cfg["vision"]["num_hidden_layers"] = 3
+    sd = O.seeded_state_dict(cfg, 5, only=lambda n: "vision_tower" in n or "mm_projector" in n)
+    tower, conn = HipCLIPVisionTower(cfg, sd, DEV), HipSTCConnector(sd, DEV)
+    frames = torch.randn(8, 3, 336, 336, generator=torch.Generator().manual_seed(4)).bfloat16().to(DEV)
+    from videollama2_amd import ops
+    ref = conn(tower(frames).view(1, 8, 576, 1024))      # same kernels on row subsets -> identical
+    out = FrameSharder.encode_video_all_ranks_locally(tower, conn, frames, world)
+    assert out.shape == ref.shape == (1, (8 // 2 + 1) * 13 * 13, 4096)
+    assert torch.equal(out, ref), f"max |d| = {(out.float() - ref.float()).abs().max().item():.3e}"
+    try:                                   # opt-in split-K reorders fp32 partial sums: two bf16 pipelines that round differently
+        ops.set_splitk(True)               # end up one bf16 noise floor apart (the STC floor is 1.7e-2, SURVEY 7.3-6)
+        out2 = FrameSharder.encode_video_all_ranks_locally(tower, conn, frames, world)
+    finally:
+        ops.set_splitk(False)
+    assert rel(out2, ref) < 3.4e-2, f"with split-K: rel {rel(out2, ref):.3e}"

@@ -40,6 +40,8 @@ class HipSTCConnector(nn.Module):
         super().__init__()
         self._dev = torch.device(device)
         self.w = pack_connector(state_dict, self._dev, prefix)
+        if self._dev.type == "cuda":
+            ops.attach_workspace(self._dev)       # split-K (opt-in, ops.set_splitk): Conv3d taps, s2 on few output frames
         self._idx_cache = {}
 
     def _bottleneck(self, x, b, F, H, W):

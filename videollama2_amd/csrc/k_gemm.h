@@ -109,7 +109,17 @@ __device__ __forceinline__ void gemm_store_patch(const GemmArgs& p, const float*
         }
 }
 
-template <int ACT, bool SWIGLU, bool OUT_F32, bool GATHER, bool REMAP = false>
+#define VL2_DRAIN_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+
+// SPLITK: gridDim.y workgroups share one output tile, each owning a contiguous 1/gridDim.y of the K-tiles (the launcher
+// picks a divisor).  Used when the plain grid would leave most CUs idle (small M: the per-rank shapes of the frame-sharded
+// encoder, the Conv3d-as-GEMM with K = 32768): a workgroup streams its operands at a fixed ~50-65 GB/s through LDS-DMA, so
+// a lone tile's latency is K/64 x 0.64 us whatever the rest of the chip does.  Every workgroup publishes its fp32
+// accumulators (sk_ws, [tile][split][64][256] floats, lane-coalesced), then takes a ticket on the tile's counter
+// (sk_flags[tile]); the LAST arriver re-reads all partials in split order (deterministic sum, whoever is last), re-arms
+// the counter for the next launch and runs the normal epilogue.  Hand-off = guide G16: drain, barrier, one lane
+// agent-scope release + drain + relaxed ticket; the reducer: agent-scope acquire, barrier, plain loads.
+template <int ACT, bool SWIGLU, bool OUT_F32, bool GATHER, bool REMAP = false, bool SPLITK = false>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char vl2_smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -132,7 +142,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nt = p.K / GEMM_BK;
+    const int nsplit = SPLITK ? (int)gridDim.y : 1;
+    const int nt = p.K / GEMM_BK / nsplit;                  // K-tiles of this workgroup
+    const int kt0 = SPLITK ? (int)blockIdx.y * nt : 0;      // first K-tile of this workgroup
     const int frow = lane & 31, fchk = lane >> 5;
 
     if constexpr (!GATHER) {
@@ -163,7 +175,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
             b_rd[ks] = 16384 + gemm_lds_off(wn * 64 + frow, ks * 2 + fchk);
         }
         auto stage = [&](unsigned lds_buf, int kt) {
-            const unsigned kb = (unsigned)kt * (GEMM_BK * 2);
+            const unsigned kb = (unsigned)(kt0 + kt) * (GEMM_BK * 2);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(vl2_smem + lds_buf + ((i * 4 + wave) << 10)),
@@ -230,9 +242,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
             a_rd[ks] = gemm_lds_off(wm * 64 + frow, ks * 2 + fchk);
             b_rd[ks] = 16384 + gemm_lds_off(wn * 64 + frow, ks * 2 + fchk);
         }
-        auto stage = [&](unsigned lds_buf, int kt) {
+        auto stage = [&](unsigned lds_buf, int ktl) {
+            const int kt = kt0 + ktl;
             const int seg = kt / tps, kl = kt - seg * tps;
-            if (kl == 0) {
+            if (kl == 0 || ktl == 0) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int r = p.a_idx[(size_t)seg * p.M + g_row[i]];
@@ -282,6 +295,48 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
         }
     }
 
+    if constexpr (SPLITK) {
+        float* ws = p.sk_ws + ((size_t)t * nsplit + blockIdx.y) * (64 * 256);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ws[((i * 2 + j) * 16 + r) * 256 + tid] = acc[i][j][r];
+        VL2_DRAIN_VMEM();
+        __syncthreads();
+        int* is_last = (int*)(vl2_smem + GEMM_LDS_BYTES - 16);
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            VL2_DRAIN_VMEM();
+            const int ticket = __hip_atomic_fetch_add(p.sk_flags + t, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (ticket == nsplit - 1) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                __hip_atomic_store(p.sk_flags + t, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
+            }
+            *is_last = ticket == nsplit - 1;
+        }
+        __syncthreads();
+        if (!*is_last) return;
+        const float* w0 = p.sk_ws + (size_t)t * nsplit * (64 * 256);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = w0[((i * 2 + j) * 16 + r) * 256 + tid];
+        for (int sp = 1; sp < nsplit; ++sp) {
+            const float* wsp = w0 + (size_t)sp * (64 * 256);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] += wsp[((i * 2 + j) * 16 + r) * 256 + tid];
+        }
+        __syncthreads();
+    }
+
     // ---- epilogue: acc (col = lane&31, rows (r&3)+8(r>>2)+4(lane>>5)) -> fp32 LDS patch [32][68] per wave -> rows
     float* ep = (float*)vl2_smem + wave * (32 * 68);
 #pragma unroll
@@ -309,7 +364,6 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
 // fence + drain + relaxed agent flag store; consumer: one lane polls relaxed, agent-scope acquire, barrier, plain loads.
 // The waiter always waits on HIGHER logical workgroup ids whose contribution is the FIRST thing they compute, so there is
 // no wait chain; every spin is bounded (a timeout leaves the tile unreduced and sets flag slot [grid]).
-#define VL2_DRAIN_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
 template <int ACT, bool SWIGLU, bool OUT_F32>
 __global__ __launch_bounds__(256, 2) void gemm_sk_bf16_kernel(GemmArgs p) {

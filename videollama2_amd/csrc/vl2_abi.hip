@@ -35,11 +35,19 @@ static int g_gemm_variant = 0;
 static void* g_ws = nullptr;          // caller-owned device workspace (vl2_set_workspace)
 static int64_t g_ws_bytes = 0;
 #define SK_GRID 512                  // persistent stream-K workgroups: 2 per CU
-#define SK_WS_BYTES ((int64_t)SK_GRID * 64 * 256 * 4 + (SK_GRID + 1) * 4)
+#define SPLITK_MAX_WG 1024           // split-K: at most this many (tile, split) workgroups -> 64 MiB of fp32 partials
+#define SPLITK_MAX_TILES 192         // split-K only when the plain grid leaves most of the 512 resident slots empty
+// workspace layout: [SPLITK_MAX_WG][64][256] fp32 partial tiles (stream-K uses the first SK_GRID) | stream-K flags
+// [SK_GRID + 1] | split-K tile counters [SPLITK_MAX_TILES] (zero when attached, re-armed by the kernel itself)
+#define SK_FLAGS_OFF ((int64_t)SPLITK_MAX_WG * 64 * 256 * 4)
+#define SPLITK_CNT_OFF (SK_FLAGS_OFF + (int64_t)(SK_GRID + 1) * 4 + 12)
+#define SK_WS_BYTES (SPLITK_CNT_OFF + (int64_t)SPLITK_MAX_TILES * 4)
+static int g_splitk = 0;             // VL2_TUNE_SPLITK: 0 = never (default: results independent of M), 1 = small grids split K
 static int g_gemv_rpw = 1;   // measured on MI355X: 3.09 / 3.30 / 3.97 ms per 7B decode token at 1 / 2 / 4 rows per wave
 extern "C" int32_t vl2_set_tuning(int32_t key, int32_t value) {
     if (key == VL2_TUNE_GEMM_VARIANT && (value == 0 || value == 1 || value == 2 || value == 4 || value == 8)) { g_gemm_variant = value; return 0; }
     if (key == VL2_TUNE_GEMV_ROWS_PER_WAVE && (value == 1 || value == 2 || value == 4)) { g_gemv_rpw = value; return 0; }
+    if (key == VL2_TUNE_SPLITK && (value == 0 || value == 1)) { g_splitk = value; return 0; }
     return fail(VL2_E_BADARG, "vl2_set_tuning: unknown key/value %d/%d", key, value);
 }
 
@@ -75,8 +83,41 @@ static int choose_gemm_kernel(const GemmArgs& a) {
     return best;
 }
 
+// Split-K factor for the 128x128 kernel (1 = do not split).  Only for grids that leave most resident slots empty: a lone
+// workgroup streams its K-tiles at ~0.64 us each (0.95 us when two share a CU), so a 96-tile grid with K = 4096 takes 42 us
+// however idle the chip is (scripts/kernel_bench.py --small).  Cost model in us per launch, d over the divisors of the
+// K-tile count: (K-tiles / d) x per-tile time at the resulting occupancy + partial write/reduce.
+static int choose_splitk(const GemmArgs& a) {
+    if (!g_ws || !g_splitk || (g_gemm_variant != 0 && g_gemm_variant != 1)) return 1;
+    const int tiles = a.tiles_m * a.tiles_n, nt = a.K / GEMM_BK;
+    if (tiles > SPLITK_MAX_TILES || nt < 32) return 1;       // measured: K = 1024 GEMMs lose (14.0 -> 19.7 us)
+    int best = 1;
+    double cb = 1e30;
+    for (int d = 1; d <= 32 && d * tiles <= SPLITK_MAX_WG; ++d) {
+        if (nt % d || nt / d < 4) continue;
+        const int wg = tiles * d;
+        const double per = wg <= 256 ? 0.64 : 0.95 * ((wg + 511) / 512);
+        const double c = (nt / d) * per + (d > 1 ? 2.0 + 0.3 * d : 0.0);
+        if (c < cb * (d > 1 ? 0.85 : 1.0)) { cb = c; best = d; }
+    }
+    return best;
+}
+
 template <int ACT, bool SW, bool F32, bool G>
 static void launch_gemm(const GemmArgs& a0, hipStream_t s) {
+    if (const int split = choose_splitk(a0); split > 1) {
+        static bool attr_k = false;
+        if (!attr_k) {
+            hipFuncSetAttribute((const void*)gemm_bf16_kernel<ACT, SW, F32, G, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                GEMM_LDS_BYTES);
+            attr_k = true;
+        }
+        GemmArgs a = a0;
+        a.sk_ws = (float*)g_ws;
+        a.sk_flags = (int*)((char*)g_ws + SPLITK_CNT_OFF);
+        hipLaunchKernelGGL((gemm_bf16_kernel<ACT, SW, F32, G, false, true>), dim3(a.tiles_m * a.tiles_n, split), dim3(256), GEMM_LDS_BYTES, s, a);
+        return;
+    }
     if constexpr (!G) {
         const int kern = g_gemm_variant == 0 ? choose_gemm_kernel(a0) : g_gemm_variant;
         if (kern == 4 && a0.N % GEMM3_BN == 0) {
@@ -116,7 +157,7 @@ static void launch_gemm(const GemmArgs& a0, hipStream_t s) {
             GemmArgs a = a0;
             const int total = a.tiles_m * a.tiles_n * (a.K / GEMM_BK);
             a.sk_ws = (float*)g_ws;
-            a.sk_flags = (int*)((char*)g_ws + (int64_t)SK_GRID * 64 * 256 * 4);
+            a.sk_flags = (int*)((char*)g_ws + SK_FLAGS_OFF);
             a.sk_per = (total + SK_GRID - 1) / SK_GRID;
             hipMemsetAsync(a.sk_flags, 0, (SK_GRID + 1) * 4, s);               // flags re-armed before EVERY launch (guide G16)
             hipLaunchKernelGGL((gemm_sk_bf16_kernel<ACT, SW, F32>), dim3(SK_GRID), dim3(256), GEMM_LDS_BYTES, s, a);

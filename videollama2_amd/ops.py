@@ -34,7 +34,8 @@ _WORKSPACE = {}
 
 
 def attach_workspace(device):
-    """Allocate (once per device) and attach the stream-K workspace; the library itself never allocates."""
+    """Allocate (once per device, zero-filled) and attach the GEMM workspace (split-K partial tiles + tile counters, stream-K);
+    the library itself never allocates."""
     key = str(device)
     if key not in _WORKSPACE:
         n = int(_lib.load().vl2_workspace_bytes())
@@ -42,6 +43,14 @@ def attach_workspace(device):
     ws = _WORKSPACE[key]
     _lib.call("vl2_set_workspace", _p(ws), ws.numel())
     return ws
+
+
+def set_splitk(on):
+    """Split-K for small-grid GEMMs (include/vl2hip.h VL2_TUNE_SPLITK; needs `attach_workspace`).  Off by default: it
+    trades the "same rows -> same bits whatever M" property for latency on small-M shapes (measured on MI355X:
+    1154x1024x4096 45.9 -> 39.7 us, 169x4096x4096 40.8 -> 27.9 us, 338x4096x32768 436 -> 160 us).  Never enable it while
+    GEMMs run concurrently on several streams (they would share the one workspace)."""
+    _lib.call("vl2_set_tuning", 3, 1 if on else 0)
 
 
 def set_gemm_variant(v):

@@ -37,6 +37,8 @@ class HipCLIPVisionTower(nn.Module):
         self.image_processor = image_processor
         self._dev = torch.device(device)
         self.w = pack_tower(state_dict, cfg, self._dev, prefix)
+        if self._dev.type == "cuda":
+            ops.attach_workspace(self._dev)       # split-K (opt-in, ops.set_splitk) for small per-rank grids
         self.config = types.SimpleNamespace(**v)
         self.is_loaded = True
         # frames as chunks on this many HIP streams.  Measured on MI355X (encode ms, 1 / 2 / 3 / 4 streams): T=16 14.15 /
