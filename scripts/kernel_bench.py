@@ -55,6 +55,9 @@ SMALL = [  # per-rank shapes of the frame-sharded encoder at 8 ranks (2 / 4 fram
     ("stc_s1_2f", 1152, 4096, 4096, dict()), ("stc_s1_b1_2f", 1152, 4096, 1024, dict()), ("stc_s1_4f", 2304, 4096, 4096, dict()),
     ("stc_s2_1to", 169, 4096, 4096, dict()), ("stc_s2_2to", 338, 4096, 4096, dict()),
     ("conv3d_as_plain_2to", 338, 4096, 32768, dict(bias=True, act=3)),
+    ("vit_wo_4f", 2308, 1024, 1024, dict(bias=True, res=True)), ("vit_fc1_4f", 2308, 4096, 1024, dict(bias=True, act=1)),
+    ("stc_s2_3to", 507, 4096, 4096, dict()), ("stc_s2_5to", 845, 4096, 4096, dict()), ("vit_fc2_8f", 4616, 1024, 4096, dict(bias=True, res=True)),
+    ("vit_wo_8f", 4616, 1024, 1024, dict(bias=True, res=True)), ("vit_qkv_1f", 577, 3072, 1024, dict(bias=True)), ("vit_fc1_1f", 577, 4096, 1024, dict(bias=True, act=1)),
 ]
 
 
@@ -63,7 +66,7 @@ def main():
     out = {}
     ops.attach_workspace(dev)
     if "--small" in sys.argv:
-        SHAPES, VARIANTS = SMALL, (0, 1, 4, 8)      # 0 = auto (split-K where eligible); 1/4/8 with split-K off
+        SHAPES, VARIANTS = SMALL, (1, 0, 32, 's')   # 0 = auto, 1 = 128x128, 32 = 64x64 small-M kernel, 's' = 128x128 + split-K
     rounds = 2 if "--quick" in sys.argv else 3
     for name, M, N, K, kw in SHAPES:
         a, w = rnd(M, K), rnd(N, K, scale=K ** -0.5)
@@ -76,13 +79,13 @@ def main():
             for v in VARIANTS:
                 if v in (4, 8) and N % 256:
                     continue
-                ops.set_gemm_variant(v)
-                ops.set_splitk(v == 0)
+                ops.set_gemm_variant(1 if v == 's' else v)
+                ops.set_splitk(v == 's')
                 us = timeit(lambda: ops.gemm(a, w, bias=bias, res=res, act=kw.get("act", 0), swiglu=kw.get("swiglu", False), out=c))
                 best[v] = min(best.get(v, 1e9), us)
                 if v == 1:
                     ref = c.clone()
-                elif r == 0 and v != 0:
+                elif r == 0 and v != 's':
                     d = (ref.float() - c.float()).abs().max().item()
                     if d > 0.05 * ref.float().abs().max().item():
                         print(f"   !! variant {v} differs from v1 on {name}: max|d| = {d:.4g}")

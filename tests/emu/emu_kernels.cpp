@@ -57,6 +57,13 @@ static void run_gemm(GemmArgs a) {
             return;
         }
     }
+    if constexpr (!SW && !F32) {
+        if (g_gemm_variant == 32) {                             // small-M 64x64 form (plain and gathered)
+            a.tiles_m = (a.M + 63) / 64; a.tiles_n = a.N / 64;
+            emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(128), [=] { gemm_s_bf16_kernel<ACT, G>(a); });
+            return;
+        }
+    }
     if (g_gemm_variant == 16) {                                 // split-K form of the 128x128 kernel (plain and gathered)
         const int nt = a.K / 64;
         const int split = nt % 4 == 0 && nt >= 8 ? 4 : nt % 3 == 0 && nt >= 6 ? 3 : nt % 2 == 0 ? 2 : 1;

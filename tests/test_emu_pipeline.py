@@ -78,6 +78,31 @@ def test_emu_gemm_splitk_plain_and_gathered(emu):
         ops.set_gemm_variant(0)
 
 
+def test_emu_gemm_small_m_kernel_is_bit_identical(emu):
+    """64x64 small-M kernel (knob 32): same K order as the 128-wide kernels -> identical bits, plain and gathered, ragged M,
+    K-tile counts below / at / above the ring depth."""
+    from videollama2_amd import ops
+    from videollama2_amd.connector import conv3d_k2s2p1_index
+    for M, K in ((70, 64), (129, 128), (200, 192), (33, 448)):
+        a, w, bias, res = bf(M, K), bf(256, K), torch.randn(256), bf(M, 256)
+        ref = ops.gemm(a, w, bias=bias, res=res, act=ops.ACT_GELU)
+        try:
+            ops.set_gemm_variant(32)
+            assert torch.equal(ops.gemm(a, w, bias=bias, res=res, act=ops.ACT_GELU), ref)
+        finally:
+            ops.set_gemm_variant(0)
+    T, H, C = 4, 4, 128
+    pool, w3, b3 = bf(T * H * H, C), bf(128, 8 * C, scale=0.05), torch.randn(128)
+    idx, _ = conv3d_k2s2p1_index(T, H, H, "cpu")
+    zero = torch.zeros(C, dtype=torch.bfloat16)
+    refg = ops.gemm(pool, w3, bias=b3, act=ops.ACT_SILU, gather=(idx, zero, C))
+    try:
+        ops.set_gemm_variant(32)
+        assert torch.equal(ops.gemm(pool, w3, bias=b3, act=ops.ACT_SILU, gather=(idx, zero, C)), refg)
+    finally:
+        ops.set_gemm_variant(0)
+
+
 def test_emu_attention_ragged_and_causal(emu):
     from videollama2_amd import ops
     B, H, N, D = 2, 2, 150, 64

@@ -77,6 +77,36 @@ def test_gemm_stream_k_variant(ops):
         ops.set_gemm_variant(0)
 
 
+def test_gemm_small_m_kernel_bit_identical(ops):
+    """Small-M shapes take the 64x64 kernel automatically; it must give the bits of the 128x128 kernel (knob 1)."""
+    from videollama2_amd.connector import conv3d_k2s2p1_index
+    for M, N, K, kw in [(1154, 1024, 4096, dict(bias=True, res=True)), (338, 4096, 4096, dict()), (169, 4096, 4096, dict(act=ops.ACT_GELU, bias=True)),
+                        (1154, 1024, 1024, dict(bias=True, res=True)), (77, 256, 64, dict(act=ops.ACT_QGELU, bias=True))]:
+        a, w = bf(M, K).to(DEV), bf(N, K, scale=K ** -0.5).to(DEV)
+        bias = torch.randn(N, device=DEV) if kw.get("bias") else None
+        res = bf(M, N).to(DEV) if kw.get("res") else None
+        out = ops.gemm(a, w, bias=bias, res=res, act=kw.get("act", 0))
+        try:
+            ops.set_gemm_variant(32)
+            forced = ops.gemm(a, w, bias=bias, res=res, act=kw.get("act", 0))
+            ops.set_gemm_variant(1)
+            ref = ops.gemm(a, w, bias=bias, res=res, act=kw.get("act", 0))
+        finally:
+            ops.set_gemm_variant(0)
+        assert torch.equal(forced, ref) and torch.equal(out, ref), (M, N, K)
+    T, H, C = 4, 24, 1024
+    x, wp, b = bf(T * H * H, C).to(DEV), bf(C, 8 * C, scale=(8 * C) ** -0.5).to(DEV), torch.randn(C, device=DEV)
+    idx, (To, Ho, Wo) = conv3d_k2s2p1_index(T, H, H, DEV, to_range=(1, 3))
+    zero = torch.zeros(C, dtype=torch.bfloat16, device=DEV)
+    out = ops.gemm(x, wp, bias=b, act=3, gather=(idx, zero, C))
+    try:
+        ops.set_gemm_variant(1)
+        ref = ops.gemm(x, wp, bias=b, act=3, gather=(idx, zero, C))
+    finally:
+        ops.set_gemm_variant(0)
+    assert torch.equal(out, ref)
+
+
 def test_gemm_splitk_small_grids(ops):
     """Opt-in: small-grid GEMMs split K once a workspace is attached (include/vl2hip.h VL2_TUNE_SPLITK): the per-rank shapes of the
     frame-sharded encoder and a long-K gathered Conv3d.  Same products, fp32 partial sums in a different order; the tile

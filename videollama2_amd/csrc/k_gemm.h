@@ -770,3 +770,121 @@ __global__ __launch_bounds__(512, 2) void gemm3_bf16_kernel(GemmArgs p) {
         __syncthreads();
     }
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// gemm_s "small-M" form: 64 x 64 block tile, 2 waves (wave w owns rows [32w, 32w+32) x 64 columns = 2 accumulators),
+// BK = 64, 4-stage 64 KiB LDS ring with counted vmcnt and ONE raw barrier per K-tile.
+// Why it exists: a workgroup pulls its operands through LDS-DMA at a fixed ~50-60 GB/s whatever the rest of the chip does
+// (scripts/kernel_bench.py --small: a lone 128x128 tile with K = 4096 takes 41-46 us for 2 MB of operands), so a GEMM
+// whose 128x128 grid has fewer tiles than there are CUs is bound by (bytes per workgroup) / 55 GB/s, not by FLOPs.  That
+// is the regime of the frame-sharded encoder (2-4 frames per rank: M = 1154...2308, or 169...507 output-frame rows) and
+// of short videos.  Quartering the tile puts 4x the workgroups on the idle CUs with half the bytes each.  The K order of
+// the accumulation is the same as in every other kernel here (sequential 16-deep MFMA steps), so a row's result does not
+// depend on which kernel -- i.e. on M -- computed it: a sharded run stays bit-identical to the single-GPU run.
+#define GEMMS_BM 64
+#define GEMMS_BN 64
+#define GEMMS_STAGES 4
+#define GEMMS_STAGE_BYTES 16384
+#define GEMMS_LDS_BYTES (GEMMS_STAGES * GEMMS_STAGE_BYTES)
+
+template <int ACT, bool GATHER>
+__global__ __launch_bounds__(128, 2) void gemm_s_bf16_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char vl2_smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // consecutive workgroups (one XCD after the remap) walk the M tiles of one W panel: the panel is fetched once per XCD
+    const int t = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = t % p.tiles_m, tn = t / p.tiles_m;
+    const int m0 = tm * GEMMS_BM, n0 = tn * GEMMS_BN;
+    const int nt = p.K / GEMM_BK;
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x7fffffff, 0x00020000);
+    const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0x7fffffff, 0x00020000);
+    // stage image: A 64 rows x 128 B (8 pieces of 1 KiB) | W 64 rows x 128 B; wave w issues pieces 2i + w; same bank swizzle
+    // as the 128-wide kernels (slot s of bank row R stored at s ^ (R & 15), applied to the SOURCE address)
+    unsigned a_vo[4], w_vo[4], g_chk[4];
+    int g_row[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int slot = ((i * 2 + wave) << 6) + lane;
+        const int R = slot >> 4, sx = (slot & 15) ^ (R & 15);
+        int am = m0 + 2 * R + (sx >> 3);
+        am = am < p.M ? am : p.M - 1;
+        g_row[i] = am;
+        g_chk[i] = (sx & 7) * 16;
+        a_vo[i] = GATHER ? 0x80000000u : ((unsigned)am * (unsigned)p.lda + (sx & 7) * 8) * 2;
+        w_vo[i] = ((unsigned)(n0 + 2 * R + (sx >> 3)) * (unsigned)p.ldw + (sx & 7) * 8) * 2;
+    }
+    const int tps = GATHER ? p.seg_k / GEMM_BK : 1;               // K-tiles per gather segment
+    const int frow = lane & 31, fchk = lane >> 5;
+    unsigned a_rd[4], b_rd[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        a_rd[ks] = gemm_lds_off(wave * 32 + frow, ks * 2 + fchk);
+        b_rd[ks] = 8192 + gemm_lds_off(frow, ks * 2 + fchk);       // second 32 W rows: + 4096 B
+    }
+    auto stage = [&](int kt) {
+        const unsigned lds_buf = (unsigned)(kt & (GEMMS_STAGES - 1)) * GEMMS_STAGE_BYTES;
+        unsigned ka = (unsigned)kt * (GEMM_BK * 2);
+        const unsigned kw = ka;
+        if (GATHER) {
+            const int seg = kt / tps, kl = kt - seg * tps;
+            if (kl == 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = p.a_idx[(size_t)seg * p.M + g_row[i]];
+                    a_vo[i] = r < 0 ? 0x80000000u : (unsigned)r * (unsigned)p.lda * 2u + g_chk[i];
+                }
+            }
+            ka = (unsigned)kl * (GEMM_BK * 2);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(vl2_smem + lds_buf + ((i * 2 + wave) << 10)),
+                                                     16, a_vo[i], ka, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(vl2_smem + lds_buf + 8192 + ((i * 2 + wave) << 10)),
+                                                     16, w_vo[i], kw, 0, 0);
+    };
+    // prologue: three K-tiles in flight
+#pragma unroll
+    for (int s = 0; s < GEMMS_STAGES - 1; ++s)
+        if (s < nt) stage(s);
+    for (int kt = 0; kt < nt; ++kt) {
+        // this wave's pieces of tile kt have landed once at most (tiles issued after kt) x 8 loads are outstanding
+        const int newer = nt - 1 - kt < GEMMS_STAGES - 2 ? nt - 1 - kt : GEMMS_STAGES - 2;
+        if (newer >= 2) VL2_WAIT_VMCNT(16); else if (newer == 1) VL2_WAIT_VMCNT(8); else VL2_WAIT_VMCNT(0);
+        VL2_PHASE_BARRIER();                                        // everyone's pieces landed; buffer (kt-1)&3 is free
+        if (kt + GEMMS_STAGES - 1 < nt) stage(kt + GEMMS_STAGES - 1);
+        const unsigned lds_buf = (unsigned)(kt & (GEMMS_STAGES - 1)) * GEMMS_STAGE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 af = *(const bf16x8*)(vl2_smem + lds_buf + a_rd[ks]);
+            const bf16x8 b0 = *(const bf16x8*)(vl2_smem + lds_buf + b_rd[ks]);
+            const bf16x8 b1 = *(const bf16x8*)(vl2_smem + lds_buf + b_rd[ks] + 4096);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b1, acc[1], 0, 0, 0);
+        }
+    }
+    VL2_WAIT_LGKMCNT0();
+    VL2_PHASE_BARRIER();
+
+    // ---- epilogue: one 32 x 64 fp32 patch per wave -> rows (same fused bias / activation / residual as the 128-wide kernel)
+    float* ep = (float*)vl2_smem + wave * (32 * 68);
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            ep[row * 68 + ni * 32 + (lane & 31)] = acc[ni][r];
+        }
+    __syncthreads();
+    gemm_store_patch<ACT, false, false, false>(p, ep, m0 + wave * 32, n0, lane);
+}

@@ -45,7 +45,7 @@ static int64_t g_ws_bytes = 0;
 static int g_splitk = 0;             // VL2_TUNE_SPLITK: 0 = never (default: results independent of M), 1 = small grids split K
 static int g_gemv_rpw = 1;   // measured on MI355X: 3.09 / 3.30 / 3.97 ms per 7B decode token at 1 / 2 / 4 rows per wave
 extern "C" int32_t vl2_set_tuning(int32_t key, int32_t value) {
-    if (key == VL2_TUNE_GEMM_VARIANT && (value == 0 || value == 1 || value == 2 || value == 4 || value == 8)) { g_gemm_variant = value; return 0; }
+    if (key == VL2_TUNE_GEMM_VARIANT && (value == 0 || value == 1 || value == 2 || value == 4 || value == 8 || value == 32)) { g_gemm_variant = value; return 0; }
     if (key == VL2_TUNE_GEMV_ROWS_PER_WAVE && (value == 1 || value == 2 || value == 4)) { g_gemv_rpw = value; return 0; }
     if (key == VL2_TUNE_SPLITK && (value == 0 || value == 1)) { g_splitk = value; return 0; }
     return fail(VL2_E_BADARG, "vl2_set_tuning: unknown key/value %d/%d", key, value);
@@ -103,8 +103,31 @@ static int choose_splitk(const GemmArgs& a) {
     return best;
 }
 
+// Small-M form (64x64 tiles, gemm_s_bf16_kernel): when the 128x128 grid cannot even give every CU one tile, quartering the
+// tile spreads the operand stream over the idle CUs (a workgroup streams at ~55 GB/s whatever the chip does).  Same K order
+// as every other kernel -> same bits.  Measured crossover (scripts/kernel_bench.py --small): see profiles/.
+static bool want_small_m(const GemmArgs& a) {
+    if (g_gemm_variant == 32) return true;
+    if (g_gemm_variant != 0) return false;
+    return a.tiles_m * a.tiles_n <= 128 && a.K >= 512;   // measured crossover: wins at <= 128 tiles, loses at 152-160
+}
+
 template <int ACT, bool SW, bool F32, bool G>
 static void launch_gemm(const GemmArgs& a0, hipStream_t s) {
+    if constexpr (!SW && !F32) {
+        if (choose_splitk(a0) <= 1 && want_small_m(a0)) {
+            static bool attr_s = false;
+            if (!attr_s) {
+                hipFuncSetAttribute((const void*)gemm_s_bf16_kernel<ACT, G>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMMS_LDS_BYTES);
+                attr_s = true;
+            }
+            GemmArgs a = a0;
+            a.tiles_m = (a.M + GEMMS_BM - 1) / GEMMS_BM;
+            a.tiles_n = a.N / GEMMS_BN;
+            hipLaunchKernelGGL((gemm_s_bf16_kernel<ACT, G>), dim3(a.tiles_m * a.tiles_n), dim3(128), GEMMS_LDS_BYTES, s, a);
+            return;
+        }
+    }
     if (const int split = choose_splitk(a0); split > 1) {
         static bool attr_k = false;
         if (!attr_k) {
