@@ -107,7 +107,9 @@ extern "C" int32_t vl2_gemm_bf16(const void* A, const void* W, void* C, const fl
 static int32_t run_norm(NormArgs a, bool rms) {
     const int nv = (a.C + 511) / 512;
     dim3 g((a.rows + 3) / 4), blk(256);
-    if (rms) {
+    if (rms && a.C > 2048 && a.rows > 1) {
+        emu::launch(dim3(a.rows), blk, [=] { norm_wide_kernel<true>(a); });
+    } else if (rms) {
         if (nv <= 1) emu::launch(g, blk, [=] { norm_kernel<1, true>(a); });
         else if (nv <= 2) emu::launch(g, blk, [=] { norm_kernel<2, true>(a); });
         else emu::launch(g, blk, [=] { norm_kernel<8, true>(a); });
@@ -166,7 +168,7 @@ extern "C" int32_t vl2_chan_mean(const void* x, float* mean, int32_t F, int32_t 
 extern "C" int32_t vl2_small_linear(const float* x, const void* W, const float* b, float* out, int32_t F, int32_t N, int32_t K,
                                     int32_t act, void*) {
     const int a = act == 3 ? 1 : act == 4 ? 2 : 0;
-    emu::launch(dim3((N + 3) / 4), dim3(256), [=] { small_linear_kernel(x, (const bf16_t*)W, b, out, F, N, K, a); });
+    emu::launch(dim3((N + SL_NB - 1) / SL_NB), dim3(256), [=] { small_linear_kernel(x, (const bf16_t*)W, b, out, F, N, K, a); });
     return 0;
 }
 extern "C" int32_t vl2_se_scale(void* x, const float* gate, int32_t F, int32_t HW, int32_t C, void*) {

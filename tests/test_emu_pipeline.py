@@ -103,6 +103,19 @@ def test_emu_gemm_small_m_kernel_is_bit_identical(emu):
         ops.set_gemm_variant(0)
 
 
+def test_emu_wide_rmsnorm_and_se_linear(emu):
+    """The workgroup-per-row RMSNorm (C > 2048, several rows) and the K-split SE linear against torch."""
+    from videollama2_amd import ops
+    x, w = bf(5, 4096), 1 + 0.1 * torch.randn(4096)
+    xf = x.float()
+    ref = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-5) * w
+    assert rel(ops.rmsnorm(x, w, 1e-5), ref) < TOL_BF16_OUT
+    g, wl, b = torch.randn(19, 4096), bf(24, 4096, scale=0.02), torch.randn(24)
+    assert rel(ops.small_linear(g, wl, b, ops.ACT_SILU), F.silu(F.linear(g, wl.float(), b))) < 1e-5
+    g2, wl2 = torch.randn(3, 1024), bf(40, 1024, scale=0.03)
+    assert rel(ops.small_linear(g2, wl2, None, ops.ACT_SIGMOID), torch.sigmoid(F.linear(g2, wl2.float()))) < 1e-5
+
+
 def test_emu_attention_ragged_and_causal(emu):
     from videollama2_amd import ops
     B, H, N, D = 2, 2, 150, 64

@@ -85,3 +85,82 @@ __global__ __launch_bounds__(256) void norm_kernel(NormArgs p) {
         }
     }
 }
+
+// Wide form for FEW, LONG rows (the LLM prefill: 1621 rows x 4096): one workgroup per row, 256 lanes x up to 2 vectors,
+// so the row count, not rows/4, is the number of workgroups in flight (one wave per row leaves a 256-CU chip with ~1.6
+// workgroups per CU: 13 us for 26 MB).  Same per-element arithmetic; the row sums are reduced wave-then-LDS instead of in
+// one wave, i.e. in a different fp32 order than norm_kernel -- the launcher picks by C and the row count only for RMSNorm
+// (rows of one sequence), never for the per-frame LayerNorms, so a frame's result does not depend on how many frames a
+// rank holds.
+template <bool RMS>
+__global__ __launch_bounds__(256) void norm_wide_kernel(NormArgs p) {
+    __shared__ float red[8];
+    const int row = blockIdx.x;
+    const bf16_t* x = p.x + (size_t)row * p.ldx;
+    float v[2][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = (i * 256 + threadIdx.x) * 8;
+        if (c < p.C) {
+            unpack8(*(const u32x4*)(x + c), v[i]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += RMS ? v[i][j] * v[i][j] : v[i][j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
+        }
+    }
+    auto block_sum = [&](float t) {
+        t = wave_sum(t);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
+        __syncthreads();
+        return red[0] + red[1] + red[2] + red[3];
+    };
+    s = block_sum(s);
+    const float inv_c = 1.0f / (float)p.C;
+    float mean = 0.f, rstd;
+    if (RMS) {
+        rstd = rsqrtf(s * inv_c + p.eps);
+    } else {
+        mean = s * inv_c;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = (i * 256 + threadIdx.x) * 8;
+            if (c < p.C) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mean; q += d * d; }
+            }
+        }
+        q = block_sum(q);
+        rstd = rsqrtf(q * inv_c + p.eps);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = (i * 256 + threadIdx.x) * 8;
+        if (c < p.C) {
+            const f32x4 w0 = *(const f32x4*)(p.w + c), w1 = *(const f32x4*)(p.w + c + 4);
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (v[i][j] - mean) * rstd * (j < 4 ? w0[j] : w1[j - 4]);
+            if (!RMS && p.b) {
+                const f32x4 b0 = *(const f32x4*)(p.b + c), b1 = *(const f32x4*)(p.b + c + 4);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] += (j < 4 ? b0[j] : b1[j - 4]);
+            }
+            if (p.res) {
+                float r[8];
+                unpack8(*(const u32x4*)(p.res + (size_t)row * p.ldres + c), r);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] += r[j];
+            }
+            if (p.silu) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = silu_f(o[j]);
+            }
+            *(u32x4*)(p.y + (size_t)row * p.ldy + c) = pack8(o);
+        }
+    }
+}

@@ -104,41 +104,74 @@ __global__ __launch_bounds__(256) void chan_mean_kernel(const bf16_t* __restrict
     }
 }
 
-// out[f][n] = act( sum_k W[n][k] * x[f][k] + b[n] );  x fp32 [F,K], W bf16 [N,K], out fp32 [F,N]; one wave per n;
-// act: 0 none, 1 SiLU, 2 sigmoid.  grid = ceil(N/4), block 256.  F is processed 8 frames at a time.
+// out[f][n] = act( sum_k W[n][k] * x[f][k] + b[n] );  x fp32 [F,K], W bf16 [N,K], out fp32 [F,N]; act: 0 none, 1 SiLU,
+// 2 sigmoid.  The cost is re-reading x, not the weights (one-output-per-wave forms pull F*K*4 bytes of x per output
+// from L2: 256 MB for the 4096 -> 1024 SE squeeze, 29-33 us).  Here a workgroup owns SL_NB = 8 outputs and 8 frames at a
+// time: each lane keeps its k-slice of the 8 frames in registers (lane owns 8 consecutive k per 2048-wide step, up to two
+// steps per 4096-wide chunk) and streams the 8 weight rows past it; partial sums meet in LDS.  The k -> lane assignment
+// does not depend on F, so a frame's result is the same whichever rank computes it.
+#define SL_NB 8
 __global__ __launch_bounds__(256) void small_linear_kernel(const float* __restrict__ x, const bf16_t* __restrict__ W,
                                                            const float* __restrict__ b, float* __restrict__ out, int F,
                                                            int N, int K, int act) {
-    const int lane = threadIdx.x & 63;
-    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (n >= N) return;
+    __shared__ float part[4][SL_NB][8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n0 = blockIdx.x * SL_NB;
     for (int f0 = 0; f0 < F; f0 += 8) {
-        float acc[8];
+        float acc[SL_NB][8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-        for (int k = lane * 8; k < K; k += 512) {
-            float w[8];
-            unpack8(*(const u32x4*)(W + (size_t)n * K + k), w);
+        for (int j = 0; j < SL_NB; ++j)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                if (f0 + i < F) {
-                    const float* xp = x + (size_t)(f0 + i) * K + k;
-                    const f32x4 xa = *(const f32x4*)xp, xb = *(const f32x4*)(xp + 4);
+            for (int i = 0; i < 8; ++i) acc[j][i] = 0.f;
+        for (int kc = 0; kc < K; kc += 4096) {
+            f32x4 xa[2][8], xb[2][8];
+            int kk[2];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i] += w[j] * xa[j] + w[4 + j] * xb[j];
+            for (int st = 0; st < 2; ++st) {
+                const int k = kc + st * 2048 + threadIdx.x * 8;
+                kk[st] = k < K ? k : -1;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int f = f0 + i < F ? f0 + i : F - 1;
+                    const float* xp = x + (size_t)f * K + (k < K ? k : 0);
+                    xa[st][i] = *(const f32x4*)xp;
+                    xb[st][i] = *(const f32x4*)(xp + 4);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < SL_NB; ++j) {
+                const int n = n0 + j < N ? n0 + j : N - 1;
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    if (kk[st] >= 0) {
+                        float w[8];
+                        unpack8(*(const u32x4*)(W + (size_t)n * K + kk[st]), w);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[j][i] += w[e] * xa[st][i][e] + w[4 + e] * xb[st][i][e];
+                    }
                 }
             }
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float t = wave_sum(acc[i]);
-            if (lane == 0 && f0 + i < F) {
-                float v = t + (b ? b[n] : 0.f);
+        for (int j = 0; j < SL_NB; ++j)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float t = wave_sum(acc[j][i]);
+                if (lane == 0) part[wave][j][i] = t;
+            }
+        __syncthreads();
+        if (threadIdx.x < SL_NB * 8) {
+            const int j = threadIdx.x >> 3, i = threadIdx.x & 7, n = n0 + j;
+            if (n < N && f0 + i < F) {
+                float v = part[0][j][i] + part[1][j][i] + part[2][j][i] + part[3][j][i] + (b ? b[n] : 0.f);
                 if (act == 1) v = silu_f(v);
                 if (act == 2) v = sigmoid_f(v);
                 out[(size_t)(f0 + i) * N + n] = v;
             }
         }
+        __syncthreads();
     }
 }
 

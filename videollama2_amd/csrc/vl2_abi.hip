@@ -253,7 +253,9 @@ static int32_t launch_norm(const NormArgs& a, bool rms, hipStream_t s, const cha
         return fail(VL2_E_SHAPE, "%s: need C%%8==0, C<=4096, aligned strides (C=%d)", what, a.C);
     const int nv = (a.C + 511) / 512;
     dim3 g((a.rows + 3) / 4), b(256);
-    if (rms) {
+    if (rms && a.C > 2048 && a.rows > 1) {        // one sequence's rows: the wide form (a workgroup per row)
+        hipLaunchKernelGGL((norm_wide_kernel<true>), dim3(a.rows), b, 0, s, a);
+    } else if (rms) {
         if (nv <= 1) hipLaunchKernelGGL((norm_kernel<1, true>), g, b, 0, s, a);
         else if (nv <= 2) hipLaunchKernelGGL((norm_kernel<2, true>), g, b, 0, s, a);
         else hipLaunchKernelGGL((norm_kernel<8, true>), g, b, 0, s, a);
@@ -339,7 +341,7 @@ extern "C" int32_t vl2_small_linear(const float* x, const void* W, const float* 
     if (K % 8) return fail(VL2_E_SHAPE, "vl2_small_linear: need K%%8==0");
     const int a = act == VL2_ACT_SILU ? 1 : act == VL2_ACT_SIGMOID ? 2 : act == VL2_ACT_NONE ? 0 : -1;
     if (a < 0) return fail(VL2_E_UNSUPP, "vl2_small_linear: act %d", act);
-    hipLaunchKernelGGL(small_linear_kernel, dim3((N + 3) / 4), dim3(256), 0, ST(stream), x, (const bf16_t*)W, b, out, F, N, K, a);
+    hipLaunchKernelGGL(small_linear_kernel, dim3((N + SL_NB - 1) / SL_NB), dim3(256), 0, ST(stream), x, (const bf16_t*)W, b, out, F, N, K, a);
     return launched("vl2_small_linear");
 }
 extern "C" int32_t vl2_se_scale(void* x, const float* gate, int32_t F, int32_t HW, int32_t C, void* stream) {
