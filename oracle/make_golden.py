@@ -20,8 +20,8 @@ OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 
 SEED = 1234
 
 
-def mint_small(T=4, n_new=8):
-    cfg = O.config_small(T)
+def mint_small(T=4, n_new=8, cfg=None, fname="small_T4.pt"):
+    cfg = cfg or O.config_small(T)
     model, ref = RH.build_reference_model(cfg)
     RH.reseed_weights(model, SEED)
     # round weights once to bf16 (what the HIP path stores), keep fp32 math
@@ -72,9 +72,13 @@ def mint_small(T=4, n_new=8):
         g["new_tokens"] = out.sequences[0]
         g["step_logits"] = torch.stack([s[0] for s in out.scores])
     os.makedirs(OUT, exist_ok=True)
-    torch.save(g, os.path.join(OUT, "small_T4.pt"))
-    print("wrote small_T4.pt;", {k: (tuple(v.shape) if torch.is_tensor(v) else type(v).__name__) for k, v in g.items()})
+    torch.save(g, os.path.join(OUT, fname))
+    print("wrote", fname, ";", {k: (tuple(v.shape) if torch.is_tensor(v) else type(v).__name__) for k, v in g.items()})
 
 
 if __name__ == "__main__":
-    mint_small()
+    which = sys.argv[1:] or ["v2", "v21"]
+    if "v2" in which:
+        mint_small()
+    if "v21" in which:      # VideoLLaMA2.1 family: SigLIP tower + stc_connector_v35 + Qwen2
+        mint_small(cfg=O.config_small_v21(4), fname="small_v21_T4.pt")

@@ -59,6 +59,14 @@ def import_reference():
             super().__init__(config, *a, **k)
 
     enc.CLIPVisionModel = _EagerCLIPVisionModel
+    real_siglip = enc.SiglipVisionModel
+
+    class _EagerSiglipVisionModel(real_siglip):  # shim 4 again: encoder.py:97 hard-codes flash_attention_2 for SigLIP too
+        def __init__(self, config, *a, **k):
+            config._attn_implementation = "eager"
+            super().__init__(config, *a, **k)
+
+    enc.SiglipVisionModel = _EagerSiglipVisionModel
     _ref = videollama2
     return _ref
 
@@ -85,8 +93,48 @@ def write_clip_dir(cfg, root=None):
     return d
 
 
+def write_siglip_dir(cfg, root=None):
+    """Same for SiglipVisionTower (encoder.py:94-96): a path containing 'siglip' with config.json + preprocessor_config.json
+    (public google/siglip-so400m-patch14-384 preprocessor values: plain resize to image_size^2, mean = std = 0.5)."""
+    v = cfg["vision"]
+    root = root or tempfile.mkdtemp(prefix="vl2_siglip_")
+    d = os.path.join(root, "siglip-synthetic")
+    os.makedirs(d, exist_ok=True)
+    with open(os.path.join(d, "config.json"), "w") as f:
+        json.dump(dict(model_type="siglip_vision_model", hidden_size=v["hidden_size"], intermediate_size=v["intermediate_size"],
+                       num_hidden_layers=v["num_hidden_layers"], num_attention_heads=v["num_attention_heads"],
+                       image_size=v["image_size"], patch_size=v["patch_size"], hidden_act="gelu_pytorch_tanh",
+                       layer_norm_eps=v["layer_norm_eps"], num_channels=3), f)
+    with open(os.path.join(d, "preprocessor_config.json"), "w") as f:
+        json.dump(dict(image_processor_type="SiglipImageProcessor", do_resize=True, size={"height": v["image_size"], "width": v["image_size"]},
+                       resample=3, do_rescale=True, rescale_factor=1 / 255, do_normalize=True, do_convert_rgb=None,
+                       image_mean=[0.5, 0.5, 0.5], image_std=[0.5, 0.5, 0.5]), f)
+    return d
+
+
+def build_reference_model_qwen2(cfg, seed=1234, tower_dir=None):
+    """Videollama2Qwen2ForCausalLM(config) with a SigLIP tower and stc_connector_v35 (the VideoLLaMA2.1 family); fp32, eval."""
+    ref = import_reference()
+    from videollama2.model.videollama2_qwen2 import Videollama2Qwen2ForCausalLM, Videollama2Qwen2Config
+    l = cfg["llm"]
+    tower_dir = tower_dir or write_siglip_dir(cfg)
+    hf_cfg = Videollama2Qwen2Config(
+        hidden_size=l["hidden_size"], intermediate_size=l["intermediate_size"], num_hidden_layers=l["num_hidden_layers"],
+        num_attention_heads=l["num_attention_heads"], num_key_value_heads=l["num_key_value_heads"], vocab_size=l["vocab_size"],
+        rms_norm_eps=l["rms_norm_eps"], rope_theta=l["rope_theta"], max_position_embeddings=32768, use_sliding_window=False,
+        tie_word_embeddings=False, attn_implementation="eager",
+        mm_vision_tower=tower_dir, mm_projector_type=cfg.get("projector", "stc_connector_v35"),
+        mm_hidden_size=cfg["vision"]["hidden_size"], mm_vision_select_layer=cfg["vision"]["select_layer"],
+        mm_vision_select_feature="patch", num_frames=cfg["num_frames"], bos_token_id=1, eos_token_id=2, pad_token_id=0)
+    torch.manual_seed(seed)
+    model = Videollama2Qwen2ForCausalLM(hf_cfg).float().eval()
+    return model, ref
+
+
 def build_reference_model(cfg, seed=1234, clip_dir=None):
     """Videollama2MistralForCausalLM(config) as SURVEY 8(c) 'Local files needed' describes; fp32, eval, CPU."""
+    if cfg["llm"].get("family", "mistral") == "qwen2":
+        return build_reference_model_qwen2(cfg, seed, clip_dir)
     ref = import_reference()
     from videollama2.model.videollama2_mistral import Videollama2MistralForCausalLM, Videollama2MistralConfig
     l = cfg["llm"]

@@ -45,6 +45,42 @@ def config_small(num_frames=4):
         num_frames=num_frames)
 
 
+def config_videollama2_1_7b_16f(num_frames=16):
+    """VideoLLaMA2.1-7B-16F public hyper-parameters: SigLIP-so400m-patch14-384 tower
+    (encoder.py:84-151), stc_connector_v35 (projector.py:225-238), Qwen2-7B decoder (videollama2_qwen2.py)."""
+    return dict(
+        vision=dict(family="siglip", hidden_size=1152, intermediate_size=4304, num_hidden_layers=27, num_attention_heads=16,
+                    image_size=384, patch_size=14, layer_norm_eps=1e-6, select_layer=-2),
+        llm=dict(family="qwen2", hidden_size=3584, intermediate_size=18944, num_hidden_layers=28, num_attention_heads=28,
+                 num_key_value_heads=4, head_dim=128, vocab_size=152064, rms_norm_eps=1e-6, rope_theta=1e6),
+        projector="stc_connector_v35", num_frames=num_frames)
+
+
+def config_small_v21(num_frames=4):
+    """Small VideoLLaMA2.1-shaped config: SigLIP tower whose head_dim (32) and MLP width (200) are NOT multiples the HIP
+    kernels take directly (exercises the head/MLP padding the real 72 / 4304 need), v35 connector (Conv3d padding 0:
+    4x4 -> 2x2, t -> t/2), Qwen2 decoder with QKV bias and an odd GQA group (3 q heads per kv head)."""
+    return dict(
+        vision=dict(family="siglip", hidden_size=128, intermediate_size=200, num_hidden_layers=3, num_attention_heads=4,
+                    image_size=56, patch_size=14, layer_norm_eps=1e-6, select_layer=-2),
+        llm=dict(family="qwen2", hidden_size=384, intermediate_size=512, num_hidden_layers=2, num_attention_heads=3,
+                 num_key_value_heads=1, head_dim=128, vocab_size=512, rms_norm_eps=1e-6, rope_theta=1e6),
+        projector="stc_connector_v35", num_frames=num_frames)
+
+
+def vision_family(cfg):
+    return cfg["vision"].get("family", "clip")
+
+
+def llm_family(cfg):
+    return cfg["llm"].get("family", "mistral")
+
+
+def conv3d_padding(cfg):
+    """STCConnector pads the Conv3d sampler by 1 (projector.py:164-174), STCConnectorV35 by 0 (projector.py:225-238)."""
+    return 0 if cfg.get("projector", "stc_connector") == "stc_connector_v35" else 1
+
+
 # ------------------------------------------------------------------------------- seeded synthetic weights
 
 
@@ -87,10 +123,15 @@ def state_dict_names(cfg):
     hd, nh, nkv = l["head_dim"], l["num_attention_heads"], l["num_key_value_heads"]
     out = []
     vt = "model.vision_tower.vision_tower."
-    out += [(vt + "embeddings.class_embedding", (Dv,)),
-            (vt + "embeddings.patch_embedding.weight", (Dv, 3, P, P)),
-            (vt + "embeddings.position_embedding.weight", (npos, Dv)),
-            (vt + "pre_layrnorm.weight", (Dv,)), (vt + "pre_layrnorm.bias", (Dv,))]
+    siglip = vision_family(cfg) == "siglip"
+    if siglip:      # HF:models/siglip/modeling_siglip.py SiglipVisionEmbeddings: biased patch conv, no CLS, no pre-LN
+        out += [(vt + "embeddings.patch_embedding.weight", (Dv, 3, P, P)), (vt + "embeddings.patch_embedding.bias", (Dv,)),
+                (vt + "embeddings.position_embedding.weight", (npos - 1, Dv))]
+    else:
+        out += [(vt + "embeddings.class_embedding", (Dv,)),
+                (vt + "embeddings.patch_embedding.weight", (Dv, 3, P, P)),
+                (vt + "embeddings.position_embedding.weight", (npos, Dv)),
+                (vt + "pre_layrnorm.weight", (Dv,)), (vt + "pre_layrnorm.bias", (Dv,))]
     for i in range(v["num_hidden_layers"]):
         p = f"{vt}encoder.layers.{i}."
         for n in ("k_proj", "v_proj", "q_proj", "out_proj"):
@@ -100,6 +141,12 @@ def state_dict_names(cfg):
                 (p + "mlp.fc2.weight", (Dv, Iv)), (p + "mlp.fc2.bias", (Dv,)),
                 (p + "layer_norm2.weight", (Dv,)), (p + "layer_norm2.bias", (Dv,))]
     out += [(vt + "post_layernorm.weight", (Dv,)), (vt + "post_layernorm.bias", (Dv,))]
+    if siglip:      # SiglipMultiheadAttentionPoolingHead: exists in the module, never reached by hidden_states[-2]
+        out += [(vt + "head.probe", (1, 1, Dv)), (vt + "head.attention.in_proj_weight", (3 * Dv, Dv)),
+                (vt + "head.attention.in_proj_bias", (3 * Dv,)), (vt + "head.attention.out_proj.weight", (Dv, Dv)),
+                (vt + "head.attention.out_proj.bias", (Dv,)), (vt + "head.layernorm.weight", (Dv,)),
+                (vt + "head.layernorm.bias", (Dv,)), (vt + "head.mlp.fc1.weight", (Iv, Dv)), (vt + "head.mlp.fc1.bias", (Iv,)),
+                (vt + "head.mlp.fc2.weight", (Dv, Iv)), (vt + "head.mlp.fc2.bias", (Dv,))]
     mp = "model.mm_projector."
     for stage, cin in (("s1", Dv), ("s2", D)):
         for b in range(1, 5):
@@ -125,6 +172,9 @@ def state_dict_names(cfg):
                 (p + "mlp.gate_proj.weight", (I, D)), (p + "mlp.up_proj.weight", (I, D)),
                 (p + "mlp.down_proj.weight", (D, I)),
                 (p + "input_layernorm.weight", (D,)), (p + "post_attention_layernorm.weight", (D,))]
+        if llm_family(cfg) == "qwen2":      # HF:models/qwen2/modeling_qwen2.py Qwen2Attention: bias on q/k/v only
+            out += [(p + "self_attn.q_proj.bias", (nh * hd,)), (p + "self_attn.k_proj.bias", (nkv * hd,)),
+                    (p + "self_attn.v_proj.bias", (nkv * hd,))]
     out += [("model.norm.weight", (D,)), ("lm_head.weight", (l["vocab_size"], D))]
     return out
 
@@ -238,6 +288,65 @@ def clip_tower(sd, cfg, frames, return_hidden=False):
     return (out, hs) if return_hidden else out
 
 
+# ------------------------------------------------------------------------------------- 8f-1: SigLIP tower
+
+SIGLIP_MEAN = (0.5, 0.5, 0.5)
+SIGLIP_STD = (0.5, 0.5, 0.5)
+
+
+def normalise_frames_u8_siglip(frames_u8_thwc):
+    """Arithmetic tail of SiglipImageProcessor for frames already image_size^2: x/255 -> (x-0.5)/0.5 -> NCHW fp32."""
+    x = torch.from_numpy(np.ascontiguousarray(frames_u8_thwc)).float() * (1.0 / 255.0)
+    return ((x - 0.5) / 0.5).permute(0, 3, 1, 2).contiguous()
+
+
+def gelu_tanh(x):
+    """HF:activations.py `gelu_pytorch_tanh` = nn.GELU(approximate='tanh')."""
+    return F.gelu(x, approximate="tanh")
+
+
+def siglip_embeddings(sd, cfg, pixel_values):
+    """HF:models/siglip/modeling_siglip.py SiglipVisionEmbeddings.forward: biased patch conv (valid padding), flatten,
+    + position_embedding (one row per patch, no CLS).  = hidden_states[0]."""
+    w = sd[_VT + "embeddings.patch_embedding.weight"]
+    x = F.conv2d(pixel_values.to(w.dtype), w, sd[_VT + "embeddings.patch_embedding.bias"], stride=cfg["vision"]["patch_size"])
+    return x.flatten(2).transpose(1, 2) + sd[_VT + "embeddings.position_embedding.weight"].unsqueeze(0)
+
+
+def siglip_layer(sd, cfg, i, x):
+    """SiglipEncoderLayer.forward: pre-LN; SiglipAttention (same arithmetic as CLIP's: scale d^-0.5, fp32 softmax);
+    +res; LN; fc1; gelu_pytorch_tanh; fc2; +res."""
+    eps = cfg["vision"]["layer_norm_eps"]
+    p = f"{_VT}encoder.layers.{i}."
+    D = x.shape[-1]
+    h = F.layer_norm(x, (D,), sd[p + "layer_norm1.weight"], sd[p + "layer_norm1.bias"], eps)
+    x = x + clip_attention(sd, cfg, p + "self_attn.", h)
+    h = F.layer_norm(x, (D,), sd[p + "layer_norm2.weight"], sd[p + "layer_norm2.bias"], eps)
+    h = F.linear(h, sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"])
+    h = F.linear(gelu_tanh(h), sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"])
+    return x + h
+
+
+def siglip_tower(sd, cfg, frames, return_hidden=False):
+    """videollama2/model/encoder.py:111-123 SiglipVisionTower.forward + feature_select (:103-109): hidden_states[
+    select_layer] with NO token dropped ('patch' is the identity here), cast back to the input dtype."""
+    v = cfg["vision"]
+    L, sel = v["num_hidden_layers"], v["select_layer"]
+    n_run = (L + 1 + sel) if sel < 0 else sel
+    x = siglip_embeddings(sd, cfg, frames)
+    hs = [x]
+    for i in range(n_run):
+        x = siglip_layer(sd, cfg, i, x)
+        hs.append(x)
+    out = x.to(frames.dtype)
+    return (out, hs) if return_hidden else out
+
+
+def vision_tower(sd, cfg, frames, return_hidden=False):
+    """build_vision_tower's dispatch (encoder.py:154-164) on the tower family."""
+    return (siglip_tower if vision_family(cfg) == "siglip" else clip_tower)(sd, cfg, frames, return_hidden)
+
+
 # ------------------------------------------------------------------------------------ a7: STC connector
 
 _MP = "model.mm_projector."
@@ -275,15 +384,16 @@ def stc_stage(sd, stage, x):
     return x
 
 
-def stc_connector(sd, x, return_stages=False):
-    """videollama2/model/projector.py:189-215 STCConnector.forward.  x [b, t, l, d] -> [b, (t' h' w'), D]."""
+def stc_connector(sd, x, return_stages=False, padding=1):
+    """videollama2/model/projector.py:189-215 STCConnector.forward.  x [b, t, l, d] -> [b, (t' h' w'), D].
+    padding = 1: STCConnector; padding = 0: STCConnectorV35 (projector.py:225-238) -- the only difference."""
     b, t, l, d = x.shape
     hw = int(l ** 0.5)
     x = x.view(b, t, hw, hw, d).permute(0, 4, 1, 2, 3)                 # b d t h w      (:199)
     x = x.permute(0, 2, 1, 3, 4).reshape(b * t, d, hw, hw)             # (b t) d h w    (:202)
     s1 = stc_stage(sd, "s1", x)                                        # (:205)
     x = s1.view(b, t, -1, hw, hw).permute(0, 2, 1, 3, 4)               # b d t h w      (:206)
-    samp = F.silu(F.conv3d(x, sd[_MP + "sampler.0.weight"], sd[_MP + "sampler.0.bias"], stride=2, padding=1))  # (:208)
+    samp = F.silu(F.conv3d(x, sd[_MP + "sampler.0.weight"], sd[_MP + "sampler.0.bias"], stride=2, padding=padding))  # (:208)
     nt, nh, nw = samp.shape[2:]
     x = samp.permute(0, 2, 1, 3, 4).reshape(b * nt, -1, nh, nw)        # (:211)
     s2 = stc_stage(sd, "s2", x)                                        # (:212)
@@ -302,8 +412,8 @@ def encode_images_or_videos(sd, cfg, images):
     batch = torch.stack(batch, 0)
     assert batch.dim() == 5
     b, t = batch.shape[:2]
-    feats = clip_tower(sd, cfg, batch.reshape(b * t, *batch.shape[2:]))
-    return stc_connector(sd, feats.view(b, t, *feats.shape[1:]))
+    feats = vision_tower(sd, cfg, batch.reshape(b * t, *batch.shape[2:]))
+    return stc_connector(sd, feats.view(b, t, *feats.shape[1:]), padding=conv3d_padding(cfg))
 
 
 # -------------------------------------------------------------------------------- a4: multimodal splice
@@ -365,9 +475,10 @@ def mistral_layer(sd, cfg, i, x, cos, sin, kv=None):
     p = f"model.layers.{i}."
     S = x.shape[0]
     h = rmsnorm(x, sd[p + "input_layernorm.weight"], eps)
-    q = F.linear(h, sd[p + "self_attn.q_proj.weight"]).view(S, nh, hd).transpose(0, 1)
-    k = F.linear(h, sd[p + "self_attn.k_proj.weight"]).view(S, nkv, hd).transpose(0, 1)
-    v = F.linear(h, sd[p + "self_attn.v_proj.weight"]).view(S, nkv, hd).transpose(0, 1)
+    # Qwen2Attention (HF:models/qwen2/modeling_qwen2.py) is the same arithmetic with a bias on q/k/v
+    q = F.linear(h, sd[p + "self_attn.q_proj.weight"], sd.get(p + "self_attn.q_proj.bias")).view(S, nh, hd).transpose(0, 1)
+    k = F.linear(h, sd[p + "self_attn.k_proj.weight"], sd.get(p + "self_attn.k_proj.bias")).view(S, nkv, hd).transpose(0, 1)
+    v = F.linear(h, sd[p + "self_attn.v_proj.weight"], sd.get(p + "self_attn.v_proj.bias")).view(S, nkv, hd).transpose(0, 1)
     q = q * cos + rotate_half(q) * sin
     k = k * cos + rotate_half(k) * sin
     if kv is not None:
@@ -433,7 +544,8 @@ def generate(sd, cfg, input_ids_1d, frames, max_new_tokens, eos_token_id=None):
     return greedy_generate(sd, cfg, emb, max_new_tokens, eos_token_id)
 
 
-def n_visual_tokens(T, grid=24):
-    """(T/2+1) * (grid/2+1)^2 for Conv3d(k=2,s=2,p=1): 845 / 1521 / 2873 for T=8/16/32."""
-    o = lambda n: (n + 2 - 2) // 2 + 1
+def n_visual_tokens(T, grid=24, padding=1):
+    """(T/2+1) * (grid/2+1)^2 for Conv3d(k=2,s=2,p=1): 845 / 1521 / 2873 for T=8/16/32; with padding 0
+    (v35, 27x27 SigLIP grid): (T/2) * 13 * 13 = 1352 at T=16."""
+    o = lambda n: (n + 2 * padding - 2) // 2 + 1
     return o(T) * o(grid) * o(grid)

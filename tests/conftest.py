@@ -16,3 +16,10 @@ def pytest_configure(config):
 def golden_small():
     import torch
     return torch.load(os.path.join(ROOT, "tests", "golden", "small_T4.pt"), weights_only=False)
+
+
+@pytest.fixture(scope="session")
+def golden_small_v21():
+    """VideoLLaMA2.1-shaped fixture (SigLIP tower + stc_connector_v35 + Qwen2), minted from the real reference."""
+    import torch
+    return torch.load(os.path.join(ROOT, "tests", "golden", "small_v21_T4.pt"), weights_only=False)
