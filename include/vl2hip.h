@@ -55,6 +55,7 @@ const char* vl2_last_error_string(void);      /* host pointer, thread-local, val
 #define VL2_ACT_GELU    2   /* exact erf GELU     torch nn.GELU() in projector.py:125-130 build_mlp (STC readout) */
 #define VL2_ACT_SILU    3   /* nn.SiLU            projector.py:164-174 sampler, timm act_layer */
 #define VL2_ACT_SIGMOID 4   /* only vl2_small_linear */
+#define VL2_ACT_GELU_TANH 5 /* nn.GELU(approximate='tanh') = HF gelu_pytorch_tanh (SigLIP MLP, HF:models/siglip/modeling_siglip.py SiglipMLP) */
 /* flags for vl2_gemm_bf16 */
 #define VL2_GEMM_SWIGLU  1  /* W = blocks of 64 rows {32 gate rows, 32 up rows}; C[m, j] = silu(gate_j) * up_j; C has N/2 cols.
                                HF:models/mistral/modeling_mistral.py MistralMLP.forward */
@@ -114,9 +115,10 @@ int32_t vl2_se_scale(void* x, const float* gate, int32_t F, int32_t HW, int32_t 
 int32_t vl2_rope_kv(const void* qkv, void* q_out, void* kcache, void* vcache, const float* cos_t, const float* sin_t,
                     int32_t S, int32_t nh, int32_t nkv, int32_t smax, int32_t pos0, void* stream);
 
-/* y[N] = W[N,K] x[K] for one token (decode).  norm_w != NULL fuses MistralRMSNorm on x first.  flags as vl2_gemm_bf16. */
-int32_t vl2_gemv_bf16(const void* W, const void* x, const float* norm_w, const void* res, void* y, int32_t N, int32_t K,
-                      int32_t ldw, float eps, int32_t flags, void* stream);
+/* y[N] = W[N,K] x[K] (+ bias[N]) (+ res[N]) for one token (decode).  norm_w != NULL fuses MistralRMSNorm on x first;
+ * bias (fp32, may be NULL) is Qwen2's q/k/v bias (HF:models/qwen2/modeling_qwen2.py Qwen2Attention).  flags as vl2_gemm_bf16. */
+int32_t vl2_gemv_bf16(const void* W, const void* x, const float* norm_w, const void* res, const float* bias, void* y,
+                      int32_t N, int32_t K, int32_t ldw, float eps, int32_t flags, void* stream);
 /* Decode attention for ONE new token at position pos, fused with RoPE and the KV-cache append:
  *   qkv [(nh+2*nkv)*128] = un-roped fused q|k|v projection of the token; the kernel ropes q, ropes k and appends k,v to
  *   cache row pos (HF apply_rotary_pos_emb + DynamicCache.update), then softmax(q K^T / sqrt(d)) V over rows [0, pos]

@@ -100,6 +100,7 @@ extern "C" int32_t vl2_gemm_bf16(const void* A, const void* W, void* C, const fl
         case 1: run_gemm<1, false, false, false>(a); break;
         case 2: run_gemm<2, false, false, false>(a); break;
         case 3: run_gemm<3, false, false, false>(a); break;
+        case 5: run_gemm<5, false, false, false>(a); break;
         default: return -3;
     }
     return 0;
@@ -182,9 +183,9 @@ extern "C" int32_t vl2_rope_kv(const void* qkv, void* q_out, void* kc, void* vc,
     emu::launch(dim3(5), dim3(256), [=] { rope_kv_kernel((const bf16_t*)qkv, (bf16_t*)q_out, (bf16_t*)kc, (bf16_t*)vc, cos_t, sin_t, S, nh, nkv, smax, pos0); });
     return 0;
 }
-extern "C" int32_t vl2_gemv_bf16(const void* W, const void* x, const float* norm_w, const void* res, void* y, int32_t N,
-                                 int32_t K, int32_t ldw, float eps, int32_t flags, void*) {
-    GemvArgs a{(const bf16_t*)W, (const bf16_t*)x, norm_w, (const bf16_t*)res, y, N, K, ldw, eps};
+extern "C" int32_t vl2_gemv_bf16(const void* W, const void* x, const float* norm_w, const void* res, const float* bias, void* y,
+                                 int32_t N, int32_t K, int32_t ldw, float eps, int32_t flags, void*) {
+    GemvArgs a{(const bf16_t*)W, (const bf16_t*)x, norm_w, (const bf16_t*)res, y, N, K, ldw, eps, bias};
     const bool sw = flags & 1, f32 = flags & 2;
     const int n_out = sw ? N / 2 : N;
     dim3 g((n_out + 7) / 8), blk(256);
@@ -198,7 +199,7 @@ extern "C" int32_t vl2_attn_decode(const void* qkv, void* kc, void* vc, const fl
                                    int32_t ctx_cap, float scale, void*) {
     const int group = nh / nkv, cap = pos_dev ? ctx_cap : pos + 1, nsplit = (cap + 63) / 64;
     if (cap <= 0 || cap > smax) return -2;
-    emu::launch(dim3(nsplit, nkv), dim3(256), [=] {
+    emu::launch(dim3(nsplit, nkv, (group + 3) / 4), dim3(256), [=] {
         attn_decode_kernel((const bf16_t*)qkv, (bf16_t*)kc, (bf16_t*)vc, cos_t, sin_t, partial, nh, group, nkv, smax, pos, pos_dev, scale * 1.4426950408889634f); });
     emu::launch(dim3(nh), dim3(128), [=] { attn_decode_combine_kernel(partial, (bf16_t*)out, nsplit, pos, pos_dev); });
     return 0;

@@ -26,10 +26,11 @@ struct Wave {
     int arrived = 0;
     unsigned gen = 0;
     alignas(16) unsigned char scratch[64][128];   // per-lane operand deposit area
+    alignas(16) unsigned char shfl[2][64][16];    // double-buffered deposit area of the shuffles (one sync per shuffle)
 };
 struct Thread {
     dim3 tid;
-    int lane = 0, wave = 0, flat = 0;
+    int lane = 0, wave = 0, flat = 0, shfl_phase = 0;
     ucontext_t ctx;
     char* stack = nullptr;
     bool done = false;
@@ -82,7 +83,7 @@ inline void launch(dim3 grid, dim3 block, std::function<void()> fn, size_t stack
         int f = 0;
         for (unsigned z = 0; z < block.z; ++z) for (unsigned y = 0; y < block.y; ++y) for (unsigned x = 0; x < block.x; ++x, ++f) {
             Thread& t = threads[f];
-            t.tid = dim3(x, y, z); t.flat = f; t.lane = f & 63; t.wave = f >> 6; t.done = false;
+            t.tid = dim3(x, y, z); t.flat = f; t.lane = f & 63; t.wave = f >> 6; t.done = false; t.shfl_phase = 0;
             getcontext(&t.ctx);
             t.ctx.uc_stack.ss_sp = t.stack; t.ctx.uc_stack.ss_size = stack_bytes; t.ctx.uc_link = &main_ctx;
             makecontext(&t.ctx, (void (*)())trampoline, 0);
@@ -165,11 +166,13 @@ inline bool wave_all(bool pred) {
     return r;
 }
 template <class T> inline T shfl_idx(T v, int src) {
+    static_assert(sizeof(T) <= 16, "shuffle operand");
     Wave& w = waves[cur->wave];
-    memcpy(w.scratch[cur->lane], &v, sizeof(T));
+    const int ph = cur->shfl_phase;           // lanes shuffle in lockstep, so their phases agree; a lane that races ahead
+    cur->shfl_phase ^= 1;                     // deposits into the OTHER buffer, and cannot reach this one again before the
+    memcpy(w.shfl[ph][cur->lane], &v, sizeof(T));   // next shuffle's sync, which every lane passes only after this read
     wave_sync();
-    T r; memcpy(&r, w.scratch[src & 63], sizeof(T));
-    wave_sync();
+    T r; memcpy(&r, w.shfl[ph][src & 63], sizeof(T));
     return r;
 }
 // LDS-DMA: destination = wave-uniform base (first lane's) + lane*size; source address is per lane.

@@ -54,19 +54,21 @@ def test_frame_shard_allgather_world2(T):
         assert seen == [parts[rank]]          # every rank ran the tower on its own slice only
 
 
-def _worker_sharded(rank, world, port, q):
+def _worker_sharded(rank, world, port, q, fixture):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle import vl2_oracle as O
     from tests.emu.backend import emulated_backend
-    g = torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "small_T4.pt"), weights_only=False)
+    g = torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", fixture), weights_only=False)
     cfg = g["cfg"]
     sd = O.seeded_state_dict(cfg, g["seed"])
     with emulated_backend():
         from videollama2_amd.connector import HipSTCConnector
         from videollama2_amd.dist import FrameSharder
-        from videollama2_amd.tower import HipCLIPVisionTower
-        tower, conn = HipCLIPVisionTower(cfg, sd, "cpu"), HipSTCConnector(sd, "cpu")
+        from videollama2_amd.tower import HipCLIPVisionTower, HipSiglipVisionTower
+        siglip = O.vision_family(cfg) == "siglip"
+        tower = (HipSiglipVisionTower if siglip else HipCLIPVisionTower)(cfg, sd, "cpu")
+        conn = HipSTCConnector(sd, "cpu", padding=O.conv3d_padding(cfg))
         sh = FrameSharder()
         assert sh.can_shard_connector(4)
         out = sh.encode_video(tower, conn, g["frames"])                     # sharded ViT + s1 + halo + conv3d/s2/readout
@@ -77,9 +79,11 @@ def _worker_sharded(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_sharded_connector_world2_bit_identical():
-    """The 'better cut' (SURVEY 8e): ViT + STC s1 sharded by frames, one-frame halo, Conv3d/s2/readout on the rank's output
-    frames, all-gather of final tokens -- must equal the unsharded connector bit for bit (real kernel sources, emulated)."""
+@pytest.mark.parametrize("fixture,shape", [("small_T4.pt", (1, 27, 256)), ("small_v21_T4.pt", (1, 8, 384))])
+def test_sharded_connector_world2_bit_identical(fixture, shape):
+    """The 'better cut' (SURVEY 8e): ViT + STC s1 sharded by frames, one-frame halo (none for the unpadded v35 sampler),
+    Conv3d/s2/readout on the rank's output frames, all-gather of final tokens -- must equal the unsharded connector bit for
+    bit (real kernel sources, emulated)."""
     from tests.emu.build_emu import build
     build()
     s = socket.socket()
@@ -88,11 +92,11 @@ def test_sharded_connector_world2_bit_identical():
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker_sharded, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker_sharded, args=(r, 2, port, q, fixture)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=600) for _ in procs)
     for p in procs:
         p.join(60)
-    for rank, same, shape, err in res:
-        assert same and shape == (1, 27, 256) and err < 2.5e-2
+    for rank, same, shp, err in res:
+        assert same and shp == shape and err < 2.5e-2

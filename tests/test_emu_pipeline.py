@@ -164,6 +164,29 @@ def test_emu_small_config_end_to_end_vs_reference_goldens(emu, golden_small):
         m.vision_tower(torch.zeros(1, 3, 28, 28))
 
 
+def test_emu_v21_family_end_to_end_vs_reference_goldens(emu, golden_small_v21):
+    """VideoLLaMA2.1 family (SigLIP tower with padded heads / MLP, unpadded v35 sampler, Qwen2 decoder with q/k/v bias and an
+    odd GQA group) against goldens minted from the real reference."""
+    from videollama2_amd.model import VideoLLaMA2Hip
+    from videollama2_amd.tower import HipSiglipVisionTower
+    g = golden_small_v21
+    cfg = g["cfg"]
+    sd = O.seeded_state_dict(cfg, g["seed"])
+    m = VideoLLaMA2Hip(cfg, sd, "cpu", max_seq_len=64)
+    assert isinstance(m.vision_tower, HipSiglipVisionTower) and m.mm_projector.padding == 0
+    assert m.vision_tower.w["hd"] == 32 and m.vision_tower.w["hdp"] == 64 and m.vision_tower.w["layers"][0]["w1"].shape[0] == 256
+    tower = m.vision_tower(g["frames"])
+    assert tuple(tower.shape) == tuple(g["tower_out"].shape) and rel(tower, g["tower_out"]) < 1.2e-2
+    out, st = m.mm_projector(tower.view(1, *tower.shape), return_stages=True)
+    assert rel(st["sampler"].permute(3, 0, 1, 2)[None], g["stc_sampler"]) < 2e-2
+    assert rel(out, g["mm_features"]) < 2.5e-2
+    ids = g["input_ids"][None]
+    toks, logits = m.generate(ids, images=[(g["frames"], "video")], do_sample=False, max_new_tokens=3,
+                              attention_mask=torch.ones_like(ids), return_logits=True)
+    assert toks[0].tolist() == g["new_tokens"][:3].tolist()
+    assert rel(logits, g["step_logits"][:3]) < 2.5e-2
+
+
 def test_emu_drop_in_accelerate_reference_model(emu, golden_small):
     """The seam test: a live reference model (build container only) re-routed by install.accelerate(); the reference's own
     `encode_images_or_videos` and `generate` entry points then run on the HIP host path (emulated kernels here)."""

@@ -361,3 +361,16 @@ def test_abi_rejects_bad_shapes(ops):
         ops.gemm(a, w)                      # K % 64 != 0
     with pytest.raises(Vl2HipError):
         ops.gemm(bf(16, 64).to(DEV), bf(100, 64).to(DEV))   # N % 128 != 0
+
+
+def test_small_linear_is_independent_of_the_frame_slot(ops):
+    """A frame's SE vector must come out bit-identical whichever slot of the 8-frame pass it occupies (= however many frames
+    the rank holds): the frame-sharded encoder relies on it.  (Regression: -ffast-math re-associated the unrolled FMA chains
+    differently per slot.)"""
+    g = torch.Generator().manual_seed(0)
+    for N, K in ((1024, 4096), (4096, 1024), (96, 384)):
+        x = torch.randn(11, K, generator=g).to(DEV)
+        w, b = bf(N, K, scale=K ** -0.5).to(DEV), torch.randn(N, generator=g).to(DEV)
+        full = ops.small_linear(x, w, b, ops.ACT_SILU)
+        for lo, hi in ((0, 2), (3, 8), (5, 11), (10, 11)):
+            assert torch.equal(ops.small_linear(x[lo:hi].contiguous(), w, b, ops.ACT_SILU), full[lo:hi]), (N, K, lo, hi)

@@ -12,18 +12,32 @@ def videollama2_7b(num_frames=16):
         num_frames=num_frames)
 
 
+def videollama2_1_7b_16f(num_frames=16):
+    """VideoLLaMA2.1-7B-16F (the reference's default checkpoint, README.md:327): SigLIP-so400m-patch14-384 tower
+    (encoder.py:84-151), stc_connector_v35 (projector.py:225-238), Qwen2-7B decoder (videollama2_qwen2.py)."""
+    return dict(
+        vision=dict(family="siglip", hidden_size=1152, intermediate_size=4304, num_hidden_layers=27, num_attention_heads=16,
+                    image_size=384, patch_size=14, layer_norm_eps=1e-6, select_layer=-2),
+        llm=dict(family="qwen2", hidden_size=3584, intermediate_size=18944, num_hidden_layers=28, num_attention_heads=28,
+                 num_key_value_heads=4, head_dim=128, vocab_size=152064, rms_norm_eps=1e-6, rope_theta=1e6),
+        projector="stc_connector_v35", num_frames=num_frames)
+
+
 def from_hf_config(hf_cfg, vision_cfg):
     """Build the dict from a Videollama2MistralConfig + CLIPVisionConfig (videollama2_arch.py:49-68 keys)."""
     g = lambda o, k, d=None: getattr(o, k, d)
     rope_theta = g(hf_cfg, "rope_theta", None)
     if rope_theta is None and g(hf_cfg, "rope_parameters", None):
         rope_theta = hf_cfg.rope_parameters.get("rope_theta", 1e6)
+    vfam = "siglip" if "siglip" in str(g(vision_cfg, "model_type", "")) else "clip"
+    lfam = "qwen2" if "qwen2" in str(g(hf_cfg, "model_type", "")) else "mistral"
     return dict(
-        vision=dict(hidden_size=vision_cfg.hidden_size, intermediate_size=vision_cfg.intermediate_size,
+        projector=g(hf_cfg, "mm_projector_type", "stc_connector"),
+        vision=dict(family=vfam, hidden_size=vision_cfg.hidden_size, intermediate_size=vision_cfg.intermediate_size,
                     num_hidden_layers=vision_cfg.num_hidden_layers, num_attention_heads=vision_cfg.num_attention_heads,
                     image_size=vision_cfg.image_size, patch_size=vision_cfg.patch_size,
                     layer_norm_eps=vision_cfg.layer_norm_eps, select_layer=g(hf_cfg, "mm_vision_select_layer", -2)),
-        llm=dict(hidden_size=hf_cfg.hidden_size, intermediate_size=hf_cfg.intermediate_size,
+        llm=dict(family=lfam, hidden_size=hf_cfg.hidden_size, intermediate_size=hf_cfg.intermediate_size,
                  num_hidden_layers=hf_cfg.num_hidden_layers, num_attention_heads=hf_cfg.num_attention_heads,
                  num_key_value_heads=hf_cfg.num_key_value_heads,
                  head_dim=g(hf_cfg, "head_dim", None) or hf_cfg.hidden_size // hf_cfg.num_attention_heads,
@@ -32,18 +46,23 @@ def from_hf_config(hf_cfg, vision_cfg):
 
 
 def check_supported(cfg):
-    """The gfx950 kernels are built for head_dim 64 (ViT) / 128 (LLM), GEMM N%128==0, K%64==0."""
+    """The gfx950 kernels are built for head_dim 64 / 128 (the SigLIP tower pads other head dims <= 128 and its MLP width
+    with zeros at load time), LLM head_dim 128, GEMM N%128==0, K%64==0."""
     v, l = cfg["vision"], cfg["llm"]
     hd_v = v["hidden_size"] // v["num_attention_heads"]
+    siglip = v.get("family", "clip") == "siglip"
     errs = []
-    if hd_v != 64:
-        errs.append(f"vision head_dim {hd_v} != 64")
+    if (hd_v != 64 and not siglip) or hd_v > 128:
+        errs.append(f"vision head_dim {hd_v} not supported")
     if l["head_dim"] != 128:
         errs.append(f"llm head_dim {l['head_dim']} != 128")
-    if l["num_attention_heads"] // l["num_key_value_heads"] > 4:
-        errs.append("GQA group > 4")
-    for name, n in (("vision hidden", v["hidden_size"]), ("vision mlp", v["intermediate_size"]),
-                    ("llm hidden", l["hidden_size"]), ("llm mlp", l["intermediate_size"]), ("vocab", l["vocab_size"])):
+    if l["num_attention_heads"] % l["num_key_value_heads"]:
+        errs.append("q heads not a multiple of kv heads")
+    if cfg.get("projector", "stc_connector") not in ("stc_connector", "stc_connector_v35"):
+        errs.append(f"projector {cfg.get('projector')} not built (stc_connector, stc_connector_v35)")
+    dims = [("vision hidden", v["hidden_size"]), ("llm hidden", l["hidden_size"]), ("llm mlp", l["intermediate_size"]),
+            ("vocab", l["vocab_size"])] + ([] if siglip else [("vision mlp", v["intermediate_size"])])
+    for name, n in dims:
         if n % 128:
             errs.append(f"{name} {n} % 128 != 0")
     if l["hidden_size"] > 4096 or v["hidden_size"] > 4096:

@@ -9,12 +9,14 @@ from . import ops
 from .weights import pack_connector
 
 
-def conv3d_k2s2p1_index(T, H, W, device, to_range=None, frame_lo=0, n_local=None):
-    """Gather table for Conv3d(kernel 2, stride 2, padding 1) (projector.py:164-174): output (to,ho,wo) tap (kt,kh,kw)
-    reads input (2*to-1+kt, 2*ho-1+kh, 2*wo-1+kw) or zero outside the [T,H,W] volume.
+def conv3d_k2s2p1_index(T, H, W, device, to_range=None, frame_lo=0, n_local=None, padding=1):
+    """Gather table for Conv3d(kernel 2, stride 2, padding p): p = 1 is STCConnector's sampler (projector.py:164-174), p = 0
+    STCConnectorV35's (projector.py:225-238).  Output (to,ho,wo) tap (kt,kh,kw) reads input (2*to-p+kt, 2*ho-p+kh,
+    2*wo-p+kw) or zero outside the [T,H,W] volume (with p = 0 nothing falls outside; an odd trailing row/column/frame is
+    simply never read, as in nn.Conv3d).
     Sharded form: only the output frames `to_range = (to0, to1)` are produced, from a local row pool that holds the
     `n_local` input frames starting at global frame `frame_lo`.  Returns (int32 [8, n_to*Ho*Wo], (n_to, Ho, Wo))."""
-    o = lambda n: (n + 2 - 2) // 2 + 1
+    o = lambda n: (n + 2 * padding - 2) // 2 + 1
     To, Ho, Wo = o(T), o(H), o(W)
     to0, to1 = to_range if to_range is not None else (0, To)
     n_local = T if n_local is None else n_local
@@ -25,7 +27,7 @@ def conv3d_k2s2p1_index(T, H, W, device, to_range=None, frame_lo=0, n_local=None
     for kt in range(2):
         for kh in range(2):
             for kw in range(2):
-                t, h, w = 2 * to - 1 + kt, 2 * ho - 1 + kh, 2 * wo - 1 + kw
+                t, h, w = 2 * to - padding + kt, 2 * ho - padding + kh, 2 * wo - padding + kw
                 ok = (t >= 0) & (t < T) & (h >= 0) & (h < H) & (w >= 0) & (w < W)
                 tl = t - frame_lo
                 if bool((ok & ((tl < 0) | (tl >= n_local))).any()):
@@ -36,8 +38,12 @@ def conv3d_k2s2p1_index(T, H, W, device, to_range=None, frame_lo=0, n_local=None
 
 
 class HipSTCConnector(nn.Module):
-    def __init__(self, state_dict, device="cuda", prefix="model.mm_projector."):
+    """padding = 1: `stc_connector`; padding = 0: `stc_connector_v35` (projector.py:225-238: the same module with an unpadded
+    Conv3d sampler, the VideoLLaMA2.1 checkpoints' projector)."""
+
+    def __init__(self, state_dict, device="cuda", prefix="model.mm_projector.", padding=1):
         super().__init__()
+        self.padding = int(padding)
         self._dev = torch.device(device)
         self.w = pack_connector(state_dict, self._dev, prefix)
         if self._dev.type == "cuda":
@@ -68,7 +74,7 @@ class HipSTCConnector(nn.Module):
         """Conv3d(k2,s2,p1)+bias+SiLU as the gathered GEMM over a row pool of s1 frames -> ([n_to*Ho*Wo, C], (n_to,Ho,Wo))."""
         key = (T, hw, to_range, frame_lo, n_local)
         if key not in self._idx_cache:
-            self._idx_cache[key] = conv3d_k2s2p1_index(T, hw, hw, self._dev, to_range, frame_lo, n_local)
+            self._idx_cache[key] = conv3d_k2s2p1_index(T, hw, hw, self._dev, to_range, frame_lo, n_local, self.padding)
         idx, dims = self._idx_cache[key]
         h = ops.gemm(pool, self.w["samp_w"], bias=self.w["samp_b"], act=ops.ACT_SILU,
                      gather=(idx, self.w["zero_row"], self.w["cin"]))

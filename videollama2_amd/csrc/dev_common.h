@@ -59,6 +59,12 @@ __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float quick_gelu_f(float x) { return x / (1.0f + __expf(-1.702f * x)); }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// nn.GELU(approximate="tanh") = HF `gelu_pytorch_tanh` (SigLIP MLP): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3))),
+// tanh(u) = 1 - 2 / (1 + e^{2u})
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+    return 0.5f * x * (2.0f - 2.0f / (1.0f + __expf(2.0f * u)));
+}
 
 // XCD-aware, bijective remap of a 1-D block id: block b runs on XCD b%8 (observed); give every XCD one
 // contiguous chunk of the logical tile order so neighbouring tiles share an L2.

@@ -61,6 +61,7 @@ struct GemvArgs {
     void* y;                // bf16 or fp32 [N_out]
     int N, K, ldw;
     float eps;
+    const float* bias;      // [N_out] added before the residual (Qwen2 q/k/v bias) or null; not with SWIGLU
 };
 
 // grid = ceil(N_out / (4*RPW)), block 256; dynamic LDS = K * 2 bytes (x as bf16)
@@ -136,6 +137,7 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvArgs p) {
         if (SWIGLU) a1 = wave_sum(a1);
         if (lane == 0) {
             float o = SWIGLU ? silu_f(a0) * a1 : a0;
+            if (!SWIGLU && p.bias) o += p.bias[j];
             if (p.res) o += bf2f(p.res[j]);
             if (OUT_F32) ((float*)p.y)[j] = o;
             else ((bf16_t*)p.y)[j] = f2bf(o);
@@ -145,11 +147,13 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvArgs p) {
 
 // ---- decode attention (flash-decoding) fused with RoPE and the KV-cache append of the new token.
 // qkv [(nh+2*nkv)*128] = the un-roped fused projection of the ONE new token at position pos (pos = *pos_dev when pos_dev
-// is non-null, so a captured hipGraph replays with a moving position).  grid = (nsplit_cap, nkv), 256 threads:
-// one workgroup per (64-key slice, kv head), 4 waves x 16 keys; slices at or beyond ctx = pos+1 exit at once.
-// A lane is (key = lane&15, head-in-group = lane>>4): a K row is read once and scored against all `group` q heads;
+// is non-null, so a captured hipGraph replays with a moving position).  grid = (nsplit_cap, nkv, ceil(group/4)), 256
+// threads: one workgroup per (64-key slice, kv head, block of <= 4 q heads of the group), 4 waves x 16 keys; slices at or
+// beyond ctx = pos+1 exit at once.  (Mistral-7B: group 4 = one block; Qwen2-7B: group 7 = two blocks.)
+// A lane is (key = lane&15, head-in-block = lane>>4): a K row is read once and scored against the block's q heads;
 // V rows are requested up front (they do not depend on the scores) so the kernel is ONE memory round trip.
-// The workgroup whose slice contains pos ropes k_new, appends k_new / v_new to the cache (DynamicCache.update) first.
+// The workgroup(s) whose slice contains pos rope k_new and append k_new / v_new to the cache (DynamicCache.update) first
+// (with two head blocks both write the same bytes, and each reads the row back only after its own barrier).
 // partial: fp32 [nh][nsplit_cap][130] = {m (exp2 domain), l, o[128]}
 __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ kcache,
                                                           bf16_t* __restrict__ vcache, const float* __restrict__ cos_t,
@@ -164,6 +168,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kl = lane & 15, hh = lane >> 4;
     const int split = blockIdx.x, hk = blockIdx.y, nsplit = gridDim.x;
+    const int h0 = blockIdx.z * 4;                                  // first q head (within the group) of this block
+    const int ng = group - h0 < 4 ? group - h0 : 4;                 // q heads of this block
     const int pos = pos_dev ? *pos_dev : pos_arg;
     const int ctx = pos + 1;
     const int k0 = split * 64;
@@ -174,9 +180,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
     const float* sp = sin_t + (size_t)pos * HALF;
 
     // roped q of the `group` heads of this kv head -> LDS (rounded through bf16 like the unfused path)
-    for (int t = tid; t < group * HALF; t += 256) {
+    for (int t = tid; t < ng * HALF; t += 256) {
         const int h = t / HALF, d = t % HALF;
-        const bf16_t* qh = qkv + (size_t)(hk * group + h) * HD;
+        const bf16_t* qh = qkv + (size_t)(hk * group + h0 + h) * HD;
         const float x1 = bf2f(qh[d]), x2 = bf2f(qh[d + HALF]), c = cp[d], sn = sp[d];
         qs[h][d] = bf2f(f2bf(x1 * c - x2 * sn));
         qs[h][d + HALF] = bf2f(f2bf(x2 * c + x1 * sn));
@@ -208,7 +214,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
 #pragma unroll
     for (int c = 0; c < 16; ++c) kreg[c] = *(const u32x4*)(kr + c * 8);
 
-    const int hq = hh < group ? hh : group - 1;
+    const int hq = hh < ng ? hh : ng - 1;
     float acc = 0.f;
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
@@ -246,9 +252,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
 #pragma unroll
     for (int h = 0; h < 4; ++h) { oacc[wave][h][lane * 2] = o[h][0]; oacc[wave][h][lane * 2 + 1] = o[h][1]; }
     __syncthreads();
-    for (int t = tid; t < group * HD; t += 256) {
+    for (int t = tid; t < ng * HD; t += 256) {
         const int h = t / HD, d = t % HD;
-        float* dst = partial + ((size_t)(hk * group + h) * nsplit + split) * 130;
+        float* dst = partial + ((size_t)(hk * group + h0 + h) * nsplit + split) * 130;
         dst[2 + d] = oacc[0][h][d] + oacc[1][h][d] + oacc[2][h][d] + oacc[3][h][d];
         if (d == 0) {
             dst[0] = fmaxf(fmaxf(wred[0][0][h], wred[0][1][h]), fmaxf(wred[0][2][h], wred[0][3][h]));

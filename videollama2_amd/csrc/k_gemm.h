@@ -35,7 +35,7 @@ struct GemmArgs {
     int sk_per;
 };
 
-enum { ACT_NONE = 0, ACT_QGELU = 1, ACT_GELU = 2, ACT_SILU = 3 };
+enum { ACT_NONE = 0, ACT_QGELU = 1, ACT_GELU = 2, ACT_SILU = 3, ACT_GELU_TANH = 5 };
 
 #define GEMM_BM 128
 #define GEMM_BN 128
@@ -83,6 +83,7 @@ __device__ __forceinline__ void gemm_store_patch(const GemmArgs& p, const float*
                         if (ACT == ACT_QGELU) v[j] = quick_gelu_f(v[j]);
                         if (ACT == ACT_GELU) v[j] = gelu_erf_f(v[j]);
                         if (ACT == ACT_SILU) v[j] = silu_f(v[j]);
+                        if (ACT == ACT_GELU_TANH) v[j] = gelu_tanh_f(v[j]);
                     }
                 }
                 const int n = SWIGLU ? (n_base >> 1) + cg : nfull;

@@ -114,6 +114,9 @@ __global__ __launch_bounds__(256) void chan_mean_kernel(const bf16_t* __restrict
 __global__ __launch_bounds__(256) void small_linear_kernel(const float* __restrict__ x, const bf16_t* __restrict__ W,
                                                            const float* __restrict__ b, float* __restrict__ out, int F,
                                                            int N, int K, int act) {
+    // -ffast-math may re-associate the unrolled FMA chains differently per frame slot; a frame's result must not depend on
+    // which slot (i.e. how many frames this rank holds) it is computed in -> fixed association inside this kernel
+#pragma clang fp reassociate(off)
     __shared__ float part[4][SL_NB][8];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n0 = blockIdx.x * SL_NB;
@@ -149,18 +152,26 @@ __global__ __launch_bounds__(256) void small_linear_kernel(const float* __restri
 #pragma unroll
                         for (int i = 0; i < 8; ++i)
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) acc[j][i] += w[e] * xa[st][i][e] + w[4 + e] * xb[st][i][e];
+                            for (int e = 0; e < 4; ++e)
+                                acc[j][i] = __builtin_fmaf(w[4 + e], xb[st][i][e], __builtin_fmaf(w[e], xa[st][i][e], acc[j][i]));
                     }
                 }
             }
         }
+        // 64 partial sums per lane -> lane L ends up with the wave total of value L (= j*8 + i): a reduce-scatter butterfly,
+        // 63 shuffles instead of 64 full reductions (384)
+        float* v = &acc[0][0];
 #pragma unroll
-        for (int j = 0; j < SL_NB; ++j)
+        for (int m = 32, half = 32; m >= 1; m >>= 1, half >>= 1) {
+            const bool up = lane & m;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float t = wave_sum(acc[j][i]);
-                if (lane == 0) part[wave][j][i] = t;
+            for (int k = 0; k < half; ++k) {
+                const float send = up ? v[k] : v[k + half];
+                const float keep = up ? v[k + half] : v[k];
+                v[k] = keep + __shfl_xor(send, m);
             }
+        }
+        part[wave][lane >> 3][lane & 7] = v[0];
         __syncthreads();
         if (threadIdx.x < SL_NB * 8) {
             const int j = threadIdx.x >> 3, i = threadIdx.x & 7, n = n0 + j;

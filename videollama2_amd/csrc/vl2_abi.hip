@@ -240,6 +240,7 @@ extern "C" int32_t vl2_gemm_bf16(const void* A, const void* W, void* C, const fl
             case VL2_ACT_QGELU: launch_gemm<ACT_QGELU, false, false, false>(a, s); break;
             case VL2_ACT_GELU: launch_gemm<ACT_GELU, false, false, false>(a, s); break;
             case VL2_ACT_SILU: launch_gemm<ACT_SILU, false, false, false>(a, s); break;
+            case VL2_ACT_GELU_TANH: launch_gemm<ACT_GELU_TANH, false, false, false>(a, s); break;
             default: return fail(VL2_E_UNSUPP, "vl2_gemm_bf16: unknown act %d", act);
         }
     }
@@ -375,13 +376,13 @@ static void launch_gemv(const GemvArgs& a, int n_out, hipStream_t s) {
     else
         hipLaunchKernelGGL((gemv_bf16_kernel<SW, F32, 1>), dim3((n_out + 3) / 4), dim3(256), (size_t)a.K * 2, s, a);
 }
-extern "C" int32_t vl2_gemv_bf16(const void* W, const void* x, const float* norm_w, const void* res, void* y, int32_t N,
-                                 int32_t K, int32_t ldw, float eps, int32_t flags, void* stream) {
+extern "C" int32_t vl2_gemv_bf16(const void* W, const void* x, const float* norm_w, const void* res, const float* bias, void* y,
+                                 int32_t N, int32_t K, int32_t ldw, float eps, int32_t flags, void* stream) {
     if (!W || !x || !y || N <= 0 || K <= 0) return fail(VL2_E_BADARG, "vl2_gemv_bf16: bad args");
     if (K % 8 || ldw % 8 || K > 28672) return fail(VL2_E_SHAPE, "vl2_gemv_bf16: need K%%8==0, K<=28672 (K=%d)", K);
     const bool sw = flags & VL2_GEMM_SWIGLU, f32 = flags & VL2_GEMM_OUT_F32;
-    if (sw && (N % 64 || f32)) return fail(VL2_E_SHAPE, "vl2_gemv_bf16: SWIGLU needs N%%64==0 and bf16 output");
-    GemvArgs a{(const bf16_t*)W, (const bf16_t*)x, norm_w, (const bf16_t*)res, y, N, K, ldw, eps};
+    if (sw && (N % 64 || f32 || bias)) return fail(VL2_E_SHAPE, "vl2_gemv_bf16: SWIGLU needs N%%64==0, bf16 output, no bias");
+    GemvArgs a{(const bf16_t*)W, (const bf16_t*)x, norm_w, (const bf16_t*)res, y, N, K, ldw, eps, bias};
     if (sw) launch_gemv<true, false>(a, N / 2, ST(stream));
     else if (f32) launch_gemv<false, true>(a, N, ST(stream));
     else launch_gemv<false, false>(a, N, ST(stream));
@@ -393,11 +394,11 @@ extern "C" int32_t vl2_attn_decode(const void* qkv, void* kcache, void* vcache, 
     if (!qkv || !kcache || !vcache || !cos_t || !sin_t || !partial || !out || nh <= 0 || nkv <= 0)
         return fail(VL2_E_BADARG, "vl2_attn_decode: bad args");
     const int group = nh / nkv;
-    if (group * nkv != nh || group > 4) return fail(VL2_E_SHAPE, "vl2_attn_decode: need nh = nkv*group, group<=4");
+    if (group * nkv != nh) return fail(VL2_E_SHAPE, "vl2_attn_decode: need nh = nkv*group");
     const int cap = pos_dev ? ctx_cap : pos + 1;                 // positions the launch must be able to cover
     if (cap <= 0 || cap > smax || (!pos_dev && pos < 0)) return fail(VL2_E_SHAPE, "vl2_attn_decode: position %d outside the cache (%d)", cap - 1, smax);
     const int nsplit = (cap + 63) / 64;
-    hipLaunchKernelGGL(attn_decode_kernel, dim3(nsplit, nkv), dim3(256), 0, ST(stream), (const bf16_t*)qkv, (bf16_t*)kcache,
+    hipLaunchKernelGGL(attn_decode_kernel, dim3(nsplit, nkv, (group + 3) / 4), dim3(256), 0, ST(stream), (const bf16_t*)qkv, (bf16_t*)kcache,
                        (bf16_t*)vcache, cos_t, sin_t, partial, nh, group, nkv, smax, pos, pos_dev, scale * 1.4426950408889634f);
     hipLaunchKernelGGL(attn_decode_combine_kernel, dim3(nh), dim3(128), 0, ST(stream), partial, (bf16_t*)out, nsplit, pos, pos_dev);
     return launched("vl2_attn_decode");

@@ -1,5 +1,6 @@
 """HipMistralDecoder -- the decoder backend behind `Videollama2MistralForCausalLM.generate(inputs, images=...)`
-(videollama2/model/videollama2_mistral.py:110-144): consumes `inputs_embeds [S, hidden]`, runs the Mistral prefill and
+(videollama2/model/videollama2_mistral.py:110-144) and, with the q/k/v bias HF Qwen2Attention adds, behind
+`Videollama2Qwen2ForCausalLM.generate` (videollama2/model/videollama2_qwen2.py:108-142; alias `HipQwen2Decoder`): consumes `inputs_embeds [S, hidden]`, runs the Mistral prefill and
 the greedy decode loop on its own KV cache and returns the NEW token ids, as HF `generate` does on the
 `inputs_embeds` path.  Per-layer math follows HF:models/mistral/modeling_mistral.py (RMSNorm fp32 statistics,
 rotate-half RoPE theta=1e6, causal GQA attention, SwiGLU), executed by libvl2hip.so kernels only."""
@@ -59,7 +60,7 @@ class HipMistralDecoder(nn.Module):
         smax = self.max_seq_len
         for li, lw in enumerate(self.w["layers"]):
             h = ops.rmsnorm(x, lw["ln1_w"], self.eps)
-            qkv = ops.gemm(h, lw["wqkv"])
+            qkv = ops.gemm(h, lw["wqkv"], bias=lw["bqkv"])              # bqkv: Qwen2 only (None for Mistral)
             ops.rope_kv(qkv, q, self.kcache[li], self.vcache[li], self.cos_t, self.sin_t, nh, nkv, 0)
             ops.attn_fwd(q, self.kcache[li], self.vcache[li], o, (0, hd, nh * hd), (0, smax * hd, hd), (0, smax * hd, hd),
                          (0, hd, nh * hd), 1, nh, S, S, nh // nkv, hd ** -0.5, True, 0, hd)
@@ -84,7 +85,7 @@ class HipMistralDecoder(nn.Module):
         ops.embed_rows(self.tok, self.w["embed"], b["x0"])
         x = b["x0"][0]
         for li, lw in enumerate(self.w["layers"]):
-            ops.gemv(lw["wqkv"], x, norm_w=lw["ln1_w"], eps=self.eps, out=b["qkv"])
+            ops.gemv(lw["wqkv"], x, norm_w=lw["ln1_w"], eps=self.eps, out=b["qkv"], bias=lw["bqkv"])
             ops.attn_decode(b["qkv"], self.kcache[li], self.vcache[li], self.cos_t, self.sin_t, self.partial, b["o"], nh, nkv,
                             self.pos, hd ** -0.5, pos_dev=pos_dev, ctx_cap=self.max_seq_len)
             ops.gemv(lw["wo"], b["o"], res=x, out=b["x1"])                       # x1 = x + attn
@@ -169,3 +170,6 @@ class HipMistralDecoder(nn.Module):
                 self.decode_step()
         out = torch.tensor([toks], dtype=torch.long, device=self._dev)
         return (out, torch.stack(all_logits)) if return_logits else out
+
+
+HipQwen2Decoder = HipMistralDecoder      # same decoder; the q/k/v bias is picked up from the state dict (weights.pack_decoder)

@@ -74,23 +74,27 @@ class FrameSharder:
             return connector(feats.view(1, *feats.shape))
         world, rank = self.world, self.rank
         s1, n, in_dtype = self.local_s1(tower, connector, frames, rank, world)
-        # halo: frame f0-1 comes from rank-1; our last frame goes to rank+1
+        # halo: frame f0-1 comes from rank-1; our last frame goes to rank+1 (padding 1 only: the unpadded v35 sampler pairs
+        # frames 2to, 2to+1, which an even frames-per-rank split never separates)
         halo = torch.empty((n, s1.shape[1]), dtype=s1.dtype, device=s1.device)
         reqs = []
-        if rank + 1 < world:
+        if connector.padding == 0:
+            pass
+        elif rank + 1 < world:
             reqs.append(dist.P2POp(dist.isend, s1[s1.shape[0] - n:].contiguous(), self._peer(rank + 1), self.group))
-        if rank > 0:
+        if rank > 0 and connector.padding == 1:
             reqs.append(dist.P2POp(dist.irecv, halo, self._peer(rank - 1), self.group))
         for r in (dist.batch_isend_irecv(reqs) if reqs else []):
             r.wait()
         tok = self.local_tokens(connector, s1, halo if rank > 0 else None, T, rank, world)
-        per = tok.shape[0] // (T // world // 2 + (1 if rank == world - 1 else 0))
-        max_rows = (T // world // 2 + 1) * per
+        extra = connector.padding                                  # padding 1: the last rank also owns output frame T/2
+        per = tok.shape[0] // (T // world // 2 + (extra if rank == world - 1 else 0))
+        max_rows = (T // world // 2 + extra) * per
         send = torch.zeros((max_rows, tok.shape[1]), dtype=tok.dtype, device=tok.device)
         send[:tok.shape[0]].copy_(tok)
         recv = torch.empty((world * max_rows, tok.shape[1]), dtype=tok.dtype, device=tok.device)
         dist.all_gather_into_tensor(recv, send, group=self.group)
-        return self._assemble(recv, T, world, per, max_rows).to(in_dtype)
+        return self._assemble(recv, T, world, per, max_rows, extra).to(in_dtype)
 
     # ---- the rank-local pieces of the sharded-connector cut (no communication inside: also driven rank by rank in ONE
     #      process by `encode_video_all_ranks_locally`, which is how the cut is validated and timed on a 1-GPU box)
@@ -112,21 +116,24 @@ class FrameSharder:
         n = s1.shape[0] // fpr
         hw = int(n ** 0.5)
         f0 = rank * fpr
+        to0 = f0 // 2
+        if connector.padding == 0:                                  # v35: output `to` reads frames 2to, 2to+1 -- all local
+            samp, (nto, Ho, Wo) = connector.run_sampler(s1, T, hw, to_range=(to0, to0 + fpr // 2), frame_lo=f0, n_local=fpr)
+            return connector.run_s2_readout(samp, nto, Ho, Wo)
         pool = torch.empty(((fpr + 1) * n, s1.shape[1]), dtype=s1.dtype, device=s1.device)
         pool[n:].copy_(s1)
         if halo is None:
             pool[:n].zero_()
         else:
             pool[:n].copy_(halo)
-        to0 = f0 // 2
         to1 = to0 + fpr // 2 + (1 if rank == world - 1 else 0)
         samp, (nto, Ho, Wo) = connector.run_sampler(pool, T, hw, to_range=(to0, to1), frame_lo=f0 - 1, n_local=fpr + 1)
         return connector.run_s2_readout(samp, nto, Ho, Wo)                   # [nto*Ho*Wo, D]
 
     @staticmethod
-    def _assemble(recv, T, world, per, max_rows):
+    def _assemble(recv, T, world, per, max_rows, extra=1):
         fpr = T // world
-        parts = [recv[r * max_rows:r * max_rows + (fpr // 2 + (1 if r == world - 1 else 0)) * per] for r in range(world)]
+        parts = [recv[r * max_rows:r * max_rows + (fpr // 2 + (extra if r == world - 1 else 0)) * per] for r in range(world)]
         return torch.cat(parts, 0).unsqueeze(0)
 
     @classmethod

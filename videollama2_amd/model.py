@@ -1,4 +1,5 @@
-"""VideoLLaMA2Hip -- the reference's inference surface for ONE model family (CLIP-ViT + stc_connector + Mistral),
+"""VideoLLaMA2Hip -- the reference's inference surface for the two families its released checkpoints use (VideoLLaMA2:
+CLIP-ViT + stc_connector + Mistral; VideoLLaMA2.1: SigLIP + stc_connector_v35 + Qwen2 -- picked from the config dict),
 method for method (videollama2/model/videollama2_arch.py:99-263, videollama2_mistral.py:110-144), on the HIP path:
     encode_images_or_videos(images)                   arch.py:114-134   (+ temporal_aggregator :136-159)
     prepare_inputs_labels_for_multimodal(...)         arch.py:161-263   (inference subset: batch 1, no labels)
@@ -14,21 +15,23 @@ from .connector import HipSTCConnector
 from .constants import MODAL_INDEX_MAP, NUM_FRAMES
 from .decoder import HipMistralDecoder
 from .dist import FrameSharder
-from .tower import HipCLIPVisionTower
+from .tower import HipCLIPVisionTower, HipSiglipVisionTower
 
 
 class VideoLLaMA2Hip(nn.Module):
     def __init__(self, cfg, state_dict, device="cuda", max_seq_len=4096, image_processor=None, n_llm_layers=None,
-                 mm_projector_type="stc_connector", sharder=None):
+                 mm_projector_type=None, sharder=None):
         super().__init__()
         check_supported(cfg)
-        if "tc_connector" not in mm_projector_type or mm_projector_type != "stc_connector":
+        mm_projector_type = mm_projector_type or cfg.get("projector", "stc_connector")
+        if mm_projector_type not in ("stc_connector", "stc_connector_v35"):
             raise Exception(f"Unsupported projector type {mm_projector_type}!!!")     # arch.py:157 / projector.py:122
         self.cfg = cfg
         self.mm_projector_type = mm_projector_type
         self._dev = torch.device(device)
-        self.vision_tower = HipCLIPVisionTower(cfg, state_dict, device, image_processor=image_processor)
-        self.mm_projector = HipSTCConnector(state_dict, device)
+        tower_cls = HipSiglipVisionTower if cfg["vision"].get("family", "clip") == "siglip" else HipCLIPVisionTower   # encoder.py:157-160
+        self.vision_tower = tower_cls(cfg, state_dict, device, image_processor=image_processor)
+        self.mm_projector = HipSTCConnector(state_dict, device, padding=0 if mm_projector_type == "stc_connector_v35" else 1)
         self.decoder = HipMistralDecoder(cfg, state_dict, device, max_seq_len, n_llm_layers)
         self.sharder = sharder or FrameSharder()
 

@@ -5,7 +5,7 @@ import torch
 
 from . import _lib
 
-ACT_NONE, ACT_QGELU, ACT_GELU, ACT_SILU, ACT_SIGMOID = 0, 1, 2, 3, 4
+ACT_NONE, ACT_QGELU, ACT_GELU, ACT_SILU, ACT_SIGMOID, ACT_GELU_TANH = 0, 1, 2, 3, 4, 5
 GEMM_SWIGLU, GEMM_OUT_F32 = 1, 2
 BF16 = torch.bfloat16
 PROFILE = None      # bench.py sets this to a list: every gemm launch is then bracketed by HIP events on the launch stream
@@ -173,14 +173,14 @@ def rope_kv(qkv, q_out, kcache, vcache, cos_t, sin_t, nh, nkv, pos0):
     _lib.call("vl2_rope_kv", _p(qkv), _p(q_out), _p(kcache), _p(vcache), _p(cos_t), _p(sin_t), S, nh, nkv, smax, pos0, _stream())
 
 
-def gemv(w, x, norm_w=None, eps=1e-5, res=None, swiglu=False, out_f32=False, out=None):
-    _chk(w, BF16, "w"); _chk(x, BF16, "x")
+def gemv(w, x, norm_w=None, eps=1e-5, res=None, swiglu=False, out_f32=False, out=None, bias=None):
+    _chk(w, BF16, "w"); _chk(x, BF16, "x"); _chk(bias, torch.float32, "bias")
     N, K = w.shape
     n_out = N // 2 if swiglu else N
     if out is None:
         out = torch.empty((n_out,), dtype=torch.float32 if out_f32 else BF16, device=w.device)
     flags = (GEMM_SWIGLU if swiglu else 0) | (GEMM_OUT_F32 if out_f32 else 0)
-    _lib.call("vl2_gemv_bf16", _p(w), _p(x), _p(norm_w), _p(res), _p(out), N, K, w.stride(0), float(eps), flags, _stream())
+    _lib.call("vl2_gemv_bf16", _p(w), _p(x), _p(norm_w), _p(res), _p(bias), _p(out), N, K, w.stride(0), float(eps), flags, _stream())
     return out
 
 

@@ -9,7 +9,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .weights import pack_tower
+from .weights import pack_siglip_tower, pack_tower
 
 
 def default_image_processor(image_size=336):
@@ -36,7 +36,7 @@ class HipCLIPVisionTower(nn.Module):
             raise ValueError(f"Unexpected select feature: {select_feature}")      # encoder.py:38
         self.image_processor = image_processor
         self._dev = torch.device(device)
-        self.w = pack_tower(state_dict, cfg, self._dev, prefix)
+        self.w = self._pack(state_dict, cfg, self._dev, prefix)
         if self._dev.type == "cuda":
             ops.attach_workspace(self._dev)       # split-K (opt-in, ops.set_splitk) for small per-rank grids
         self.config = types.SimpleNamespace(**v)
@@ -46,6 +46,9 @@ class HipCLIPVisionTower(nn.Module):
         # power-limited, idle CUs in a GEMM's last round already return their power to the busy ones) -> default 1.
         self.streams = 1
         self._side = None
+
+    _pack = staticmethod(pack_tower)
+    _cls_tokens = 1                     # rows per frame in front of the patches (CLIP: the CLS token)
 
     # ---- attributes the reference reads (encoder.py:55-81, videollama2_arch.py:66, model/__init__.py:186)
     @property
@@ -82,7 +85,7 @@ class HipCLIPVisionTower(nn.Module):
             return self._hidden(images)
         v = self.cfg["vision"]
         T = images.shape[0]
-        N1 = (images.shape[2] // v["patch_size"]) ** 2 + 1
+        N1 = (images.shape[2] // v["patch_size"]) ** 2 + self._cls_tokens
         images = images.to(self._dev)
         out = torch.empty((T * N1, v["hidden_size"]), dtype=torch.bfloat16, device=self._dev)
         cur = torch.cuda.current_stream(self._dev)
@@ -140,3 +143,66 @@ class HipCLIPVisionTower(nn.Module):
         if self.select_feature == "patch":                                         # encoder.py:33-34
             x = x[:, 1:]
         return x.contiguous().to(in_dtype)                                         # encoder.py:51 `.to(images.dtype)`
+
+
+def default_siglip_image_processor(image_size=384):
+    """The SiglipImageProcessor the reference gets from `SiglipImageProcessor.from_pretrained(tower)` (encoder.py:94), built
+    from the public google/siglip-so400m-patch14-384 preprocessor values (no hub access): plain bicubic resize to
+    image_size^2 -> 1/255 -> (x - 0.5) / 0.5."""
+    from transformers import SiglipImageProcessor
+    return SiglipImageProcessor(do_resize=True, size={"height": image_size, "width": image_size}, resample=3, do_rescale=True,
+                                rescale_factor=1 / 255, do_normalize=True, image_mean=[0.5, 0.5, 0.5], image_std=[0.5, 0.5, 0.5])
+
+
+class HipSiglipVisionTower(HipCLIPVisionTower):
+    """Drop-in for videollama2/model/encoder.py:84-151 `SiglipVisionTower` (what `build_vision_tower` returns when the tower
+    name contains 'siglip', encoder.py:159-160): `tower(frames[(b t),3,H,W]) -> [(b t), num_patches, hidden]` =
+    hidden_states[select_layer] of HF SiglipVisionModel with NO token dropped (feature_select 'patch' is the identity there,
+    encoder.py:103-109).  Differences from the CLIP tower, all in HF:models/siglip/modeling_siglip.py: biased patch conv, no
+    CLS / no pre-LayerNorm, gelu_pytorch_tanh MLP, and shapes (head_dim 72, MLP 4304) that are zero-padded at load time
+    (weights.pack_siglip_tower)."""
+    _pack = staticmethod(pack_siglip_tower)
+    _cls_tokens = 0
+
+    def __init__(self, cfg, state_dict, device="cuda", select_feature="patch", image_processor=None,
+                 prefix="model.vision_tower.vision_tower."):
+        if select_feature != "patch":
+            raise ValueError(f"Unexpected select feature: {select_feature}")      # encoder.py:108
+        super().__init__(cfg, state_dict, device, select_feature, image_processor, prefix)
+
+    def _hidden(self, images, out=None):
+        v = self.cfg["vision"]
+        if images.dim() != 4 or images.shape[1] != 3:
+            raise ValueError(f"expected frames [T,3,H,W], got {tuple(images.shape)}")
+        T, _, H, W = images.shape
+        if H != v["image_size"] or W != v["image_size"]:                          # HF:modeling_siglip.py SiglipVisionEmbeddings
+            raise ValueError(f"Input image size ({H}*{W}) doesn't match model ({v['image_size']}*{v['image_size']}).")
+        images = images.to(self._dev)
+        w = self.w
+        D, P, nh = v["hidden_size"], v["patch_size"], v["num_attention_heads"]
+        G = H // P
+        N = G * G
+        hdp, eps = w["hdp"], v["layer_norm_eps"]
+        Hh = nh * hdp
+        a = ops.patchify(images, P, w["kp"])
+        x = torch.empty((T * N, D), dtype=torch.bfloat16, device=self._dev)
+        ops.gemm(a, w["patch_w"], bias=w["patch_b"], res=w["pos"], out=x, res_map=(N, 0), flop_k=3 * P * P)
+        o = torch.empty((T * N, Hh), dtype=torch.bfloat16, device=self._dev)
+        for li, lw in enumerate(w["layers"]):
+            h = ops.layernorm(x, lw["ln1_w"], lw["ln1_b"], eps)
+            qkv = ops.gemm(h, lw["wqkv"], bias=lw["bqkv"])                         # [T*N, 3*Hh] = q | k | v, heads padded to hdp
+            st = (N * 3 * Hh, hdp, 3 * Hh)
+            ops.attn_fwd(qkv, qkv[:, Hh:], qkv[:, 2 * Hh:], o, st, st, st, (N * Hh, hdp, Hh), T, nh, N, N, 1,
+                         w["hd"] ** -0.5, False, 0, hdp)
+            x = ops.gemm(o, lw["wo"], bias=lw["bo"], res=x)
+            h = ops.layernorm(x, lw["ln2_w"], lw["ln2_b"], eps)
+            h = ops.gemm(h, lw["w1"], bias=lw["b1"], act=ops.ACT_GELU_TANH)
+            x = ops.gemm(h, lw["w2"], bias=lw["b2"], res=x, out=out if li == len(w["layers"]) - 1 else None)
+        return x, T, N
+
+    @torch.no_grad()
+    def forward(self, images):
+        if type(images) is list:                                                   # encoder.py:113-118
+            return [self.forward(im.unsqueeze(0)) for im in images]
+        x, T, N = self.forward_hidden(images)
+        return x.view(T, N, -1).to(images.dtype)                                   # encoder.py:121 `.to(images.dtype)`

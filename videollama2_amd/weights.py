@@ -51,6 +51,58 @@ def pack_tower(sd, cfg, dev, prefix="model.vision_tower.vision_tower."):
     return out
 
 
+def padded_head_dim(hd):
+    """The attention kernel is built for head_dim 64 and 128: other head dims (SigLIP-so400m: 72) run zero-padded."""
+    if hd > 128:
+        raise ValueError(f"vision head_dim {hd} > 128 is not supported")
+    return 64 if hd <= 64 else 128
+
+
+def pack_siglip_tower(sd, cfg, dev, prefix="model.vision_tower.vision_tower."):
+    """SiglipVisionModel weights (HF:models/siglip/modeling_siglip.py) for the layers feeding hidden_states[select_layer].
+    Two exact paddings make the so400m shapes fit the kernels (zeros in, zeros out):
+      * heads: head_dim 72 -> 128.  q/k/v rows of every head are followed by zero rows (and zero bias), so q.k is unchanged
+        and the padded v columns come out 0; out_proj gets zero COLUMNS at those positions.
+      * MLP: 4304 -> 4352 (next multiple of 128).  fc1 gets zero rows + zero bias -> gelu_tanh(0) = 0 -> fc2's zero columns."""
+    sd = normalise_keys(sd)
+    v = cfg["vision"]
+    D, P, H, I = v["hidden_size"], v["patch_size"], v["num_attention_heads"], v["intermediate_size"]
+    L, sel = v["num_hidden_layers"], v["select_layer"]
+    n_run = (L + 1 + sel) if sel < 0 else sel
+    hd = D // H
+    hdp = padded_head_dim(hd)
+    Ip = (I + 127) // 128 * 128
+    kreal = 3 * P * P
+    kp = (kreal + 63) // 64 * 64
+    pw = torch.zeros((D, kp), dtype=BF16, device=dev)
+    pw[:, :kreal] = _bf(sd[prefix + "embeddings.patch_embedding.weight"].reshape(D, kreal), dev)
+
+    def pad_rows(w):                                # [H*hd, ...] -> [H*hdp, ...], zero rows after every head
+        w = w.detach().to(BF16)
+        out = torch.zeros((H, hdp) + tuple(w.shape[1:]), dtype=BF16)
+        out[:, :hd] = w.reshape((H, hd) + tuple(w.shape[1:]))
+        return out.reshape((H * hdp,) + tuple(w.shape[1:]))
+
+    out = dict(kp=kp, n_run=n_run, hd=hd, hdp=hdp, patch_w=pw, patch_b=_f32(sd[prefix + "embeddings.patch_embedding.bias"], dev),
+               pos=_bf(sd[prefix + "embeddings.position_embedding.weight"], dev), layers=[])
+    for i in range(n_run):
+        p = f"{prefix}encoder.layers.{i}."
+        a = p + "self_attn."
+        wo = torch.zeros((D, H, hdp), dtype=BF16)
+        wo[:, :, :hd] = sd[a + "out_proj.weight"].detach().to(BF16).reshape(D, H, hd)
+        w1 = torch.zeros((Ip, D), dtype=BF16); w1[:I] = sd[p + "mlp.fc1.weight"].detach().to(BF16)
+        b1 = torch.zeros((Ip,), dtype=BF16); b1[:I] = sd[p + "mlp.fc1.bias"].detach().to(BF16)
+        w2 = torch.zeros((D, Ip), dtype=BF16); w2[:, :I] = sd[p + "mlp.fc2.weight"].detach().to(BF16)
+        out["layers"].append(dict(
+            ln1_w=_f32(sd[p + "layer_norm1.weight"], dev), ln1_b=_f32(sd[p + "layer_norm1.bias"], dev),
+            wqkv=_bf(torch.cat([pad_rows(sd[a + n + "_proj.weight"]) for n in "qkv"], 0), dev),
+            bqkv=_f32(torch.cat([pad_rows(sd[a + n + "_proj.bias"]) for n in "qkv"], 0), dev),
+            wo=_bf(wo.reshape(D, H * hdp), dev), bo=_f32(sd[a + "out_proj.bias"], dev),
+            ln2_w=_f32(sd[p + "layer_norm2.weight"], dev), ln2_b=_f32(sd[p + "layer_norm2.bias"], dev),
+            w1=_bf(w1, dev), b1=_f32(b1, dev), w2=_bf(w2, dev), b2=_f32(sd[p + "mlp.fc2.bias"], dev)))
+    return out
+
+
 def _pack_bottleneck(sd, p, dev):
     C = sd[p + "conv1.conv.weight"].shape[0]
     blk = dict(
@@ -89,7 +141,8 @@ def pack_gate_up(gate, up):
 
 
 def pack_decoder(sd, cfg, dev, n_layers=None):
-    """MistralForCausalLM weights (HF:models/mistral/modeling_mistral.py)."""
+    """MistralForCausalLM / Qwen2ForCausalLM weights (HF:models/mistral/modeling_mistral.py, models/qwen2/modeling_qwen2.py:
+    the same decoder, Qwen2 with a bias on q/k/v)."""
     l = cfg["llm"]
     n_layers = l["num_hidden_layers"] if n_layers is None else n_layers
     out = dict(embed=_bf(sd["model.embed_tokens.weight"], dev), norm_w=_f32(sd["model.norm.weight"], dev),
@@ -97,8 +150,12 @@ def pack_decoder(sd, cfg, dev, n_layers=None):
     for i in range(n_layers):
         p = f"model.layers.{i}."
         a = p + "self_attn."
+        bqkv = None                                    # Qwen2Attention: bias on q/k/v (HF:models/qwen2/modeling_qwen2.py)
+        if (a + "q_proj.bias") in sd:
+            bqkv = _f32(torch.cat([sd[a + "q_proj.bias"], sd[a + "k_proj.bias"], sd[a + "v_proj.bias"]], 0), dev)
         out["layers"].append(dict(
             ln1_w=_f32(sd[p + "input_layernorm.weight"], dev), ln2_w=_f32(sd[p + "post_attention_layernorm.weight"], dev),
+            bqkv=bqkv,
             wqkv=_bf(torch.cat([sd[a + "q_proj.weight"], sd[a + "k_proj.weight"], sd[a + "v_proj.weight"]], 0), dev),
             wo=_bf(sd[a + "o_proj.weight"], dev),
             wgu=_bf(pack_gate_up(sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"]), dev),
@@ -108,16 +165,21 @@ def pack_decoder(sd, cfg, dev, n_layers=None):
 
 def state_dict_names(cfg):
     """(name, shape) of every parameter the hot path reads, transformers-5.x key naming (what
-    `Videollama2MistralForCausalLM(config).state_dict()` yields for CLIP + stc_connector + Mistral)."""
+    `Videollama2MistralForCausalLM(config).state_dict()` yields for CLIP + stc_connector + Mistral, or
+    `Videollama2Qwen2ForCausalLM` for SigLIP + stc_connector_v35 + Qwen2, minus the SigLIP pooling head)."""
     v, l = cfg["vision"], cfg["llm"]
     Dv, Iv, P = v["hidden_size"], v["intermediate_size"], v["patch_size"]
     npos = (v["image_size"] // P) ** 2 + 1
     D, I = l["hidden_size"], l["intermediate_size"]
     hd, nh, nkv = l["head_dim"], l["num_attention_heads"], l["num_key_value_heads"]
     vt, mp = "model.vision_tower.vision_tower.", "model.mm_projector."
-    out = [(vt + "embeddings.class_embedding", (Dv,)), (vt + "embeddings.patch_embedding.weight", (Dv, 3, P, P)),
-           (vt + "embeddings.position_embedding.weight", (npos, Dv)),
-           (vt + "pre_layrnorm.weight", (Dv,)), (vt + "pre_layrnorm.bias", (Dv,))]
+    if v.get("family", "clip") == "siglip":
+        out = [(vt + "embeddings.patch_embedding.weight", (Dv, 3, P, P)), (vt + "embeddings.patch_embedding.bias", (Dv,)),
+               (vt + "embeddings.position_embedding.weight", (npos - 1, Dv))]
+    else:
+        out = [(vt + "embeddings.class_embedding", (Dv,)), (vt + "embeddings.patch_embedding.weight", (Dv, 3, P, P)),
+               (vt + "embeddings.position_embedding.weight", (npos, Dv)),
+               (vt + "pre_layrnorm.weight", (Dv,)), (vt + "pre_layrnorm.bias", (Dv,))]
     for i in range(v["num_hidden_layers"]):
         p = f"{vt}encoder.layers.{i}."
         for n in ("k_proj", "v_proj", "q_proj", "out_proj"):
@@ -150,6 +212,9 @@ def state_dict_names(cfg):
                 (p + "mlp.gate_proj.weight", (I, D)), (p + "mlp.up_proj.weight", (I, D)),
                 (p + "mlp.down_proj.weight", (D, I)),
                 (p + "input_layernorm.weight", (D,)), (p + "post_attention_layernorm.weight", (D,))]
+        if l.get("family", "mistral") == "qwen2":
+            out += [(p + "self_attn.q_proj.bias", (nh * hd,)), (p + "self_attn.k_proj.bias", (nkv * hd,)),
+                    (p + "self_attn.v_proj.bias", (nkv * hd,))]
     out += [("model.norm.weight", (D,)), ("lm_head.weight", (l["vocab_size"], D))]
     return out
 
