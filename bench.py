@@ -27,25 +27,41 @@ PEAK_MFMA_BF16_TFLOPS = 2500.0   # dense, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 
 
-def algorithmic_tflop(T, S_text=100):
-    """SURVEY.md 8(d) formulas (2*MAC; the discarded 24th CLIP layer is not counted)."""
-    vit = T * (2 * 576 * 588 * 1024 + 23 * (577 * 2 * (4 * 1024 ** 2 + 2 * 1024 * 4096) + 4 * 577 ** 2 * 1024))
-    b1 = 2 * (576 * (1024 * 4096 * 2 + 4096 ** 2) + 576 * 4096 * 9 + 2 * 4096 * 256)
-    b = 2 * (576 * 2 * 4096 ** 2 + 576 * 4096 * 9 + 2 * 4096 * 1024)
-    to = T // 2 + 1
-    nvis = to * 169
-    stc = T * (b1 + 3 * b) + 2 * to * 169 * 4096 ** 2 * 8 + to * 4 * 2 * (169 * 2 * 4096 ** 2 + 169 * 4096 * 9 + 2 * 4096 * 1024) \
-        + 2 * nvis * 2 * 4096 ** 2
+def algorithmic_tflop(cfg, T, S_text=100):
+    """SURVEY.md 8(d) formulas (2*MAC; encoder layers beyond hidden_states[select_layer] are not counted), written over the
+    config dict so the same accounting serves VideoLLaMA2-7B (CLIP / stc_connector / Mistral: 5.857 + 3.243 + 23.32 =
+    32.42 TF at T=16) and VideoLLaMA2.1-7B (SigLIP / stc_connector_v35 / Qwen2).  Unpadded (real) shapes."""
+    v, l = cfg["vision"], cfg["llm"]
+    Dv, Iv, P = v["hidden_size"], v["intermediate_size"], v["patch_size"]
+    g = v["image_size"] // P
+    npatch = g * g
+    ntok = npatch + (0 if v.get("family", "clip") == "siglip" else 1)
+    nrun = v["num_hidden_layers"] + 1 + v["select_layer"] if v["select_layer"] < 0 else v["select_layer"]
+    vit = T * (2 * npatch * 3 * P * P * Dv + nrun * (ntok * 2 * (4 * Dv * Dv + 2 * Dv * Iv) + 4 * ntok * ntok * Dv))
+    D, I, nl = l["hidden_size"], l["intermediate_size"], l["num_hidden_layers"]
+    pad = 0 if cfg.get("projector", "stc_connector") == "stc_connector_v35" else 1
+    o = lambda n: (n + 2 * pad - 2) // 2 + 1
+    to, go = o(T), o(g)
+    rd1, rd = int(round(Dv * 0.25)), int(round(D * 0.25))
+    b1 = 2 * (npatch * (Dv * D * 2 + D * D) + npatch * D * 9 + 2 * D * rd1)
+    b = 2 * (npatch * 2 * D * D + npatch * D * 9 + 2 * D * rd)
+    nvis = to * go * go
+    stc = T * (b1 + 3 * b) + 2 * nvis * D * D * 8 + to * 4 * 2 * (go * go * 2 * D * D + go * go * D * 9 + 2 * D * rd) + 2 * nvis * 2 * D * D
     S = nvis + S_text
-    lin = 32 * 2 * (4096 * 4096 * 2 + 2 * 4096 * 1024 + 3 * 4096 * 14336)
-    prefill = S * lin + 32 * 4 * (S * (S + 1) // 2) * 4096 + 2 * 4096 * 32000
+    kvd = l["num_key_value_heads"] * l["head_dim"]
+    qd = l["num_attention_heads"] * l["head_dim"]
+    lin = nl * 2 * (D * qd * 2 + 2 * D * kvd + 3 * D * I)
+    prefill = S * lin + nl * 4 * (S * (S + 1) // 2) * qd + 2 * D * l["vocab_size"]
     return vit / 1e12, stc / 1e12, prefill / 1e12, S
 
 
-def decode_bytes_per_token(ctx):
+def decode_bytes_per_token(cfg, ctx):
     """bf16 weights streamed per token (embedding table excluded: one row) + KV read; SURVEY.md 8(d)."""
-    params = 32 * (4096 * 4096 * 2 + 2 * 4096 * 1024 + 3 * 4096 * 14336) + 32000 * 4096
-    return 2 * params + 131072 * ctx
+    l = cfg["llm"]
+    D, I = l["hidden_size"], l["intermediate_size"]
+    kvd, qd = l["num_key_value_heads"] * l["head_dim"], l["num_attention_heads"] * l["head_dim"]
+    params = l["num_hidden_layers"] * (D * qd * 2 + 2 * D * kvd + 3 * D * I) + l["vocab_size"] * D
+    return 2 * params + l["num_hidden_layers"] * 2 * kvd * 2 * ctx
 
 
 def cpu_baseline(threads):
@@ -83,6 +99,9 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=16)
+    ap.add_argument("--model", choices=["v2", "v21"], default="v2",
+                    help="v2 = VideoLLaMA2-7B (CLIP + stc_connector + Mistral-7B; BASELINE.json's metric), "
+                         "v21 = VideoLLaMA2.1-7B-16F (SigLIP + stc_connector_v35 + Qwen2-7B; SURVEY 8f row 1)")
     ap.add_argument("--new-tokens", type=int, default=32)
     ap.add_argument("--llm-layers", type=int, default=None, help="debug only: fewer decoder layers (INVALID as a result)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -104,7 +123,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)        # backend "nccl" is RCCL on ROCm
 
     from videollama2_amd import ops
-    from videollama2_amd.config import videollama2_7b
+    from videollama2_amd.config import videollama2_1_7b_16f, videollama2_7b
     from videollama2_amd.model import VideoLLaMA2Hip
     from videollama2_amd.weights import random_state_dict
 
@@ -113,7 +132,8 @@ def main():
         k, v = kv.split("=")
         _lib.call("vl2_set_tuning", int(k), int(v))
     T, n_new = args.frames, args.new_tokens
-    cfg = videollama2_7b(T)
+    cfg = videollama2_7b(T) if args.model == "v2" else videollama2_1_7b_16f(T)
+    side = cfg["vision"]["image_size"]
     sd = random_state_dict(cfg, dev, seed=1234, n_llm_layers=args.llm_layers)
     model = VideoLLaMA2Hip(cfg, sd, dev, max_seq_len=4096, n_llm_layers=args.llm_layers)
     del sd
@@ -122,7 +142,7 @@ def main():
         model.vision_tower.streams = args.vit_streams
 
     g = torch.Generator(device=dev).manual_seed(0)
-    frames = torch.randn((T, 3, 336, 336), generator=g, device=dev, dtype=torch.float32).to(torch.bfloat16)
+    frames = torch.randn((T, 3, side, side), generator=g, device=dev, dtype=torch.float32).to(torch.bfloat16)
     V = cfg["llm"]["vocab_size"]
     cg = torch.Generator().manual_seed(1)
     ids = torch.cat([torch.tensor([1]), torch.randint(3, V, (31,), generator=cg), torch.tensor([-201]),
@@ -199,7 +219,7 @@ def main():
         traffic, tpath = None, os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_gemm_traffic.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
-            if T == 16 and tj.get("launches_per_step") == ngemm:
+            if T == 16 and args.model == "v2" and tj.get("launches_per_step") == ngemm:
                 traffic = tj["hbm_bytes_per_launch"]
         roof = dict(bound="mfma", kernel="gemm_bf16_kernel", achieved=round(ach, 2), peak=PEAK_MFMA_BF16_TFLOPS,
                     unit="TFLOP/s", frac=round(ach / PEAK_MFMA_BF16_TFLOPS, 4), traffic=traffic,
@@ -207,15 +227,19 @@ def main():
                     flop_per_launch_avg=round(1e9 * gflop / max(ngemm, 1), 0))
 
     if rank == 0:
-        vit_tf, stc_tf, pre_tf, S_alg = algorithmic_tflop(T)
+        vit_tf, stc_tf, pre_tf, S_alg = algorithmic_tflop(cfg, T)
         fwd_ms = enc_ms + pre_ms
         out = {
-            "metric": "video-frames/sec encoded (CLIP-ViT + STC), VideoLLaMA2-7B 16f@336^2; prefill/decode tokens/sec as extra keys",
+            "metric": ("video-frames/sec encoded (CLIP-ViT + STC), VideoLLaMA2-7B 16f@336^2; prefill/decode tokens/sec as extra keys"
+                       if args.model == "v2" else
+                       "video-frames/sec encoded (SigLIP + STC v35), VideoLLaMA2.1-7B-16F 16f@384^2; prefill/decode tokens/sec as extra keys"),
             "value": round(T / (enc_ms / 1e3), 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"VideoLLaMA2-7B, {T}-frame 336^2 video, bf16, S={S} prefill, {n_new} greedy decode tokens "
-                                   f"(BASELINE.json configs[1])", "frames": T, "prefill_tokens": S, "new_tokens": n_new,
+            "config": {"workload": (f"VideoLLaMA2-7B, {T}-frame 336^2 video, bf16, S={S} prefill, {n_new} greedy decode tokens "
+                                    f"(BASELINE.json configs[1])" if args.model == "v2" else
+                                    f"VideoLLaMA2.1-7B-16F (SigLIP-so400m-384 + stc_connector_v35 + Qwen2-7B), {T}-frame 384^2 video, bf16, "
+                                    f"S={S} prefill, {n_new} greedy decode tokens (SURVEY 8f row 1; not BASELINE.json's metric config)"), "frames": T, "prefill_tokens": S, "new_tokens": n_new,
                        "parallelism": (f"frames sharded over {world} ranks (ViT + STC s1/conv3d/s2 per rank, halo + RCCL all-gather of visual tokens); "
                                        f"LLM replicated" if world > 1 else "single GPU"),
                        "llm_layers": len(model.decoder.w["layers"]),
@@ -224,7 +248,7 @@ def main():
             "prefill_tokens_per_s": round(S / (pre_ms / 1e3), 1), "decode_tokens_per_s": round(n_new / (dec_ms / 1e3), 2),
             "forward_tflop": round(vit_tf + stc_tf + pre_tf, 3),
             "forward_mfma_frac": round((vit_tf + stc_tf + pre_tf) / (fwd_ms / 1e3) / PEAK_MFMA_BF16_TFLOPS, 4),
-            "decode_hbm_frac": round(decode_bytes_per_token(S + n_new // 2) / (dec_ms / n_new / 1e3) / 1e9 / PEAK_HBM_GBS, 4),
+            "decode_hbm_frac": round(decode_bytes_per_token(cfg, S + n_new // 2) / (dec_ms / n_new / 1e3) / 1e9 / PEAK_HBM_GBS, 4),
             "roofline": roof,
         }
         if not args.no_cpu_baseline:

@@ -187,14 +187,16 @@ def test_emu_v21_family_end_to_end_vs_reference_goldens(emu, golden_small_v21):
     assert rel(logits, g["step_logits"][:3]) < 2.5e-2
 
 
-def test_emu_drop_in_accelerate_reference_model(emu, golden_small):
-    """The seam test: a live reference model (build container only) re-routed by install.accelerate(); the reference's own
-    `encode_images_or_videos` and `generate` entry points then run on the HIP host path (emulated kernels here)."""
+@pytest.mark.parametrize("family", ["v2", "v21"])
+def test_emu_drop_in_accelerate_reference_model(emu, golden_small, golden_small_v21, family):
+    """The seam test: a live reference model (build container only; Videollama2MistralForCausalLM and the VideoLLaMA2.1
+    Videollama2Qwen2ForCausalLM) re-routed by install.accelerate(); the reference's own `encode_images_or_videos` and
+    `generate` entry points then run on the HIP host path (emulated kernels here)."""
     from oracle import ref_harness as RH
     if not RH.reference_available():
         pytest.skip("reference tree only exists in the build container")
     from videollama2_amd.install import accelerate
-    g = golden_small
+    g = golden_small if family == "v2" else golden_small_v21
     model, _ = RH.build_reference_model(g["cfg"])
     RH.reseed_weights(model, g["seed"])
     accelerate(model, device="cpu", max_seq_len=64)

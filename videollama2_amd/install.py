@@ -1,10 +1,11 @@
 """Drop-in seams into the reference package (only meaningful where `videollama2` is importable).
 
-    accelerate(model)   -- take a loaded reference `Videollama2MistralForCausalLM` (what `model_init` returns,
-                           videollama2/__init__.py:14-29) and re-route its three seams to the HIP path:
-                             model.get_model().vision_tower  -> HipCLIPVisionTower     (encoder.py:154 seam)
-                             model.get_model().mm_projector  -> HipSTCConnector        (projector.py:95 seam)
-                             model.generate                  -> HipMistralDecoder loop (videollama2_mistral.py:110 seam)
+    accelerate(model)   -- take a loaded reference `Videollama2MistralForCausalLM` or `Videollama2Qwen2ForCausalLM` (what
+                           `model_init` returns, videollama2/__init__.py:14-29) and re-route its three seams to the HIP path:
+                             model.get_model().vision_tower  -> HipCLIPVisionTower / HipSiglipVisionTower (encoder.py:154 seam)
+                             model.get_model().mm_projector  -> HipSTCConnector (stc_connector / _v35)     (projector.py:95 seam)
+                             model.generate                  -> HipMistralDecoder / HipQwen2Decoder loop
+                                                                (videollama2_mistral.py:110, videollama2_qwen2.py:108 seams)
                            `mm_infer(tensor, instruct, model, tokenizer)` then runs unchanged.
     install()           -- wrap `videollama2.model_init` so every model it returns is accelerated.
 The reference's modules are NOT kept as a fallback: after accelerate() the HF decoder layers are dropped."""
@@ -18,10 +19,12 @@ from .model import VideoLLaMA2Hip
 
 def accelerate(ref_model, device="cuda", max_seq_len=4096, free_reference_weights=True):
     hf_cfg = ref_model.config
-    if getattr(hf_cfg, "mm_projector_type", None) != "stc_connector":
+    if getattr(hf_cfg, "mm_projector_type", None) not in ("stc_connector", "stc_connector_v35"):
         raise Exception(f"Unsupported projector type {getattr(hf_cfg, 'mm_projector_type', None)}!!!")
+    if getattr(hf_cfg, "model_type", "") not in ("videollama2_mistral", "videollama2_qwen2"):
+        raise ValueError(f"HIP path: model type {getattr(hf_cfg, 'model_type', None)} not built (videollama2_mistral, videollama2_qwen2)")
     tower = ref_model.get_vision_tower()
-    if "clip" not in type(tower).__name__.lower():
+    if not any(t in type(tower).__name__.lower() for t in ("clip", "siglip")):
         raise ValueError(f"Unknown vision tower: {type(tower).__name__}")          # encoder.py:162
     cfg = from_hf_config(hf_cfg, tower.config)
     check_supported(cfg)
