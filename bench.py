@@ -115,12 +115,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # VL2_DIST_BACKEND=gloo (debug): lets several ranks share one GPU, to exercise the multi-rank control flow on a 1-GPU box
+    backend = os.environ.get("VL2_DIST_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)        # backend "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)    # backend "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
 
     from videollama2_amd import ops
     from videollama2_amd.config import videollama2_1_7b_16f, videollama2_7b
@@ -204,10 +210,10 @@ def main():
     # ---- roofline of the dominant kernel (gemm_bf16_kernel, MFMA-bound): one extra profiled pass, every GEMM launch
     #      bracketed by HIP events on the launch stream; achieved = sum(algorithmic FLOPs) / sum(kernel time)
     roof = None
+    ops.PROFILE = [] if rank == 0 else None      # EVERY rank runs the extra pass (it contains the encoder's collectives);
+    step()                                       # only rank 0 brackets its GEMM launches with events
+    torch.cuda.synchronize()
     if rank == 0:
-        ops.PROFILE = []
-        step()
-        torch.cuda.synchronize()
         prof = ops.PROFILE
         ops.PROFILE = None
         gflop = sum(p[1] for p in prof if p[0] == "gemm") / 1e9
@@ -219,7 +225,7 @@ def main():
         traffic, tpath = None, os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_gemm_traffic.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
-            if T == 16 and args.model == "v2" and tj.get("launches_per_step") == ngemm:
+            if T == 16 and args.model == "v2" and world == 1 and tj.get("launches_per_step") == ngemm:
                 traffic = tj["hbm_bytes_per_launch"]
         roof = dict(bound="mfma", kernel="gemm_bf16_kernel", achieved=round(ach, 2), peak=PEAK_MFMA_BF16_TFLOPS,
                     unit="TFLOP/s", frac=round(ach / PEAK_MFMA_BF16_TFLOPS, 4), traffic=traffic,
@@ -251,7 +257,7 @@ def main():
             "decode_hbm_frac": round(decode_bytes_per_token(cfg, S + n_new // 2) / (dec_ms / n_new / 1e3) / 1e9 / PEAK_HBM_GBS, 4),
             "roofline": roof,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # the CPU leg is reported at N=1 only
             try:
                 out["cpu_baseline"] = cpu_baseline(min(os.cpu_count() or 1, 32))   # eager torch oversubscribes badly beyond ~32 threads
             except Exception as exc:  # the oracle is a checker, never a dependency of the measured path

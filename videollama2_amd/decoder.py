@@ -120,7 +120,7 @@ class HipMistralDecoder(nn.Module):
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):   # a RCCL watchdog thread may be polling events
             ops.argmax(self.logits, self.tok, self.hist, 0, self.state)
             self._decode_kernels(dyn=True)
         self.state.copy_(saved[0]); self.tok.copy_(saved[1]); self.logits.copy_(saved[2]); self.hist[:2].copy_(saved[3])

@@ -11,6 +11,34 @@ class FrameSharder:
     def __init__(self, group=None):
         self.group = group
 
+    # ---- collectives.  RCCL takes device tensors directly; with the gloo backend (CPU tests, or the debug mode that lets
+    #      several ranks share one GPU) device tensors are staged through host memory.
+    def _host_staged(self, t):
+        return t.is_cuda and dist.get_backend(self.group) == "gloo"
+
+    def _all_gather(self, recv, send):
+        if self._host_staged(send):
+            r = torch.empty(recv.shape, dtype=recv.dtype)
+            dist.all_gather_into_tensor(r, send.cpu(), group=self.group)
+            recv.copy_(r)
+        else:
+            dist.all_gather_into_tensor(recv, send, group=self.group)
+
+    def _halo_exchange(self, send_to_next, recv_from_prev, rank, world):
+        """Send `send_to_next` to rank+1 (if any) and fill `recv_from_prev` from rank-1 (if any)."""
+        staged = self._host_staged(recv_from_prev)
+        out_t = send_to_next.cpu() if staged else send_to_next
+        in_t = torch.empty(recv_from_prev.shape, dtype=recv_from_prev.dtype) if staged else recv_from_prev
+        reqs = []
+        if rank + 1 < world:
+            reqs.append(dist.P2POp(dist.isend, out_t, self._peer(rank + 1), self.group))
+        if rank > 0:
+            reqs.append(dist.P2POp(dist.irecv, in_t, self._peer(rank - 1), self.group))
+        for r in (dist.batch_isend_irecv(reqs) if reqs else []):
+            r.wait()
+        if staged and rank > 0:
+            recv_from_prev.copy_(in_t)
+
     @property
     def world(self):
         return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
@@ -47,7 +75,7 @@ class FrameSharder:
         if c > 0:
             send[:c].copy_(local)
         recv = torch.empty((world * maxc, n, h), dtype=dtype, device=dev)
-        dist.all_gather_into_tensor(recv, send, group=self.group)          # ONE collective: ncclAllGather over xGMI
+        self._all_gather(recv, send)                                       # ONE collective: ncclAllGather over xGMI
         if all(p[1] == maxc for p in parts):
             return recv
         return torch.cat([recv[r * maxc:r * maxc + p[1]] for r, p in enumerate(parts)], 0)
@@ -77,15 +105,8 @@ class FrameSharder:
         # halo: frame f0-1 comes from rank-1; our last frame goes to rank+1 (padding 1 only: the unpadded v35 sampler pairs
         # frames 2to, 2to+1, which an even frames-per-rank split never separates)
         halo = torch.empty((n, s1.shape[1]), dtype=s1.dtype, device=s1.device)
-        reqs = []
-        if connector.padding == 0:
-            pass
-        elif rank + 1 < world:
-            reqs.append(dist.P2POp(dist.isend, s1[s1.shape[0] - n:].contiguous(), self._peer(rank + 1), self.group))
-        if rank > 0 and connector.padding == 1:
-            reqs.append(dist.P2POp(dist.irecv, halo, self._peer(rank - 1), self.group))
-        for r in (dist.batch_isend_irecv(reqs) if reqs else []):
-            r.wait()
+        if connector.padding == 1:
+            self._halo_exchange(s1[s1.shape[0] - n:].contiguous(), halo, rank, world)
         tok = self.local_tokens(connector, s1, halo if rank > 0 else None, T, rank, world)
         extra = connector.padding                                  # padding 1: the last rank also owns output frame T/2
         per = tok.shape[0] // (T // world // 2 + (extra if rank == world - 1 else 0))
@@ -93,7 +114,7 @@ class FrameSharder:
         send = torch.zeros((max_rows, tok.shape[1]), dtype=tok.dtype, device=tok.device)
         send[:tok.shape[0]].copy_(tok)
         recv = torch.empty((world * max_rows, tok.shape[1]), dtype=tok.dtype, device=tok.device)
-        dist.all_gather_into_tensor(recv, send, group=self.group)
+        self._all_gather(recv, send)
         return self._assemble(recv, T, world, per, max_rows, extra).to(in_dtype)
 
     # ---- the rank-local pieces of the sharded-connector cut (no communication inside: also driven rank by rank in ONE
