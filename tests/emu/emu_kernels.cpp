@@ -146,8 +146,9 @@ extern "C" int32_t vl2_attn_fwd(const void* q, const void* k, const void* v, voi
                                 int64_t o_bs, int64_t o_hs, int32_t o_rs, int32_t B, int32_t H, int32_t nq, int32_t nk,
                                 int32_t group, float scale, int32_t causal, int32_t causal_off, int32_t D, void*) {
     AttnArgs a{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, q_bs, q_hs, q_rs, k_bs, k_hs, k_rs,
-               v_bs, v_hs, v_rs, o_bs, o_hs, o_rs, nq, nk, group, scale * 1.4426950408889634f, causal_off};
+               v_bs, v_hs, v_rs, o_bs, o_hs, o_rs, nq, nk, group, H, B, scale * 1.4426950408889634f, causal_off};
     dim3 g((nq + 127) / 128, H, B), blk(256);
+    if (causal) g = dim3(((nq + 127) / 128) * H * B, 1, 1);
     if (D == 64 && !causal) emu::launch(g, blk, [=] { attn_fwd_kernel<64, false>(a); });
     else if (D == 128 && causal) emu::launch(g, blk, [=] { attn_fwd_kernel<128, true>(a); });
     else if (D == 128 && !causal) emu::launch(g, blk, [=] { attn_fwd_kernel<128, false>(a); });

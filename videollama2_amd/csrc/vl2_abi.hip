@@ -309,8 +309,9 @@ extern "C" int32_t vl2_attn_fwd(const void* q, const void* k, const void* v, voi
         return fail(VL2_E_SHAPE, "vl2_attn_fwd: strides must keep 16-byte row alignment");
     if (causal && causal_off < 0) return fail(VL2_E_SHAPE, "vl2_attn_fwd: causal_off must be >= 0");
     AttnArgs a{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, q_bs, q_hs, q_rs, k_bs, k_hs, k_rs,
-               v_bs, v_hs, v_rs, o_bs, o_hs, o_rs, nq, nk, group, scale * 1.4426950408889634f, causal_off};
+               v_bs, v_hs, v_rs, o_bs, o_hs, o_rs, nq, nk, group, H, B, scale * 1.4426950408889634f, causal_off};
     dim3 g((nq + 127) / 128, H, B), b(256);
+    if (causal) g = dim3(((nq + 127) / 128) * H * B, 1, 1);
     hipStream_t s = ST(stream);
     if (D == 64 && !causal) hipLaunchKernelGGL((attn_fwd_kernel<64, false>), g, b, 0, s, a);
     else if (D == 64 && causal) hipLaunchKernelGGL((attn_fwd_kernel<64, true>), g, b, 0, s, a);
