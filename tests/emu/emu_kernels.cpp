@@ -117,6 +117,7 @@ static int32_t run_norm(NormArgs a, bool rms) {
     } else {
         if (nv <= 1) emu::launch(g, blk, [=] { norm_kernel<1, false>(a); });
         else if (nv <= 2) emu::launch(g, blk, [=] { norm_kernel<2, false>(a); });
+        else if (nv <= 3) emu::launch(g, blk, [=] { norm_kernel<3, false>(a); });
         else emu::launch(g, blk, [=] { norm_kernel<8, false>(a); });
     }
     return 0;
@@ -153,6 +154,7 @@ extern "C" int32_t vl2_attn_fwd(const void* q, const void* k, const void* v, voi
     else if (D == 128 && causal) emu::launch(g, blk, [=] { attn_fwd_kernel<128, true>(a); });
     else if (D == 128 && !causal) emu::launch(g, blk, [=] { attn_fwd_kernel<128, false>(a); });
     else if (D == 64 && causal) emu::launch(g, blk, [=] { attn_fwd_kernel<64, true>(a); });
+    else if (D == 96 && !causal) emu::launch(g, blk, [=] { attn_fwd_kernel<96, false>(a); });
     else return -2;
     return 0;
 }

@@ -136,6 +136,17 @@ def test_emu_attention_ragged_and_causal(emu):
     sc = (qf @ kf.transpose(1, 2) * D ** -0.5).masked_fill(torch.triu(torch.ones(S, S, dtype=torch.bool), 1), float("-inf"))
     ref = (torch.softmax(sc, -1) @ vf).transpose(0, 1).reshape(S, nh * D)
     assert rel(o, ref) < TOL_BF16_OUT
+    # head_dim 96 (SigLIP's 72 zero-padded): non-causal, ragged N, real scale = 72^-0.5
+    B, H, N, D = 1, 2, 150, 96
+    qkv = bf(B * N, 3 * H * D)
+    qkv.view(B * N, 3 * H, D)[:, :, 72:] = 0
+    o = torch.zeros(B * N, H * D, dtype=torch.bfloat16)
+    st = (N * 3 * H * D, D, 3 * H * D)
+    ops.attn_fwd(qkv, qkv[:, H * D:], qkv[:, 2 * H * D:], o, st, st, st, (N * H * D, D, H * D), B, H, N, N, 1, 72 ** -0.5, False, 0, D)
+    q9, k9, v9 = [t.view(B, N, H, D).transpose(1, 2).float() for t in qkv.view(B * N, 3, H * D).unbind(1)]
+    ref96 = (torch.softmax(q9 @ k9.transpose(-1, -2) * 72 ** -0.5, -1) @ v9).transpose(1, 2).reshape(B * N, H * D)
+    assert rel(o, ref96) < TOL_BF16_OUT and o.view(B * N, H, D)[:, :, 72:].abs().max() == 0
+    S, nh, nkv, D, smax = 200, 4, 2, 128, 256
     o2 = torch.zeros(40, nh * D, dtype=torch.bfloat16)          # 40 new rows against 200 keys (chunked prefill form)
     ops.attn_fwd(q[160:].contiguous(), kc, vc, o2, *args, 40, S, nh // nkv, D ** -0.5, True, 160, D)
     assert rel(o2, ref[160:]) < TOL_BF16_OUT

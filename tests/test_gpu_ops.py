@@ -166,7 +166,7 @@ def test_gemm_conv3d_gather_full_size(ops):
     assert rel(y, ref) < TOL_BF16_OUT
 
 
-@pytest.mark.parametrize("C,rows", [(128, 37), (1024, 9232), (4096, 1521)])
+@pytest.mark.parametrize("C,rows", [(128, 37), (1024, 9232), (1152, 1458), (4096, 1521), (3584, 301)])
 def test_layernorm_rmsnorm(ops, C, rows):
     x, w, b, r = bf(rows, C, scale=2.0) + 0.5, torch.randn(C), torch.randn(C), bf(rows, C)
     x = x.bfloat16()
@@ -374,3 +374,18 @@ def test_small_linear_is_independent_of_the_frame_slot(ops):
         full = ops.small_linear(x, w, b, ops.ACT_SILU)
         for lo, hi in ((0, 2), (3, 8), (5, 11), (10, 11)):
             assert torch.equal(ops.small_linear(x[lo:hi].contiguous(), w, b, ops.ACT_SILU), full[lo:hi]), (N, K, lo, hi)
+
+
+def test_attn_fwd_head_dim_96_padded_72(ops):
+    """SigLIP-so400m attention: head_dim 72 zero-padded to 96, 729 tokens, scale 72^-0.5, non-causal."""
+    B, H, N, D, hd = 2, 16, 729, 96, 72
+    qkv = bf(B * N, 3 * H * D)
+    qkv.view(B * N, 3 * H, D)[:, :, hd:] = 0
+    qd = qkv.to(DEV)
+    o = torch.zeros(B * N, H * D, dtype=torch.bfloat16, device=DEV)
+    st = (N * 3 * H * D, D, 3 * H * D)
+    ops.attn_fwd(qd, qd[:, H * D:], qd[:, 2 * H * D:], o, st, st, st, (N * H * D, D, H * D), B, H, N, N, 1, hd ** -0.5, False, 0, D)
+    q, k, v = [t.view(B, N, H, D).transpose(1, 2).float() for t in qkv.view(B * N, 3, H * D).unbind(1)]
+    ref = (torch.softmax(q @ k.transpose(-1, -2) * hd ** -0.5, -1) @ v).transpose(1, 2).reshape(B * N, H * D)
+    assert rel(o, ref) < TOL_BF16_OUT
+    assert o.view(B * N, H, D)[:, :, hd:].abs().max().item() == 0

@@ -66,7 +66,7 @@ def test_full_width_siglip_layer():
     with torch.no_grad():
         ref = O.siglip_tower(sd, cfg, frames.bfloat16().float())
     tower = HipSiglipVisionTower(cfg, sd, DEV)
-    assert tower.w["hd"] == 72 and tower.w["hdp"] == 128 and tower.w["layers"][0]["w1"].shape == (4352, 1152)
+    assert tower.w["hd"] == 72 and tower.w["hdp"] == 96 and tower.w["layers"][0]["w1"].shape == (4352, 1152)
     out = tower(frames.to(DEV))
     assert tuple(out.shape) == (2, 729, 1152) and tower.num_patches == 729
     stage_ok("full-width SigLIP layer", out, ref, FULL_TOL["vit_layer"], [])

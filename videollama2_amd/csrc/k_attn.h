@@ -30,6 +30,9 @@ struct AttnArgs {
 
 template <int D> __device__ __forceinline__ int attn_k_off(int row, int chunk);
 template <> __device__ __forceinline__ int attn_k_off<128>(int row, int chunk) { return ((row << 4) + (chunk ^ (row & 15))) << 4; }
+// D = 96 (SigLIP-so400m's head_dim 72 padded to the next multiple of 32): the K image keeps the 256-B row pitch of D = 128,
+// only 12 of the 16 chunks of a row are filled and read
+template <> __device__ __forceinline__ int attn_k_off<96>(int row, int chunk) { return attn_k_off<128>(row, chunk); }
 template <> __device__ __forceinline__ int attn_k_off<64>(int row, int chunk) {
     const int R = row >> 1, s = ((row & 1) << 3) | chunk;
     return ((R << 4) + (s ^ (R & 15))) << 4;
@@ -46,10 +49,11 @@ template <int D, bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
     constexpr int KCH = D / 8;                 // 16-B chunks per K row
     constexpr int KPT = 64 * KCH / 256;        // K chunks per thread per tile
-    constexpr int VPT = 32 * KCH / 256;        // V (key-pair, chunk) items per thread per tile
+    constexpr int VITEMS = 32 * KCH;           // V (key-pair, chunk) items per tile
+    constexpr int VPT = (VITEMS + 255) / 256;  // ... per thread (D = 96: 1.5 -> 2 passes, the second half-populated)
     constexpr int NKS = D / 16;                // k-steps of the QK^T MFMA chain
     constexpr int NDB = D / 32;                // 32-row d blocks of O^T
-    __shared__ __attribute__((aligned(16))) unsigned char Ks[64 * D * 2];
+    __shared__ __attribute__((aligned(16))) unsigned char Ks[64 * (D == 96 ? 128 : D) * 2];
     __shared__ __attribute__((aligned(16))) unsigned char Vt[D * 128];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -98,6 +102,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
         for (int i = 0; i < VPT; ++i) {
             const int c = tid + 256 * i, kp = c / KCH, ch = c % KCH;
+            if (VITEMS % 256 != 0 && c >= VITEMS) continue;
             int r0 = kv0 + 2 * kp, r1 = r0 + 1;
             r0 = r0 < p.nk ? r0 : p.nk - 1; r1 = r1 < p.nk ? r1 : p.nk - 1;
             vreg[i][0] = *(const u32x4*)(V + (size_t)r0 * p.v_rs + ch * 8);
@@ -113,6 +118,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
         for (int i = 0; i < VPT; ++i) {
             const int c = tid + 256 * i, kp = c / KCH, ch = c % KCH;
+            if (VITEMS % 256 != 0 && c >= VITEMS) continue;
             // keys 2kp, 2kp+1 -> chunk (kb = key>>4, hi = bit 2 of key), element (bit 3 of key)*4 + (key & 3)
             const int k16 = (2 * kp) & 15;
             const int c16 = ((2 * kp) >> 4) * 2 + ((k16 >> 2) & 1);

@@ -263,6 +263,7 @@ static int32_t launch_norm(const NormArgs& a, bool rms, hipStream_t s, const cha
     } else {
         if (nv <= 1) hipLaunchKernelGGL((norm_kernel<1, false>), g, b, 0, s, a);
         else if (nv <= 2) hipLaunchKernelGGL((norm_kernel<2, false>), g, b, 0, s, a);
+        else if (nv <= 3) hipLaunchKernelGGL((norm_kernel<3, false>), g, b, 0, s, a);      // SigLIP hidden 1152
         else hipLaunchKernelGGL((norm_kernel<8, false>), g, b, 0, s, a);
     }
     return launched(what);
@@ -317,7 +318,8 @@ extern "C" int32_t vl2_attn_fwd(const void* q, const void* k, const void* v, voi
     else if (D == 64 && causal) hipLaunchKernelGGL((attn_fwd_kernel<64, true>), g, b, 0, s, a);
     else if (D == 128 && !causal) hipLaunchKernelGGL((attn_fwd_kernel<128, false>), g, b, 0, s, a);
     else if (D == 128 && causal) hipLaunchKernelGGL((attn_fwd_kernel<128, true>), g, b, 0, s, a);
-    else return fail(VL2_E_SHAPE, "vl2_attn_fwd: head_dim %d not built (64, 128)", D);
+    else if (D == 96 && !causal) hipLaunchKernelGGL((attn_fwd_kernel<96, false>), g, b, 0, s, a);
+    else return fail(VL2_E_SHAPE, "vl2_attn_fwd: head_dim %d not built (64, 96 non-causal, 128)", D);
     return launched("vl2_attn_fwd");
 }
 

@@ -52,16 +52,16 @@ def pack_tower(sd, cfg, dev, prefix="model.vision_tower.vision_tower."):
 
 
 def padded_head_dim(hd):
-    """The attention kernel is built for head_dim 64 and 128: other head dims (SigLIP-so400m: 72) run zero-padded."""
+    """The attention kernel is built for head_dim 64, 96 and 128: other head dims (SigLIP-so400m: 72 -> 96) run zero-padded."""
     if hd > 128:
         raise ValueError(f"vision head_dim {hd} > 128 is not supported")
-    return 64 if hd <= 64 else 128
+    return 64 if hd <= 64 else 96 if hd <= 96 else 128
 
 
 def pack_siglip_tower(sd, cfg, dev, prefix="model.vision_tower.vision_tower."):
     """SiglipVisionModel weights (HF:models/siglip/modeling_siglip.py) for the layers feeding hidden_states[select_layer].
     Two exact paddings make the so400m shapes fit the kernels (zeros in, zeros out):
-      * heads: head_dim 72 -> 128.  q/k/v rows of every head are followed by zero rows (and zero bias), so q.k is unchanged
+      * heads: head_dim 72 -> 96.  q/k/v rows of every head are followed by zero rows (and zero bias), so q.k is unchanged
         and the padded v columns come out 0; out_proj gets zero COLUMNS at those positions.
       * MLP: 4304 -> 4352 (next multiple of 128).  fc1 gets zero rows + zero bias -> gelu_tanh(0) = 0 -> fc2's zero columns."""
     sd = normalise_keys(sd)
