@@ -889,3 +889,4 @@ __global__ __launch_bounds__(128, 2) void gemm_s_bf16_kernel(GemmArgs p) {
     __syncthreads();
     gemm_store_patch<ACT, false, false, false>(p, ep, m0 + wave * 32, n0, lane);
 }
+
