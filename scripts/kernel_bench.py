@@ -61,10 +61,23 @@ SMALL = [  # per-rank shapes of the frame-sharded encoder at 8 ranks (2 / 4 fram
 ]
 
 
+def shapes_for(T):
+    """The GEMM shapes of a T-frame VideoLLaMA2-7B step (to check the per-shape kernel choice away from T=16)."""
+    Mv, Ms, To = T * 577, T * 576, (T // 2 + 1) * 169
+    S = To + 100
+    return [("vit_qkv", Mv, 3072, 1024, dict(bias=True)), ("vit_wo", Mv, 1024, 1024, dict(bias=True, res=True)),
+            ("vit_fc1", Mv, 4096, 1024, dict(bias=True, act=1)), ("vit_fc2", Mv, 1024, 4096, dict(bias=True, res=True)),
+            ("stc_s1_conv", Ms, 4096, 4096, dict()), ("stc_s1_b1", Ms, 4096, 1024, dict()), ("stc_s2_conv", To, 4096, 4096, dict()),
+            ("llm_qkv", S, 6144, 4096, dict()), ("llm_wo", S, 4096, 4096, dict(res=True)),
+            ("llm_gateup", S, 28672, 4096, dict(swiglu=True)), ("llm_down", S, 4096, 14336, dict(res=True))]
+
+
 def main():
     global SHAPES, VARIANTS
     out = {}
     ops.attach_workspace(dev)
+    if "--frames" in sys.argv:
+        SHAPES, VARIANTS = shapes_for(int(sys.argv[sys.argv.index("--frames") + 1])), (1, 0, 4, 8)
     if "--small" in sys.argv:
         SHAPES, VARIANTS = SMALL, (1, 0, 32, 's')   # 0 = auto, 1 = 128x128, 32 = 64x64 small-M kernel, 's' = 128x128 + split-K
     rounds = 2 if "--quick" in sys.argv else 3
@@ -85,7 +98,7 @@ def main():
                 best[v] = min(best.get(v, 1e9), us)
                 if v == 1:
                     ref = c.clone()
-                elif r == 0 and v != 's':
+                elif r == 0 and v not in ('s', 0):
                     d = (ref.float() - c.float()).abs().max().item()
                     if d > 0.05 * ref.float().abs().max().item():
                         print(f"   !! variant {v} differs from v1 on {name}: max|d| = {d:.4g}")
@@ -94,7 +107,7 @@ def main():
         fl = 2.0 * M * N * K
         out[name] = {f"v{v}": dict(us=round(us, 1), tflops=round(fl / us / 1e6, 1)) for v, us in best.items()}
         print(name, M, N, K, out[name], flush=True)
-    if "--small" in sys.argv:
+    if "--small" in sys.argv or "--frames" in sys.argv:
         return
     # attention
     B, H, Nn, D = 16, 16, 577, 64

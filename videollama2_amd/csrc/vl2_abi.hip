@@ -71,6 +71,9 @@ static bool want_stream_k(const GemmArgs&) { return g_ws && g_gemm_variant == 2;
 // short-K GEMMs (ViT fc1, STC b1) stay on 128x128.  Returns 1, 4 (gemm3) or 8 (gemm4).
 static int choose_gemm_kernel(const GemmArgs& a) {
     if (a.N % 256) return 1;
+    // at most one 128x128 tile per CU: a bigger tile only halves the CUs in use and doubles the latency of the single round
+    // (measured, T=8: 845x4096x4096 44.6 us here vs 50.2 us on 128x256; 945x4096x4096 47.2 vs 51.2)
+    if ((long)((a.M + 127) / 128) * (a.N / 128) <= 256) return 1;
     const auto fill = [](double rounds) { return rounds / (double)(long)(rounds + 0.999999); };
     const double m128 = (double)a.M / (((a.M + 127) / 128) * 128.0), m256 = (double)a.M / (((a.M + 255) / 256) * 256.0);
     const double e1 = fill((double)((a.M + 127) / 128) * (a.N / 128) / 512.0) * m128;           // 2 WG/CU
