@@ -105,6 +105,7 @@ def main():
     ap.add_argument("--new-tokens", type=int, default=32)
     ap.add_argument("--llm-layers", type=int, default=None, help="debug only: fewer decoder layers (INVALID as a result)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--u8-frames", action="store_true", help="feed raw uint8 [T,S,S,3] frames (normalised in the patch-row kernel) instead of bf16 [T,3,S,S]")
     ap.add_argument("--no-graph", action="store_true", help="eager decode loop instead of hipGraph replay")
     ap.add_argument("--vit-streams", type=int, default=None, help="ViT frames as N chunks on N HIP streams (default: the tower's own, 3)")
     ap.add_argument("--tune", type=str, default="", help="debug: comma list key=value for vl2_set_tuning")
@@ -149,6 +150,8 @@ def main():
 
     g = torch.Generator(device=dev).manual_seed(0)
     frames = torch.randn((T, 3, side, side), generator=g, device=dev, dtype=torch.float32).to(torch.bfloat16)
+    if args.u8_frames:
+        frames = torch.randint(0, 256, (T, side, side, 3), generator=g, device=dev, dtype=torch.uint8)
     V = cfg["llm"]["vocab_size"]
     cg = torch.Generator().manual_seed(1)
     ids = torch.cat([torch.tensor([1]), torch.randint(3, V, (31,), generator=cg), torch.tensor([-201]),

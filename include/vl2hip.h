@@ -90,6 +90,11 @@ int32_t vl2_rmsnorm(const void* x, void* y, const float* w, int32_t rows, int32_
  * patch_embedding (Conv2d k=P s=P, no bias). */
 int32_t vl2_patchify(const void* frames, int32_t dtype, void* out, int32_t T, int32_t H, int32_t W, int32_t P, int32_t G,
                      int32_t Kp, void* stream);
+/* uint8 ingest: frames [T,H,W,3] uint8 (device) -> the same im2col rows, with the image processor's x*rescale, (x-mean)/std
+ * (videollama2/mm_utils.py:196-201 -> HF CLIPImageProcessor / SiglipImageProcessor preprocess) done in registers.
+ * mean3 / std3 are HOST pointers to 3 floats. */
+int32_t vl2_patchify_u8(const void* frames_thwc, void* out, int32_t T, int32_t H, int32_t W, int32_t P, int32_t G, int32_t Kp,
+                        float rescale, const float* mean3, const float* std3, void* stream);
 /* x[t*rows_per_frame, :] = cls_pos (class_embedding + position_embedding[0]). */
 int32_t vl2_fill_cls(void* x, const void* cls_pos, int32_t T, int32_t D, int32_t rows_per_frame, void* stream);
 

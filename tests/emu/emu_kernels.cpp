@@ -138,6 +138,12 @@ extern "C" int32_t vl2_patchify(const void* frames, int32_t dtype, void* out, in
     else emu::launch(g, blk, [=] { patchify_kernel<bf16_t>((const bf16_t*)frames, (bf16_t*)out, H, W, P, G, Kp); });
     return 0;
 }
+extern "C" int32_t vl2_patchify_u8(const void* frames, void* out, int32_t T, int32_t H, int32_t W, int32_t P, int32_t G, int32_t Kp,
+                                   float rescale, const float* m, const float* sd, void*) {
+    U8Norm n{rescale, {m[0], m[1], m[2]}, {1.0f / sd[0], 1.0f / sd[1], 1.0f / sd[2]}};
+    emu::launch(dim3(G, T), dim3(256), [=] { patchify_u8_kernel((const unsigned char*)frames, (bf16_t*)out, H, W, P, G, Kp, n); });
+    return 0;
+}
 extern "C" int32_t vl2_fill_cls(void* x, const void* cls_pos, int32_t T, int32_t D, int32_t rows_per_frame, void*) {
     emu::launch(dim3(T), dim3(128), [=] { fill_cls_kernel((bf16_t*)x, (const bf16_t*)cls_pos, D, rows_per_frame); });
     return 0;

@@ -217,3 +217,41 @@ def test_emu_drop_in_accelerate_reference_model(emu, golden_small, golden_small_
     out = model.generate(ids, attention_mask=torch.ones_like(ids), images=[(g["frames"], "video")], do_sample=False,
                          max_new_tokens=2, use_cache=True, pad_token_id=0, eos_token_id=None)
     assert out[0].tolist() == g["new_tokens"][:2].tolist()
+
+
+@pytest.mark.parametrize("family", ["v2", "v21"])
+def test_emu_uint8_frame_ingest_matches_process_video(emu, golden_small, golden_small_v21, family):
+    """uint8 ingest: raw uint8 [T,H,W,3] frames through `process_video_u8` + the in-register normalise of
+    the patch-row kernel give the tower output of the fp32 `process_video` path (reciprocal instead of division: identical up
+    to rare bf16 rounding ties)."""
+    from videollama2_amd.mm_utils import process_video, process_video_u8
+    from videollama2_amd.tower import (HipCLIPVisionTower, HipSiglipVisionTower, default_image_processor,
+                                       default_siglip_image_processor)
+    g = golden_small if family == "v2" else golden_small_v21
+    cfg = g["cfg"]
+    S = cfg["vision"]["image_size"]
+    siglip = O.vision_family(cfg) == "siglip"
+    proc = (default_siglip_image_processor if siglip else default_image_processor)(S)
+    sd = O.seeded_state_dict(cfg, g["seed"], only=lambda n: "vision_tower" in n)
+    tower = (HipSiglipVisionTower if siglip else HipCLIPVisionTower)(cfg, sd, "cpu", image_processor=proc)
+    u8 = g["frames_u8"].numpy()
+    ref_frames = process_video(u8, proc, aspect_ratio=None, num_frames=u8.shape[0])
+    assert torch.allclose(ref_frames, g["frames"], atol=1e-6)                      # the mirror reproduces the reference's frames
+    raw = process_video_u8(u8, proc, aspect_ratio=None, num_frames=u8.shape[0])
+    assert raw.dtype == torch.uint8 and tuple(raw.shape) == (u8.shape[0], S, S, 3) and torch.equal(raw, g["frames_u8"])
+    from videollama2_amd import ops
+    P, kp = cfg["vision"]["patch_size"], tower.w["kp"]
+    rows_f = ops.patchify(ref_frames, P, kp)                                      # fp32 frames -> bf16 patch rows
+    rows_u = ops.patchify_u8(raw, P, kp, proc.rescale_factor, proc.image_mean, proc.image_std)
+    same = (rows_f == rows_u).float().mean().item()
+    ulp = (rows_f.float() - rows_u.float()).abs() / rows_f.float().abs().clamp_min(1e-3)
+    assert same > 0.99 and ulp.max().item() <= 2 ** -7, (same, ulp.max().item())    # at most one bf16 ulp, on rounding ties only
+    a = tower(ref_frames.bfloat16())
+    b = tower(raw)
+    assert b.dtype == torch.bfloat16 and a.shape == b.shape
+    assert rel(b, a.float()) < 1e-2                                                # a few flipped input ulps -> bf16 noise floor
+    odd = g["odd_u8"].numpy()                                                       # non-square, bicubic resize + crop on the host
+    ro = process_video_u8([f for f in odd], proc, aspect_ratio=None, num_frames=4)
+    fo = process_video([f for f in odd], proc, aspect_ratio=None, num_frames=4)
+    assert tuple(ro.shape) == (4, S, S, 3)
+    assert rel(tower(ro), tower(fo.bfloat16()).float()) < 2e-2

@@ -389,3 +389,21 @@ def test_attn_fwd_head_dim_96_padded_72(ops):
     ref = (torch.softmax(q @ k.transpose(-1, -2) * hd ** -0.5, -1) @ v).transpose(1, 2).reshape(B * N, H * D)
     assert rel(o, ref) < TOL_BF16_OUT
     assert o.view(B * N, H, D)[:, :, hd:].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("S,mean,std", [(336, (0.48145466, 0.4578275, 0.40821073), (0.26862954, 0.26130258, 0.27577711)), (384, (0.5,) * 3, (0.5,) * 3)])
+def test_patchify_u8_matches_normalise_then_patchify(ops, S, mean, std):
+    """uint8 ingest: patch rows from raw uint8 [T,H,W,3] frames (normalise in registers) vs the processor's fp32 arithmetic
+    followed by the float patchify: identical except on bf16 rounding ties (reciprocal instead of division)."""
+    T, P = 3, 14
+    u8 = torch.randint(0, 256, (T, S, S, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(S))
+    x = u8.float() * (1 / 255)
+    frames = ((x - torch.tensor(mean)) / torch.tensor(std)).permute(0, 3, 1, 2).contiguous()
+    kp = (3 * P * P + 63) // 64 * 64
+    rows_f = ops.patchify(frames.to(DEV), P, kp)
+    rows_u = ops.patchify_u8(u8.to(DEV), P, kp, 1 / 255, mean, std)
+    assert rows_u.shape == rows_f.shape == (T * (S // P) ** 2, kp)
+    same = (rows_f == rows_u).float().mean().item()
+    ulp = ((rows_f.float() - rows_u.float()).abs() / rows_f.float().abs().clamp_min(1e-3)).max().item()
+    assert same > 0.995 and ulp <= 2 ** -7, (same, ulp)
+    assert rows_u[:, 3 * P * P:].abs().max().item() == 0

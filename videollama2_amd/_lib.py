@@ -17,6 +17,7 @@ SIGNATURES = {
     "vl2_layernorm": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp],
     "vl2_rmsnorm": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp],
     "vl2_patchify": [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
+    "vl2_patchify_u8": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp],
     "vl2_fill_cls": [_vp, _vp, _i32, _i32, _i32, _vp],
     "vl2_attn_fwd": [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _i64, _i64, _i32, _i64, _i64, _i32, _i64, _i64, _i32, _i32, _i32,
                      _i32, _i32, _i32, _f32, _i32, _i32, _i32, _vp],

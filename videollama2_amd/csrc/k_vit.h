@@ -37,6 +37,35 @@ __global__ __launch_bounds__(256) void patchify_kernel(const T* __restrict__ fra
     }
 }
 
+// uint8 ingest: frames [T,H,W,3] uint8 exactly as the decoder / resize step leaves them -> the same im2col
+// rows, with the image processor's arithmetic tail (HF image_processing: x * rescale_factor, then (x - mean) / std, fp32)
+// done in registers: half the bytes of bf16 frames over PCIe and HBM, no normalised copy on the host.
+// nrm = {rescale, mean[3], 1/std[3]} (the division is a multiplication by the fp32 reciprocal: <= 1 fp32 ulp from the
+// processor's, invisible after the bf16 rounding except on exact rounding ties).  grid = (G, T); block 256
+struct U8Norm { float rescale, mean[3], inv_std[3]; };
+__global__ __launch_bounds__(256) void patchify_u8_kernel(const unsigned char* __restrict__ frames, bf16_t* __restrict__ out,
+                                                          int H, int W, int P, int G, int Kp, U8Norm nrm) {
+    const int py = blockIdx.x, t = blockIdx.y;
+    const int kvec = Kp >> 3, PP = P * P, Kreal = 3 * PP;
+    const unsigned char* f = frames + (size_t)t * H * W * 3;
+    for (int e = threadIdx.x; e < G * kvec; e += 256) {
+        const int px = e / kvec, k0 = (e - px * kvec) * 8;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = k0 + j;
+            if (k < Kreal) {
+                const int c = k / PP, r = k - c * PP, ky = r / P, kx = r - ky * P;
+                const float x = (float)f[((size_t)(py * P + ky) * W + px * P + kx) * 3 + c] * nrm.rescale;
+                v[j] = (x - nrm.mean[c]) * nrm.inv_std[c];
+            } else {
+                v[j] = 0.f;
+            }
+        }
+        *(u32x4*)(out + ((size_t)(t * G + py) * G + px) * Kp + k0) = pack8(v);
+    }
+}
+
 // rows t*rows_per_frame of x [T*rows_per_frame, D] <- cls_pos [D];  grid = T, block 128 (D/8 <= 128... loop anyway)
 __global__ __launch_bounds__(128) void fill_cls_kernel(bf16_t* __restrict__ x, const bf16_t* __restrict__ cls_pos, int D,
                                                        int rows_per_frame) {

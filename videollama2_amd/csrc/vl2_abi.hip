@@ -295,6 +295,14 @@ extern "C" int32_t vl2_patchify(const void* frames, int32_t dtype, void* out, in
     else return fail(VL2_E_UNSUPP, "vl2_patchify: dtype %d", dtype);
     return launched("vl2_patchify");
 }
+extern "C" int32_t vl2_patchify_u8(const void* frames_thwc, void* out, int32_t T, int32_t H, int32_t W, int32_t P, int32_t G, int32_t Kp,
+                                   float rescale, const float* mean3, const float* std3, void* stream) {
+    if (!frames_thwc || !out || !mean3 || !std3 || T <= 0) return fail(VL2_E_BADARG, "vl2_patchify_u8: null pointer or empty shape");
+    if (G * P > H || G * P > W || Kp % 8 || Kp < 3 * P * P) return fail(VL2_E_SHAPE, "vl2_patchify_u8: bad geometry");
+    U8Norm n{rescale, {mean3[0], mean3[1], mean3[2]}, {1.0f / std3[0], 1.0f / std3[1], 1.0f / std3[2]}};   // host pointers
+    hipLaunchKernelGGL(patchify_u8_kernel, dim3(G, T), dim3(256), 0, ST(stream), (const unsigned char*)frames_thwc, (bf16_t*)out, H, W, P, G, Kp, n);
+    return launched("vl2_patchify_u8");
+}
 extern "C" int32_t vl2_fill_cls(void* x, const void* cls_pos, int32_t T, int32_t D, int32_t rows_per_frame, void* stream) {
     if (!x || !cls_pos || T <= 0 || D % 8) return fail(VL2_E_BADARG, "vl2_fill_cls: bad args");
     hipLaunchKernelGGL(fill_cls_kernel, dim3(T), dim3(128), 0, ST(stream), (bf16_t*)x, (const bf16_t*)cls_pos, D, rows_per_frame);

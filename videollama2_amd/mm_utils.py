@@ -109,6 +109,21 @@ def process_video(video_path, processor, s=None, e=None, aspect_ratio="pad", num
     return processor.preprocess(frames, return_tensors="pt")["pixel_values"]
 
 
+def process_video_u8(video_path, processor, s=None, e=None, aspect_ratio="pad", num_frames=NUM_FRAMES):
+    """uint8 ingest (not in the reference): the same frame loading / padding / resize / crop as
+    `process_video`, but the arithmetic tail (x/255, (x-mean)/std) is left to the GPU: returns uint8 [T, S, S, 3] (CPU), a
+    quarter of the fp32 bytes, which `HipCLIPVisionTower` / `HipSiglipVisionTower` accept directly (the tower normalises in
+    registers while building the patch rows, with the processor's own rescale_factor / image_mean / image_std)."""
+    import copy
+    raw = copy.copy(processor)
+    raw.do_rescale = False
+    raw.do_normalize = False
+    px = process_video(video_path, raw, s=s, e=e, aspect_ratio=aspect_ratio, num_frames=num_frames)   # [T,3,S,S] values 0..255
+    if px.dtype != torch.uint8:
+        px = px.round().clamp_(0, 255).to(torch.uint8)
+    return px.permute(0, 2, 3, 1).contiguous()
+
+
 def tokenizer_multimodal_token(prompt, tokenizer, multimodal_token=DEFAULT_IMAGE_TOKEN, return_tensors=None):
     """Tokenize the text around each `<video>`/`<image>` tag without special tokens and put the (negative) sentinel id
     of MODAL_INDEX_MAP where the tag stood."""

@@ -52,7 +52,7 @@ class VideoLLaMA2Hip(nn.Module):
         batch = []
         for data, modal in images:
             batch.append(data.expand(num_frames, -1, -1, -1) if modal == "image" else data)
-        batch = torch.stack(batch, dim=0)
+        batch = batch[0].unsqueeze(0) if len(batch) == 1 else torch.stack(batch, dim=0)   # one video: a view, not a copy
         assert len(batch.size()) == 5                                                   # arch.py:127
         b, t = batch.shape[:2]
         frames = batch.reshape(b * t, *batch.shape[2:])                                  # 'b t c h w -> (b t) c h w'

@@ -126,6 +126,23 @@ def patchify(frames, patch, kp):
     return out
 
 
+def patchify_u8(frames_thwc, patch, kp, rescale, mean, std):
+    """frames [T,H,W,3] uint8 (device) -> [T*G*G, kp] bf16 im2col rows of (x*rescale - mean) / std."""
+    import ctypes
+    _chk(frames_thwc, torch.uint8, "frames")
+    frames_thwc = frames_thwc.contiguous()
+    T, H, W, C = frames_thwc.shape
+    if C != 3:
+        raise ValueError(f"expected uint8 frames [T,H,W,3], got {tuple(frames_thwc.shape)}")
+    G = H // patch
+    out = torch.empty((T * G * G, kp), dtype=BF16, device=frames_thwc.device)
+    m3 = (ctypes.c_float * 3)(*[float(v) for v in mean])
+    s3 = (ctypes.c_float * 3)(*[float(v) for v in std])
+    _lib.call("vl2_patchify_u8", _p(frames_thwc), _p(out), T, H, W, patch, G, kp, float(rescale), ctypes.addressof(m3),
+              ctypes.addressof(s3), _stream())
+    return out
+
+
 def fill_cls(x, cls_pos, T, rows_per_frame):
     _lib.call("vl2_fill_cls", _p(x), _p(cls_pos), T, x.shape[1], rows_per_frame, _stream())
 

@@ -49,6 +49,25 @@ class HipCLIPVisionTower(nn.Module):
 
     _pack = staticmethod(pack_tower)
     _cls_tokens = 1                     # rows per frame in front of the patches (CLIP: the CLS token)
+    _default_norm = (1 / 255, (0.48145466, 0.4578275, 0.40821073), (0.26862954, 0.26130258, 0.27577711))   # openai/clip preprocessor
+
+    @staticmethod
+    def _frame_geometry(images):
+        """Float frames [T,3,H,W] (what `process_video` returns) or raw uint8 frames [T,H,W,3] (`mm_utils.process_video_u8`)."""
+        if images.dim() == 4 and images.dtype == torch.uint8 and images.shape[-1] == 3:
+            return images.shape[0], images.shape[1], images.shape[2], True
+        if images.dim() != 4 or images.shape[1] != 3:
+            raise ValueError(f"expected frames [T,3,H,W] (or uint8 [T,H,W,3]), got {tuple(images.shape)}")
+        return images.shape[0], images.shape[2], images.shape[3], False
+
+    def _patch_rows(self, images, u8, P, kp):
+        if not u8:
+            return ops.patchify(images, P, kp)
+        ip = self.image_processor               # the arithmetic tail of the processor, applied in registers
+        rescale, mean, std = self._default_norm
+        if ip is not None:
+            rescale, mean, std = getattr(ip, "rescale_factor", rescale), getattr(ip, "image_mean", mean), getattr(ip, "image_std", std)
+        return ops.patchify_u8(images, P, kp, rescale, mean, std)
 
     # ---- attributes the reference reads (encoder.py:55-81, videollama2_arch.py:66, model/__init__.py:186)
     @property
@@ -81,6 +100,8 @@ class HipCLIPVisionTower(nn.Module):
         With `self.streams` > 1 the (independent) frames run as that many interleaved chunks on separate HIP streams,
         so one chunk's partial last round of GEMM tiles overlaps the other chunk's kernels."""
         ns = min(int(self.streams), images.shape[0] // 4 if images.dim() == 4 else 1)    # >= 4 frames per chunk
+        if images.dtype == torch.uint8:
+            ns = 1
         if ns <= 1:
             return self._hidden(images)
         v = self.cfg["vision"]
@@ -102,9 +123,7 @@ class HipCLIPVisionTower(nn.Module):
 
     def _hidden(self, images, out=None):
         v = self.cfg["vision"]
-        if images.dim() != 4 or images.shape[1] != 3:
-            raise ValueError(f"expected frames [T,3,H,W], got {tuple(images.shape)}")
-        T, _, H, W = images.shape
+        T, H, W, u8 = self._frame_geometry(images)
         if H != v["image_size"] or W != v["image_size"]:                          # HF:modeling_clip.py:203-207
             raise ValueError(f"Input image size ({H}*{W}) doesn't match model ({v['image_size']}*{v['image_size']}).")
         images = images.to(self._dev)
@@ -115,7 +134,7 @@ class HipCLIPVisionTower(nn.Module):
         nh = v["num_attention_heads"]
         hd = D // nh
         eps = v["layer_norm_eps"]
-        a = ops.patchify(images, P, w["kp"])
+        a = self._patch_rows(images, u8, P, w["kp"])
         x = torch.empty((T * N1, D), dtype=torch.bfloat16, device=self._dev)
         ops.gemm(a, w["patch_w"], res=w["pos"], out=x, out_map=(G * G, 1, 1), res_map=(G * G, 1), flop_k=3 * P * P)
         ops.fill_cls(x, w["cls_pos"], T, N1)
@@ -137,7 +156,7 @@ class HipCLIPVisionTower(nn.Module):
     def forward(self, images):
         if type(images) is list:                                                   # encoder.py:43-48
             return [self.forward(im.unsqueeze(0)) for im in images]
-        in_dtype = images.dtype
+        in_dtype = images.dtype if images.dtype != torch.uint8 else torch.bfloat16
         x, T, N1 = self.forward_hidden(images)
         x = x.view(T, N1, -1)
         if self.select_feature == "patch":                                         # encoder.py:33-34
@@ -163,6 +182,7 @@ class HipSiglipVisionTower(HipCLIPVisionTower):
     (weights.pack_siglip_tower)."""
     _pack = staticmethod(pack_siglip_tower)
     _cls_tokens = 0
+    _default_norm = (1 / 255, (0.5, 0.5, 0.5), (0.5, 0.5, 0.5))                  # google/siglip-so400m-patch14-384 preprocessor
 
     def __init__(self, cfg, state_dict, device="cuda", select_feature="patch", image_processor=None,
                  prefix="model.vision_tower.vision_tower."):
@@ -172,9 +192,7 @@ class HipSiglipVisionTower(HipCLIPVisionTower):
 
     def _hidden(self, images, out=None):
         v = self.cfg["vision"]
-        if images.dim() != 4 or images.shape[1] != 3:
-            raise ValueError(f"expected frames [T,3,H,W], got {tuple(images.shape)}")
-        T, _, H, W = images.shape
+        T, H, W, u8 = self._frame_geometry(images)
         if H != v["image_size"] or W != v["image_size"]:                          # HF:modeling_siglip.py SiglipVisionEmbeddings
             raise ValueError(f"Input image size ({H}*{W}) doesn't match model ({v['image_size']}*{v['image_size']}).")
         images = images.to(self._dev)
@@ -184,7 +202,7 @@ class HipSiglipVisionTower(HipCLIPVisionTower):
         N = G * G
         hdp, eps = w["hdp"], v["layer_norm_eps"]
         Hh = nh * hdp
-        a = ops.patchify(images, P, w["kp"])
+        a = self._patch_rows(images, u8, P, w["kp"])
         x = torch.empty((T * N, D), dtype=torch.bfloat16, device=self._dev)
         ops.gemm(a, w["patch_w"], bias=w["patch_b"], res=w["pos"], out=x, res_map=(N, 0), flop_k=3 * P * P)
         o = torch.empty((T * N, Hh), dtype=torch.bfloat16, device=self._dev)
@@ -205,4 +223,4 @@ class HipSiglipVisionTower(HipCLIPVisionTower):
         if type(images) is list:                                                   # encoder.py:113-118
             return [self.forward(im.unsqueeze(0)) for im in images]
         x, T, N = self.forward_hidden(images)
-        return x.view(T, N, -1).to(images.dtype)                                   # encoder.py:121 `.to(images.dtype)`
+        return x.view(T, N, -1).to(images.dtype if images.dtype != torch.uint8 else torch.bfloat16)   # encoder.py:121
