@@ -32,7 +32,7 @@ def test_abi_argument_validation_without_gpu():
     with pytest.raises(_lib.Vl2HipError, match="N%128"):
         _lib.call("vl2_gemm_bf16", 16, 16, 16, None, None, 4, 100, 64, 64, 64, 104, 0, 0, 0, None, None, 0, 0, 0, 0, 0, 0, None)
     with pytest.raises(_lib.Vl2HipError, match="head_dim"):
-        _lib.call("vl2_attn_fwd", 16, 16, 16, 16, 0, 96, 96, 0, 96, 96, 0, 96, 96, 0, 96, 96, 1, 1, 4, 4, 1, 1.0, 0, 0, 96, None)
+        _lib.call("vl2_attn_fwd", 16, 16, 16, 16, 0, 80, 80, 0, 80, 80, 0, 80, 80, 0, 80, 80, 1, 1, 4, 4, 1, 1.0, 0, 0, 80, None)
 
 
 def test_product_never_imports_oracle():
