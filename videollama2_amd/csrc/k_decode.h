@@ -71,6 +71,28 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvArgs p) {
     __shared__ float red[8];
     bf16_t* xs = (bf16_t*)vl2_smem;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_out = SWIGLU ? p.N / 2 : p.N;
+    const int nvec = p.K >> 3;                       // 16-B vectors per row
+    // K <= 4096 (every projection except down_proj): a row is ONE pass of 8 loads per lane.  The weights do not depend on
+    // x, so the first row's loads are issued BEFORE x is normalised and staged: the two memory latencies overlap instead
+    // of adding up (these GEMVs are a single round trip long: 11.9 -> ~9 us for the 50 MB qkv projection).
+    const bool one_pass = nvec <= 512;
+    u32x4 wv[8], uv[8];
+    auto issue_row = [&](int j, int v0) {
+        const int row0 = SWIGLU ? (j >> 5) * 64 + (j & 31) : j;
+        const bf16_t* w0p = p.W + (size_t)row0 * p.ldw;
+        const bf16_t* w1p = w0p + (size_t)32 * p.ldw;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int v = v0 + i * 64 + lane;
+            if (v < nvec) {
+                wv[i] = __builtin_nontemporal_load((const u32x4*)(w0p + (size_t)v * 8));
+                if (SWIGLU) uv[i] = __builtin_nontemporal_load((const u32x4*)(w1p + (size_t)v * 8));
+            }
+        }
+    };
+    const int jfirst = (blockIdx.x * 4 + wave) * RPW;
+    if (one_pass && jfirst < n_out) issue_row(jfirst, 0);
     // stage x (optionally RMS-normalised: HF MistralRMSNorm, fp32 statistics, result rounded to bf16)
     float rstd = 1.f;
     if (p.norm_w) {
@@ -100,26 +122,13 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvArgs p) {
     }
     __syncthreads();
 
-    const int n_out = SWIGLU ? p.N / 2 : p.N;
-    const int nvec = p.K >> 3;                       // 16-B vectors per row
 #pragma unroll 1
     for (int r = 0; r < RPW; ++r) {
-        const int j = (blockIdx.x * 4 + wave) * RPW + r;
+        const int j = jfirst + r;
         if (j >= n_out) break;
-        const int row0 = SWIGLU ? (j >> 5) * 64 + (j & 31) : j;
-        const bf16_t* w0p = p.W + (size_t)row0 * p.ldw;
-        const bf16_t* w1p = w0p + (size_t)32 * p.ldw;
         float a0 = 0.f, a1 = 0.f;
         for (int v0 = 0; v0 < nvec; v0 += 64 * 8) {
-            u32x4 wv[8], uv[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int v = v0 + i * 64 + lane;
-                if (v < nvec) {
-                    wv[i] = __builtin_nontemporal_load((const u32x4*)(w0p + (size_t)v * 8));
-                    if (SWIGLU) uv[i] = __builtin_nontemporal_load((const u32x4*)(w1p + (size_t)v * 8));
-                }
-            }
+            if (!(one_pass && r == 0)) issue_row(j, v0);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int v = v0 + i * 64 + lane;
