@@ -10,10 +10,10 @@ pieces concurrently on their own GPUs); the two collectives are modelled from me
 import argparse, json, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from videollama2_amd.config import videollama2_7b
+from videollama2_amd.config import videollama2_1_7b_16f, videollama2_7b
 from videollama2_amd.connector import HipSTCConnector
 from videollama2_amd.dist import FrameSharder
-from videollama2_amd.tower import HipCLIPVisionTower
+from videollama2_amd.tower import HipCLIPVisionTower, HipSiglipVisionTower
 from videollama2_amd.weights import random_state_dict
 
 LINK_GBS, COLL_FIXED_US = 153.0, 30.0
@@ -24,13 +24,16 @@ def main():
     ap.add_argument("--frames", type=int, nargs="+", default=[16, 32])
     ap.add_argument("--worlds", type=int, nargs="+", default=[2, 4, 8])
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--model", choices=["v2", "v21"], default="v2")
     ap.add_argument("--splitk", action="store_true", help="opt-in split-K for the small per-rank grids (not bit-identical to 1 GPU)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
-    cfg = videollama2_7b(16)
+    v21 = args.model == "v21"
+    cfg = videollama2_1_7b_16f(16) if v21 else videollama2_7b(16)
+    side, ntok, C = cfg["vision"]["image_size"], (cfg["vision"]["image_size"] // 14) ** 2, cfg["llm"]["hidden_size"]
     sd = random_state_dict(cfg, dev, seed=1234, n_llm_layers=0)
-    tower = HipCLIPVisionTower(cfg, sd, dev)
-    conn = HipSTCConnector(sd, dev)
+    tower = (HipSiglipVisionTower if v21 else HipCLIPVisionTower)(cfg, sd, dev)
+    conn = HipSTCConnector(sd, dev, padding=0 if v21 else 1)
     del sd
     from videollama2_amd import ops
 
@@ -41,7 +44,7 @@ def main():
 
     rows = []
     for T in args.frames:
-        frames = torch.randn((T, 3, 336, 336), generator=torch.Generator(device=dev).manual_seed(0), device=dev).bfloat16()
+        frames = torch.randn((T, 3, side, side), generator=torch.Generator(device=dev).manual_seed(0), device=dev).bfloat16()
         feats = tower(frames)
         ref = conn(feats.view(1, *feats.shape))
         torch.cuda.synchronize()
@@ -64,12 +67,11 @@ def main():
             ops.set_splitk(False)
             same = bool(torch.equal(out, ref))
             relerr = ((out.float() - ref.float()).norm() / ref.float().norm()).item()
-            n, C = 576, 4096
-            halo_us = COLL_FIXED_US + n * C * 2 / (LINK_GBS * 1e3)                     # one s1 frame to the next rank
-            per_out = (T // R // 2 + 1) * 169 * C * 2
+            halo_us = 0.0 if v21 else COLL_FIXED_US + ntok * C * 2 / (LINK_GBS * 1e3)  # one s1 frame to the next rank (v35: none)
+            per_out = (T // R // 2 + (0 if v21 else 1)) * 169 * C * 2
             ag_us = COLL_FIXED_US + per_out / (LINK_GBS * 1e3)                        # each peer's shard arrives on its own link
             crit = max(best) + (halo_us + ag_us) / 1e3
-            rows.append(dict(T=T, world=R, splitk=args.splitk, identical_to_unsharded=same, rel_l2_vs_unsharded=float(f"{relerr:.3e}"), one_gpu_ms=round(one, 3),
+            rows.append(dict(model=args.model, T=T, world=R, splitk=args.splitk, identical_to_unsharded=same, rel_l2_vs_unsharded=float(f"{relerr:.3e}"), one_gpu_ms=round(one, 3),
                              per_rank_ms=[round(x, 3) for x in best], modelled_collectives_us=round(halo_us + ag_us, 1),
                              critical_path_ms=round(crit, 3), speedup=round(one / crit, 2)))
             print(json.dumps(rows[-1]), flush=True)
