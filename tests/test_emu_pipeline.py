@@ -255,3 +255,67 @@ def test_emu_uint8_frame_ingest_matches_process_video(emu, golden_small, golden_
     fo = process_video([f for f in odd], proc, aspect_ratio=None, num_frames=4)
     assert tuple(ro.shape) == (4, S, S, 3)
     assert rel(tower(ro), tower(fo.bfloat16()).float()) < 2e-2
+
+
+class _ToyTokenizer:
+    """Whitespace tokenizer with the attributes mm_infer / KeywordsStoppingCriteria touch (no tokenizer files on the box)."""
+    eos_token, eos_token_id, bos_token_id, unk_token, pad_token, pad_token_id = "</s>", 2, 1, "<unk>", None, 0
+
+    def __init__(self, vocab):
+        self.vocab, self.prompts = vocab, []
+
+    def _id(self, w):
+        return 3 + (sum(ord(c) * (i + 7) for i, c in enumerate(w)) % (self.vocab - 3))
+
+    def __call__(self, text, add_special_tokens=True):
+        ids = [2 if w == "</s>" else self._id(w) for w in text.split()]
+        return type("Enc", (), {"input_ids": ([1] if add_special_tokens else []) + ids})()
+
+    def apply_chat_template(self, message, tokenize=False, add_generation_prompt=True):
+        self.prompts.append(message)
+        return "".join(f"[{m['role']}] {m['content']} " for m in message) + "[assistant]"
+
+    def batch_decode(self, ids, skip_special_tokens=True):
+        return [" ".join(f"t{int(t)}" for t in row if not (skip_special_tokens and int(t) in (0, 1, 2))) for row in ids]
+
+
+@pytest.mark.parametrize("family", ["v2", "v21"])
+def test_emu_standalone_model_init_and_mm_infer(emu, golden_small, golden_small_v21, family, tmp_path):
+    """videollama2_amd.api: `model_init(local checkpoint dir)` + `mm_infer` (the reference's videollama2/__init__.py:14-114
+    surface) on a synthetic safetensors checkpoint of each family."""
+    import json
+    from safetensors.torch import save_file
+    from videollama2_amd import api
+    g = golden_small if family == "v2" else golden_small_v21
+    cfg = g["cfg"]
+    v, l = cfg["vision"], cfg["llm"]
+    sd = {k: t.bfloat16().contiguous() for k, t in O.seeded_state_dict(cfg, g["seed"]).items()}
+    save_file(sd, str(tmp_path / "model.safetensors"))
+    hf = dict(model_type="videollama2_qwen2" if O.llm_family(cfg) == "qwen2" else "videollama2_mistral",
+              hidden_size=l["hidden_size"], intermediate_size=l["intermediate_size"], num_hidden_layers=l["num_hidden_layers"],
+              num_attention_heads=l["num_attention_heads"], num_key_value_heads=l["num_key_value_heads"], head_dim=l["head_dim"],
+              vocab_size=l["vocab_size"], rms_norm_eps=l["rms_norm_eps"], rope_theta=l["rope_theta"], num_frames=4,
+              mm_vision_tower="somewhere/" + ("siglip-synthetic" if O.vision_family(cfg) == "siglip" else "clip-synthetic"),
+              mm_projector_type=cfg.get("projector", "stc_connector"), mm_vision_select_layer=v["select_layer"])
+    json.dump(hf, open(tmp_path / "config.json", "w"))
+    json.dump({k: v[k] for k in v if k != "select_layer"}, open(tmp_path / "vision_config.json", "w"))
+    got, _ = api.config_from_checkpoint(str(tmp_path))
+    assert got["llm"] == {**l, "family": O.llm_family(cfg)} and got["projector"] == cfg.get("projector", "stc_connector")
+    assert got["vision"] == {**v, "family": O.vision_family(cfg)}
+    tok = _ToyTokenizer(l["vocab_size"])
+    model, processor, tok2 = api.model_init(str(tmp_path), device="cpu", max_seq_len=160, tokenizer=tok)
+    assert tok2.pad_token == "<unk>" and set(processor) == {"image", "video"}
+    frames = processor["video"](g["frames_u8"].numpy())
+    assert torch.allclose(frames, g["frames"], atol=1e-6)
+    text = api.mm_infer(frames, "what happens in the clip ?", model, tok, modal="video", max_new_tokens=4)
+    roles = [m["role"] for m in tok.prompts[-1]]
+    assert roles == (["system", "user"] if family == "v2" else ["user"])            # __init__.py:72-83
+    assert tok.prompts[-1][-1]["content"].startswith("<video>\n")
+    prompt = tok.apply_chat_template(tok.prompts[-1])
+    ids = api.tokenizer_multimodal_token(prompt, tok, "<video>", return_tensors="pt")[None]
+    assert (ids == -201).sum().item() == 1
+    ref = model.generate(ids, attention_mask=torch.ones_like(ids), images=[(frames.bfloat16(), "video")], do_sample=False,
+                         max_new_tokens=4, eos_token_id=2)
+    assert text == tok.batch_decode(ref)[0].strip() and len(text) > 0
+    with pytest.raises(ValueError, match="Unsupported modal"):
+        api.mm_infer(frames, "x", model, tok, modal="audio")

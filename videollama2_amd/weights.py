@@ -11,13 +11,19 @@ def normalise_keys(sd):
     return {k.replace("vision_tower.vision_tower.vision_model.", "vision_tower.vision_tower."): v for k, v in sd.items()}
 
 
+def _aligned(t):
+    """The C ABI wants 16-byte aligned pointers; a tensor that came straight out of a memory-mapped checkpoint file (and
+    needed no dtype / device conversion) may not be."""
+    return t if t.data_ptr() % 16 == 0 else t.clone()
+
+
 def _bf(t, dev):
-    return t.detach().to(device=dev, dtype=BF16).contiguous()
+    return _aligned(t.detach().to(device=dev, dtype=BF16).contiguous())
 
 
 def _f32(t, dev):
     # parameters are stored in bf16 by the reference's bf16 path; bf16 -> fp32 is exact
-    return t.detach().to(dtype=BF16).to(device=dev, dtype=torch.float32).contiguous()
+    return _aligned(t.detach().to(dtype=BF16).to(device=dev, dtype=torch.float32).contiguous())
 
 
 def pack_tower(sd, cfg, dev, prefix="model.vision_tower.vision_tower."):
