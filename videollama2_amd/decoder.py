@@ -5,6 +5,7 @@ the greedy decode loop on its own KV cache and returns the NEW token ids, as HF 
 `inputs_embeds` path.  Per-layer math follows HF:models/mistral/modeling_mistral.py (RMSNorm fp32 statistics,
 rotate-half RoPE theta=1e6, causal GQA attention, SwiGLU), executed by libvl2hip.so kernels only."""
 import torch
+import torch.distributed as dist
 import torch.nn as nn
 
 from . import ops
@@ -12,14 +13,25 @@ from .weights import pack_decoder
 
 
 class HipMistralDecoder(nn.Module):
-    def __init__(self, cfg, state_dict, device="cuda", max_seq_len=4096, n_layers=None):
+    """tp_group: optional torch.distributed group for tensor parallelism over the heads / MLP width (the
+    reference has none -- its 72B path is accelerate's device_map="auto").  Every rank holds 1/tp of the q/k/v/gate/up rows
+    and of the o/down columns and of the KV cache; the two row-parallel projections of a layer produce partial sums that are
+    all-reduced (RCCL over xGMI; 2 x [S, D] bf16 per layer in the prefill, 2 x [D] per layer per token in the decode loop).
+    The residual is folded into rank 0's partial so the sum needs no extra pass."""
+
+    def __init__(self, cfg, state_dict, device="cuda", max_seq_len=4096, n_layers=None, tp_group=None, tp_shard=None):
         super().__init__()
         self.cfg = cfg
         l = cfg["llm"]
         self._dev = torch.device(device)
-        self.w = pack_decoder(state_dict, cfg, self._dev, n_layers)
+        self.tp_group = tp_group
+        self.tp = dist.get_world_size(tp_group) if tp_group is not None else 1
+        self.tp_rank = dist.get_rank(tp_group) if tp_group is not None else 0
+        if tp_shard is not None:                 # (rank, size) WITHOUT a group: one rank's shard run alone, no collectives --
+            self.tp_rank, self.tp = tp_shard     # timing model only (scripts/tp_model.py); the numbers it produces are partial sums
+        self.w = pack_decoder(state_dict, cfg, self._dev, n_layers, self.tp_rank, self.tp)
         self.n_layers = len(self.w["layers"])
-        self.nh, self.nkv, self.hd = l["num_attention_heads"], l["num_key_value_heads"], l["head_dim"]
+        self.nh, self.nkv, self.hd = l["num_attention_heads"] // self.tp, l["num_key_value_heads"] // self.tp, l["head_dim"]
         self.D, self.V, self.eps = l["hidden_size"], l["vocab_size"], l["rms_norm_eps"]
         self.max_seq_len = max_seq_len
         # RoPE tables, fp32, HF MistralRotaryEmbedding: inv_freq = theta^(-2i/d); cos/sin of pos*inv_freq
@@ -37,13 +49,25 @@ class HipMistralDecoder(nn.Module):
         self.tok = torch.zeros((1,), dtype=torch.int32, device=self._dev)
         self.state = torch.zeros((2,), dtype=torch.int32, device=self._dev)
         self.hist = torch.zeros((max_seq_len,), dtype=torch.int32, device=self._dev)
-        I = l["intermediate_size"]
+        I = l["intermediate_size"] // self.tp
         self._b = dict(x0=torch.empty((1, self.D), **bf), qkv=torch.empty(((self.nh + 2 * self.nkv) * self.hd,), **bf),
                        o=torch.empty((self.nh * self.hd,), **bf), x1=torch.empty((self.D,), **bf),
                        a=torch.empty((I,), **bf))
         self.logits = torch.empty((self.V,), dtype=torch.float32, device=self._dev)
         self.graph = None
         self.pos = 0
+
+    def _reduce(self, t):
+        """Sum the row-parallel partial results over the tensor-parallel group (no-op without one).  gloo (CPU tests, debug)
+        takes device tensors through host memory."""
+        if self.tp > 1 and self.tp_group is not None:
+            if t.is_cuda and dist.get_backend(self.tp_group) == "gloo":
+                h = t.cpu()
+                dist.all_reduce(h, group=self.tp_group)
+                t.copy_(h)
+            else:
+                dist.all_reduce(t, group=self.tp_group)
+        return t
 
     # ------------------------------------------------------------------ prefill (M = S tokens, MFMA GEMMs)
     @torch.no_grad()
@@ -64,10 +88,10 @@ class HipMistralDecoder(nn.Module):
             ops.rope_kv(qkv, q, self.kcache[li], self.vcache[li], self.cos_t, self.sin_t, nh, nkv, 0)
             ops.attn_fwd(q, self.kcache[li], self.vcache[li], o, (0, hd, nh * hd), (0, smax * hd, hd), (0, smax * hd, hd),
                          (0, hd, nh * hd), 1, nh, S, S, nh // nkv, hd ** -0.5, True, 0, hd)
-            x = ops.gemm(o, lw["wo"], res=x)
+            x = self._reduce(ops.gemm(o, lw["wo"], res=x if self.tp_rank == 0 else None))
             h = ops.rmsnorm(x, lw["ln2_w"], self.eps)
             a = ops.gemm(h, lw["wgu"], swiglu=True)
-            x = ops.gemm(a, lw["wd"], res=x)
+            x = self._reduce(ops.gemm(a, lw["wd"], res=x if self.tp_rank == 0 else None))
         self.pos = S
         self.last_hidden = x
         if return_all_logits:
@@ -88,9 +112,10 @@ class HipMistralDecoder(nn.Module):
             ops.gemv(lw["wqkv"], x, norm_w=lw["ln1_w"], eps=self.eps, out=b["qkv"], bias=lw["bqkv"])
             ops.attn_decode(b["qkv"], self.kcache[li], self.vcache[li], self.cos_t, self.sin_t, self.partial, b["o"], nh, nkv,
                             self.pos, hd ** -0.5, pos_dev=pos_dev, ctx_cap=self.max_seq_len)
-            ops.gemv(lw["wo"], b["o"], res=x, out=b["x1"])                       # x1 = x + attn
+            r0 = self.tp_rank == 0                                              # the residual rides on rank 0's partial sum
+            self._reduce(ops.gemv(lw["wo"], b["o"], res=x if r0 else None, out=b["x1"]))          # x1 = x + attn
             ops.gemv(lw["wgu"], b["x1"], norm_w=lw["ln2_w"], eps=self.eps, swiglu=True, out=b["a"])
-            ops.gemv(lw["wd"], b["a"], res=b["x1"], out=x)                      # x = x1 + mlp (x's old value is dead)
+            self._reduce(ops.gemv(lw["wd"], b["a"], res=b["x1"] if r0 else None, out=x))          # x = x1 + mlp (x's old value is dead)
         ops.gemv(self.w["lm_head"], x, norm_w=self.w["norm_w"], eps=self.eps, out_f32=True, out=self.logits)
 
     @torch.no_grad()
@@ -108,6 +133,8 @@ class HipMistralDecoder(nn.Module):
     def capture_graph(self):
         """Capture {argmax -> decode step} once as a hipGraph (torch.cuda.CUDAGraph records the launches libvl2hip.so
         enqueues on the capture stream).  Replays read token / position / step from device memory."""
+        if self.tp > 1:
+            raise NotImplementedError("hipGraph decode is built for the single-GPU decoder (collectives are launched eagerly)")
         if self.graph is not None:
             return self.graph
         saved = (self.state.clone(), self.tok.clone(), self.logits.clone(), self.hist[:2].clone())

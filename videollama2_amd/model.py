@@ -20,7 +20,7 @@ from .tower import HipCLIPVisionTower, HipSiglipVisionTower
 
 class VideoLLaMA2Hip(nn.Module):
     def __init__(self, cfg, state_dict, device="cuda", max_seq_len=4096, image_processor=None, n_llm_layers=None,
-                 mm_projector_type=None, sharder=None):
+                 mm_projector_type=None, sharder=None, tp_group=None):
         super().__init__()
         check_supported(cfg)
         mm_projector_type = mm_projector_type or cfg.get("projector", "stc_connector")
@@ -32,7 +32,7 @@ class VideoLLaMA2Hip(nn.Module):
         tower_cls = HipSiglipVisionTower if cfg["vision"].get("family", "clip") == "siglip" else HipCLIPVisionTower   # encoder.py:157-160
         self.vision_tower = tower_cls(cfg, state_dict, device, image_processor=image_processor)
         self.mm_projector = HipSTCConnector(state_dict, device, padding=0 if mm_projector_type == "stc_connector_v35" else 1)
-        self.decoder = HipMistralDecoder(cfg, state_dict, device, max_seq_len, n_llm_layers)
+        self.decoder = HipMistralDecoder(cfg, state_dict, device, max_seq_len, n_llm_layers, tp_group=tp_group)
         self.sharder = sharder or FrameSharder()
 
     def get_vision_tower(self):

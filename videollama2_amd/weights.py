@@ -146,11 +146,20 @@ def pack_gate_up(gate, up):
     return torch.stack([gate.reshape(I // 32, 32, D), up.reshape(I // 32, 32, D)], 1).reshape(2 * I, D).contiguous()
 
 
-def pack_decoder(sd, cfg, dev, n_layers=None):
+def pack_decoder(sd, cfg, dev, n_layers=None, tp_rank=0, tp_size=1):
     """MistralForCausalLM / Qwen2ForCausalLM weights (HF:models/mistral/modeling_mistral.py, models/qwen2/modeling_qwen2.py:
-    the same decoder, Qwen2 with a bias on q/k/v)."""
+    the same decoder, Qwen2 with a bias on q/k/v).
+    tp_size > 1: this rank's Megatron-style shard -- q/k/v and gate/up split by output rows (whole heads; whole 32-row
+    SwiGLU blocks), o_proj and down_proj split by input columns (their outputs are partial sums that the caller all-reduces);
+    norms, embedding and lm_head replicated."""
     l = cfg["llm"]
     n_layers = l["num_hidden_layers"] if n_layers is None else n_layers
+    nh, nkv, hd, I = l["num_attention_heads"], l["num_key_value_heads"], l["head_dim"], l["intermediate_size"]
+    if nh % tp_size or nkv % tp_size or I % tp_size or (I // tp_size) % 64:
+        raise ValueError(f"tensor-parallel degree {tp_size} does not divide heads {nh}/{nkv} or the MLP width {I} into 64-multiples")
+    q0, q1 = tp_rank * (nh // tp_size) * hd, (tp_rank + 1) * (nh // tp_size) * hd
+    k0, k1 = tp_rank * (nkv // tp_size) * hd, (tp_rank + 1) * (nkv // tp_size) * hd
+    i0, i1 = tp_rank * (I // tp_size), (tp_rank + 1) * (I // tp_size)
     out = dict(embed=_bf(sd["model.embed_tokens.weight"], dev), norm_w=_f32(sd["model.norm.weight"], dev),
                lm_head=_bf(sd["lm_head.weight"], dev), layers=[])
     for i in range(n_layers):
@@ -158,14 +167,14 @@ def pack_decoder(sd, cfg, dev, n_layers=None):
         a = p + "self_attn."
         bqkv = None                                    # Qwen2Attention: bias on q/k/v (HF:models/qwen2/modeling_qwen2.py)
         if (a + "q_proj.bias") in sd:
-            bqkv = _f32(torch.cat([sd[a + "q_proj.bias"], sd[a + "k_proj.bias"], sd[a + "v_proj.bias"]], 0), dev)
+            bqkv = _f32(torch.cat([sd[a + "q_proj.bias"][q0:q1], sd[a + "k_proj.bias"][k0:k1], sd[a + "v_proj.bias"][k0:k1]], 0), dev)
         out["layers"].append(dict(
             ln1_w=_f32(sd[p + "input_layernorm.weight"], dev), ln2_w=_f32(sd[p + "post_attention_layernorm.weight"], dev),
             bqkv=bqkv,
-            wqkv=_bf(torch.cat([sd[a + "q_proj.weight"], sd[a + "k_proj.weight"], sd[a + "v_proj.weight"]], 0), dev),
-            wo=_bf(sd[a + "o_proj.weight"], dev),
-            wgu=_bf(pack_gate_up(sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"]), dev),
-            wd=_bf(sd[p + "mlp.down_proj.weight"], dev)))
+            wqkv=_bf(torch.cat([sd[a + "q_proj.weight"][q0:q1], sd[a + "k_proj.weight"][k0:k1], sd[a + "v_proj.weight"][k0:k1]], 0), dev),
+            wo=_bf(sd[a + "o_proj.weight"][:, q0:q1], dev),
+            wgu=_bf(pack_gate_up(sd[p + "mlp.gate_proj.weight"][i0:i1], sd[p + "mlp.up_proj.weight"][i0:i1]), dev),
+            wd=_bf(sd[p + "mlp.down_proj.weight"][:, i0:i1], dev)))
     return out
 
 
