@@ -99,9 +99,10 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=16)
-    ap.add_argument("--model", choices=["v2", "v21"], default="v2",
+    ap.add_argument("--model", choices=["v2", "v21", "72b"], default="v2",
                     help="v2 = VideoLLaMA2-7B (CLIP + stc_connector + Mistral-7B; BASELINE.json's metric), "
-                         "v21 = VideoLLaMA2.1-7B-16F (SigLIP + stc_connector_v35 + Qwen2-7B; SURVEY 8f row 1)")
+                         "v21 = VideoLLaMA2.1-7B-16F (SigLIP + stc_connector_v35 + Qwen2-7B; SURVEY 8f row 1), "
+                         "72b = VideoLLaMA2-72B (CLIP + stc_connector + Qwen2-72B; 150 GB of weights on ONE GPU)")
     ap.add_argument("--new-tokens", type=int, default=32)
     ap.add_argument("--llm-layers", type=int, default=None, help="debug only: fewer decoder layers (INVALID as a result)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -130,18 +131,21 @@ def main():
             dist.init_process_group(backend)
 
     from videollama2_amd import ops
-    from videollama2_amd.config import videollama2_1_7b_16f, videollama2_7b
+    from videollama2_amd.config import videollama2_1_7b_16f, videollama2_72b, videollama2_7b
     from videollama2_amd.model import VideoLLaMA2Hip
-    from videollama2_amd.weights import random_state_dict
+    from videollama2_amd.weights import LazyRandomStateDict, random_state_dict
 
     from videollama2_amd import _lib
     for kv in filter(None, args.tune.split(",")):
         k, v = kv.split("=")
         _lib.call("vl2_set_tuning", int(k), int(v))
     T, n_new = args.frames, args.new_tokens
-    cfg = videollama2_7b(T) if args.model == "v2" else videollama2_1_7b_16f(T)
+    cfg = {"v2": videollama2_7b, "v21": videollama2_1_7b_16f, "72b": videollama2_72b}[args.model](T)
     side = cfg["vision"]["image_size"]
-    sd = random_state_dict(cfg, dev, seed=1234, n_llm_layers=args.llm_layers)
+    if args.model == "72b":      # generated parameter by parameter while packing: the raw + packed copies would not fit 288 GB
+        sd = LazyRandomStateDict(cfg, dev, seed=1234, n_llm_layers=args.llm_layers)
+    else:
+        sd = random_state_dict(cfg, dev, seed=1234, n_llm_layers=args.llm_layers)
     model = VideoLLaMA2Hip(cfg, sd, dev, max_seq_len=4096, n_llm_layers=args.llm_layers)
     del sd
     torch.cuda.empty_cache()
@@ -239,14 +243,16 @@ def main():
         vit_tf, stc_tf, pre_tf, S_alg = algorithmic_tflop(cfg, T)
         fwd_ms = enc_ms + pre_ms
         out = {
-            "metric": ("video-frames/sec encoded (CLIP-ViT + STC), VideoLLaMA2-7B 16f@336^2; prefill/decode tokens/sec as extra keys"
-                       if args.model == "v2" else
-                       "video-frames/sec encoded (SigLIP + STC v35), VideoLLaMA2.1-7B-16F 16f@384^2; prefill/decode tokens/sec as extra keys"),
+            "metric": {"v2": "video-frames/sec encoded (CLIP-ViT + STC), VideoLLaMA2-7B 16f@336^2; prefill/decode tokens/sec as extra keys",
+                       "v21": "video-frames/sec encoded (SigLIP + STC v35), VideoLLaMA2.1-7B-16F 16f@384^2; prefill/decode tokens/sec as extra keys",
+                       "72b": "video-frames/sec encoded (CLIP-ViT + STC-8192), VideoLLaMA2-72B 16f@336^2 on ONE GPU; prefill/decode tokens/sec as extra keys"}[args.model],
             "value": round(T / (enc_ms / 1e3), 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": (f"VideoLLaMA2-7B, {T}-frame 336^2 video, bf16, S={S} prefill, {n_new} greedy decode tokens "
                                     f"(BASELINE.json configs[1])" if args.model == "v2" else
+                                    f"VideoLLaMA2-72B (CLIP-ViT-L + stc_connector + Qwen2-72B, 74.9 B parameters resident on one MI355X), {T}-frame 336^2 video, "
+                                    f"bf16, S={S} prefill, {n_new} greedy decode tokens (BASELINE.json configs[3] without the TP=8 split)" if args.model == "72b" else
                                     f"VideoLLaMA2.1-7B-16F (SigLIP-so400m-384 + stc_connector_v35 + Qwen2-7B), {T}-frame 384^2 video, bf16, "
                                     f"S={S} prefill, {n_new} greedy decode tokens (SURVEY 8f row 1; not BASELINE.json's metric config)"), "frames": T, "prefill_tokens": S, "new_tokens": n_new,
                        "parallelism": (f"frames sharded over {world} ranks (ViT + STC s1/conv3d/s2 per rank, halo + RCCL all-gather of visual tokens); "

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Tensor-parallel decoder on a ONE-GPU box: rank 0's shard of the Mistral-7B / Qwen2-7B decoder at TP = 1 / 2 / 4 / 8 run
+"""Tensor-parallel decoder on a ONE-GPU box: rank 0's shard of the Mistral-7B / Qwen2-7B / Qwen2-72B decoder at TP = 1 / 2 / 4 / 8 run
 alone (no collectives: `tp_shard`), prefill (S = 1621) and decode steps timed with HIP events.  The all-reduces are modelled
 separately from message size and the xGMI link rate (full mesh, 7 links x ~153 GB/s per GPU: a direct reduce-scatter +
 all-gather moves 2 x bytes/N over each link) plus a fixed launch/sync cost per collective.
@@ -9,25 +9,28 @@ all-gather moves 2 x bytes/N over each link) plus a fixed launch/sync cost per c
 import argparse, json, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from videollama2_amd.config import videollama2_1_7b_16f, videollama2_7b
+from videollama2_amd.config import videollama2_1_7b_16f, videollama2_72b, videollama2_7b
 from videollama2_amd.decoder import HipMistralDecoder
-from videollama2_amd.weights import random_state_dict
+from videollama2_amd.weights import LazyRandomStateDict, random_state_dict
 
 LINK_GBS, COLL_FIXED_US = 153.0, 20.0
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--model", choices=["v2", "v21"], default="v2")
+    ap.add_argument("--model", choices=["v2", "v21", "72b"], default="v2")
     ap.add_argument("--tps", type=int, nargs="+", default=[1, 2, 4, 8])
     ap.add_argument("--tokens", type=int, default=1621)
     ap.add_argument("--new", type=int, default=16)
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
-    cfg = videollama2_7b(16) if args.model == "v2" else videollama2_1_7b_16f(16)
+    cfg = {"v2": videollama2_7b, "v21": videollama2_1_7b_16f, "72b": videollama2_72b}[args.model](16)
     l = cfg["llm"]
     keep = ("model.layers.", "model.norm", "model.embed_tokens", "lm_head")
-    sd = {k: v for k, v in random_state_dict(cfg, dev, seed=1234).items() if k.startswith(keep)}
+    if args.model == "72b":
+        sd = LazyRandomStateDict(cfg, dev, seed=1234)      # every shard is generated while it is packed
+    else:
+        sd = {k: v for k, v in random_state_dict(cfg, dev, seed=1234).items() if k.startswith(keep)}
     x = (torch.randn(args.tokens, l["hidden_size"], device=dev) * 0.5).bfloat16()
     ev = lambda: torch.cuda.Event(enable_timing=True)
     base = None

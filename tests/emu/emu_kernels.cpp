@@ -109,7 +109,7 @@ static int32_t run_norm(NormArgs a, bool rms) {
     const int nv = (a.C + 511) / 512;
     dim3 g((a.rows + 3) / 4), blk(256);
     if (rms && a.C > 2048 && a.rows > 1) {
-        emu::launch(dim3(a.rows), blk, [=] { norm_wide_kernel<true>(a); });
+        emu::launch(dim3(a.rows), blk, [=] { norm_wide_kernel<true, 2>(a); });
     } else if (rms) {
         if (nv <= 1) emu::launch(g, blk, [=] { norm_kernel<1, true>(a); });
         else if (nv <= 2) emu::launch(g, blk, [=] { norm_kernel<2, true>(a); });

@@ -166,7 +166,7 @@ def test_gemm_conv3d_gather_full_size(ops):
     assert rel(y, ref) < TOL_BF16_OUT
 
 
-@pytest.mark.parametrize("C,rows", [(128, 37), (1024, 9232), (1152, 1458), (4096, 1521), (3584, 301)])
+@pytest.mark.parametrize("C,rows", [(128, 37), (1024, 9232), (1152, 1458), (4096, 1521), (3584, 301), (8192, 333), (8192, 1)])
 def test_layernorm_rmsnorm(ops, C, rows):
     x, w, b, r = bf(rows, C, scale=2.0) + 0.5, torch.randn(C), torch.randn(C), bf(rows, C)
     x = x.bfloat16()
@@ -242,8 +242,9 @@ def test_attn_softmax_spike(ops):
     assert rel(o[17], ref[17]) < 1e-2
 
 
-def test_stc_direct_kernels_full_width(ops):
-    Fr, H, C = 2, 24, 4096
+@pytest.mark.parametrize("C", [4096, 8192])          # 8192: the STC connector in front of the 72B decoder
+def test_stc_direct_kernels_full_width(ops, C):
+    Fr, H = 2, 24
     x = bf(Fr * H * H, C)
     wt, lnw, lnb = torch.randn(C, 1, 3, 3) * 0.3, torch.randn(C), torch.randn(C)
     wt = wt.bfloat16().float()
@@ -253,8 +254,8 @@ def test_stc_direct_kernels_full_width(ops):
     assert rel(y, ref) < TOL_BF16_OUT
     m = ops.chan_mean(x.to(DEV), Fr, H * H)
     assert rel(m, x.float().view(Fr, H * H, C).mean(1)) < 1e-5
-    w1, b1 = bf(1024, C, scale=C ** -0.5), torch.randn(1024) * 0.1
-    w2, b2 = bf(C, 1024, scale=1 / 32), torch.randn(C) * 0.1
+    w1, b1 = bf(C // 4, C, scale=C ** -0.5), torch.randn(C // 4) * 0.1
+    w2, b2 = bf(C, C // 4, scale=1 / 32), torch.randn(C) * 0.1
     g1 = ops.small_linear(m, w1.to(DEV), b1.to(DEV), ops.ACT_SILU)
     g2 = ops.small_linear(g1, w2.to(DEV), b2.to(DEV), ops.ACT_SIGMOID)
     mref = x.float().view(Fr, H * H, C).mean(1)

@@ -116,3 +116,33 @@ def test_full_width_qwen2_layers_prefill_and_decode():
         assert out[0, 0].item() == toks[0] or (top2[0] - top2[1]).item() < 0.05
     graph = dec.generate(x.to(DEV), max_new_tokens=4, use_graph=True)
     assert graph.tolist() == out.tolist()
+
+
+def test_72b_width_decoder_layer_single_and_tp_shard():
+    """Qwen2-72B widths (hidden 8192, 64 q / 8 kv heads, MLP 29568, q/k/v bias), ONE layer, vocab cut to 2048 for the CPU
+    oracle: S=96 prefill + 2 decode steps vs the fp32 oracle; and the TP=8 shard of rank 3 (MLP slice 3696 zero-padded to
+    3712) loads and runs (its output is a partial sum, only shapes are checked)."""
+    from videollama2_amd.config import videollama2_72b
+    from videollama2_amd.decoder import HipQwen2Decoder
+    cfg = videollama2_72b(16)
+    cfg["llm"]["num_hidden_layers"] = 1
+    cfg["llm"]["vocab_size"] = 2048
+    ocfg = dict(vision=O.config_videollama2_7b(16)["vision"], llm=dict(cfg["llm"]), num_frames=16)
+    keep = lambda n: n.startswith(("model.layers.", "model.norm", "model.embed_tokens", "lm_head"))
+    sd = O.seeded_state_dict(ocfg, 9, only=keep)
+    S = 96
+    x = torch.randn(S, 8192, generator=torch.Generator().manual_seed(2)).bfloat16().float() * 0.5
+    with torch.no_grad():
+        toks, lg = O.greedy_generate(sd, ocfg, x, 3)
+    dec = HipQwen2Decoder(cfg, sd, DEV, max_seq_len=256)
+    out, mine = dec.generate(x.to(DEV), max_new_tokens=3, return_logits=True)
+    rec = []
+    stage_ok("72B-width prefill logits", mine[0], lg[0], FULL_TOL["logits"], rec)
+    if out[0].tolist() == toks:
+        for s in range(1, 3):
+            stage_ok(f"72B-width decode logits {s}", mine[s], lg[s], FULL_TOL["logits"], rec)
+    shard = HipQwen2Decoder(cfg, sd, DEV, max_seq_len=256, tp_shard=(3, 8))
+    assert shard.nh == 8 and shard.nkv == 1 and shard.w["layers"][0]["wd"].shape == (8192, 3712)
+    assert shard.w["layers"][0]["wgu"].shape == (2 * 3712, 8192)
+    part = shard.prefill(x.to(DEV))
+    assert part.shape == (2048,) and torch.isfinite(part).all()

@@ -23,6 +23,18 @@ def videollama2_1_7b_16f(num_frames=16):
         projector="stc_connector_v35", num_frames=num_frames)
 
 
+def videollama2_72b(num_frames=16):
+    """VideoLLaMA2-72B (BASELINE.json configs[3]): CLIP-ViT-L/14-336 + stc_connector + Qwen2-72B-Instruct (public config:
+    hidden 8192, 80 layers, 64 q / 8 kv heads x 128, MLP 29568, vocab 152064).  145 GB of bf16 weights: fits ONE MI355X (288 GB
+    HBM3E); `HipMistralDecoder(tp_group=...)` shards it (29568 / 8 = 3696 per rank is zero-padded to 3712)."""
+    return dict(
+        vision=dict(hidden_size=1024, intermediate_size=4096, num_hidden_layers=24, num_attention_heads=16,
+                    image_size=336, patch_size=14, layer_norm_eps=1e-5, select_layer=-2),
+        llm=dict(family="qwen2", hidden_size=8192, intermediate_size=29568, num_hidden_layers=80, num_attention_heads=64,
+                 num_key_value_heads=8, head_dim=128, vocab_size=152064, rms_norm_eps=1e-6, rope_theta=1e6),
+        projector="stc_connector", num_frames=num_frames)
+
+
 def from_hf_config(hf_cfg, vision_cfg):
     """Build the dict from a Videollama2MistralConfig + CLIPVisionConfig (videollama2_arch.py:49-68 keys)."""
     g = lambda o, k, d=None: getattr(o, k, d)
@@ -65,7 +77,7 @@ def check_supported(cfg):
     for name, n in dims:
         if n % 128:
             errs.append(f"{name} {n} % 128 != 0")
-    if l["hidden_size"] > 4096 or v["hidden_size"] > 4096:
-        errs.append("hidden size > 4096 (row-norm kernels)")
+    if l["hidden_size"] > 8192 or v["hidden_size"] > 8192:
+        errs.append("hidden size > 8192 (row-norm / depthwise kernels)")
     if errs:
         raise ValueError("config not supported by the gfx950 kernels: " + "; ".join(errs))

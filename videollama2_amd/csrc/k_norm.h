@@ -86,21 +86,22 @@ __global__ __launch_bounds__(256) void norm_kernel(NormArgs p) {
     }
 }
 
-// Wide form for FEW, LONG rows (the LLM prefill: 1621 rows x 4096): one workgroup per row, 256 lanes x up to 2 vectors,
+// Wide form for FEW, LONG rows (the LLM prefill: 1621 rows x 4096): one workgroup per row, 256 lanes x NVW (2: C <= 4096,
+// 4: C <= 8192, the 72B decoder) vectors,
 // so the row count, not rows/4, is the number of workgroups in flight (one wave per row leaves a 256-CU chip with ~1.6
 // workgroups per CU: 13 us for 26 MB).  Same per-element arithmetic; the row sums are reduced wave-then-LDS instead of in
 // one wave, i.e. in a different fp32 order than norm_kernel -- the launcher picks by C and the row count only for RMSNorm
 // (rows of one sequence), never for the per-frame LayerNorms, so a frame's result does not depend on how many frames a
 // rank holds.
-template <bool RMS>
+template <bool RMS, int NVW>
 __global__ __launch_bounds__(256) void norm_wide_kernel(NormArgs p) {
     __shared__ float red[8];
     const int row = blockIdx.x;
     const bf16_t* x = p.x + (size_t)row * p.ldx;
-    float v[2][8];
+    float v[NVW][8];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NVW; ++i) {
         const int c = (i * 256 + threadIdx.x) * 8;
         if (c < p.C) {
             unpack8(*(const u32x4*)(x + c), v[i]);
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(256) void norm_wide_kernel(NormArgs p) {
         mean = s * inv_c;
         float q = 0.f;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NVW; ++i) {
             const int c = (i * 256 + threadIdx.x) * 8;
             if (c < p.C) {
 #pragma unroll
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(256) void norm_wide_kernel(NormArgs p) {
         rstd = rsqrtf(q * inv_c + p.eps);
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NVW; ++i) {
         const int c = (i * 256 + threadIdx.x) * 8;
         if (c < p.C) {
             const f32x4 w0 = *(const f32x4*)(p.w + c), w1 = *(const f32x4*)(p.w + c + 4);

@@ -253,12 +253,13 @@ extern "C" int32_t vl2_gemm_bf16(const void* A, const void* W, void* C, const fl
 // ------------------------------------------------------------------------------------------------ norms
 static int32_t launch_norm(const NormArgs& a, bool rms, hipStream_t s, const char* what) {
     if (!a.x || !a.y || !a.w || a.rows <= 0 || a.C <= 0) return fail(VL2_E_BADARG, "%s: null pointer or empty shape", what);
-    if (a.C % 8 || a.C > 4096 || a.ldx % 8 || a.ldy % 8 || (a.res && a.ldres % 8))
-        return fail(VL2_E_SHAPE, "%s: need C%%8==0, C<=4096, aligned strides (C=%d)", what, a.C);
+    if (a.C % 8 || a.C > 8192 || a.ldx % 8 || a.ldy % 8 || (a.res && a.ldres % 8))
+        return fail(VL2_E_SHAPE, "%s: need C%%8==0, C<=8192, aligned strides (C=%d)", what, a.C);
     const int nv = (a.C + 511) / 512;
     dim3 g((a.rows + 3) / 4), b(256);
-    if (rms && a.C > 2048 && a.rows > 1) {        // one sequence's rows: the wide form (a workgroup per row)
-        hipLaunchKernelGGL((norm_wide_kernel<true>), dim3(a.rows), b, 0, s, a);
+    if (rms && (a.C > 4096 || (a.C > 2048 && a.rows > 1))) {     // one sequence's rows: the wide form (a workgroup per row)
+        if (a.C <= 4096) hipLaunchKernelGGL((norm_wide_kernel<true, 2>), dim3(a.rows), b, 0, s, a);
+        else hipLaunchKernelGGL((norm_wide_kernel<true, 4>), dim3(a.rows), b, 0, s, a);
     } else if (rms) {
         if (nv <= 1) hipLaunchKernelGGL((norm_kernel<1, true>), g, b, 0, s, a);
         else if (nv <= 2) hipLaunchKernelGGL((norm_kernel<2, true>), g, b, 0, s, a);
@@ -267,7 +268,8 @@ static int32_t launch_norm(const NormArgs& a, bool rms, hipStream_t s, const cha
         if (nv <= 1) hipLaunchKernelGGL((norm_kernel<1, false>), g, b, 0, s, a);
         else if (nv <= 2) hipLaunchKernelGGL((norm_kernel<2, false>), g, b, 0, s, a);
         else if (nv <= 3) hipLaunchKernelGGL((norm_kernel<3, false>), g, b, 0, s, a);      // SigLIP hidden 1152
-        else hipLaunchKernelGGL((norm_kernel<8, false>), g, b, 0, s, a);
+        else if (nv <= 8) hipLaunchKernelGGL((norm_kernel<8, false>), g, b, 0, s, a);
+        else hipLaunchKernelGGL((norm_kernel<16, false>), g, b, 0, s, a);                  // STC at the 72B decoder's width 8192
     }
     return launched(what);
 }
@@ -338,10 +340,11 @@ extern "C" int32_t vl2_attn_fwd(const void* q, const void* k, const void* v, voi
 extern "C" int32_t vl2_dwconv3x3_ln_silu(const void* x, void* y, const float* w9c, const float* lnw, const float* lnb, int32_t F,
                                          int32_t H, int32_t W, int32_t C, float eps, void* stream) {
     if (!x || !y || !w9c || !lnw || !lnb || F <= 0 || H <= 0 || W <= 0) return fail(VL2_E_BADARG, "vl2_dwconv3x3_ln_silu: bad args");
-    if (C % 8 || C > 4096) return fail(VL2_E_SHAPE, "vl2_dwconv3x3_ln_silu: need C%%8==0 and C<=4096");
+    if (C % 8 || C > 8192) return fail(VL2_E_SHAPE, "vl2_dwconv3x3_ln_silu: need C%%8==0 and C<=8192");
     dim3 g(F * H * W), b(256);
     if (C <= 2048) hipLaunchKernelGGL((dwconv_ln_silu_kernel<1>), g, b, 0, ST(stream), (const bf16_t*)x, (bf16_t*)y, w9c, lnw, lnb, H, W, C, eps);
-    else hipLaunchKernelGGL((dwconv_ln_silu_kernel<2>), g, b, 0, ST(stream), (const bf16_t*)x, (bf16_t*)y, w9c, lnw, lnb, H, W, C, eps);
+    else if (C <= 4096) hipLaunchKernelGGL((dwconv_ln_silu_kernel<2>), g, b, 0, ST(stream), (const bf16_t*)x, (bf16_t*)y, w9c, lnw, lnb, H, W, C, eps);
+    else hipLaunchKernelGGL((dwconv_ln_silu_kernel<4>), g, b, 0, ST(stream), (const bf16_t*)x, (bf16_t*)y, w9c, lnw, lnb, H, W, C, eps);
     return launched("vl2_dwconv3x3_ln_silu");
 }
 extern "C" int32_t vl2_chan_mean(const void* x, float* mean, int32_t F, int32_t HW, int32_t C, void* stream) {
@@ -393,7 +396,7 @@ static void launch_gemv(const GemvArgs& a, int n_out, hipStream_t s) {
 extern "C" int32_t vl2_gemv_bf16(const void* W, const void* x, const float* norm_w, const void* res, const float* bias, void* y,
                                  int32_t N, int32_t K, int32_t ldw, float eps, int32_t flags, void* stream) {
     if (!W || !x || !y || N <= 0 || K <= 0) return fail(VL2_E_BADARG, "vl2_gemv_bf16: bad args");
-    if (K % 8 || ldw % 8 || K > 28672) return fail(VL2_E_SHAPE, "vl2_gemv_bf16: need K%%8==0, K<=28672 (K=%d)", K);
+    if (K % 8 || ldw % 8 || K > 32704) return fail(VL2_E_SHAPE, "vl2_gemv_bf16: need K%%8==0, K<=32704 (x lives in LDS; K=%d)", K);
     const bool sw = flags & VL2_GEMM_SWIGLU, f32 = flags & VL2_GEMM_OUT_F32;
     if (sw && (N % 64 || f32 || bias)) return fail(VL2_E_SHAPE, "vl2_gemv_bf16: SWIGLU needs N%%64==0, bf16 output, no bias");
     GemvArgs a{(const bf16_t*)W, (const bf16_t*)x, norm_w, (const bf16_t*)res, y, N, K, ldw, eps, bias};

@@ -8,6 +8,8 @@ BF16 = torch.bfloat16
 
 
 def normalise_keys(sd):
+    if getattr(sd, "lazy", False):            # generated on demand, already in 5.x naming: never materialise it
+        return sd
     return {k.replace("vision_tower.vision_tower.vision_model.", "vision_tower.vision_tower."): v for k, v in sd.items()}
 
 
@@ -155,11 +157,30 @@ def pack_decoder(sd, cfg, dev, n_layers=None, tp_rank=0, tp_size=1):
     l = cfg["llm"]
     n_layers = l["num_hidden_layers"] if n_layers is None else n_layers
     nh, nkv, hd, I = l["num_attention_heads"], l["num_key_value_heads"], l["head_dim"], l["intermediate_size"]
-    if nh % tp_size or nkv % tp_size or I % tp_size or (I // tp_size) % 64:
-        raise ValueError(f"tensor-parallel degree {tp_size} does not divide heads {nh}/{nkv} or the MLP width {I} into 64-multiples")
+    if nh % tp_size or nkv % tp_size or I % tp_size:
+        raise ValueError(f"tensor-parallel degree {tp_size} does not divide heads {nh}/{nkv} or the MLP width {I}")
     q0, q1 = tp_rank * (nh // tp_size) * hd, (tp_rank + 1) * (nh // tp_size) * hd
     k0, k1 = tp_rank * (nkv // tp_size) * hd, (tp_rank + 1) * (nkv // tp_size) * hd
     i0, i1 = tp_rank * (I // tp_size), (tp_rank + 1) * (I // tp_size)
+    Ip = (i1 - i0 + 63) // 64 * 64            # this rank's MLP slice, zero-padded to the GEMM's K granularity (Qwen2-72B at TP=8:
+                                              # 29568 / 8 = 3696 -> 3712; silu(0) * 0 = 0 meets down_proj's zero columns: exact)
+
+    def rows_padded(w):
+        w = w[i0:i1]
+        if Ip == i1 - i0:
+            return w
+        out = torch.zeros((Ip, w.shape[1]), dtype=w.dtype, device=w.device)
+        out[:i1 - i0] = w
+        return out
+
+    def cols_padded(w):
+        w = w[:, i0:i1]
+        if Ip == i1 - i0:
+            return w
+        out = torch.zeros((w.shape[0], Ip), dtype=w.dtype, device=w.device)
+        out[:, :i1 - i0] = w
+        return out
+
     out = dict(embed=_bf(sd["model.embed_tokens.weight"], dev), norm_w=_f32(sd["model.norm.weight"], dev),
                lm_head=_bf(sd["lm_head.weight"], dev), layers=[])
     for i in range(n_layers):
@@ -173,8 +194,8 @@ def pack_decoder(sd, cfg, dev, n_layers=None, tp_rank=0, tp_size=1):
             bqkv=bqkv,
             wqkv=_bf(torch.cat([sd[a + "q_proj.weight"][q0:q1], sd[a + "k_proj.weight"][k0:k1], sd[a + "v_proj.weight"][k0:k1]], 0), dev),
             wo=_bf(sd[a + "o_proj.weight"][:, q0:q1], dev),
-            wgu=_bf(pack_gate_up(sd[p + "mlp.gate_proj.weight"][i0:i1], sd[p + "mlp.up_proj.weight"][i0:i1]), dev),
-            wd=_bf(sd[p + "mlp.down_proj.weight"][:, i0:i1], dev)))
+            wgu=_bf(pack_gate_up(rows_padded(sd[p + "mlp.gate_proj.weight"]), rows_padded(sd[p + "mlp.up_proj.weight"])), dev),
+            wd=_bf(cols_padded(sd[p + "mlp.down_proj.weight"]), dev)))
     return out
 
 
@@ -259,3 +280,51 @@ def random_state_dict(cfg, device, seed=1234, n_llm_layers=None):
             x = 0.5 * x
         sd[name] = x.to(BF16)
     return sd
+
+
+class LazyRandomStateDict:
+    """`random_state_dict` without ever holding the model twice: every parameter is generated ON the device when it is indexed
+    (its own generator, seeded by the parameter name) and dropped by the caller after packing.  What bench.py needs for the
+    72B decoder: 145 GB of bf16 weights fit one MI355X (288 GB), the raw copy plus the packed copy would not."""
+    lazy = True
+
+    def __init__(self, cfg, device, seed=1234, n_llm_layers=None):
+        self.device, self.seed = device, seed
+        self.shapes = {}
+        for name, shape in state_dict_names(cfg):
+            if n_llm_layers is not None and name.startswith("model.layers.") and int(name.split(".")[2]) >= n_llm_layers:
+                continue
+            self.shapes[name] = shape
+
+    def __contains__(self, name):
+        return name in self.shapes
+
+    def __len__(self):
+        return len(self.shapes)
+
+    def keys(self):
+        return self.shapes.keys()
+
+    def get(self, name, default=None):
+        return self[name] if name in self.shapes else default
+
+    def __getitem__(self, name):
+        import hashlib
+        shape = self.shapes[name]
+        h = int.from_bytes(hashlib.sha256(f"{self.seed}:{name}".encode()).digest()[:7], "little")
+        g = torch.Generator(device=self.device).manual_seed(h)
+        x = torch.randn(shape, generator=g, device=self.device, dtype=torch.float32)
+        leaf = name.split(".")[-1]
+        is_norm = any(t in name for t in ("layernorm", "layer_norm", "layrnorm", ".bn.")) or name == "model.norm.weight"
+        if leaf == "weight" and is_norm:
+            x = 1.0 + 0.1 * x
+        elif leaf == "bias":
+            x = 0.02 * x
+        elif len(shape) >= 2:
+            fan_in = 1
+            for d in shape[1:]:
+                fan_in *= d
+            x = x * (fan_in ** -0.5)
+        else:
+            x = 0.5 * x
+        return x.to(BF16)
