@@ -107,6 +107,8 @@ def main():
     ap.add_argument("--llm-layers", type=int, default=None, help="debug only: fewer decoder layers (INVALID as a result)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--u8-frames", action="store_true", help="feed raw uint8 [T,S,S,3] frames (normalised in the patch-row kernel) instead of bf16 [T,3,S,S]")
+    ap.add_argument("--tp", action="store_true", help="with --gpus N > 1: shard the LLM decoder tensor-parallel over the N ranks "
+                                                      "(BASELINE.json configs[3]); default keeps the decoder replicated like the reference")
     ap.add_argument("--no-graph", action="store_true", help="eager decode loop instead of hipGraph replay")
     ap.add_argument("--vit-streams", type=int, default=None, help="ViT frames as N chunks on N HIP streams (default: the tower's own, 3)")
     ap.add_argument("--tune", type=str, default="", help="debug: comma list key=value for vl2_set_tuning")
@@ -146,7 +148,10 @@ def main():
         sd = LazyRandomStateDict(cfg, dev, seed=1234, n_llm_layers=args.llm_layers)
     else:
         sd = random_state_dict(cfg, dev, seed=1234, n_llm_layers=args.llm_layers)
-    model = VideoLLaMA2Hip(cfg, sd, dev, max_seq_len=4096, n_llm_layers=args.llm_layers)
+    tp_group = dist.group.WORLD if (args.tp and world > 1) else None
+    model = VideoLLaMA2Hip(cfg, sd, dev, max_seq_len=4096, n_llm_layers=args.llm_layers, tp_group=tp_group)
+    if tp_group is not None:
+        args.no_graph = True                       # collectives inside the decode step: eager launches
     del sd
     torch.cuda.empty_cache()
     if args.vit_streams is not None:
@@ -256,7 +261,7 @@ def main():
                                     f"VideoLLaMA2.1-7B-16F (SigLIP-so400m-384 + stc_connector_v35 + Qwen2-7B), {T}-frame 384^2 video, bf16, "
                                     f"S={S} prefill, {n_new} greedy decode tokens (SURVEY 8f row 1; not BASELINE.json's metric config)"), "frames": T, "prefill_tokens": S, "new_tokens": n_new,
                        "parallelism": (f"frames sharded over {world} ranks (ViT + STC s1/conv3d/s2 per rank, halo + RCCL all-gather of visual tokens); "
-                                       f"LLM replicated" if world > 1 else "single GPU"),
+                                       f"LLM {'tensor-parallel over the ranks' if args.tp else 'replicated'}" if world > 1 else "single GPU"),
                        "llm_layers": len(model.decoder.w["layers"]),
                        "decode": "eager launches" if graph is None else "hipGraph replay (argmax + 32-layer step per token)"},
             "encode_ms": round(enc_ms, 3), "prefill_ms": round(pre_ms, 3), "decode_ms_per_token": round(dec_ms / n_new, 4),
