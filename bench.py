@@ -107,6 +107,9 @@ def main():
     ap.add_argument("--llm-layers", type=int, default=None, help="debug only: fewer decoder layers (INVALID as a result)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--u8-frames", action="store_true", help="feed raw uint8 [T,S,S,3] frames (normalised in the patch-row kernel) instead of bf16 [T,3,S,S]")
+    ap.add_argument("--decode-batch", type=int, default=0,
+                    help="extra measurement: after the timed steps, decode this many copies of the request TOGETHER (batched decode, "
+                         "SURVEY 8f row 4) and report aggregate decode tokens/s as `batched_decode`")
     ap.add_argument("--tp", action="store_true", help="with --gpus N > 1: shard the LLM decoder tensor-parallel over the N ranks "
                                                       "(BASELINE.json configs[3]); default keeps the decoder replicated like the reference")
     ap.add_argument("--no-graph", action="store_true", help="eager decode loop instead of hipGraph replay")
@@ -221,6 +224,50 @@ def main():
 
     # ---- roofline of the dominant kernel (gemm_bf16_kernel, MFMA-bound): one extra profiled pass, every GEMM launch
     #      bracketed by HIP events on the launch stream; achieved = sum(algorithmic FLOPs) / sum(kernel time)
+    batched = None
+    if args.decode_batch > 1 and world == 1:
+        # the same spliced prompt, `decode_batch` times: prefill each copy, then time n_new batched decode steps
+        _, _, _, emb, _ = model.prepare_inputs_labels_for_multimodal(ids, mask, None, None, [(frames, "video")])
+        dec, nb = model.decoder, args.decode_batch
+        bb = dec._ensure_batch(nb)
+        for b in range(nb):
+            dec.prefill(emb[0], cache=([k[b] for k in bb["k"]], [v[b] for v in bb["v"]]), logits_out=bb["logits"][b])
+        bb["pos"][:nb].fill_(emb.shape[1])
+        for b in range(nb):
+            ops.argmax(bb["logits"][b], bb["tok"][b:b + 1])
+        dec._decode_kernels_batched(nb)
+        torch.cuda.synchronize()
+
+        def bstep():
+            for b in range(nb):
+                ops.argmax(bb["logits"][b], bb["tok"][b:b + 1])
+            dec._decode_kernels_batched(nb)
+
+        bgraph = None
+        if not args.no_graph:                      # positions / tokens live on the device: the whole batched step replays
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                bstep()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            bgraph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(bgraph, capture_error_mode="thread_local"):
+                bstep()
+            torch.cuda.synchronize()
+        e0, e1 = ev(), ev()
+        e0.record()
+        for _ in range(n_new):
+            if bgraph is not None:
+                bgraph.replay()
+            else:
+                bstep()
+        e1.record()
+        torch.cuda.synchronize()
+        bms = e0.elapsed_time(e1) / n_new
+        batched = {"sequences": nb, "launch": "eager" if bgraph is None else "hipGraph replay", "ms_per_step": round(bms, 4), "tokens_per_s": round(nb / (bms / 1e3), 1),
+                   "hbm_frac_weights_once": round(decode_bytes_per_token(cfg, S + n_new // 2) / (bms / 1e3) / 1e9 / PEAK_HBM_GBS, 4)}
+
     roof = None
     ops.PROFILE = [] if rank == 0 else None      # EVERY rank runs the extra pass (it contains the encoder's collectives);
     step()                                       # only rank 0 brackets its GEMM launches with events
@@ -271,6 +318,8 @@ def main():
             "decode_hbm_frac": round(decode_bytes_per_token(cfg, S + n_new // 2) / (dec_ms / n_new / 1e3) / 1e9 / PEAK_HBM_GBS, 4),
             "roofline": roof,
         }
+        if batched is not None:
+            out["batched_decode"] = batched
         if not args.no_cpu_baseline and world == 1:          # the CPU leg is reported at N=1 only
             try:
                 out["cpu_baseline"] = cpu_baseline(min(os.cpu_count() or 1, 32))   # eager torch oversubscribes badly beyond ~32 threads

@@ -33,6 +33,7 @@ int32_t vl2_version(void);
  *           vl2_set_workspace), 4 = 128x256x64 ping-pong always, 8 = 256x256x32 ping-pong always (4, 8: where N%256==0).  See profiles/r01_gemm_experiments.md. */
 #define VL2_TUNE_GEMM_VARIANT 1
 #define VL2_TUNE_GEMV_ROWS_PER_WAVE 2   /* 1 (default), 2 or 4 output rows streamed by each wave of the decode GEMV */
+#define VL2_TUNE_GEMV_MR_ROWS_PER_WAVE 4 /* 1, 2 (default) or 4 output rows per wave of the batched (multi-row) decode GEMV */
 #define VL2_TUNE_SPLITK 3               /* 0 (default): never; 1: small-grid GEMMs split K when a workspace is attached */
 int32_t vl2_set_tuning(int32_t key, int32_t value);
 /* Optional caller-owned device workspace (>= vl2_workspace_bytes(), 16-byte aligned; NULL detaches).  With a workspace
@@ -124,6 +125,12 @@ int32_t vl2_rope_kv(const void* qkv, void* q_out, void* kcache, void* vcache, co
  * bias (fp32, may be NULL) is Qwen2's q/k/v bias (HF:models/qwen2/modeling_qwen2.py Qwen2Attention).  flags as vl2_gemm_bf16. */
 int32_t vl2_gemv_bf16(const void* W, const void* x, const float* norm_w, const void* res, const float* bias, void* y,
                       int32_t N, int32_t K, int32_t ldw, float eps, int32_t flags, void* stream);
+/* Batched decode: y[b][N] = W[N,K] x[b][K] (+ bias) (+ res[b]) for MB sequences in ONE pass over W (up to
+ * 4 rows per launch, as many as fit 64 KiB of LDS; larger MB is split).  ldx / ldy / ldres = element strides between rows.
+ * Same fused RMSNorm / bias / residual / SwiGLU semantics as vl2_gemv_bf16, applied per row. */
+int32_t vl2_gemv_batched_bf16(const void* W, const void* x, const float* norm_w, const void* res, const float* bias, void* y,
+                              int32_t MB, int32_t N, int32_t K, int32_t ldw, int32_t ldx, int32_t ldy, int32_t ldres, float eps,
+                              int32_t flags, void* stream);
 /* Decode attention for ONE new token at position pos, fused with RoPE and the KV-cache append:
  *   qkv [(nh+2*nkv)*128] = un-roped fused q|k|v projection of the token; the kernel ropes q, ropes k and appends k,v to
  *   cache row pos (HF apply_rotary_pos_emb + DynamicCache.update), then softmax(q K^T / sqrt(d)) V over rows [0, pos]
@@ -133,6 +140,12 @@ int32_t vl2_gemv_bf16(const void* W, const void* x, const float* norm_w, const v
 int32_t vl2_attn_decode(const void* qkv, void* kcache, void* vcache, const float* cos_t, const float* sin_t, float* partial,
                         void* out, int32_t nh, int32_t nkv, int32_t smax, int32_t pos, const int32_t* pos_dev,
                         int32_t ctx_cap, float scale, void* stream);
+/* Batched form: B sequences, each with its own KV cache (kcache + b*cache_bs ...), fused qkv row (qkv + b*qkv_bs), output row
+ * (out + b*out_bs) and position pos_dev[b] (device int32[B]; the launch covers positions < ctx_cap).  partial must hold
+ * B * nh * ceil(ctx_cap/64) * 130 floats. */
+int32_t vl2_attn_decode_batched(const void* qkv, void* kcache, void* vcache, const float* cos_t, const float* sin_t, float* partial,
+                                void* out, int32_t B, int64_t qkv_bs, int64_t cache_bs, int64_t out_bs, int32_t nh, int32_t nkv,
+                                int32_t smax, const int32_t* pos_dev, int32_t ctx_cap, float scale, void* stream);
 /* greedy argmax (first maximal index) of fp32 logits -> *tok (device int32) and hist[step] if hist != NULL.
  * state != NULL (device int32[2] = {position, step}): hist index = state[1], then both counters advance by one, so the
  * whole decode step is replayable from a hipGraph.  HF:generation/utils.py _sample with do_sample=False. */

@@ -21,7 +21,7 @@ extern "C" int64_t vl2_workspace_bytes(void) { return 0; }
 extern "C" int32_t vl2_set_workspace(void*, int64_t) { return 0; }
 
 static int g_gemm_variant = 0;
-extern "C" int32_t vl2_set_tuning(int32_t key, int32_t value) { if (key == 1) { g_gemm_variant = value; return 0; } return (key == 2 || key == 3) ? 0 : -1; }
+extern "C" int32_t vl2_set_tuning(int32_t key, int32_t value) { if (key == 1) { g_gemm_variant = value; return 0; } return (key == 2 || key == 3 || key == 4) ? 0 : -1; }
 template <int ACT, bool SW, bool F32, bool G>
 static void run_gemm(GemmArgs a) {
     if constexpr (!G) {
@@ -194,7 +194,7 @@ extern "C" int32_t vl2_rope_kv(const void* qkv, void* q_out, void* kc, void* vc,
 }
 extern "C" int32_t vl2_gemv_bf16(const void* W, const void* x, const float* norm_w, const void* res, const float* bias, void* y,
                                  int32_t N, int32_t K, int32_t ldw, float eps, int32_t flags, void*) {
-    GemvArgs a{(const bf16_t*)W, (const bf16_t*)x, norm_w, (const bf16_t*)res, y, N, K, ldw, eps, bias};
+    GemvArgs a{(const bf16_t*)W, (const bf16_t*)x, norm_w, (const bf16_t*)res, y, N, K, ldw, eps, bias, 0, 0, 0};
     const bool sw = flags & 1, f32 = flags & 2;
     const int n_out = sw ? N / 2 : N;
     dim3 g((n_out + 7) / 8), blk(256);
@@ -203,14 +203,53 @@ extern "C" int32_t vl2_gemv_bf16(const void* W, const void* x, const float* norm
     else emu::launch(g, blk, [=] { gemv_bf16_kernel<false, false, 2>(a); });
     return 0;
 }
+extern "C" int32_t vl2_gemv_batched_bf16(const void* W, const void* x, const float* norm_w, const void* res, const float* bias,
+                                         void* y, int32_t MB, int32_t N, int32_t K, int32_t ldw, int32_t ldx, int32_t ldy,
+                                         int32_t ldres, float eps, int32_t flags, void*) {
+    const bool sw = flags & 1, f32 = flags & 2;
+    const int n_out = sw ? N / 2 : N, esz = f32 ? 4 : 2;
+    static std::vector<unsigned char> lds;
+    for (int b0 = 0; b0 < MB;) {
+        const int mb = MB - b0 < 3 ? MB - b0 : 3;                // 3 rows per pass: exercises the split and the odd width
+        GemvArgs a{(const bf16_t*)W, (const bf16_t*)x + (size_t)b0 * ldx, norm_w, res ? (const bf16_t*)res + (size_t)b0 * ldres : nullptr,
+                   (char*)y + (size_t)b0 * ldy * esz, N, K, ldw, eps, bias, ldx, ldy, ldres};
+        dim3 g((n_out + 7) / 8), blk(256);                       // 2 rows per wave
+        if (mb == 1) {
+            dim3 g1((n_out + 7) / 8);
+            if (sw) emu::launch(g1, blk, [=] { gemv_bf16_kernel<true, false, 2>(a); });
+            else if (f32) emu::launch(g1, blk, [=] { gemv_bf16_kernel<false, true, 2>(a); });
+            else emu::launch(g1, blk, [=] { gemv_bf16_kernel<false, false, 2>(a); });
+        } else if (mb == 2) {
+            if (sw) emu::launch(g, blk, [=] { gemv_mr_bf16_kernel<true, false, 2, 2>(a); });
+            else if (f32) emu::launch(g, blk, [=] { gemv_mr_bf16_kernel<false, true, 2, 2>(a); });
+            else emu::launch(g, blk, [=] { gemv_mr_bf16_kernel<false, false, 2, 2>(a); });
+        } else {
+            if (sw) emu::launch(g, blk, [=] { gemv_mr_bf16_kernel<true, false, 3, 2>(a); });
+            else if (f32) emu::launch(g, blk, [=] { gemv_mr_bf16_kernel<false, true, 3, 2>(a); });
+            else emu::launch(g, blk, [=] { gemv_mr_bf16_kernel<false, false, 3, 2>(a); });
+        }
+        b0 += mb;
+    }
+    return 0;
+}
 extern "C" int32_t vl2_attn_decode(const void* qkv, void* kc, void* vc, const float* cos_t, const float* sin_t, float* partial,
                                    void* out, int32_t nh, int32_t nkv, int32_t smax, int32_t pos, const int32_t* pos_dev,
                                    int32_t ctx_cap, float scale, void*) {
     const int group = nh / nkv, cap = pos_dev ? ctx_cap : pos + 1, nsplit = (cap + 63) / 64;
     if (cap <= 0 || cap > smax) return -2;
     emu::launch(dim3(nsplit, nkv, (group + 3) / 4), dim3(256), [=] {
-        attn_decode_kernel((const bf16_t*)qkv, (bf16_t*)kc, (bf16_t*)vc, cos_t, sin_t, partial, nh, group, nkv, smax, pos, pos_dev, scale * 1.4426950408889634f); });
-    emu::launch(dim3(nh), dim3(128), [=] { attn_decode_combine_kernel(partial, (bf16_t*)out, nsplit, pos, pos_dev); });
+        attn_decode_kernel((const bf16_t*)qkv, (bf16_t*)kc, (bf16_t*)vc, cos_t, sin_t, partial, nh, group, nkv, smax, pos, pos_dev, scale * 1.4426950408889634f, 0L, 0L, 0L); });
+    emu::launch(dim3(nh), dim3(128), [=] { attn_decode_combine_kernel(partial, (bf16_t*)out, nsplit, pos, pos_dev, 0L, 0L); });
+    return 0;
+}
+extern "C" int32_t vl2_attn_decode_batched(const void* qkv, void* kc, void* vc, const float* cos_t, const float* sin_t, float* partial,
+                                           void* out, int32_t B, int64_t qkv_bs, int64_t cache_bs, int64_t out_bs, int32_t nh, int32_t nkv,
+                                           int32_t smax, const int32_t* pos_dev, int32_t ctx_cap, float scale, void*) {
+    const int group = nh / nkv, nsplit = (ctx_cap + 63) / 64;
+    const long pbs = (long)nh * nsplit * 130;
+    emu::launch(dim3(nsplit, nkv * B, (group + 3) / 4), dim3(256), [=] {
+        attn_decode_kernel((const bf16_t*)qkv, (bf16_t*)kc, (bf16_t*)vc, cos_t, sin_t, partial, nh, group, nkv, smax, 0, pos_dev, scale * 1.4426950408889634f, (long)qkv_bs, (long)cache_bs, pbs); });
+    emu::launch(dim3(nh, B), dim3(128), [=] { attn_decode_combine_kernel(partial, (bf16_t*)out, nsplit, 0, pos_dev, pbs, (long)out_bs); });
     return 0;
 }
 extern "C" int32_t vl2_argmax(const float* logits, int32_t V, int32_t* tok, int32_t* hist, int32_t step, int32_t* state, void*) {

@@ -408,3 +408,25 @@ def test_patchify_u8_matches_normalise_then_patchify(ops, S, mean, std):
     ulp = ((rows_f.float() - rows_u.float()).abs() / rows_f.float().abs().clamp_min(1e-3)).max().item()
     assert same > 0.995 and ulp <= 2 ** -7, (same, ulp)
     assert rows_u[:, 3 * P * P:].abs().max().item() == 0
+
+
+def test_gemv_batched_rows_equal_single_row(ops):
+    """Multi-row GEMV at 7B shapes: each of the MB rows equals the single-row kernel bit for bit, incl. the K = 14336 case
+    that only fits 2 rows of x in LDS per pass (the launcher splits a batch of 4)."""
+    from videollama2_amd.weights import pack_gate_up
+    for N, K, kw in ((6144, 4096, dict(norm=True)), (4096, 14336, dict(res=True)), (4096, 4096, dict(res=True, bias=True))):
+        w = bf(N, K, scale=K ** -0.5).to(DEV)
+        x = bf(4, K).to(DEV)
+        nw = (1 + 0.1 * torch.randn(K)).to(DEV) if kw.get("norm") else None
+        res = bf(4, N).to(DEV) if kw.get("res") else None
+        bias = torch.randn(N).to(DEV) if kw.get("bias") else None
+        for mb in (2, 3, 4):
+            got = ops.gemv_batched(w, x[:mb], norm_w=nw, res=None if res is None else res[:mb], bias=bias)
+            for b in range(mb):
+                one = ops.gemv(w, x[b], norm_w=nw, res=None if res is None else res[b], bias=bias)
+                assert torch.equal(got[b], one), (N, K, mb, b)
+    wgu = pack_gate_up(bf(2048, 4096, scale=1 / 64), bf(2048, 4096, scale=1 / 64, seed=1)).to(DEV)
+    x, nw = bf(4, 4096).to(DEV), (1 + 0.1 * torch.randn(4096)).to(DEV)
+    got = ops.gemv_batched(wgu, x, norm_w=nw, swiglu=True)
+    for b in range(4):
+        assert torch.equal(got[b], ops.gemv(wgu, x[b], norm_w=nw, swiglu=True))

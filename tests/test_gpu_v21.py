@@ -146,3 +146,23 @@ def test_72b_width_decoder_layer_single_and_tp_shard():
     assert shard.w["layers"][0]["wgu"].shape == (2 * 3712, 8192)
     part = shard.prefill(x.to(DEV))
     assert part.shape == (2048,) and torch.isfinite(part).all()
+
+
+def test_batched_decode_equals_sequential_full_width():
+    """Batched decode at Mistral-7B widths (2 layers): 4 requests of different lengths decoded together vs one at a time --
+    same tokens, bit-identical logits (the multi-row GEMV streams the weights once for the 4 tokens of a step)."""
+    from videollama2_amd.decoder import HipMistralDecoder
+    cfg = O.config_videollama2_7b(16)
+    cfg["llm"]["num_hidden_layers"] = 2
+    keep = lambda n: n.startswith(("model.layers.", "model.norm", "model.embed_tokens", "lm_head"))
+    sd = O.seeded_state_dict(cfg, 5, only=keep)
+    dec = HipMistralDecoder(cfg, sd, DEV, max_seq_len=512)
+    g = torch.Generator().manual_seed(8)
+    embeds = [(torch.randn(n, 4096, generator=g) * 0.5).bfloat16().to(DEV) for n in (300, 77, 129, 1)]
+    seq = [dec.generate(e, max_new_tokens=6, return_logits=True) for e in embeds]
+    outs, blogits = dec.generate_batch(embeds, max_new_tokens=6, return_logits=True)
+    for b, (toks, logits) in enumerate(seq):
+        assert outs[b].tolist() == toks[0].tolist(), b
+        assert torch.equal(blogits[:, b], logits), b
+    again = dec.generate_batch(embeds[:3], max_new_tokens=6)                 # smaller batch on the same buffers
+    assert [o.tolist() for o in again] == [s[0][0].tolist() for s in seq[:3]]

@@ -62,6 +62,7 @@ struct GemvArgs {
     int N, K, ldw;
     float eps;
     const float* bias;      // [N_out] added before the residual (Qwen2 q/k/v bias) or null; not with SWIGLU
+    int ldx, ldy, ldres;    // gemv_mr only: element strides between the MB rows of x / y / res
 };
 
 // grid = ceil(N_out / (4*RPW)), block 256; dynamic LDS = K * 2 bytes (x as bf16)
@@ -154,6 +155,114 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvArgs p) {
     }
 }
 
+// Multi-row form for BATCHED decode: y[b][:] = W x[b][:] for MB = 2..4 sequences in one pass over W.
+// Decode is bound by streaming the weights; with MB tokens (one per sequence) sharing the stream, the weights are read once
+// for MB outputs.  Same structure as gemv_bf16_kernel (one output row per wave, the row's 8 loads issued before x is
+// staged); x rows live in LDS as [MB][K] bf16 (MB * K * 2 <= 64 KiB: the launcher splits larger batches), every weight
+// vector is multiplied against the MB x vectors it meets.  grid = ceil(N_out / 4), block 256.
+template <bool SWIGLU, bool OUT_F32, int MB, int RPW>
+__global__ __launch_bounds__(256) void gemv_mr_bf16_kernel(GemvArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char vl2_smem[];
+    __shared__ float red[MB][4];
+    bf16_t* xs = (bf16_t*)vl2_smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_out = SWIGLU ? p.N / 2 : p.N;
+    const int nvec = p.K >> 3;
+    const bool one_pass = nvec <= 512;
+    u32x4 wv[8], uv[8];
+    auto issue_row = [&](int j, int v0) {
+        const int row0 = SWIGLU ? (j >> 5) * 64 + (j & 31) : j;
+        const bf16_t* w0p = p.W + (size_t)row0 * p.ldw;
+        const bf16_t* w1p = w0p + (size_t)32 * p.ldw;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int v = v0 + i * 64 + lane;
+            if (v < nvec) {
+                wv[i] = __builtin_nontemporal_load((const u32x4*)(w0p + (size_t)v * 8));
+                if (SWIGLU) uv[i] = __builtin_nontemporal_load((const u32x4*)(w1p + (size_t)v * 8));
+            }
+        }
+    };
+    const int jfirst = (blockIdx.x * 4 + wave) * RPW;      // RPW consecutive output rows per wave: staging MB rows of x
+    if (one_pass && jfirst < n_out) issue_row(jfirst, 0);  // (MB x the single-row prologue) is amortised over 4*RPW rows
+    float rstd[MB];
+#pragma unroll
+    for (int b = 0; b < MB; ++b) rstd[b] = 1.f;
+    if (p.norm_w) {
+#pragma unroll
+        for (int b = 0; b < MB; ++b) {
+            float ss = 0.f;
+            for (int k = tid * 8; k < p.K; k += 2048) {
+                float v[8];
+                unpack8(*(const u32x4*)(p.x + (size_t)b * p.ldx + k), v);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) ss += v[q] * v[q];
+            }
+            ss = wave_sum(ss);
+            if (lane == 0) red[b][wave] = ss;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < MB; ++b) rstd[b] = rsqrtf((red[b][0] + red[b][1] + red[b][2] + red[b][3]) / (float)p.K + p.eps);
+    }
+#pragma unroll
+    for (int b = 0; b < MB; ++b)
+        for (int k = tid * 8; k < p.K; k += 2048) {
+            u32x4 raw = *(const u32x4*)(p.x + (size_t)b * p.ldx + k);
+            if (p.norm_w) {
+                float v[8];
+                unpack8(raw, v);
+                const f32x4 w0 = *(const f32x4*)(p.norm_w + k), w1 = *(const f32x4*)(p.norm_w + k + 4);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = v[q] * rstd[b] * (q < 4 ? w0[q] : w1[q - 4]);
+                raw = pack8(v);
+            }
+            *(u32x4*)(xs + (size_t)b * p.K + k) = raw;
+        }
+    __syncthreads();
+#pragma unroll 1
+    for (int r = 0; r < RPW; ++r) {
+    const int j = jfirst + r;
+    if (j >= n_out) break;
+    float a0[MB], a1[MB];
+#pragma unroll
+    for (int b = 0; b < MB; ++b) a0[b] = a1[b] = 0.f;
+    for (int v0 = 0; v0 < nvec; v0 += 64 * 8) {
+        if (!(one_pass && r == 0)) issue_row(j, v0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int v = v0 + i * 64 + lane;
+            if (v < nvec) {
+#pragma unroll
+                for (int b = 0; b < MB; ++b) {
+                    const u32x4 xv = *(const u32x4*)(xs + (size_t)b * p.K + (size_t)v * 8);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        a0[b] = dot2_bf16(wv[i][q], xv[q], a0[b]);
+                        if (SWIGLU) a1[b] = dot2_bf16(uv[i][q], xv[q], a1[b]);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < MB; ++b) {
+        a0[b] = wave_sum(a0[b]);
+        if (SWIGLU) a1[b] = wave_sum(a1[b]);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int b = 0; b < MB; ++b) {
+            float o = SWIGLU ? silu_f(a0[b]) * a1[b] : a0[b];
+            if (!SWIGLU && p.bias) o += p.bias[j];
+            if (p.res) o += bf2f(p.res[(size_t)b * p.ldres + j]);
+            if (OUT_F32) ((float*)p.y)[(size_t)b * p.ldy + j] = o;
+            else ((bf16_t*)p.y)[(size_t)b * p.ldy + j] = f2bf(o);
+        }
+    }
+    }
+}
+
 // ---- decode attention (flash-decoding) fused with RoPE and the KV-cache append of the new token.
 // qkv [(nh+2*nkv)*128] = the un-roped fused projection of the ONE new token at position pos (pos = *pos_dev when pos_dev
 // is non-null, so a captured hipGraph replays with a moving position).  grid = (nsplit_cap, nkv, ceil(group/4)), 256
@@ -168,7 +277,10 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
                                                           bf16_t* __restrict__ vcache, const float* __restrict__ cos_t,
                                                           const float* __restrict__ sin_t, float* __restrict__ partial,
                                                           int nh, int group, int nkv, int smax, int pos_arg,
-                                                          const int* __restrict__ pos_dev, float scale_log2e) {
+                                                          const int* __restrict__ pos_dev, float scale_log2e,
+                                                          long qkv_bs, long cache_bs, long partial_bs) {
+    // batched decode: blockIdx.y = kv head + nkv * sequence; sequence b uses qkv + b*qkv_bs, caches + b*cache_bs,
+    // partial + b*partial_bs and position pos_dev[b] (single sequence: strides 0, b = 0)
     constexpr int HD = 128, HALF = 64;
     __shared__ __attribute__((aligned(16))) float qs[4][HD];
     __shared__ __attribute__((aligned(16))) float pk[64][4];       // p[key][head]
@@ -176,10 +288,14 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
     __shared__ __attribute__((aligned(16))) float oacc[4][4][HD];   // [wave][head][d]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kl = lane & 15, hh = lane >> 4;
-    const int split = blockIdx.x, hk = blockIdx.y, nsplit = gridDim.x;
+    const int split = blockIdx.x, hk = (int)blockIdx.y % nkv, bseq = (int)blockIdx.y / nkv, nsplit = gridDim.x;
     const int h0 = blockIdx.z * 4;                                  // first q head (within the group) of this block
     const int ng = group - h0 < 4 ? group - h0 : 4;                 // q heads of this block
-    const int pos = pos_dev ? *pos_dev : pos_arg;
+    const int pos = pos_dev ? pos_dev[bseq] : pos_arg;
+    qkv += (size_t)bseq * qkv_bs;
+    kcache += (size_t)bseq * cache_bs;
+    vcache += (size_t)bseq * cache_bs;
+    partial += (size_t)bseq * partial_bs;
     const int ctx = pos + 1;
     const int k0 = split * 64;
     if (k0 >= ctx) return;
@@ -276,13 +392,15 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
 // Wave 0 turns the (m_i, l_i) pairs into weights with two shuffle reductions; then every thread sums its column with
 // independent, coalesced loads (no dependent chain over the slices).
 __global__ __launch_bounds__(128) void attn_decode_combine_kernel(const float* __restrict__ partial, bf16_t* __restrict__ out,
-                                                                  int nsplit_cap, int pos_arg, const int* __restrict__ pos_dev) {
+                                                                  int nsplit_cap, int pos_arg, const int* __restrict__ pos_dev,
+                                                                  long partial_bs, long out_bs) {
     __shared__ float wgt[64];
     __shared__ float inv_l;
-    const int h = blockIdx.x, d = threadIdx.x;
-    const int pos = pos_dev ? *pos_dev : pos_arg;
+    const int h = blockIdx.x, d = threadIdx.x, bseq = blockIdx.y;       // grid = (nh, sequences)
+    const int pos = pos_dev ? pos_dev[bseq] : pos_arg;
     const int nsplit = (pos + 64) >> 6;                       // <= 64 (max context 4096)
-    const float* src = partial + (size_t)h * nsplit_cap * 130;
+    const float* src = partial + (size_t)bseq * partial_bs + (size_t)h * nsplit_cap * 130;
+    out += (size_t)bseq * out_bs;
     if (d < 64) {
         const bool live = d < nsplit;
         const float m = live ? src[d * 130] : -1e30f;

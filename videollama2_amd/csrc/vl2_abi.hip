@@ -43,11 +43,13 @@ static int64_t g_ws_bytes = 0;
 #define SPLITK_CNT_OFF (SK_FLAGS_OFF + (int64_t)(SK_GRID + 1) * 4 + 12)
 #define SK_WS_BYTES (SPLITK_CNT_OFF + (int64_t)SPLITK_MAX_TILES * 4)
 static int g_splitk = 0;             // VL2_TUNE_SPLITK: 0 = never (default: results independent of M), 1 = small grids split K
+static int g_gemv_mr_rpw = 2;   // batched GEMV rows per wave (VL2_TUNE_GEMV_MR_ROWS_PER_WAVE); measured at B=4: 5.56 / 5.04 / 5.56 ms per step at 1 / 2 / 4
 static int g_gemv_rpw = 1;   // measured on MI355X: 3.09 / 3.30 / 3.97 ms per 7B decode token at 1 / 2 / 4 rows per wave
 extern "C" int32_t vl2_set_tuning(int32_t key, int32_t value) {
     if (key == VL2_TUNE_GEMM_VARIANT && (value == 0 || value == 1 || value == 2 || value == 4 || value == 8 || value == 32)) { g_gemm_variant = value; return 0; }
     if (key == VL2_TUNE_GEMV_ROWS_PER_WAVE && (value == 1 || value == 2 || value == 4)) { g_gemv_rpw = value; return 0; }
     if (key == VL2_TUNE_SPLITK && (value == 0 || value == 1)) { g_splitk = value; return 0; }
+    if (key == VL2_TUNE_GEMV_MR_ROWS_PER_WAVE && (value == 1 || value == 2 || value == 4)) { g_gemv_mr_rpw = value; return 0; }
     return fail(VL2_E_BADARG, "vl2_set_tuning: unknown key/value %d/%d", key, value);
 }
 
@@ -399,11 +401,49 @@ extern "C" int32_t vl2_gemv_bf16(const void* W, const void* x, const float* norm
     if (K % 8 || ldw % 8 || K > 32704) return fail(VL2_E_SHAPE, "vl2_gemv_bf16: need K%%8==0, K<=32704 (x lives in LDS; K=%d)", K);
     const bool sw = flags & VL2_GEMM_SWIGLU, f32 = flags & VL2_GEMM_OUT_F32;
     if (sw && (N % 64 || f32 || bias)) return fail(VL2_E_SHAPE, "vl2_gemv_bf16: SWIGLU needs N%%64==0, bf16 output, no bias");
-    GemvArgs a{(const bf16_t*)W, (const bf16_t*)x, norm_w, (const bf16_t*)res, y, N, K, ldw, eps, bias};
+    GemvArgs a{(const bf16_t*)W, (const bf16_t*)x, norm_w, (const bf16_t*)res, y, N, K, ldw, eps, bias, 0, 0, 0};
     if (sw) launch_gemv<true, false>(a, N / 2, ST(stream));
     else if (f32) launch_gemv<false, true>(a, N, ST(stream));
     else launch_gemv<false, false>(a, N, ST(stream));
     return launched("vl2_gemv_bf16");
+}
+template <bool SW, bool F32>
+static void launch_gemv_mr(const GemvArgs& a, int mb, int n_out, hipStream_t s) {
+    const int rpw = g_gemv_mr_rpw;                    // output rows per wave (amortises staging MB rows of x)
+    const dim3 g((n_out + 4 * rpw - 1) / (4 * rpw)), b(256);
+    const size_t lds = (size_t)mb * a.K * 2;
+#define VL2_MR(MBV) do { if (rpw == 1) hipLaunchKernelGGL((gemv_mr_bf16_kernel<SW, F32, MBV, 1>), g, b, lds, s, a); \
+                         else if (rpw == 2) hipLaunchKernelGGL((gemv_mr_bf16_kernel<SW, F32, MBV, 2>), g, b, lds, s, a); \
+                         else hipLaunchKernelGGL((gemv_mr_bf16_kernel<SW, F32, MBV, 4>), g, b, lds, s, a); } while (0)
+    if (mb == 2) VL2_MR(2); else if (mb == 3) VL2_MR(3); else VL2_MR(4);
+#undef VL2_MR
+}
+extern "C" int32_t vl2_gemv_batched_bf16(const void* W, const void* x, const float* norm_w, const void* res, const float* bias,
+                                         void* y, int32_t MB, int32_t N, int32_t K, int32_t ldw, int32_t ldx, int32_t ldy,
+                                         int32_t ldres, float eps, int32_t flags, void* stream) {
+    if (!W || !x || !y || N <= 0 || K <= 0 || MB <= 0) return fail(VL2_E_BADARG, "vl2_gemv_batched_bf16: bad args");
+    if (K % 8 || ldw % 8 || ldx % 8 || K > 32704) return fail(VL2_E_SHAPE, "vl2_gemv_batched_bf16: need K%%8==0, K<=32704 (K=%d)", K);
+    const bool sw = flags & VL2_GEMM_SWIGLU, f32 = flags & VL2_GEMM_OUT_F32;
+    if (sw && (N % 64 || f32 || bias)) return fail(VL2_E_SHAPE, "vl2_gemv_batched_bf16: SWIGLU needs N%%64==0, bf16 output, no bias");
+    const int n_out = sw ? N / 2 : N;
+    const int esz = f32 ? 4 : 2;
+    const int cap = 65536 / (K * 2) < 4 ? 65536 / (K * 2) : 4;        // x rows that fit the 64 KiB of LDS, at most 4 per pass
+    for (int b0 = 0; b0 < MB;) {
+        const int mb = MB - b0 < cap ? MB - b0 : cap;
+        GemvArgs a{(const bf16_t*)W, (const bf16_t*)x + (size_t)b0 * ldx, norm_w, res ? (const bf16_t*)res + (size_t)b0 * ldres : nullptr,
+                   (char*)y + (size_t)b0 * ldy * esz, N, K, ldw, eps, bias, ldx, ldy, ldres};
+        if (mb == 1) {
+            if (sw) launch_gemv<true, false>(a, n_out, ST(stream));
+            else if (f32) launch_gemv<false, true>(a, n_out, ST(stream));
+            else launch_gemv<false, false>(a, n_out, ST(stream));
+        } else {
+            if (sw) launch_gemv_mr<true, false>(a, mb, n_out, ST(stream));
+            else if (f32) launch_gemv_mr<false, true>(a, mb, n_out, ST(stream));
+            else launch_gemv_mr<false, false>(a, mb, n_out, ST(stream));
+        }
+        b0 += mb;
+    }
+    return launched("vl2_gemv_batched_bf16");
 }
 extern "C" int32_t vl2_attn_decode(const void* qkv, void* kcache, void* vcache, const float* cos_t, const float* sin_t,
                                    float* partial, void* out, int32_t nh, int32_t nkv, int32_t smax, int32_t pos,
@@ -416,9 +456,27 @@ extern "C" int32_t vl2_attn_decode(const void* qkv, void* kcache, void* vcache, 
     if (cap <= 0 || cap > smax || (!pos_dev && pos < 0)) return fail(VL2_E_SHAPE, "vl2_attn_decode: position %d outside the cache (%d)", cap - 1, smax);
     const int nsplit = (cap + 63) / 64;
     hipLaunchKernelGGL(attn_decode_kernel, dim3(nsplit, nkv, (group + 3) / 4), dim3(256), 0, ST(stream), (const bf16_t*)qkv, (bf16_t*)kcache,
-                       (bf16_t*)vcache, cos_t, sin_t, partial, nh, group, nkv, smax, pos, pos_dev, scale * 1.4426950408889634f);
-    hipLaunchKernelGGL(attn_decode_combine_kernel, dim3(nh), dim3(128), 0, ST(stream), partial, (bf16_t*)out, nsplit, pos, pos_dev);
+                       (bf16_t*)vcache, cos_t, sin_t, partial, nh, group, nkv, smax, pos, pos_dev, scale * 1.4426950408889634f, 0L, 0L, 0L);
+    hipLaunchKernelGGL(attn_decode_combine_kernel, dim3(nh), dim3(128), 0, ST(stream), partial, (bf16_t*)out, nsplit, pos, pos_dev, 0L, 0L);
     return launched("vl2_attn_decode");
+}
+extern "C" int32_t vl2_attn_decode_batched(const void* qkv, void* kcache, void* vcache, const float* cos_t, const float* sin_t,
+                                           float* partial, void* out, int32_t B, int64_t qkv_bs, int64_t cache_bs, int64_t out_bs,
+                                           int32_t nh, int32_t nkv, int32_t smax, const int32_t* pos_dev, int32_t ctx_cap, float scale,
+                                           void* stream) {
+    if (!qkv || !kcache || !vcache || !cos_t || !sin_t || !partial || !out || !pos_dev || nh <= 0 || nkv <= 0 || B <= 0)
+        return fail(VL2_E_BADARG, "vl2_attn_decode_batched: bad args");
+    const int group = nh / nkv;
+    if (group * nkv != nh) return fail(VL2_E_SHAPE, "vl2_attn_decode_batched: need nh = nkv*group");
+    if (ctx_cap <= 0 || ctx_cap > smax) return fail(VL2_E_SHAPE, "vl2_attn_decode_batched: ctx_cap %d outside the cache (%d)", ctx_cap, smax);
+    const int nsplit = (ctx_cap + 63) / 64;
+    const long partial_bs = (long)nh * nsplit * 130;
+    hipLaunchKernelGGL(attn_decode_kernel, dim3(nsplit, nkv * B, (group + 3) / 4), dim3(256), 0, ST(stream), (const bf16_t*)qkv,
+                       (bf16_t*)kcache, (bf16_t*)vcache, cos_t, sin_t, partial, nh, group, nkv, smax, 0, pos_dev,
+                       scale * 1.4426950408889634f, (long)qkv_bs, (long)cache_bs, partial_bs);
+    hipLaunchKernelGGL(attn_decode_combine_kernel, dim3(nh, B), dim3(128), 0, ST(stream), partial, (bf16_t*)out, nsplit, 0, pos_dev,
+                       partial_bs, (long)out_bs);
+    return launched("vl2_attn_decode_batched");
 }
 extern "C" int32_t vl2_argmax(const float* logits, int32_t V, int32_t* tok, int32_t* hist, int32_t step, int32_t* state,
                               void* stream) {

@@ -71,9 +71,11 @@ class HipMistralDecoder(nn.Module):
 
     # ------------------------------------------------------------------ prefill (M = S tokens, MFMA GEMMs)
     @torch.no_grad()
-    def prefill(self, x, return_all_logits=False):
+    def prefill(self, x, return_all_logits=False, cache=None, logits_out=None):
         """x: inputs_embeds [S, D] (any float dtype, device).  Fills the KV cache for positions 0..S-1 and returns
-        fp32 logits of the last position [V] (or all positions [S, V])."""
+        fp32 logits of the last position [V] (or all positions [S, V]).  cache = (k per layer, v per layer) overrides the
+        decoder's own single-sequence cache (batched decode gives every sequence its slice)."""
+        kcache, vcache = cache if cache is not None else (self.kcache, self.vcache)
         S = x.shape[0]
         if S > self.max_seq_len:
             raise ValueError(f"sequence length {S} exceeds the KV cache ({self.max_seq_len})")
@@ -85,8 +87,8 @@ class HipMistralDecoder(nn.Module):
         for li, lw in enumerate(self.w["layers"]):
             h = ops.rmsnorm(x, lw["ln1_w"], self.eps)
             qkv = ops.gemm(h, lw["wqkv"], bias=lw["bqkv"])              # bqkv: Qwen2 only (None for Mistral)
-            ops.rope_kv(qkv, q, self.kcache[li], self.vcache[li], self.cos_t, self.sin_t, nh, nkv, 0)
-            ops.attn_fwd(q, self.kcache[li], self.vcache[li], o, (0, hd, nh * hd), (0, smax * hd, hd), (0, smax * hd, hd),
+            ops.rope_kv(qkv, q, kcache[li], vcache[li], self.cos_t, self.sin_t, nh, nkv, 0)
+            ops.attn_fwd(q, kcache[li], vcache[li], o, (0, hd, nh * hd), (0, smax * hd, hd), (0, smax * hd, hd),
                          (0, hd, nh * hd), 1, nh, S, S, nh // nkv, hd ** -0.5, True, 0, hd)
             x = self._reduce(ops.gemm(o, lw["wo"], res=x if self.tp_rank == 0 else None))
             h = ops.rmsnorm(x, lw["ln2_w"], self.eps)
@@ -97,7 +99,8 @@ class HipMistralDecoder(nn.Module):
         if return_all_logits:
             h = ops.rmsnorm(x, self.w["norm_w"], self.eps)
             return ops.gemm(h, self.w["lm_head"], out_f32=True)
-        return ops.gemv(self.w["lm_head"], x[S - 1], norm_w=self.w["norm_w"], eps=self.eps, out_f32=True, out=self.logits)
+        return ops.gemv(self.w["lm_head"], x[S - 1], norm_w=self.w["norm_w"], eps=self.eps, out_f32=True,
+                        out=self.logits if logits_out is None else logits_out)
 
     # ------------------------------------------------------------------ decode (M = 1, HBM-bound GEMVs)
     def _decode_kernels(self, dyn):
@@ -197,6 +200,76 @@ class HipMistralDecoder(nn.Module):
                 self.decode_step()
         out = torch.tensor([toks], dtype=torch.long, device=self._dev)
         return (out, torch.stack(all_logits)) if return_logits else out
+
+    # ------------------------------------------------------------------ batched decode
+    def _ensure_batch(self, B):
+        if getattr(self, "_bb", None) is not None and self._bb["B"] >= B:
+            return self._bb
+        bf = dict(dtype=torch.bfloat16, device=self._dev)
+        smax, I = self.max_seq_len, self.cfg["llm"]["intermediate_size"] // self.tp
+        self._bb = dict(
+            B=B, k=[torch.zeros((B, self.nkv, smax, self.hd), **bf) for _ in range(self.n_layers)],
+            v=[torch.zeros((B, self.nkv, smax, self.hd), **bf) for _ in range(self.n_layers)],
+            partial=torch.empty((B * self.nh * ((smax + 63) // 64) * 130,), dtype=torch.float32, device=self._dev),
+            x0=torch.empty((B, self.D), **bf), x1=torch.empty((B, self.D), **bf), qkv=torch.empty((B, (self.nh + 2 * self.nkv) * self.hd), **bf),
+            o=torch.empty((B, self.nh * self.hd), **bf), a=torch.empty((B, I), **bf),
+            logits=torch.empty((B, self.V), dtype=torch.float32, device=self._dev),
+            tok=torch.zeros((B,), dtype=torch.int32, device=self._dev), pos=torch.zeros((B,), dtype=torch.int32, device=self._dev))
+        return self._bb
+
+    def _decode_kernels_batched(self, nb):
+        """One decode step for the nb sequences of the batch: the weights stream ONCE for nb tokens (multi-row GEMV), the
+        attention runs per sequence on its own cache slice and position (one launch for all of them)."""
+        bb, nh, nkv, hd = self._bb, self.nh, self.nkv, self.hd
+        x, x1, qkv, o, a = bb["x0"][:nb], bb["x1"][:nb], bb["qkv"][:nb], bb["o"][:nb], bb["a"][:nb]
+        ops.embed_rows(bb["tok"][:nb], self.w["embed"], x)
+        r0 = self.tp_rank == 0
+        for li, lw in enumerate(self.w["layers"]):
+            ops.gemv_batched(lw["wqkv"], x, norm_w=lw["ln1_w"], eps=self.eps, out=qkv, bias=lw["bqkv"])
+            ops.attn_decode_batched(qkv, bb["k"][li][:nb], bb["v"][li][:nb], self.cos_t, self.sin_t, bb["partial"], o, nh, nkv,
+                                    bb["pos"][:nb], self.max_seq_len, hd ** -0.5)
+            self._reduce(ops.gemv_batched(lw["wo"], o, res=x if r0 else None, out=x1))
+            ops.gemv_batched(lw["wgu"], x1, norm_w=lw["ln2_w"], eps=self.eps, swiglu=True, out=a)
+            self._reduce(ops.gemv_batched(lw["wd"], a, res=x1 if r0 else None, out=x))
+        ops.gemv_batched(self.w["lm_head"], x, norm_w=self.w["norm_w"], eps=self.eps, out_f32=True, out=bb["logits"][:nb])
+        bb["pos"][:nb] += 1
+
+    @torch.no_grad()
+    def generate_batch(self, inputs_embeds_list, max_new_tokens=2048, eos_token_id=None, return_logits=False):
+        """Greedy decode of several requests at once (not in the reference, whose eval loops run batch 1 and whose worker
+        serialises requests; its padded-batch `prepare_inputs_labels_for_multimodal`, arch.py:227-261, is the nearest thing):
+        every request is prefilled on its own (its M is already large), then ALL of them decode together, one token per
+        request per step.  Prompts may have different lengths (per-sequence positions, no padding).  Returns a list of
+        LongTensor [n_new_b] (each ends at its EOS / max_new_tokens); with return_logits also the per-step fp32 logits
+        [steps, B, V].  A row of a batched step is bit-identical to the single-sequence step."""
+        nb = len(inputs_embeds_list)
+        eos = set()
+        if eos_token_id is not None:
+            eos = set(eos_token_id) if isinstance(eos_token_id, (list, tuple, set)) else {int(eos_token_id)}
+        bb = self._ensure_batch(nb)
+        lens = []
+        for b, xb in enumerate(inputs_embeds_list):
+            cache = ([k[b] for k in bb["k"]], [v[b] for v in bb["v"]])
+            self.prefill(xb, cache=cache, logits_out=bb["logits"][b])
+            lens.append(xb.shape[0])
+        bb["pos"][:nb].copy_(torch.tensor(lens, dtype=torch.int32))
+        max_new_tokens = min(max_new_tokens, self.max_seq_len - max(lens) + 1)
+        outs, done, all_logits = [[] for _ in range(nb)], [False] * nb, []
+        for step in range(max_new_tokens):
+            if return_logits:
+                all_logits.append(bb["logits"][:nb].clone())
+            for b in range(nb):
+                ops.argmax(bb["logits"][b], bb["tok"][b:b + 1])
+            toks = bb["tok"][:nb].tolist()                                   # one small D2H per step for the stop checks
+            for b, t in enumerate(toks):
+                if not done[b]:
+                    outs[b].append(t)
+                    done[b] = t in eos
+            if all(done) or step + 1 == max_new_tokens:
+                break
+            self._decode_kernels_batched(nb)
+        res = [torch.tensor(o, dtype=torch.long, device=self._dev) for o in outs]
+        return (res, torch.stack(all_logits)) if return_logits else res
 
 
 HipQwen2Decoder = HipMistralDecoder      # same decoder; the q/k/v bias is picked up from the state dict (weights.pack_decoder)

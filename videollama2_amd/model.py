@@ -122,3 +122,27 @@ class VideoLLaMA2Hip(nn.Module):
                                      eos_token_id=kwargs.get("eos_token_id", None),
                                      stopping_criteria=kwargs.get("stopping_criteria", None),
                                      return_logits=kwargs.get("return_logits", False))
+
+    @torch.no_grad()
+    def generate_batch(self, requests, **kwargs):
+        """Several requests decoded together (the reference serialises requests): `requests` is a list of
+        (input_ids [1, L] or [L], images) pairs exactly as `generate(inputs, images=...)` takes them one at a time.  Every
+        request is encoded, spliced and prefilled on its own; the decode steps then run for all of them at once
+        (`HipMistralDecoder.generate_batch`).  Returns a list of LongTensor [n_new] with the NEW tokens of each request."""
+        if kwargs.get("do_sample", False):
+            raise NotImplementedError("HIP path implements greedy decoding (do_sample=False, the reference default)")
+        embeds = []
+        for ids, images in requests:
+            ids = ids if ids.dim() == 2 else ids[None]
+            if images is not None:
+                _, _, _, emb, _ = self.prepare_inputs_labels_for_multimodal(ids, torch.ones_like(ids), None, None, images)
+                embeds.append(emb[0])
+            else:
+                ids32 = ids[0].to(self._dev).to(torch.int32).contiguous()
+                emb = torch.empty((ids32.numel(), self.decoder.D), dtype=torch.bfloat16, device=self._dev)
+                ops.embed_rows(ids32, self.decoder.w["embed"], emb)
+                embeds.append(emb)
+        return self.decoder.generate_batch(embeds, max_new_tokens=kwargs.get("max_new_tokens", 2048),
+                                           eos_token_id=kwargs.get("eos_token_id", None),
+                                           return_logits=kwargs.get("return_logits", False))
+

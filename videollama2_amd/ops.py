@@ -201,11 +201,33 @@ def gemv(w, x, norm_w=None, eps=1e-5, res=None, swiglu=False, out_f32=False, out
     return out
 
 
+def gemv_batched(w, x, norm_w=None, eps=1e-5, res=None, swiglu=False, out_f32=False, out=None, bias=None):
+    """y[b] = W x[b] for the rows of x [MB, K] in one pass over W (batched decode).  res / out are [MB, n_out]."""
+    _chk(w, BF16, "w"); _chk(x, BF16, "x"); _chk(bias, torch.float32, "bias")
+    N, K = w.shape
+    MB = x.shape[0]
+    n_out = N // 2 if swiglu else N
+    if out is None:
+        out = torch.empty((MB, n_out), dtype=torch.float32 if out_f32 else BF16, device=w.device)
+    flags = (GEMM_SWIGLU if swiglu else 0) | (GEMM_OUT_F32 if out_f32 else 0)
+    _lib.call("vl2_gemv_batched_bf16", _p(w), _p(x), _p(norm_w), _p(res), _p(bias), _p(out), MB, N, K, w.stride(0), x.stride(0),
+              out.stride(0), 0 if res is None else res.stride(0), float(eps), flags, _stream())
+    return out
+
+
 def attn_decode(qkv, kcache, vcache, cos_t, sin_t, partial, out, nh, nkv, pos, scale, pos_dev=None, ctx_cap=0):
     """RoPE + KV append + flash-decoding attention of one new token (un-roped fused qkv row) at position `pos`
     (or *pos_dev, for hipGraph replay; then ctx_cap bounds the positions the launch covers)."""
     _lib.call("vl2_attn_decode", _p(qkv), _p(kcache), _p(vcache), _p(cos_t), _p(sin_t), _p(partial), _p(out), nh, nkv,
               kcache.shape[1], int(pos), _p(pos_dev), int(ctx_cap), float(scale), _stream())
+    return out
+
+
+def attn_decode_batched(qkv, kcache, vcache, cos_t, sin_t, partial, out, nh, nkv, pos_dev, ctx_cap, scale):
+    """Batched decode attention: qkv [B, (nh+2nkv)*128], caches [B, nkv, smax, 128], out [B, nh*128], pos_dev int32 [B]."""
+    B = qkv.shape[0]
+    _lib.call("vl2_attn_decode_batched", _p(qkv), _p(kcache), _p(vcache), _p(cos_t), _p(sin_t), _p(partial), _p(out), B,
+              qkv.stride(0), kcache.stride(0), out.stride(0), nh, nkv, kcache.shape[2], _p(pos_dev), int(ctx_cap), float(scale), _stream())
     return out
 
 
