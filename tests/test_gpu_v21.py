@@ -166,3 +166,28 @@ def test_batched_decode_equals_sequential_full_width():
         assert torch.equal(blogits[:, b], logits), b
     again = dec.generate_batch(embeds[:3], max_new_tokens=6)                 # smaller batch on the same buffers
     assert [o.tolist() for o in again] == [s[0][0].tolist() for s in seq[:3]]
+
+
+def test_batched_decode_gemm_path_matches_sequential_to_rounding():
+    """8 requests: the batched step runs its projections as MFMA GEMMs with M = 8 (weights streamed once for all of them).
+    Same arithmetic as a prefill row, so the logits equal the single-sequence decode to bf16 rounding and the greedy tokens
+    agree wherever the top-2 margin is clear."""
+    from videollama2_amd.decoder import HipMistralDecoder
+    cfg = O.config_videollama2_7b(16)
+    cfg["llm"]["num_hidden_layers"] = 2
+    keep = lambda n: n.startswith(("model.layers.", "model.norm", "model.embed_tokens", "lm_head"))
+    sd = O.seeded_state_dict(cfg, 5, only=keep)
+    dec = HipMistralDecoder(cfg, sd, DEV, max_seq_len=512)
+    g = torch.Generator().manual_seed(9)
+    embeds = [(torch.randn(n, 4096, generator=g) * 0.5).bfloat16().to(DEV) for n in (200, 31, 77, 5, 129, 64, 1, 300)]
+    assert len(embeds) >= dec.GEMM_BATCH
+    seq = [dec.generate(e, max_new_tokens=4, return_logits=True) for e in embeds]
+    outs, blogits = dec.generate_batch(embeds, max_new_tokens=4, return_logits=True)
+    for b, (toks, logits) in enumerate(seq):
+        assert torch.equal(blogits[0, b], logits[0])                          # step 0 is the prefill: identical
+        for s in range(1, blogits.shape[0]):
+            if outs[b][:s].tolist() != toks[0, :s].tolist():
+                break                                                         # diverged on a near-tie earlier: later steps differ
+            assert rel(blogits[s, b], logits[s]) < 2e-2, (b, s)
+            top2 = logits[s].topk(2).values
+            assert outs[b][s].item() == toks[0, s].item() or (top2[0] - top2[1]).item() < 0.05, (b, s)
