@@ -125,6 +125,11 @@ int32_t vl2_rope_kv(const void* qkv, void* q_out, void* kcache, void* vcache, co
  * bias (fp32, may be NULL) is Qwen2's q/k/v bias (HF:models/qwen2/modeling_qwen2.py Qwen2Attention).  flags as vl2_gemm_bf16. */
 int32_t vl2_gemv_bf16(const void* W, const void* x, const float* norm_w, const void* res, const float* bias, void* y,
                       int32_t N, int32_t K, int32_t ldw, float eps, int32_t flags, void* stream);
+/* Skinny-M GEMM for batched decode: C[M <= 64, N] = A[M,K] W[N,K]^T (+bias | +res | SwiGLU | fp32 out; flags as vl2_gemm_bf16).
+ * The weights stream from HBM straight into the B operand of v_mfma_f32_16x16x32_bf16 (GEMV-style, once for all M rows), K is
+ * split over workgroups, fp32 partial sums go through the attached workspace (required) and are reduced in order. */
+int32_t vl2_gemm_skinny_bf16(const void* A, const void* W, void* C, const float* bias, const void* res, int32_t M, int32_t N,
+                             int32_t K, int32_t lda, int32_t ldw, int32_t ldc, int32_t ldres, int32_t flags, void* stream);
 /* Batched decode: y[b][N] = W[N,K] x[b][K] (+ bias) (+ res[b]) for MB sequences in ONE pass over W (up to
  * 4 rows per launch, as many as fit 64 KiB of LDS; larger MB is split).  ldx / ldy / ldres = element strides between rows.
  * Same fused RMSNorm / bias / residual / SwiGLU semantics as vl2_gemv_bf16, applied per row. */

@@ -10,6 +10,7 @@ alignas(64) unsigned char vl2_smem[160 * 1024];
 #include "k_attn.h"
 #include "k_stc.h"
 #include "k_decode.h"
+#include "k_skinny.h"
 #include <cstdint>
 #include <algorithm>
 #include <vector>
@@ -201,6 +202,28 @@ extern "C" int32_t vl2_gemv_bf16(const void* W, const void* x, const float* norm
     if (sw) emu::launch(g, blk, [=] { gemv_bf16_kernel<true, false, 2>(a); });
     else if (f32) emu::launch(g, blk, [=] { gemv_bf16_kernel<false, true, 2>(a); });
     else emu::launch(g, blk, [=] { gemv_bf16_kernel<false, false, 2>(a); });
+    return 0;
+}
+extern "C" int32_t vl2_gemm_skinny_bf16(const void* A, const void* W, void* C, const float* bias, const void* res, int32_t M, int32_t N,
+                                        int32_t K, int32_t lda, int32_t ldw, int32_t ldc, int32_t ldres, int32_t flags, void*) {
+    const bool sw = flags & 1, f32 = flags & 2;
+    if (M > 64 || N % 64 || K % 32) return -2;
+    const int mt = M <= 16 ? 1 : M <= 32 ? 2 : 4, Mp = 16 * mt, steps = K / 32;
+    int ks = steps % 3 == 0 ? 3 : steps % 2 == 0 ? 2 : 1;       // a small odd / even split exercises the slice + chunk loops
+    const int kslice = K / ks;
+    int kchunk = kslice % 64 == 0 && kslice > 64 ? kslice / 2 : kslice;   // two chunks per slice where possible
+    static std::vector<float> part;
+    part.assign((size_t)ks * Mp * N, 0.f);
+    SkinnyArgs a{(const bf16_t*)A, (const bf16_t*)W, part.data(), M, N, K, lda, ldw, kslice, kchunk};
+    if (mt == 1) emu::launch(dim3(N / 64, ks), dim3(256), [=] { gemm_skinny_kernel<1>(a); });
+    else if (mt == 2) emu::launch(dim3(N / 64, ks), dim3(256), [=] { gemm_skinny_kernel<2>(a); });
+    else emu::launch(dim3(N / 64, ks), dim3(256), [=] { gemm_skinny_kernel<4>(a); });
+    SkinnyReduceArgs r{part.data(), C, bias, (const bf16_t*)res, M, Mp, N, ks, ldc, ldres};
+    const int ncol = sw ? N / 2 : N;
+    dim3 g((M * (ncol / 4) + 255) / 256), blk(256);
+    if (sw) emu::launch(g, blk, [=] { skinny_reduce_kernel<true, false>(r); });
+    else if (f32) emu::launch(g, blk, [=] { skinny_reduce_kernel<false, true>(r); });
+    else emu::launch(g, blk, [=] { skinny_reduce_kernel<false, false>(r); });
     return 0;
 }
 extern "C" int32_t vl2_gemv_batched_bf16(const void* W, const void* x, const float* norm_w, const void* res, const float* bias,

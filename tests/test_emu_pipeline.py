@@ -368,3 +368,20 @@ def test_emu_batched_decode_equals_sequential(emu, golden_small_v21):
     for (ids, _), o in zip(reqs, got):
         ids = ids if ids.dim() == 2 else ids[None]
         assert o.tolist() == m.generate(ids, images=None, do_sample=False, max_new_tokens=1)[0].tolist()
+
+
+def test_emu_gemm_skinny_all_epilogues(emu):
+    """Skinny-M GEMM (batched decode, 5..64 rows): weights as the MFMA B operand straight from memory, x chunks in LDS, K split
+    + ordered reduction -- against torch for every epilogue and M tile count."""
+    from videollama2_amd import ops
+    from videollama2_amd.weights import pack_gate_up
+    for M, N, K in ((5, 128, 192), (16, 64, 64), (23, 192, 384), (64, 128, 256), (33, 64, 96)):
+        a, w, bias, res = bf(M, K), bf(N, K, scale=K ** -0.5), torch.randn(N), bf(M, N)
+        ref = a.float() @ w.float().T
+        assert rel(ops.gemm_skinny(a, w, out_f32=True), ref) < TOL_F32_OUT, (M, N, K)
+        assert rel(ops.gemm_skinny(a, w, bias=bias), ref + bias) < TOL_BF16_OUT
+        assert rel(ops.gemm_skinny(a, w, res=res), ref + res.float()) < TOL_BF16_OUT
+    a = bf(19, 256)
+    wg, wu = bf(128, 256, scale=1 / 16), bf(128, 256, scale=1 / 16, seed=1)
+    ref = F.silu(a.float() @ wg.float().T) * (a.float() @ wu.float().T)
+    assert rel(ops.gemm_skinny(a, pack_gate_up(wg, wu), swiglu=True), ref) < TOL_BF16_OUT

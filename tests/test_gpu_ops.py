@@ -430,3 +430,25 @@ def test_gemv_batched_rows_equal_single_row(ops):
     got = ops.gemv_batched(wgu, x, norm_w=nw, swiglu=True)
     for b in range(4):
         assert torch.equal(got[b], ops.gemv(wgu, x[b], norm_w=nw, swiglu=True))
+
+
+def test_gemm_skinny_7b_shapes(ops):
+    """Skinny-M GEMM at the decode shapes of a batched step (M = 5..64), every epilogue, vs torch and vs the tiled GEMM."""
+    from videollama2_amd.weights import pack_gate_up
+    ops.attach_workspace(DEV)
+    for M, N, K, kw in ((8, 6144, 4096, dict(bias=True)), (16, 4096, 4096, dict(res=True)), (64, 4096, 14336, dict(res=True)),
+                        (33, 32000, 4096, dict(f32=True)), (5, 4608, 3584, dict(bias=True))):
+        a, w = bf(M, K).to(DEV), bf(N, K, scale=K ** -0.5).to(DEV)
+        bias = torch.randn(N).to(DEV) if kw.get("bias") else None
+        res = bf(M, N).to(DEV) if kw.get("res") else None
+        got = ops.gemm_skinny(a, w, bias=bias, res=res, out_f32=bool(kw.get("f32")))
+        ref = a.float() @ w.float().T + (bias if bias is not None else 0) + (res.float() if res is not None else 0)
+        assert rel(got, ref) < (TOL_F32_OUT if kw.get("f32") else TOL_BF16_OUT), (M, N, K)
+        assert rel(got, ops.gemm(a, w, bias=bias, res=res, out_f32=bool(kw.get("f32"))).float()) < 3e-3
+        for _ in range(2):
+            assert torch.equal(ops.gemm_skinny(a, w, bias=bias, res=res, out_f32=bool(kw.get("f32"))), got)   # deterministic
+    a = bf(24, 4096).to(DEV)
+    wg, wu = bf(2048, 4096, scale=1 / 64), bf(2048, 4096, scale=1 / 64, seed=1)
+    got = ops.gemm_skinny(a, pack_gate_up(wg, wu).to(DEV), swiglu=True)
+    ref = F.silu(a.float().cpu() @ wg.float().T) * (a.float().cpu() @ wu.float().T)
+    assert rel(got, ref) < TOL_BF16_OUT

@@ -9,6 +9,7 @@
 #include "k_decode.h"
 #include "k_gemm.h"
 #include "k_norm.h"
+#include "k_skinny.h"
 #include "k_stc.h"
 #include "k_vit.h"
 
@@ -250,6 +251,49 @@ extern "C" int32_t vl2_gemm_bf16(const void* A, const void* W, void* C, const fl
         }
     }
     return launched("vl2_gemm_bf16");
+}
+
+// ------------------------------------------------------------------------------------------------ skinny-M GEMM (batched decode)
+template <int MT>
+static void launch_skinny(const SkinnyArgs& a, int ks, size_t lds, hipStream_t s) {
+    static bool attr = false;
+    if (!attr) {
+        hipFuncSetAttribute((const void*)gemm_skinny_kernel<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        attr = true;
+    }
+    hipLaunchKernelGGL((gemm_skinny_kernel<MT>), dim3(a.N / 64, ks), dim3(256), lds, s, a);
+}
+extern "C" int32_t vl2_gemm_skinny_bf16(const void* A, const void* W, void* C, const float* bias, const void* res, int32_t M,
+                                        int32_t N, int32_t K, int32_t lda, int32_t ldw, int32_t ldc, int32_t ldres, int32_t flags,
+                                        void* stream) {
+    if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0) return fail(VL2_E_BADARG, "vl2_gemm_skinny_bf16: null pointer or empty shape");
+    const bool sw = flags & VL2_GEMM_SWIGLU, f32 = flags & VL2_GEMM_OUT_F32;
+    if (M > 64 || N % 64 || (sw && N % 128) || K % 32 || lda % 8 || ldw % 8 || ldc % 4 || (res && ldres % 4))
+        return fail(VL2_E_SHAPE, "vl2_gemm_skinny_bf16: need M<=64, N%%64==0, K%%32==0 (M=%d N=%d K=%d)", M, N, K);
+    if (sw && (bias || f32)) return fail(VL2_E_UNSUPP, "vl2_gemm_skinny_bf16: SWIGLU excludes bias / f32 output");
+    if (!g_ws) return fail(VL2_E_BADARG, "vl2_gemm_skinny_bf16: needs vl2_set_workspace (fp32 partial sums)");
+    const int mt = M <= 16 ? 1 : M <= 32 ? 2 : 4, Mp = 16 * mt;
+    const int steps = K / 32;
+    // K split: enough (column group, K slice) waves to keep ~4096 in flight, a divisor of the 32-deep steps, partials within
+    // the workspace
+    int ks = (4096 + N / 16 - 1) / (N / 16);
+    ks = ks < 1 ? 1 : ks > 32 ? 32 : ks;
+    while (ks > 1 && (steps % ks || (int64_t)ks * Mp * N * 4 > g_ws_bytes)) --ks;
+    const int kslice = K / ks;
+    int kchunk = kslice;                                      // largest 32-multiple divisor of the slice whose x chunk fits 64 KiB
+    while (kchunk > 32 && (kslice % kchunk || kchunk % 32 || (size_t)Mp * (kchunk + 8) * 2 > 65536)) kchunk -= 32;
+    if (kslice % kchunk || (size_t)Mp * (kchunk + 8) * 2 > 65536) return fail(VL2_E_SHAPE, "vl2_gemm_skinny_bf16: no K chunking for K=%d", K);
+    SkinnyArgs a{(const bf16_t*)A, (const bf16_t*)W, (float*)g_ws, M, N, K, lda, ldw, kslice, kchunk};
+    const size_t lds = (size_t)Mp * (kchunk + 8) * 2;
+    hipStream_t s = ST(stream);
+    if (mt == 1) launch_skinny<1>(a, ks, lds, s); else if (mt == 2) launch_skinny<2>(a, ks, lds, s); else launch_skinny<4>(a, ks, lds, s);
+    SkinnyReduceArgs r{(const float*)g_ws, C, bias, (const bf16_t*)res, M, Mp, N, ks, ldc, ldres};
+    const int ncol = sw ? N / 2 : N;
+    const dim3 g((M * (ncol / 4) + 255) / 256), b(256);
+    if (sw) hipLaunchKernelGGL((skinny_reduce_kernel<true, false>), g, b, 0, s, r);
+    else if (f32) hipLaunchKernelGGL((skinny_reduce_kernel<false, true>), g, b, 0, s, r);
+    else hipLaunchKernelGGL((skinny_reduce_kernel<false, false>), g, b, 0, s, r);
+    return launched("vl2_gemm_skinny_bf16");
 }
 
 // ------------------------------------------------------------------------------------------------ norms

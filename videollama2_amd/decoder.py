@@ -249,17 +249,19 @@ class HipMistralDecoder(nn.Module):
         bb, nh, nkv, hd = self._bb, self.nh, self.nkv, self.hd
         x, x1, qkv, o, a = bb["x0"][:nb], bb["x1"][:nb], bb["qkv"][:nb], bb["o"][:nb], bb["a"][:nb]
         r0 = self.tp_rank == 0
+        # up to 64 rows: the skinny-M kernel streams the weights GEMV-style into MFMA; beyond that the tiled GEMMs
+        mm = ops.gemm_skinny if nb <= 64 else ops.gemm
         for li, lw in enumerate(self.w["layers"]):
             h = ops.rmsnorm(x, lw["ln1_w"], self.eps)
-            ops.gemm(h, lw["wqkv"], bias=lw["bqkv"], out=qkv)
+            mm(h, lw["wqkv"], bias=lw["bqkv"], out=qkv)
             ops.attn_decode_batched(qkv, bb["k"][li][:nb], bb["v"][li][:nb], self.cos_t, self.sin_t, bb["partial"], o, nh, nkv,
                                     bb["pos"][:nb], self.max_seq_len, hd ** -0.5)
-            self._reduce(ops.gemm(o, lw["wo"], res=x if r0 else None, out=x1))
+            self._reduce(mm(o, lw["wo"], res=x if r0 else None, out=x1))
             h = ops.rmsnorm(x1, lw["ln2_w"], self.eps)
-            ops.gemm(h, lw["wgu"], swiglu=True, out=a)
-            self._reduce(ops.gemm(a, lw["wd"], res=x1 if r0 else None, out=x))
+            mm(h, lw["wgu"], swiglu=True, out=a)
+            self._reduce(mm(a, lw["wd"], res=x1 if r0 else None, out=x))
         h = ops.rmsnorm(x, self.w["norm_w"], self.eps)
-        ops.gemm(h, self.w["lm_head"], out_f32=True, out=bb["logits"][:nb])
+        mm(h, self.w["lm_head"], out_f32=True, out=bb["logits"][:nb])
         bb["pos"][:nb] += 1
 
     def _batched_gemv_step(self, nb):

@@ -201,6 +201,21 @@ def gemv(w, x, norm_w=None, eps=1e-5, res=None, swiglu=False, out_f32=False, out
     return out
 
 
+def gemm_skinny(a, w, bias=None, res=None, swiglu=False, out_f32=False, out=None):
+    """C = epilogue(a @ w.T) for M = a.shape[0] <= 64 rows (batched decode): weights streamed once, GEMV-style, into MFMA.
+    Needs `attach_workspace` (fp32 partial sums of the K split)."""
+    _chk(a, BF16, "a"); _chk(w, BF16, "w"); _chk(bias, torch.float32, "bias"); _chk(res, BF16, "res")
+    M, K = a.shape
+    N = w.shape[0]
+    ncol = N // 2 if swiglu else N
+    if out is None:
+        out = torch.empty((M, ncol), dtype=torch.float32 if out_f32 else BF16, device=a.device)
+    flags = (GEMM_SWIGLU if swiglu else 0) | (GEMM_OUT_F32 if out_f32 else 0)
+    _lib.call("vl2_gemm_skinny_bf16", _p(a), _p(w), _p(out), _p(bias), _p(res), M, N, K, a.stride(0), w.stride(0), out.stride(0),
+              0 if res is None else res.stride(0), flags, _stream())
+    return out
+
+
 def gemv_batched(w, x, norm_w=None, eps=1e-5, res=None, swiglu=False, out_f32=False, out=None, bias=None):
     """y[b] = W x[b] for the rows of x [MB, K] in one pass over W (batched decode).  res / out are [MB, n_out]."""
     _chk(w, BF16, "w"); _chk(x, BF16, "x"); _chk(bias, torch.float32, "bias")
