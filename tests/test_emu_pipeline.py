@@ -363,6 +363,20 @@ def test_emu_batched_decode_equals_sequential(emu, golden_small_v21):
     assert outs[0].tolist() == seq[0][0][0, :n0].tolist() and (n0 == 3 or outs[0][-1].item() == eos)
     for b in range(2):
         assert torch.equal(blogits[:, b], seq[b][1][:blogits.shape[0]]), b
+    class _Streamer:                                                         # HF BaseStreamer protocol (put / end)
+        def __init__(self):
+            self.ids, self.ended = [], False
+
+        def put(self, value):
+            self.ids += value.flatten().tolist()
+
+        def end(self):
+            self.ended = True
+
+    st = _Streamer()
+    ids = torch.tensor([[1, 17, 99, 5]])
+    got = m.generate(ids, images=None, do_sample=False, max_new_tokens=2, streamer=st)
+    assert st.ended and st.ids == got[0].tolist()
     reqs = [(torch.tensor([[1, 17, 99, 5]]), None), (torch.tensor([1, 300, 4]), None)]
     got = m.generate_batch(reqs, max_new_tokens=1)
     for (ids, _), o in zip(reqs, got):

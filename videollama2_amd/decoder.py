@@ -160,11 +160,13 @@ class HipMistralDecoder(nn.Module):
 
     @torch.no_grad()
     def generate(self, inputs_embeds, max_new_tokens=2048, eos_token_id=None, stopping_criteria=None,
-                 return_logits=False, use_graph=False):
+                 return_logits=False, use_graph=False, streamer=None):
         """Greedy decode (HF GenerationMixin._sample, do_sample=False): returns LongTensor [1, n_new] of NEW tokens.
         Stops at `eos_token_id` (int or list), when `stopping_criteria(output_ids, None)` is truthy
         (KeywordsStoppingCriteria semantics, videollama2/mm_utils.py:341-345), or at max_new_tokens / cache end.
-        use_graph=True replays one captured hipGraph per token (argmax + the whole decode step)."""
+        use_graph=True replays one captured hipGraph per token (argmax + the whole decode step).
+        streamer: optional object with put(LongTensor[1, n]) / end() (the HF `BaseStreamer` protocol the reference's worker
+        uses with TextIteratorStreamer, serve/model_worker.py:263-300): every new token is handed over as soon as it is known."""
         eos = set()
         if eos_token_id is not None:
             eos = set(eos_token_id) if isinstance(eos_token_id, (list, tuple, set)) else {int(eos_token_id)}
@@ -190,6 +192,8 @@ class HipMistralDecoder(nn.Module):
                 ops.argmax(self.logits, self.tok, self.hist, step)
             t = int(self.tok.item())                 # one 4-byte D2H per token (the reference syncs per token too)
             toks.append(t)
+            if streamer is not None:
+                streamer.put(torch.tensor([[t]], dtype=torch.long))
             if t in eos or last:
                 break
             if crit is not None:
@@ -198,6 +202,8 @@ class HipMistralDecoder(nn.Module):
                     break
             if not use_graph:
                 self.decode_step()
+        if streamer is not None:
+            streamer.end()
         out = torch.tensor([toks], dtype=torch.long, device=self._dev)
         return (out, torch.stack(all_logits)) if return_logits else out
 

@@ -121,7 +121,7 @@ class VideoLLaMA2Hip(nn.Module):
         return self.decoder.generate(inputs_embeds, max_new_tokens=kwargs.get("max_new_tokens", 2048),
                                      eos_token_id=kwargs.get("eos_token_id", None),
                                      stopping_criteria=kwargs.get("stopping_criteria", None),
-                                     return_logits=kwargs.get("return_logits", False))
+                                     return_logits=kwargs.get("return_logits", False), streamer=kwargs.get("streamer", None))
 
     @torch.no_grad()
     def generate_batch(self, requests, **kwargs):
