@@ -191,3 +191,23 @@ def test_batched_decode_gemm_path_matches_sequential_to_rounding():
             assert rel(blogits[s, b], logits[s]) < 2e-2, (b, s)
             top2 = logits[s].topk(2).values
             assert outs[b][s].item() == toks[0, s].item() or (top2[0] - top2[1]).item() < 0.05, (b, s)
+
+
+def test_full_width_72b_connector():
+    """stc_connector at the 72B decoder's width (1024 -> 8192 channels, 1.93 B parameters) on T=2 frames vs the fp32 oracle:
+    the 8192-channel LayerNorm / depthwise / SE kernels and the K = 65536 gathered Conv3d GEMM in place."""
+    from videollama2_amd.config import videollama2_72b
+    from videollama2_amd.connector import HipSTCConnector
+    cfg = videollama2_72b(2)
+    ocfg = dict(vision=O.config_videollama2_7b(2)["vision"], llm=dict(cfg["llm"]), num_frames=2)
+    sd = O.seeded_state_dict(ocfg, 13, only=lambda n: "mm_projector" in n)
+    x = (torch.randn(1, 2, 576, 1024, generator=torch.Generator().manual_seed(1))).bfloat16().float()
+    with torch.no_grad():
+        ref, st = O.stc_connector(sd, x, return_stages=True)
+    conn = HipSTCConnector(sd, DEV)
+    out, mine = conn(x.to(DEV), return_stages=True)
+    rec = []
+    stage_ok("72B-width stc s1", mine["s1"].permute(0, 3, 1, 2), st["s1"], FULL_TOL["stc"], rec)
+    stage_ok("72B-width stc sampler", mine["sampler"].permute(3, 0, 1, 2)[None], st["sampler"], FULL_TOL["stc"], rec)
+    stage_ok("72B-width stc out", out, ref, FULL_TOL["stc"], rec)
+    assert tuple(out.shape) == (1, 2 * 169, 8192)
