@@ -399,3 +399,22 @@ def test_emu_gemm_skinny_all_epilogues(emu):
     wg, wu = bf(128, 256, scale=1 / 16), bf(128, 256, scale=1 / 16, seed=1)
     ref = F.silu(a.float() @ wg.float().T) * (a.float() @ wu.float().T)
     assert rel(ops.gemm_skinny(a, pack_gate_up(wg, wu), swiglu=True), ref) < TOL_BF16_OUT
+
+
+def test_emu_kv_cache_limits(emu, golden_small):
+    """Maximum sizes: a prompt longer than the KV cache is refused, generation stops when the cache is full (the last token
+    is produced from the logits of the last cache row), and a sequence that exactly fills the cache still prefills."""
+    from videollama2_amd.decoder import HipMistralDecoder
+    cfg = golden_small["cfg"]
+    keep = lambda n: n.startswith(("model.layers.", "model.norm", "model.embed_tokens", "lm_head"))
+    sd = O.seeded_state_dict(cfg, golden_small["seed"], only=keep)
+    dec = HipMistralDecoder(cfg, sd, "cpu", max_seq_len=16)
+    D = cfg["llm"]["hidden_size"]
+    with pytest.raises(ValueError, match="exceeds the KV cache"):
+        dec.prefill(bf(17, D))
+    out = dec.generate(bf(13, D, scale=0.5), max_new_tokens=100)
+    assert out.shape == (1, 16 - 13 + 1) and dec.pos == 16
+    with pytest.raises(ValueError, match="KV cache exhausted"):
+        dec.decode_step()
+    full = dec.generate(bf(16, D, scale=0.5), max_new_tokens=5)
+    assert full.shape == (1, 1)
