@@ -166,6 +166,8 @@ def test_batched_decode_equals_sequential_full_width():
         assert torch.equal(blogits[:, b], logits), b
     again = dec.generate_batch(embeds[:3], max_new_tokens=6)                 # smaller batch on the same buffers
     assert [o.tolist() for o in again] == [s[0][0].tolist() for s in seq[:3]]
+    eager, elogits = dec.generate_batch(embeds, max_new_tokens=6, return_logits=True, use_graph=False)
+    assert [o.tolist() for o in eager] == [o.tolist() for o in outs] and torch.equal(elogits, blogits)   # hipGraph == eager
 
 
 def test_batched_decode_gemm_path_matches_sequential_to_rounding():

@@ -211,8 +211,9 @@ class HipMistralDecoder(nn.Module):
     def _ensure_batch(self, B):
         if getattr(self, "_bb", None) is not None and self._bb["B"] >= B:
             return self._bb
+        self._batch_graphs = {}                      # captured graphs point into the buffers replaced below
         if self._dev.type == "cuda":
-            ops.attach_workspace(self._dev)          # split-K partials of the few-tile GEMMs of a large-batch decode step
+            ops.attach_workspace(self._dev)          # fp32 partial sums of the skinny-M GEMMs of a large-batch decode step
         bf = dict(dtype=torch.bfloat16, device=self._dev)
         smax, I = self.max_seq_len, self.cfg["llm"]["intermediate_size"] // self.tp
         self._bb = dict(
@@ -285,14 +286,49 @@ class HipMistralDecoder(nn.Module):
         bb["pos"][:nb] += 1
 
     @torch.no_grad()
-    def generate_batch(self, inputs_embeds_list, max_new_tokens=2048, eos_token_id=None, return_logits=False):
+    def _batched_step(self, nb):
+        bb = self._bb
+        for b in range(nb):
+            ops.argmax(bb["logits"][b], bb["tok"][b:b + 1])
+        self._decode_kernels_batched(nb)
+
+    def capture_batch_graph(self, nb):
+        """{argmax per request + the whole batched decode step} as ONE hipGraph per batch size (tokens and positions live on
+        the device, so the same graph replays for every step)."""
+        graphs = self.__dict__.setdefault("_batch_graphs", {})
+        if nb in graphs:
+            return graphs[nb]
+        if self.tp > 1:
+            raise NotImplementedError("hipGraph decode is built for the single-GPU decoder (collectives are launched eagerly)")
+        bb = self._bb
+        saved = (bb["tok"].clone(), bb["pos"].clone(), bb["logits"].clone())
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                       # warm-up outside capture (first-launch attribute calls, allocator)
+            self._batched_step(nb)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        bb["pos"].copy_(saved[1])
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            self._batched_step(nb)
+        bb["tok"].copy_(saved[0]); bb["pos"].copy_(saved[1]); bb["logits"].copy_(saved[2])
+        torch.cuda.synchronize()
+        graphs[nb] = g
+        return g
+
+    @torch.no_grad()
+    def generate_batch(self, inputs_embeds_list, max_new_tokens=2048, eos_token_id=None, return_logits=False, use_graph=None):
         """Greedy decode of several requests at once (not in the reference, whose eval loops run batch 1 and whose worker
         serialises requests; its padded-batch `prepare_inputs_labels_for_multimodal`, arch.py:227-261, is the nearest thing):
         every request is prefilled on its own (its M is already large), then ALL of them decode together, one token per
         request per step.  Prompts may have different lengths (per-sequence positions, no padding).  Returns a list of
         LongTensor [n_new_b] (each ends at its EOS / max_new_tokens); with return_logits also the per-step fp32 logits
-        [steps, B, V].  A row of a batched step is bit-identical to the single-sequence step."""
+        [steps, B, V].  A row of a batched step is bit-identical to the single-sequence step while nb < GEMM_BATCH.
+        use_graph (default: on a GPU without tensor parallelism) replays one captured hipGraph per step."""
         nb = len(inputs_embeds_list)
+        if use_graph is None:
+            use_graph = self._dev.type == "cuda" and self.tp == 1
         eos = set()
         if eos_token_id is not None:
             eos = set(eos_token_id) if isinstance(eos_token_id, (list, tuple, set)) else {int(eos_token_id)}
@@ -305,19 +341,27 @@ class HipMistralDecoder(nn.Module):
         bb["pos"][:nb].copy_(torch.tensor(lens, dtype=torch.int32))
         max_new_tokens = min(max_new_tokens, self.max_seq_len - max(lens) + 1)
         outs, done, all_logits = [[] for _ in range(nb)], [False] * nb, []
+        graph = self.capture_batch_graph(nb) if use_graph else None
+        if graph is not None:                                                # capture clobbered nothing: state was restored
+            bb["pos"][:nb].copy_(torch.tensor(lens, dtype=torch.int32))
         for step in range(max_new_tokens):
             if return_logits:
                 all_logits.append(bb["logits"][:nb].clone())
-            for b in range(nb):
-                ops.argmax(bb["logits"][b], bb["tok"][b:b + 1])
+            last = step + 1 == max_new_tokens
+            if graph is not None and not last:
+                graph.replay()                                               # argmax(step) + forward of the new tokens
+            else:
+                for b in range(nb):
+                    ops.argmax(bb["logits"][b], bb["tok"][b:b + 1])
             toks = bb["tok"][:nb].tolist()                                   # one small D2H per step for the stop checks
             for b, t in enumerate(toks):
                 if not done[b]:
                     outs[b].append(t)
                     done[b] = t in eos
-            if all(done) or step + 1 == max_new_tokens:
+            if all(done) or last:
                 break
-            self._decode_kernels_batched(nb)
+            if graph is None:
+                self._decode_kernels_batched(nb)
         res = [torch.tensor(o, dtype=torch.long, device=self._dev) for o in outs]
         return (res, torch.stack(all_logits)) if return_logits else res
 
