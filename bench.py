@@ -110,6 +110,9 @@ def main():
     ap.add_argument("--decode-batch", type=int, default=0,
                     help="extra measurement: after the timed steps, decode this many copies of the request TOGETHER (batched decode, "
                          "SURVEY 8f row 4) and report aggregate decode tokens/s as `batched_decode`")
+    ap.add_argument("--prefill-batch", type=int, default=0,
+                    help="extra measurement: encode + prefill this many copies of the request in ONE pass (throughput mode) and report "
+                         "aggregate frames/s, prefill tokens/s and the MFMA fraction as `batched_prefill`")
     ap.add_argument("--tp", action="store_true", help="with --gpus N > 1: shard the LLM decoder tensor-parallel over the N ranks "
                                                       "(BASELINE.json configs[3]); default keeps the decoder replicated like the reference")
     ap.add_argument("--no-graph", action="store_true", help="eager decode loop instead of hipGraph replay")
@@ -268,6 +271,41 @@ def main():
         batched = {"sequences": nb, "launch": "eager" if bgraph is None else "hipGraph replay", "ms_per_step": round(bms, 4), "tokens_per_s": round(nb / (bms / 1e3), 1),
                    "hbm_frac_weights_once": round(decode_bytes_per_token(cfg, S + n_new // 2) / (bms / 1e3) / 1e9 / PEAK_HBM_GBS, 4)}
 
+    bprefill = None
+    if args.prefill_batch > 1 and world == 1:
+        # throughput mode: `prefill_batch` copies of the video + prompt encoded in one tower call and prefilled in one pass
+        nbp, dec = args.prefill_batch, model.decoder
+        bb = dec._ensure_batch(nbp)
+        caches = [([k[b] for k in bb["k"]], [v[b] for v in bb["v"]]) for b in range(nbp)]
+        allf = torch.cat([frames] * nbp, 0)
+
+        def bpass(e):
+            e[0].record()
+            tower = model.vision_tower(allf)
+            t = tower.shape[0] // nbp
+            embs = []
+            for b in range(nbp):
+                f = model.mm_projector(tower[b * t:(b + 1) * t].unsqueeze(0))
+                _, _, _, emb, _ = model.prepare_inputs_labels_for_multimodal(ids, mask, None, None, [(frames, "video")], mm_features=f)
+                embs.append(emb[0])
+            e[1].record()
+            dec.prefill_batch(embs, caches, bb["logits"][:nbp])
+            e[2].record()
+
+        bpass([ev(), ev(), ev()])
+        torch.cuda.synchronize()
+        best = None
+        for _ in range(3):
+            e = [ev(), ev(), ev()]
+            bpass(e)
+            torch.cuda.synchronize()
+            cur = (e[0].elapsed_time(e[1]), e[1].elapsed_time(e[2]))
+            best = cur if best is None or sum(cur) < sum(best) else best
+        vtf, stf, ptf, _ = algorithmic_tflop(cfg, T)
+        bprefill = {"videos": nbp, "encode_ms": round(best[0], 3), "prefill_ms": round(best[1], 3),
+                    "frames_per_s": round(nbp * T / (best[0] / 1e3), 1), "prefill_tokens_per_s": round(nbp * S / (best[1] / 1e3), 1),
+                    "forward_mfma_frac": round(nbp * (vtf + stf + ptf) / (sum(best) / 1e3) / PEAK_MFMA_BF16_TFLOPS, 4)}
+
     roof = None
     ops.PROFILE = [] if rank == 0 else None      # EVERY rank runs the extra pass (it contains the encoder's collectives);
     step()                                       # only rank 0 brackets its GEMM launches with events
@@ -320,6 +358,8 @@ def main():
         }
         if batched is not None:
             out["batched_decode"] = batched
+        if bprefill is not None:
+            out["batched_prefill"] = bprefill
         if not args.no_cpu_baseline and world == 1:          # the CPU leg is reported at N=1 only
             try:
                 out["cpu_baseline"] = cpu_baseline(min(os.cpu_count() or 1, 32))   # eager torch oversubscribes badly beyond ~32 threads

@@ -109,7 +109,7 @@ extern "C" int32_t vl2_gemm_bf16(const void* A, const void* W, void* C, const fl
 static int32_t run_norm(NormArgs a, bool rms) {
     const int nv = (a.C + 511) / 512;
     dim3 g((a.rows + 3) / 4), blk(256);
-    if (rms && a.C > 2048 && a.rows > 1) {
+    if (rms && a.C > 2048) {
         emu::launch(dim3(a.rows), blk, [=] { norm_wide_kernel<true, 2>(a); });
     } else if (rms) {
         if (nv <= 1) emu::launch(g, blk, [=] { norm_kernel<1, true>(a); });

@@ -213,3 +213,21 @@ def test_full_width_72b_connector():
     stage_ok("72B-width stc sampler", mine["sampler"].permute(3, 0, 1, 2)[None], st["sampler"], FULL_TOL["stc"], rec)
     stage_ok("72B-width stc out", out, ref, FULL_TOL["stc"], rec)
     assert tuple(out.shape) == (1, 2 * 169, 8192)
+
+
+def test_generate_batch_with_videos_equals_one_by_one(small21):
+    """Model-level batch: three video requests (one tower call for all frames, one prefill pass over the concatenated prompts,
+    batched decode) + a text-only request give each request exactly the tokens it gets alone."""
+    g, cfg, sd, model = small21
+    V = cfg["llm"]["vocab_size"]
+    rng = torch.Generator().manual_seed(5)
+    reqs = []
+    for n_pre, n_post, shift in ((7, 9, 0), (3, 2, 1), (1, 12, 2)):
+        ids = torch.cat([torch.tensor([1]), torch.randint(3, V, (n_pre,), generator=rng), torch.tensor([-201]),
+                         torch.randint(3, V, (n_post,), generator=rng)])
+        reqs.append((ids[None].to(DEV), [(torch.roll(g["frames"], shift, dims=0).to(DEV), "video")]))
+    reqs.append((torch.tensor([[1, 17, 99, 5]], device=DEV), None))
+    alone = [model.generate(ids, images=images, do_sample=False, max_new_tokens=6, attention_mask=torch.ones_like(ids))[0].tolist()
+             for ids, images in reqs]
+    together = [o.tolist() for o in model.generate_batch(reqs, max_new_tokens=6)]
+    assert together == alone

@@ -90,9 +90,9 @@ __global__ __launch_bounds__(256) void norm_kernel(NormArgs p) {
 // 4: C <= 8192, the 72B decoder) vectors,
 // so the row count, not rows/4, is the number of workgroups in flight (one wave per row leaves a 256-CU chip with ~1.6
 // workgroups per CU: 13 us for 26 MB).  Same per-element arithmetic; the row sums are reduced wave-then-LDS instead of in
-// one wave, i.e. in a different fp32 order than norm_kernel -- the launcher picks by C and the row count only for RMSNorm
-// (rows of one sequence), never for the per-frame LayerNorms, so a frame's result does not depend on how many frames a
-// rank holds.
+// one wave, i.e. in a different fp32 order than norm_kernel -- the launcher picks it by C alone (never by the row count) and
+// only for RMSNorm, so a row's result depends neither on how many rows are normalised with it (batched prefill == one by
+// one) nor, for the per-frame LayerNorms, on how many frames a rank holds.
 template <bool RMS, int NVW>
 __global__ __launch_bounds__(256) void norm_wide_kernel(NormArgs p) {
     __shared__ float red[8];

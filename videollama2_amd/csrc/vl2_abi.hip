@@ -303,7 +303,8 @@ static int32_t launch_norm(const NormArgs& a, bool rms, hipStream_t s, const cha
         return fail(VL2_E_SHAPE, "%s: need C%%8==0, C<=8192, aligned strides (C=%d)", what, a.C);
     const int nv = (a.C + 511) / 512;
     dim3 g((a.rows + 3) / 4), b(256);
-    if (rms && (a.C > 4096 || (a.C > 2048 && a.rows > 1))) {     // one sequence's rows: the wide form (a workgroup per row)
+    if (rms && a.C > 2048) {     // long rows: the wide form (a workgroup per row), whatever the row count -- a row's result must
+                                 // not depend on how many rows are normalised with it (batched prefill == one by one)
         if (a.C <= 4096) hipLaunchKernelGGL((norm_wide_kernel<true, 2>), dim3(a.rows), b, 0, s, a);
         else hipLaunchKernelGGL((norm_wide_kernel<true, 4>), dim3(a.rows), b, 0, s, a);
     } else if (rms) {

@@ -207,7 +207,40 @@ class HipMistralDecoder(nn.Module):
         out = torch.tensor([toks], dtype=torch.long, device=self._dev)
         return (out, torch.stack(all_logits)) if return_logits else out
 
-    # ------------------------------------------------------------------ batched decode
+    # ------------------------------------------------------------------ batched prefill / decode
+    @torch.no_grad()
+    def prefill_batch(self, xs, caches, logits_out):
+        """Several prompts prefilled together: the projections and norms run once on the concatenated rows [sum S_b, D] (bigger
+        M: fuller GEMM grids), RoPE / cache fill / causal attention per sequence on its own cache.  Every kernel here is
+        row-independent, so the result is bit-identical to prefilling the prompts one by one.
+        xs: list of [S_b, D]; caches: list of (k per layer, v per layer); logits_out: [B, V] fp32 (last position of each)."""
+        lens = [x.shape[0] for x in xs]
+        if max(lens) > self.max_seq_len:
+            raise ValueError(f"sequence length {max(lens)} exceeds the KV cache ({self.max_seq_len})")
+        X = torch.cat([x.to(device=self._dev, dtype=torch.bfloat16) for x in xs], 0).contiguous()
+        offs = [0]
+        for n in lens:
+            offs.append(offs[-1] + n)
+        nh, nkv, hd, smax = self.nh, self.nkv, self.hd, self.max_seq_len
+        q = torch.empty((offs[-1], nh * hd), dtype=torch.bfloat16, device=self._dev)
+        o = torch.empty((offs[-1], nh * hd), dtype=torch.bfloat16, device=self._dev)
+        r0 = self.tp_rank == 0
+        for li, lw in enumerate(self.w["layers"]):
+            h = ops.rmsnorm(X, lw["ln1_w"], self.eps)
+            qkv = ops.gemm(h, lw["wqkv"], bias=lw["bqkv"])
+            for b, (kc, vc) in enumerate(caches):
+                s0, s1, S = offs[b], offs[b + 1], lens[b]
+                ops.rope_kv(qkv[s0:s1], q[s0:s1], kc[li], vc[li], self.cos_t, self.sin_t, nh, nkv, 0)
+                ops.attn_fwd(q[s0:s1], kc[li], vc[li], o[s0:s1], (0, hd, nh * hd), (0, smax * hd, hd), (0, smax * hd, hd),
+                             (0, hd, nh * hd), 1, nh, S, S, nh // nkv, hd ** -0.5, True, 0, hd)
+            X = self._reduce(ops.gemm(o, lw["wo"], res=X if r0 else None))
+            h = ops.rmsnorm(X, lw["ln2_w"], self.eps)
+            a = ops.gemm(h, lw["wgu"], swiglu=True)
+            X = self._reduce(ops.gemm(a, lw["wd"], res=X if r0 else None))
+        for b in range(len(xs)):
+            ops.gemv(self.w["lm_head"], X[offs[b + 1] - 1], norm_w=self.w["norm_w"], eps=self.eps, out_f32=True, out=logits_out[b])
+        return lens
+
     def _ensure_batch(self, B):
         if getattr(self, "_bb", None) is not None and self._bb["B"] >= B:
             return self._bb
@@ -226,6 +259,7 @@ class HipMistralDecoder(nn.Module):
             tok=torch.zeros((B,), dtype=torch.int32, device=self._dev), pos=torch.zeros((B,), dtype=torch.int32, device=self._dev))
         return self._bb
 
+    PREFILL_GROUP_TOKENS = 8192   # rows prefilled in one pass (activation scratch: ~0.6 GB at 7B widths)
     GEMM_BATCH = 5      # from this many sequences on, the decode step runs its projections as MFMA GEMMs (M = sequences)
 
     def _decode_kernels_batched(self, nb):
@@ -333,11 +367,24 @@ class HipMistralDecoder(nn.Module):
         if eos_token_id is not None:
             eos = set(eos_token_id) if isinstance(eos_token_id, (list, tuple, set)) else {int(eos_token_id)}
         bb = self._ensure_batch(nb)
-        lens = []
+        # prompts are prefilled together in groups of <= PREFILL_GROUP_TOKENS rows (bit-identical to one by one)
+        lens, group, gtok = [], [], 0
+        caches = [([k[b] for k in bb["k"]], [v[b] for v in bb["v"]]) for b in range(nb)]
+
+        def flush():
+            if group:
+                b0 = group[0]
+                self.prefill_batch([inputs_embeds_list[b] for b in group], [caches[b] for b in group], bb["logits"][b0:b0 + len(group)])
+                group.clear()
+
         for b, xb in enumerate(inputs_embeds_list):
-            cache = ([k[b] for k in bb["k"]], [v[b] for v in bb["v"]])
-            self.prefill(xb, cache=cache, logits_out=bb["logits"][b])
+            if gtok + xb.shape[0] > self.PREFILL_GROUP_TOKENS:
+                flush()
+                gtok = 0
+            group.append(b)
+            gtok += xb.shape[0]
             lens.append(xb.shape[0])
+        flush()
         bb["pos"][:nb].copy_(torch.tensor(lens, dtype=torch.int32))
         max_new_tokens = min(max_new_tokens, self.max_seq_len - max(lens) + 1)
         outs, done, all_logits = [[] for _ in range(nb)], [False] * nb, []

@@ -69,12 +69,13 @@ class VideoLLaMA2Hip(nn.Module):
 
     # ---------------------------------------------------------------------------------- arch.py:161-263
     @torch.no_grad()
-    def prepare_inputs_labels_for_multimodal(self, input_ids, attention_mask, past_key_values, labels, images):
+    def prepare_inputs_labels_for_multimodal(self, input_ids, attention_mask, past_key_values, labels, images, mm_features=None):
         if images is None or input_ids.shape[1] == 1:                                    # arch.py:166-169
             return input_ids, attention_mask, past_key_values, None, labels
         if input_ids.shape[0] != 1 or labels is not None:
             raise NotImplementedError("HIP path: batch 1 inference only (the reference's eval loops use batch 1)")
-        mm_features = self.encode_images_or_videos(images)
+        if mm_features is None:                       # (generate_batch hands in features it encoded for several requests at once)
+            mm_features = self.encode_images_or_videos(images)
         ids = input_ids[0].to(self._dev)
         sentinels = torch.tensor(list(MODAL_INDEX_MAP.values()), device=self._dev)
         is_mm = (ids[:, None] == sentinels[None, :]).any(-1)
@@ -131,11 +132,26 @@ class VideoLLaMA2Hip(nn.Module):
         (`HipMistralDecoder.generate_batch`).  Returns a list of LongTensor [n_new] with the NEW tokens of each request."""
         if kwargs.get("do_sample", False):
             raise NotImplementedError("HIP path implements greedy decoding (do_sample=False, the reference default)")
+        # video requests with the same frame count are encoded in ONE tower call (frames are an independent batch dim), the
+        # connector then runs per video; every kernel involved is row-independent, so a request's tokens are the same as alone
+        feats = {}
+        groups = {}
+        for i, (ids, images) in enumerate(requests):
+            if images is not None and len(images) == 1 and images[0][1] == "video":
+                groups.setdefault(tuple(images[0][0].shape), []).append(i)
+        for idxs in groups.values():
+            if len(idxs) > 1 and self.sharder.world == 1:
+                frames = torch.cat([requests[i][1][0][0] for i in idxs], 0)
+                tower = self.vision_tower(frames.to(self._dev))
+                t = tower.shape[0] // len(idxs)
+                for j, i in enumerate(idxs):
+                    feats[i] = self.mm_projector(tower[j * t:(j + 1) * t].unsqueeze(0))
         embeds = []
-        for ids, images in requests:
+        for i, (ids, images) in enumerate(requests):
             ids = ids if ids.dim() == 2 else ids[None]
             if images is not None:
-                _, _, _, emb, _ = self.prepare_inputs_labels_for_multimodal(ids, torch.ones_like(ids), None, None, images)
+                _, _, _, emb, _ = self.prepare_inputs_labels_for_multimodal(ids, torch.ones_like(ids), None, None, images,
+                                                                            mm_features=feats.get(i))
                 embeds.append(emb[0])
             else:
                 ids32 = ids[0].to(self._dev).to(torch.int32).contiguous()
