@@ -260,15 +260,15 @@ class HipMistralDecoder(nn.Module):
         return self._bb
 
     PREFILL_GROUP_TOKENS = 8192   # rows prefilled in one pass (activation scratch: ~0.6 GB at 7B widths)
-    GEMM_BATCH = 5      # from this many sequences on, the decode step runs its projections as MFMA GEMMs (M = sequences)
+    GEMM_BATCH = 5      # from this many sequences on, the decode step runs its projections on MFMA (M = sequences)
 
     def _decode_kernels_batched(self, nb):
         """One decode step for the nb sequences of the batch: the weights stream ONCE for nb tokens, the attention runs per
         sequence on its own cache slice and position (one launch for all of them).
         nb < GEMM_BATCH: multi-row GEMV (a row is bit-identical to the single-sequence step).  nb >= GEMM_BATCH: the
-        projections are the prefill's MFMA GEMMs with M = nb (the 64-row small-M kernel streams every weight once for up to 64
-        sequences; RMSNorm as its own kernel) -- same arithmetic as a prefill row, i.e. equal to the single-sequence step to
-        bf16 rounding, not to the bit."""
+        projections run on the skinny-M MFMA kernel (weights streamed once, GEMV-style, for up to 64 rows; the tiled GEMMs
+        beyond that; RMSNorm as its own kernel) -- prefill-style arithmetic, i.e. equal to the single-sequence step to bf16
+        rounding, not to the bit."""
         bb, nh, nkv, hd = self._bb, self.nh, self.nkv, self.hd
         x, x1, qkv, o, a = bb["x0"][:nb], bb["x1"][:nb], bb["qkv"][:nb], bb["o"][:nb], bb["a"][:nb]
         ops.embed_rows(bb["tok"][:nb], self.w["embed"], x)
