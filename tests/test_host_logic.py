@@ -140,3 +140,33 @@ def test_config_checks():
     bad["llm"]["head_dim"] = 96
     with pytest.raises(ValueError, match="head_dim"):
         check_supported(bad)
+
+
+def test_checkpoint_config_uses_public_tower_values(tmp_path):
+    """api.config_from_checkpoint: hub tower names map to the public hyper-parameters (no hub access on the box), the model type
+    selects the decoder family, unknown towers / model types raise like the reference's factories."""
+    import json
+    from videollama2_amd import api
+    from videollama2_amd.config import check_supported, videollama2_1_7b_16f, videollama2_7b
+    base = dict(hidden_size=4096, intermediate_size=14336, num_hidden_layers=32, num_attention_heads=32, num_key_value_heads=8,
+                vocab_size=32000, rms_norm_eps=1e-5, rope_theta=1e6, num_frames=16, mm_projector_type="stc_connector",
+                model_type="videollama2_mistral", mm_vision_tower="openai/clip-vit-large-patch14-336", mm_vision_select_layer=-2)
+    json.dump(base, open(tmp_path / "config.json", "w"))
+    cfg, _ = api.config_from_checkpoint(str(tmp_path))
+    want = videollama2_7b(16)
+    assert cfg["llm"] == {**want["llm"], "family": "mistral"} and cfg["vision"] == {**want["vision"], "family": "clip"}
+    check_supported(cfg)
+    q = dict(base, hidden_size=3584, intermediate_size=18944, num_hidden_layers=28, num_attention_heads=28, num_key_value_heads=4,
+             vocab_size=152064, rms_norm_eps=1e-6, model_type="videollama2_qwen2", mm_projector_type="stc_connector_v35",
+             mm_vision_tower="google/siglip-so400m-patch14-384")
+    json.dump(q, open(tmp_path / "config.json", "w"))
+    cfg, _ = api.config_from_checkpoint(str(tmp_path))
+    want = videollama2_1_7b_16f(16)
+    assert cfg["llm"] == want["llm"] and cfg["vision"] == want["vision"] and cfg["projector"] == "stc_connector_v35"
+    check_supported(cfg)
+    json.dump(dict(base, mm_vision_tower="someone/some-other-tower"), open(tmp_path / "config.json", "w"))
+    with pytest.raises(ValueError, match="Unknown vision tower"):
+        api.config_from_checkpoint(str(tmp_path))
+    json.dump(dict(base, model_type="videollama2_mixtral"), open(tmp_path / "config.json", "w"))
+    with pytest.raises(ValueError, match="not built"):
+        api.config_from_checkpoint(str(tmp_path))
