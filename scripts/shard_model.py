@@ -71,7 +71,17 @@ def main():
             per_out = (T // R // 2 + (0 if v21 else 1)) * 169 * C * 2
             ag_us = COLL_FIXED_US + per_out / (LINK_GBS * 1e3)                        # each peer's shard arrives on its own link
             crit = max(best) + (halo_us + ag_us) / 1e3
-            rows.append(dict(model=args.model, T=T, world=R, splitk=args.splitk, identical_to_unsharded=same, rel_l2_vs_unsharded=float(f"{relerr:.3e}"), one_gpu_ms=round(one, 3),
+            # the north-star cut for comparison: ViT on the rank's frames, all-gather of [T/R, n, Dv] tokens, connector replicated
+            ns = []
+            for it in range(args.reps + 1):
+                a = stamp(); f = tower(frames[:T // R]); b = stamp(); conn(feats.view(1, *feats.shape)); c = stamp()
+                torch.cuda.synchronize()
+                if it:
+                    ns.append(a.elapsed_time(b) + b.elapsed_time(c))
+            ag_ns_us = COLL_FIXED_US + (T // R) * ntok * cfg["vision"]["hidden_size"] * 2 / (LINK_GBS * 1e3)
+            north = min(ns) + ag_ns_us / 1e3
+            rows.append(dict(model=args.model, T=T, world=R, splitk=args.splitk, north_star_cut_ms=round(north, 3),
+                             north_star_cut_speedup=round(one / north, 2), identical_to_unsharded=same, rel_l2_vs_unsharded=float(f"{relerr:.3e}"), one_gpu_ms=round(one, 3),
                              per_rank_ms=[round(x, 3) for x in best], modelled_collectives_us=round(halo_us + ag_us, 1),
                              critical_path_ms=round(crit, 3), speedup=round(one / crit, 2)))
             print(json.dumps(rows[-1]), flush=True)
