@@ -31,6 +31,10 @@ static void run_gemm(GemmArgs a) {
             emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(512), [=] { gemm3_bf16_kernel<ACT, SW, F32>(a); });
             return;
         }
+        if (g_gemm_variant == 128) {
+            emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(256), [=] { gemm_l_bf16_kernel<ACT, SW, F32>(a); });
+            return;
+        }
         if (g_gemm_variant == 8 && a.N % 256 == 0) {
             a.tiles_m = (a.M + 255) / 256; a.tiles_n = a.N / 256;
             emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(512), [=] { gemm4_bf16_kernel<ACT, SW, F32>(a); });

@@ -452,3 +452,20 @@ def test_gemm_skinny_7b_shapes(ops):
     got = ops.gemm_skinny(a, pack_gate_up(wg, wu).to(DEV), swiglu=True)
     ref = F.silu(a.float().cpu() @ wg.float().T) * (a.float().cpu() @ wu.float().T)
     assert rel(got, ref) < TOL_BF16_OUT
+
+
+def test_gemm_one_round_kernel_bit_identical(ops):
+    """Grids of <= 256 tiles with K >= 4096 take the deep-ring 128x128 kernel automatically; same bits as the 2-stage kernel."""
+    for M, N, K, kw in [(845, 4096, 4096, dict()), (945, 4096, 14336, dict(res=True)), (2308, 1024, 4096, dict(bias=True, res=True, act=ops.ACT_GELU))]:
+        a, w = bf(M, K).to(DEV), bf(N, K, scale=K ** -0.5).to(DEV)
+        bias = torch.randn(N, device=DEV) if kw.get("bias") else None
+        res = bf(M, N).to(DEV) if kw.get("res") else None
+        out = ops.gemm(a, w, bias=bias, res=res, act=kw.get("act", 0))
+        try:
+            ops.set_gemm_variant(128)
+            forced = ops.gemm(a, w, bias=bias, res=res, act=kw.get("act", 0))
+            ops.set_gemm_variant(1)
+            ref = ops.gemm(a, w, bias=bias, res=res, act=kw.get("act", 0))
+        finally:
+            ops.set_gemm_variant(0)
+        assert torch.equal(forced, ref) and torch.equal(out, ref), (M, N, K)
