@@ -31,7 +31,7 @@ int32_t vl2_version(void);
  *   key 1 = GEMM kernel variant: 0 = auto (per shape: 128x128x64 two-barrier kernel, 128x256x64 or 256x256x32 ping-pong kernel,
  *           whichever quantises best on 256 CUs), 1 = 128x128x64 always, 2 = its stream-K form (experimental; needs
  *           vl2_set_workspace), 4 = 128x256x64 ping-pong always, 8 = 256x256x32 ping-pong always (4, 8: where N%256==0),
- *           32 = 64x64 small-M kernel always, 128 = 128x128 deep-ring one-round kernel always.  See profiles/r01_gemm_experiments.md. */
+ *           32 = 64x64 small-M kernel always, 256 = 128x128 8-wave deep-ring one-round kernel always.  See profiles/r01_gemm_experiments.md. */
 #define VL2_TUNE_GEMM_VARIANT 1
 #define VL2_TUNE_GEMV_ROWS_PER_WAVE 2   /* 1 (default), 2 or 4 output rows streamed by each wave of the decode GEMV */
 #define VL2_TUNE_GEMV_MR_ROWS_PER_WAVE 4 /* 1, 2 (default) or 4 output rows per wave of the batched (multi-row) decode GEMV */

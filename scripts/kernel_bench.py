@@ -77,9 +77,9 @@ def main():
     out = {}
     ops.attach_workspace(dev)
     if "--frames" in sys.argv:
-        SHAPES, VARIANTS = shapes_for(int(sys.argv[sys.argv.index("--frames") + 1])), (1, 0, 4, 8, 128)
+        SHAPES, VARIANTS = shapes_for(int(sys.argv[sys.argv.index("--frames") + 1])), (1, 0, 4, 8, 256)
     if "--small" in sys.argv:
-        SHAPES, VARIANTS = SMALL, (1, 0, 32, 128)   # 0 = auto, 1 = 128x128, 32 = 64x64 small-M kernel, 's' = 128x128 + split-K
+        SHAPES, VARIANTS = SMALL, (1, 0, 32, 256)   # 0 = auto, 1 = 128x128, 32 = 64x64 small-M kernel, 's' = 128x128 + split-K
     rounds = 2 if "--quick" in sys.argv else 3
     for name, M, N, K, kw in SHAPES:
         a, w = rnd(M, K), rnd(N, K, scale=K ** -0.5)

@@ -31,8 +31,8 @@ static void run_gemm(GemmArgs a) {
             emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(512), [=] { gemm3_bf16_kernel<ACT, SW, F32>(a); });
             return;
         }
-        if (g_gemm_variant == 128) {
-            emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(256), [=] { gemm_l_bf16_kernel<ACT, SW, F32>(a); });
+        if (g_gemm_variant == 256) {
+            emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(512), [=] { gemm_l8_bf16_kernel<ACT, SW, F32>(a); });
             return;
         }
         if (g_gemm_variant == 8 && a.N % 256 == 0) {

@@ -48,7 +48,7 @@ def test_emu_gemm_pingpong_variant(emu):
         a, w = bf(300, K), bf(512, K)
         ref = ops.gemm(a, w, out_f32=True)
         try:
-            for v in (4, 8, 128):
+            for v in (4, 8, 256):
                 ops.set_gemm_variant(v)
                 assert torch.equal(ops.gemm(a, w, out_f32=True), ref)
         finally:

@@ -462,7 +462,7 @@ def test_gemm_one_round_kernel_bit_identical(ops):
         res = bf(M, N).to(DEV) if kw.get("res") else None
         out = ops.gemm(a, w, bias=bias, res=res, act=kw.get("act", 0))
         try:
-            ops.set_gemm_variant(128)
+            ops.set_gemm_variant(256)
             forced = ops.gemm(a, w, bias=bias, res=res, act=kw.get("act", 0))
             ops.set_gemm_variant(1)
             ref = ops.gemm(a, w, bias=bias, res=res, act=kw.get("act", 0))

@@ -892,63 +892,63 @@ __global__ __launch_bounds__(128, 2) void gemm_s_bf16_kernel(GemmArgs p) {
 
 
 // ------------------------------------------------------------------------------------------------------------------
-// gemm_l "one-round" form: the 128 x 128 tile of gemm_bf16_kernel with gemm_s's pipeline -- a 4-stage 128 KiB LDS ring, three
-// K-tiles of LDS-DMA in flight, counted vmcnt, ONE raw barrier per K-tile -- for grids of at most one tile per CU.  There
-// the 2-stage kernel is a dependent chain (DMA -> barrier -> MFMA, one tile in flight: ~0.64 us per K-tile however idle the
-// chip is) and a second workgroup per CU never arrives to hide it; with one workgroup per CU the whole LDS can hold a
-// deeper ring instead.  Same K order as every other kernel -> same bits.
+// gemm_l8 "one-round" form: the 128 x 128 tile for grids of at most one tile per CU.  There the 2-stage 4-wave kernel runs one
+// wave per SIMD as a dependent chain (DMA -> barrier -> ds_read -> MFMA: ~0.64 us per K-tile however idle the chip is) and a
+// second workgroup per CU never arrives to hide it.  Here the tile is split over EIGHT waves (wave tile 32 x 64, two waves per
+// SIMD: one's fragment reads overlap the other's MFMAs) and, with one workgroup per CU, the LDS holds a 4-stage 128 KiB ring
+// (three K-tiles of LDS-DMA in flight, counted vmcnt, ONE raw barrier per K-tile).  Measured (scripts/kernel_bench.py
+// --frames 8): 845x4096x4096 43.7 -> 35.0 us, 945x4096x14336 152.6 -> 127.0 us; a 4-wave deep-ring variant only reached
+// 39.5 / 135.6.  Same K order as every other kernel -> same bits.
 #define GEMML_STAGES 4
 #define GEMML_STAGE_BYTES 32768
 #define GEMML_LDS_BYTES (GEMML_STAGES * GEMML_STAGE_BYTES)
 
 template <int ACT, bool SWIGLU, bool OUT_F32>
-__global__ __launch_bounds__(256, 1) void gemm_l_bf16_kernel(GemmArgs p) {
+__global__ __launch_bounds__(512, 1) void gemm_l8_bf16_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char vl2_smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave >> 1, wn = wave & 1;                    // wm 0..3 (32 rows each), wn 0..1 (64 columns each)
     const int t = xcd_remap(blockIdx.x, gridDim.x);
     const int tm = t % p.tiles_m, tn = t / p.tiles_m;            // consecutive workgroups share a W panel
     const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
     const int nt = p.K / GEMM_BK;
 
-    f32x16 acc[2][2];
+    f32x16 acc[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
     const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x7fffffff, 0x00020000);
     const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0x7fffffff, 0x00020000);
-    unsigned a_vo[4], w_vo;                                     // as gemm_bf16_kernel: 4 A pieces, W piece i = +32 rows
+    unsigned a_vo[2], w_vo;                                     // 2 A pieces + 2 W pieces per wave (piece i = +64 rows)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int slot = ((i * 4 + wave) << 6) + lane;
+    for (int i = 0; i < 2; ++i) {
+        const int slot = ((i * 8 + wave) << 6) + lane;
         const int R = slot >> 4, sx = (slot & 15) ^ (R & 15);
         int am = m0 + 2 * R + (sx >> 3);
         am = am < p.M ? am : p.M - 1;
         a_vo[i] = ((unsigned)am * (unsigned)p.lda + (sx & 7) * 8) * 2;
         if (i == 0) w_vo = ((unsigned)(n0 + 2 * R + (sx >> 3)) * (unsigned)p.ldw + (sx & 7) * 8) * 2;
     }
-    const unsigned w_step = 64u * (unsigned)p.ldw;
+    const unsigned w_step = 128u * (unsigned)p.ldw;
     const int frow = lane & 31, fchk = lane >> 5;
     unsigned a_rd[4], b_rd[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-        a_rd[ks] = gemm_lds_off(wm * 64 + frow, ks * 2 + fchk);
+        a_rd[ks] = gemm_lds_off(wm * 32 + frow, ks * 2 + fchk);
         b_rd[ks] = 16384 + gemm_lds_off(wn * 64 + frow, ks * 2 + fchk);
     }
     auto stage = [&](int kt) {
         const unsigned lds_buf = (unsigned)(kt & (GEMML_STAGES - 1)) * GEMML_STAGE_BYTES, kb = (unsigned)kt * (GEMM_BK * 2);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(vl2_smem + lds_buf + ((i * 4 + wave) << 10)),
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(vl2_smem + lds_buf + ((i * 8 + wave) << 10)),
                                                      16, a_vo[i], kb, 0, 0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(vl2_smem + lds_buf + 16384 + ((i * 4 + wave) << 10)),
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(vl2_smem + lds_buf + 16384 + ((i * 8 + wave) << 10)),
                                                      16, w_vo, kb + i * w_step, 0, 0);
     };
 #pragma unroll
@@ -956,23 +956,17 @@ __global__ __launch_bounds__(256, 1) void gemm_l_bf16_kernel(GemmArgs p) {
         if (s < nt) stage(s);
     for (int kt = 0; kt < nt; ++kt) {
         const int newer = nt - 1 - kt < GEMML_STAGES - 2 ? nt - 1 - kt : GEMML_STAGES - 2;
-        if (newer >= 2) VL2_WAIT_VMCNT(16); else if (newer == 1) VL2_WAIT_VMCNT(8); else VL2_WAIT_VMCNT(0);
+        if (newer >= 2) VL2_WAIT_VMCNT(8); else if (newer == 1) VL2_WAIT_VMCNT(4); else VL2_WAIT_VMCNT(0);
         VL2_PHASE_BARRIER();                                        // everyone's pieces of tile kt landed; buffer (kt-1)&3 is free
         if (kt + GEMML_STAGES - 1 < nt) stage(kt + GEMML_STAGES - 1);
         const unsigned lds_buf = (unsigned)(kt & (GEMML_STAGES - 1)) * GEMML_STAGE_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            bf16x8 af[2], bfr[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                af[i] = *(const bf16x8*)(vl2_smem + lds_buf + a_rd[ks] + i * 4096);
-                bfr[i] = *(const bf16x8*)(vl2_smem + lds_buf + b_rd[ks] + i * 4096);
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            const bf16x8 af = *(const bf16x8*)(vl2_smem + lds_buf + a_rd[ks]);
+            const bf16x8 b0 = *(const bf16x8*)(vl2_smem + lds_buf + b_rd[ks]);
+            const bf16x8 b1 = *(const bf16x8*)(vl2_smem + lds_buf + b_rd[ks] + 4096);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b1, acc[1], 0, 0, 0);
         }
     }
     VL2_WAIT_LGKMCNT0();
@@ -980,16 +974,12 @@ __global__ __launch_bounds__(256, 1) void gemm_l_bf16_kernel(GemmArgs p) {
 
     float* ep = (float*)vl2_smem + wave * (32 * 68);
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
+    for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                ep[row * 68 + ni * 32 + (lane & 31)] = acc[mi][ni][r];
-            }
-        __syncthreads();
-        gemm_store_patch<ACT, SWIGLU, OUT_F32>(p, ep, m0 + wm * 64 + mi * 32, n0 + wn * 64, lane);
-        __syncthreads();
-    }
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            ep[row * 68 + ni * 32 + (lane & 31)] = acc[ni][r];
+        }
+    __syncthreads();
+    gemm_store_patch<ACT, SWIGLU, OUT_F32>(p, ep, m0 + wm * 32, n0 + wn * 64, lane);
 }

@@ -47,7 +47,7 @@ static int g_splitk = 0;             // VL2_TUNE_SPLITK: 0 = never (default: res
 static int g_gemv_mr_rpw = 2;   // batched GEMV rows per wave (VL2_TUNE_GEMV_MR_ROWS_PER_WAVE); measured at B=4: 5.56 / 5.04 / 5.56 ms per step at 1 / 2 / 4
 static int g_gemv_rpw = 1;   // measured on MI355X: 3.09 / 3.30 / 3.97 ms per 7B decode token at 1 / 2 / 4 rows per wave
 extern "C" int32_t vl2_set_tuning(int32_t key, int32_t value) {
-    if (key == VL2_TUNE_GEMM_VARIANT && (value == 0 || value == 1 || value == 2 || value == 4 || value == 8 || value == 32 || value == 128)) { g_gemm_variant = value; return 0; }
+    if (key == VL2_TUNE_GEMM_VARIANT && (value == 0 || value == 1 || value == 2 || value == 4 || value == 8 || value == 32 || value == 256)) { g_gemm_variant = value; return 0; }
     if (key == VL2_TUNE_GEMV_ROWS_PER_WAVE && (value == 1 || value == 2 || value == 4)) { g_gemv_rpw = value; return 0; }
     if (key == VL2_TUNE_SPLITK && (value == 0 || value == 1)) { g_splitk = value; return 0; }
     if (key == VL2_TUNE_GEMV_MR_ROWS_PER_WAVE && (value == 1 || value == 2 || value == 4)) { g_gemv_mr_rpw = value; return 0; }
@@ -148,15 +148,14 @@ static void launch_gemm(const GemmArgs& a0, hipStream_t s) {
         return;
     }
     if constexpr (!G) {
-        // measured (scripts/kernel_bench.py --small / --frames 8): wins 8-10 % at <= 256 tiles with K >= 4096 (845x4096x4096 43.8 -> 40.2 us,
-        // 945x4096x14336 149.8 -> 140.1), loses at K = 1024 (2308x3072x1024 21.3 -> 28.5) and, of course, beyond one round
-        if (g_gemm_variant == 128 || (g_gemm_variant == 0 && (long)a0.tiles_m * a0.tiles_n <= 256 && a0.K >= 4096)) {
-            static bool attrl = false;
-            if (!attrl) {
-                hipFuncSetAttribute((const void*)gemm_l_bf16_kernel<ACT, SW, F32>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMML_LDS_BYTES);
-                attrl = true;
+        // measured (scripts/kernel_bench.py --frames 8): wins 15-20 % at <= 256 tiles with K >= 4096, loses at K = 1024 and beyond one round
+        if (g_gemm_variant == 256 || (g_gemm_variant == 0 && (long)a0.tiles_m * a0.tiles_n <= 256 && a0.K >= 4096)) {
+            static bool attrl8 = false;
+            if (!attrl8) {
+                hipFuncSetAttribute((const void*)gemm_l8_bf16_kernel<ACT, SW, F32>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMML_LDS_BYTES);
+                attrl8 = true;
             }
-            hipLaunchKernelGGL((gemm_l_bf16_kernel<ACT, SW, F32>), dim3(a0.tiles_m * a0.tiles_n), dim3(256), GEMML_LDS_BYTES, s, a0);
+            hipLaunchKernelGGL((gemm_l8_bf16_kernel<ACT, SW, F32>), dim3(a0.tiles_m * a0.tiles_n), dim3(512), GEMML_LDS_BYTES, s, a0);
             return;
         }
         const int kern = g_gemm_variant == 0 ? choose_gemm_kernel(a0) : g_gemm_variant;

@@ -55,7 +55,7 @@ def set_splitk(on):
 
 def set_gemm_variant(v):
     """0 auto (per-shape choice), 1 128x128x64, 2 stream-K, 4 128x256x64 ping-pong, 8 256x256x32 ping-pong, 32 64x64 small-M,
-    128 128x128 deep-ring one-round kernel (include/vl2hip.h)."""
+    256 128x128 8-wave deep-ring one-round kernel (include/vl2hip.h)."""
     _lib.call("vl2_set_tuning", 1, int(v))
 
 
