@@ -40,9 +40,15 @@ template <> __device__ __forceinline__ int attn_k_off<64>(int row, int chunk) {
 // V^T image: row d = 64 keys * 2 B = 128 B = 8 chunks of 16 B.  Chunk (kb, hi) (kb = 16-key block 0..3) holds, in
 // order, keys 16kb + 4hi + {0,1,2,3, 8,9,10,11}: exactly the 8 keys lane-half `hi` contracts in one PV MFMA, so the
 // A fragment is ONE ds_read_b128.  Rows are swizzled like the K tile of the 64-wide case (two rows per bank row).
+template <int D>
 __device__ __forceinline__ int attn_vt_off(int d, int c16) {
+    // slot key: R & 15 alone keeps the fragment READ conflict-free (16 consecutive R per instruction), but the transposing 4-byte
+    // WRITES touch rows d, d+8, ... = R, R+4, ..., R+16, ... in one instruction and R / R+16 (+32, +48) then share banks (PMC: 32 %
+    // / 53 % of LDS-active cycles were conflicts at D = 64 / 128).  The high bits of R are folded into key bits the write
+    // pattern leaves free: bit 1 at D = 64 (a wave writes 8 key pairs: chunk bit 0 varies), bits 0-1 at D >= 96.
     const int R = d >> 1, s = ((d & 1) << 3) | c16;
-    return ((R << 4) + (s ^ (R & 15))) << 4;
+    const int key = D == 64 ? (R & 15) ^ ((R >> 4) << 1) : (R ^ (R >> 4)) & 15;
+    return ((R << 4) + (s ^ key)) << 4;
 }
 
 template <int D, bool CAUSAL>
@@ -127,7 +133,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
             for (int j = 0; j < 8; ++j) {
                 const unsigned a = (vreg[i][0][j >> 1] >> ((j & 1) * 16)) & 0xffffu;
                 const unsigned bb = (vreg[i][1][j >> 1] >> ((j & 1) * 16)) & 0xffffu;
-                *(unsigned*)(Vt + attn_vt_off(ch * 8 + j, c16) + eoff) = a | (bb << 16);
+                *(unsigned*)(Vt + attn_vt_off<D>(ch * 8 + j, c16) + eoff) = a | (bb << 16);
             }
         }
     };
@@ -215,7 +221,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
                 const int c16 = (kh * 2 + ks2) * 2 + hi;
 #pragma unroll
                 for (int db = 0; db < NDB; ++db) {
-                    const bf16x8 vf = *(const bf16x8*)(Vt + attn_vt_off(db * 32 + l31, c16));
+                    const bf16x8 vf = *(const bf16x8*)(Vt + attn_vt_off<D>(db * 32 + l31, c16));
                     oT[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oT[db], 0, 0, 0);
                 }
             }
