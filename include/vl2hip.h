@@ -36,6 +36,8 @@ int32_t vl2_version(void);
 #define VL2_TUNE_GEMV_ROWS_PER_WAVE 2   /* 1 (default), 2 or 4 output rows streamed by each wave of the decode GEMV */
 #define VL2_TUNE_GEMV_MR_ROWS_PER_WAVE 4 /* 1, 2 (default) or 4 output rows per wave of the batched (multi-row) decode GEMV */
 #define VL2_TUNE_SPLITK 3               /* 0 (default): never; 1: small-grid GEMMs split K when a workspace is attached */
+#define VL2_TUNE_ATTN_KV_GROUPS 5        /* causal D=128 attention: 0 (default) = two KV groups per workgroup when one sequence has
+                                         * <= 352 (q block, head) pairs, 1 = never, 2 = always */
 int32_t vl2_set_tuning(int32_t key, int32_t value);
 /* Optional caller-owned device workspace (>= vl2_workspace_bytes(), 16-byte aligned; NULL detaches).  With a workspace
  * attached, tuning variant 2 runs GEMMs as stream-K (512 persistent workgroups, partial tiles exchanged through the

@@ -22,7 +22,12 @@ extern "C" int64_t vl2_workspace_bytes(void) { return 0; }
 extern "C" int32_t vl2_set_workspace(void*, int64_t) { return 0; }
 
 static int g_gemm_variant = 0;
-extern "C" int32_t vl2_set_tuning(int32_t key, int32_t value) { if (key == 1) { g_gemm_variant = value; return 0; } return (key == 2 || key == 3 || key == 4) ? 0 : -1; }
+static int g_attn_kv_groups = 0;
+extern "C" int32_t vl2_set_tuning(int32_t key, int32_t value) {
+    if (key == 1) { g_gemm_variant = value; return 0; }
+    if (key == 5) { g_attn_kv_groups = value; return 0; }
+    return (key == 2 || key == 3 || key == 4) ? 0 : -1;
+}
 template <int ACT, bool SW, bool F32, bool G>
 static void run_gemm(GemmArgs a) {
     if constexpr (!G) {
@@ -162,7 +167,11 @@ extern "C" int32_t vl2_attn_fwd(const void* q, const void* k, const void* v, voi
     dim3 g((nq + 127) / 128, H, B), blk(256);
     if (causal) g = dim3(((nq + 127) / 128) * H * B, 1, 1);
     if (D == 64 && !causal) emu::launch(g, blk, [=] { attn_fwd_kernel<64, false>(a); });
-    else if (D == 128 && causal) emu::launch(g, blk, [=] { attn_fwd_kernel<128, true>(a); });
+    else if (D == 128 && causal) {
+        const long per_seq = (long)((nq + 127) / 128) * H;
+        if (g_attn_kv_groups == 2 || (g_attn_kv_groups == 0 && per_seq <= 352)) emu::launch(g, dim3(512), [=] { attn_fwd_kernel<128, true, 2>(a); });
+        else emu::launch(g, blk, [=] { attn_fwd_kernel<128, true>(a); });
+    }
     else if (D == 128 && !causal) emu::launch(g, blk, [=] { attn_fwd_kernel<128, false>(a); });
     else if (D == 64 && causal) emu::launch(g, blk, [=] { attn_fwd_kernel<64, true>(a); });
     else if (D == 96 && !causal) emu::launch(g, blk, [=] { attn_fwd_kernel<96, false>(a); });

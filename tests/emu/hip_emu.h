@@ -148,7 +148,14 @@ inline f32x4 mfma_16x16x32_bf16(s16x8 a, s16x8 b, f32x4 c) {
     wave_sync();
     return c;
 }
-struct Rsrc { const char* p; };
+struct Rsrc { const char* p; unsigned bytes; };   // bytes: NUM_RECORDS of a raw buffer (stride 0): loads past it return 0
+typedef unsigned int emu_u32x4 __attribute__((ext_vector_type(4)));
+// buffer_load_dwordx4 of a raw buffer: the range check covers voffset only (the SGPR offset is outside it, gfx9 ISA)
+inline emu_u32x4 buffer_load_b128(Rsrc r, unsigned voff, unsigned soff) {
+    emu_u32x4 v = {0u, 0u, 0u, 0u};
+    if ((unsigned long long)voff + 16 <= r.bytes) memcpy(&v, r.p + voff + soff, 16);
+    return v;
+}
 template <class T> inline float dot2(T a, T b, float c) {   // v_dot2c_f32_bf16
     uint32_t x, y; memcpy(&x, &a, 4); memcpy(&y, &b, 4);
     float r = c;
@@ -207,7 +214,8 @@ inline void buffer_load_lds(Rsrc r, void* lds, unsigned size, unsigned voff, uns
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) emu::mfma_32x32x16_bf16(a, b, c)
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) emu::mfma_16x16x32_bf16(a, b, c)
 #define __builtin_amdgcn_global_load_lds(g, l, sz, off, aux) emu::global_load_lds((const void*)(g), (void*)(l), sz, off, aux)
-#define __builtin_amdgcn_make_buffer_rsrc(p, stride, bytes, flags) emu::Rsrc{(const char*)(p)}
+#define __builtin_amdgcn_make_buffer_rsrc(p, stride, bytes, flags) emu::Rsrc{(const char*)(p), (unsigned)(bytes)}
+#define __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, aux) emu::buffer_load_b128((r), (unsigned)(voff), (unsigned)(soff))
 #define __builtin_amdgcn_raw_ptr_buffer_load_lds(r, l, sz, voff, soff, off, aux) emu::buffer_load_lds((r), (void*)(l), sz, (unsigned)(voff), (unsigned)(soff))
 #define __builtin_amdgcn_readfirstlane(x) emu::shfl_idx((x), 0)
 #define __builtin_amdgcn_fdot2_f32_bf16(a, b, c, cl) emu::dot2((a), (b), (c))

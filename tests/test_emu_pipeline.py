@@ -152,6 +152,31 @@ def test_emu_attention_ragged_and_causal(emu):
     assert rel(o2, ref[160:]) < TOL_BF16_OUT
 
 
+def test_emu_causal_attention_kv_groups(emu):
+    """Causal D=128 attention with one and with two KV groups per workgroup (the second group takes every other KV tile; the
+    partial (m, l, O) are merged through LDS): 1, 3, 4 and 6 KV tiles, so that the second group has none / fewer / as many."""
+    from videollama2_amd import ops
+    nh, nkv, D, smax = 4, 2, 128, 384
+    try:
+        for S in (60, 130, 200, 330):
+            q, kc, vc = bf(S, nh * D, seed=S), bf(nkv, smax, D, seed=S + 1), bf(nkv, smax, D, seed=S + 2)
+            args = ((0, D, nh * D), (0, smax * D, D), (0, smax * D, D), (0, D, nh * D), 1, nh)
+            qf = q.view(S, nh, D).transpose(0, 1).float()
+            kf, vf = kc[:, :S].float().repeat_interleave(2, 0), vc[:, :S].float().repeat_interleave(2, 0)
+            sc = (qf @ kf.transpose(1, 2) * D ** -0.5).masked_fill(torch.triu(torch.ones(S, S, dtype=torch.bool), 1), float("-inf"))
+            ref = (torch.softmax(sc, -1) @ vf).transpose(0, 1).reshape(S, nh * D)
+            outs = []
+            for groups in (1, 2):
+                ops.set_attn_kv_groups(groups)
+                o = torch.zeros(S, nh * D, dtype=torch.bfloat16)
+                ops.attn_fwd(q, kc, vc, o, *args, S, S, nh // nkv, D ** -0.5, True, 0, D)
+                assert rel(o, ref) < TOL_BF16_OUT, (S, groups)
+                outs.append(o)
+            assert rel(outs[0], outs[1]) < 5e-3          # same math, partial sums merged in a different order
+    finally:
+        ops.set_attn_kv_groups(0)
+
+
 def test_emu_small_config_end_to_end_vs_reference_goldens(emu, golden_small):
     from videollama2_amd.model import VideoLLaMA2Hip
     g = golden_small

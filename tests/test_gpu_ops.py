@@ -210,13 +210,18 @@ def test_attn_vit_full_size(ops):
     assert rel(o, ref) < TOL_BF16_OUT
 
 
-@pytest.mark.parametrize("S,nh,nkv", [(1621, 32, 8), (200, 4, 2), (64, 2, 1)])
-def test_attn_causal_gqa(ops, S, nh, nkv):
+@pytest.mark.parametrize("groups", [0, 1, 2])       # KV groups per workgroup: auto / one / two (split KV tiles, LDS merge)
+@pytest.mark.parametrize("S,nh,nkv", [(1621, 32, 8), (200, 4, 2), (64, 2, 1), (1345, 8, 2)])
+def test_attn_causal_gqa(ops, S, nh, nkv, groups):
     D, smax = 128, 2048
     q, kc, vc = bf(S, nh * D), bf(nkv, smax, D), bf(nkv, smax, D, seed=1)
     o = torch.zeros(S, nh * D, dtype=torch.bfloat16, device=DEV)
-    ops.attn_fwd(q.to(DEV), kc.to(DEV), vc.to(DEV), o, (0, D, nh * D), (0, smax * D, D), (0, smax * D, D), (0, D, nh * D),
-                 1, nh, S, S, nh // nkv, D ** -0.5, True, 0, D)
+    ops.set_attn_kv_groups(groups)
+    try:
+        ops.attn_fwd(q.to(DEV), kc.to(DEV), vc.to(DEV), o, (0, D, nh * D), (0, smax * D, D), (0, smax * D, D), (0, D, nh * D),
+                     1, nh, S, S, nh // nkv, D ** -0.5, True, 0, D)
+    finally:
+        ops.set_attn_kv_groups(0)
     qf = q.view(S, nh, D).transpose(0, 1).float()
     kf = kc[:, :S].float().repeat_interleave(nh // nkv, 0)
     vf = vc[:, :S].float().repeat_interleave(nh // nkv, 0)

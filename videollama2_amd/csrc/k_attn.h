@@ -13,6 +13,10 @@
 //   already owns and the V^T fragment is read with the same permutation).
 // 4 waves x 32 q rows per workgroup, KV tile = 64 keys, K/V staged global -> registers -> LDS (next tile's loads
 // are issued before the current tile's MFMAs), online softmax in the exp2 domain.
+// NG = 2 (causal prefill of ONE sequence: S*H/32 = 1664 waves for 1024 SIMDs, and the longest q block is a chain of 26
+// dependent tiles that mostly has its SIMD to itself): a second group of 4 waves takes every other KV tile of the same
+// 128 q rows with its own K/V staging buffers and its own running (m, l, O); the two partial results are merged through
+// LDS at the end (flash-decoding inside the workgroup).  Two independent chains per SIMD, half the chain length.
 #pragma once
 #include "dev_common.h"
 
@@ -51,18 +55,22 @@ __device__ __forceinline__ int attn_vt_off(int d, int c16) {
     return ((R << 4) + (s ^ key)) << 4;
 }
 
-template <int D, bool CAUSAL>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
+template <int D, bool CAUSAL, int NG = 1>
+__global__ __launch_bounds__(256 * NG, 2) void attn_fwd_kernel(AttnArgs p) {
     constexpr int KCH = D / 8;                 // 16-B chunks per K row
     constexpr int KPT = 64 * KCH / 256;        // K chunks per thread per tile
     constexpr int VITEMS = 32 * KCH;           // V (key-pair, chunk) items per tile
     constexpr int VPT = (VITEMS + 255) / 256;  // ... per thread (D = 96: 1.5 -> 2 passes, the second half-populated)
     constexpr int NKS = D / 16;                // k-steps of the QK^T MFMA chain
     constexpr int NDB = D / 32;                // 32-row d blocks of O^T
-    __shared__ __attribute__((aligned(16))) unsigned char Ks[64 * (D == 96 ? 128 : D) * 2];
-    __shared__ __attribute__((aligned(16))) unsigned char Vt[D * 128];
+    constexpr int KS_BYTES = 64 * (D == 96 ? 128 : D) * 2, VT_BYTES = D * 128;
+    static_assert(NG == 1 || (NG == 2 && NDB % 2 == 0), "KV groups: 1, or 2 with an even number of O^T blocks");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NG * (KS_BYTES + VT_BYTES)];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // tid / wave: within the KV group (all staging and fragment indexing is per group)
+    const int tid = threadIdx.x & 255, grp = NG > 1 ? (int)threadIdx.x >> 8 : 0, lane = tid & 63, wave = tid >> 6;
+    unsigned char* const Ks = lds + grp * (KS_BYTES + VT_BYTES);
+    unsigned char* const Vt = Ks + KS_BYTES;
     const int hi = lane >> 5, l31 = lane & 31;
     // Non-causal: grid = (q blocks, heads, batch).  Causal: 1-D grid over (q block, head*batch) with the heads fastest, and
     // q block b costs b+1 KV tiles: the first ceil(256 / (heads*batch)) q-block ranks -- one workgroup per CU -- are the
@@ -97,22 +105,36 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
     if (CAUSAL) { const int lim = q0 + 128 + p.causal_off; kmax = lim < kmax ? lim : kmax; }
     const int ntiles = (kmax + 63) >> 6;
 
+    // K/V tile loads as raw buffer loads: per-thread byte offsets inside a tile are loop-invariant VGPRs, the tile's position
+    // goes into the (scalar) buffer base, and rows past nk fall outside NUM_RECORDS and read as 0 (their scores are masked,
+    // their P is 0) -- no per-tile address arithmetic (it was 8 64-bit multiply-adds + clamps per tile and thread).
     u32x4 kreg[KPT], vreg[VPT][2];
-    auto load_tile = [&](int kv0) {
+    int koff[KPT], voff[VPT];
 #pragma unroll
-        for (int i = 0; i < KPT; ++i) {
-            const int c = tid + 256 * i, row = c / KCH, ch = c % KCH;
-            int kr = kv0 + row; kr = kr < p.nk ? kr : p.nk - 1;
-            kreg[i] = *(const u32x4*)(K + (size_t)kr * p.k_rs + ch * 8);
-        }
+    for (int i = 0; i < KPT; ++i) {
+        const int c = tid + 256 * i, row = c / KCH, ch = c % KCH;
+        koff[i] = (row * p.k_rs + ch * 8) * 2;
+    }
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const int c = tid + 256 * i, kp = c / KCH, ch = c % KCH;
+        voff[i] = (2 * kp * p.v_rs + ch * 8) * 2;
+    }
+    const int k_bytes = ((p.nk - 1) * p.k_rs + D) * 2, v_bytes = ((p.nk - 1) * p.v_rs + D) * 2;   // valid bytes behind K / V
+    auto load_tile = [&](int kv0) {
+        const int kskip = kv0 * p.k_rs * 2, vskip = kv0 * p.v_rs * 2;
+        const auto rsK = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)K + kskip), 0, k_bytes > kskip ? k_bytes - kskip : 0, 0x00020000);
+        const auto rsV = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)V + vskip), 0, v_bytes > vskip ? v_bytes - vskip : 0, 0x00020000);
+        const int vrow = p.v_rs * 2;
+        const auto rsV1 = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)V + vskip + vrow), 0,
+                                                            v_bytes > vskip + vrow ? v_bytes - vskip - vrow : 0, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) kreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsK, koff[i], 0, 0));
 #pragma unroll
         for (int i = 0; i < VPT; ++i) {
-            const int c = tid + 256 * i, kp = c / KCH, ch = c % KCH;
-            if (VITEMS % 256 != 0 && c >= VITEMS) continue;
-            int r0 = kv0 + 2 * kp, r1 = r0 + 1;
-            r0 = r0 < p.nk ? r0 : p.nk - 1; r1 = r1 < p.nk ? r1 : p.nk - 1;
-            vreg[i][0] = *(const u32x4*)(V + (size_t)r0 * p.v_rs + ch * 8);
-            vreg[i][1] = *(const u32x4*)(V + (size_t)r1 * p.v_rs + ch * 8);
+            if (VITEMS % 256 != 0 && tid + 256 * i >= VITEMS) continue;
+            vreg[i][0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsV, voff[i], 0, 0));
+            vreg[i][1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsV1, voff[i], 0, 0));
         }
     };
     auto store_tile = [&]() {
@@ -145,13 +167,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
         for (int r = 0; r < 16; ++r) oT[i][r] = 0.f;
     float m = -1e30f, l = 0.f;      // m: running max in the exp2 domain (first tile always rescales: mt - m is huge)
 
-    load_tile(0);
-    for (int t = 0; t < ntiles; ++t) {
-        const int kv0 = t * 64;
+    load_tile(grp * 64);                      // rows are clamped: harmless for a group without a tile
+    for (int t0 = 0; t0 < ntiles; t0 += NG) {
+        const int t = t0 + grp, kv0 = t * 64;
         __syncthreads();
         store_tile();
         __syncthreads();
-        if (t + 1 < ntiles) load_tile(kv0 + 64);
+        if (t + NG < ntiles) load_tile(kv0 + 64 * NG);
+        if (NG > 1 && t >= ntiles) continue;   // odd tile count: the last round has work for group 0 only (barriers are above)
 
         // S^T = K . Q^T
         f32x16 sT[2];
@@ -227,6 +250,46 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
             }
     }
 
+    if constexpr (NG > 1) {
+        // group 1's (m, l, O^T) -> LDS -> group 0, two O^T blocks per round (32 KiB) + 2 KiB of statistics.  Lane-major
+        // 16-B slots: conflict-free both ways.  A group that saw no tile carries m = -1e30, l = 0, O = 0 -> weight 0.
+        float* const xo = (float*)lds;
+        float* const xs = (float*)(lds + 32768);
+        float a0 = 1.f, a1 = 0.f;
+#pragma unroll
+        for (int r = 0; r < NDB / 2; ++r) {
+            __syncthreads();                                   // tile reads (r = 0) / the previous round's reads are done
+            if (grp == 1) {
+                if (r == 0) { xs[(wave * 64 + lane) * 2] = m; xs[(wave * 64 + lane) * 2 + 1] = l; }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const f32x4 w = {oT[2 * r + i][4 * q4], oT[2 * r + i][4 * q4 + 1], oT[2 * r + i][4 * q4 + 2], oT[2 * r + i][4 * q4 + 3]};
+                        *(f32x4*)(xo + (((wave * 2 + i) * 4 + q4) * 64 + lane) * 4) = w;
+                    }
+            }
+            __syncthreads();
+            if (grp == 0) {
+                if (r == 0) {
+                    const float m1 = xs[(wave * 64 + lane) * 2], l1 = xs[(wave * 64 + lane) * 2 + 1];
+                    const float ms = fmaxf(m, m1);
+                    a0 = __builtin_amdgcn_exp2f(m - ms);
+                    a1 = __builtin_amdgcn_exp2f(m1 - ms);
+                    l = a0 * l + a1 * l1;
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const f32x4 w = *(const f32x4*)(xo + (((wave * 2 + i) * 4 + q4) * 64 + lane) * 4);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) oT[2 * r + i][4 * q4 + j] = a0 * oT[2 * r + i][4 * q4 + j] + a1 * w[j];
+                    }
+            }
+        }
+        if (grp != 0) return;
+    }
     if (qrow < p.nq) {
         const float inv = 1.0f / l;
         bf16_t* O = p.o + b * p.o_bs + h * p.o_hs + (size_t)qrow * p.o_rs;

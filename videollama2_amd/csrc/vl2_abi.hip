@@ -44,6 +44,7 @@ static int64_t g_ws_bytes = 0;
 #define SPLITK_CNT_OFF (SK_FLAGS_OFF + (int64_t)(SK_GRID + 1) * 4 + 12)
 #define SK_WS_BYTES (SPLITK_CNT_OFF + (int64_t)SPLITK_MAX_TILES * 4)
 static int g_splitk = 0;             // VL2_TUNE_SPLITK: 0 = never (default: results independent of M), 1 = small grids split K
+static int g_attn_kv_groups = 0; // VL2_TUNE_ATTN_KV_GROUPS
 static int g_gemv_mr_rpw = 2;   // batched GEMV rows per wave (VL2_TUNE_GEMV_MR_ROWS_PER_WAVE); measured at B=4: 5.56 / 5.04 / 5.56 ms per step at 1 / 2 / 4
 static int g_gemv_rpw = 1;   // measured on MI355X: 3.09 / 3.30 / 3.97 ms per 7B decode token at 1 / 2 / 4 rows per wave
 extern "C" int32_t vl2_set_tuning(int32_t key, int32_t value) {
@@ -51,6 +52,7 @@ extern "C" int32_t vl2_set_tuning(int32_t key, int32_t value) {
     if (key == VL2_TUNE_GEMV_ROWS_PER_WAVE && (value == 1 || value == 2 || value == 4)) { g_gemv_rpw = value; return 0; }
     if (key == VL2_TUNE_SPLITK && (value == 0 || value == 1)) { g_splitk = value; return 0; }
     if (key == VL2_TUNE_GEMV_MR_ROWS_PER_WAVE && (value == 1 || value == 2 || value == 4)) { g_gemv_mr_rpw = value; return 0; }
+    if (key == VL2_TUNE_ATTN_KV_GROUPS && value >= 0 && value <= 2) { g_attn_kv_groups = value; return 0; }
     return fail(VL2_E_BADARG, "vl2_set_tuning: unknown key/value %d/%d", key, value);
 }
 
@@ -387,7 +389,16 @@ extern "C" int32_t vl2_attn_fwd(const void* q, const void* k, const void* v, voi
     if (D == 64 && !causal) hipLaunchKernelGGL((attn_fwd_kernel<64, false>), g, b, 0, s, a);
     else if (D == 64 && causal) hipLaunchKernelGGL((attn_fwd_kernel<64, true>), g, b, 0, s, a);
     else if (D == 128 && !causal) hipLaunchKernelGGL((attn_fwd_kernel<128, false>), g, b, 0, s, a);
-    else if (D == 128 && causal) hipLaunchKernelGGL((attn_fwd_kernel<128, true>), g, b, 0, s, a);
+    else if (D == 128 && causal) {
+        // two KV groups per workgroup when a sequence has few (q block, head) pairs: decided per SEQUENCE (B is left out) so
+        // that a prompt gets the same bits prefilled alone or in a batch.  Measured (scripts/attn_bench.py): 256 pairs (S = 945,
+        // 32 heads) 28.5 -> 27.1 us, 336 (S = 1452, 28 heads) 38.9 -> 35.8; 416 (S = 1621, 32 heads) 47.4 -> 52.2: the SIMD's
+        // per-tile throughput, not the length of the dependent tile chain, is the limit once every CU has > 1.4 workgroups.
+        const long per_seq = (long)((nq + 127) / 128) * H;
+        const bool two = g_attn_kv_groups == 2 || (g_attn_kv_groups == 0 && per_seq <= 352);
+        if (two) hipLaunchKernelGGL((attn_fwd_kernel<128, true, 2>), g, dim3(512), 0, s, a);
+        else hipLaunchKernelGGL((attn_fwd_kernel<128, true>), g, b, 0, s, a);
+    }
     else if (D == 96 && !causal) hipLaunchKernelGGL((attn_fwd_kernel<96, false>), g, b, 0, s, a);
     else return fail(VL2_E_SHAPE, "vl2_attn_fwd: head_dim %d not built (64, 96 non-causal, 128)", D);
     return launched("vl2_attn_fwd");

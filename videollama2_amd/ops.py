@@ -53,6 +53,12 @@ def set_splitk(on):
     _lib.call("vl2_set_tuning", 3, 1 if on else 0)
 
 
+def set_attn_kv_groups(n):
+    """Causal D=128 attention (include/vl2hip.h VL2_TUNE_ATTN_KV_GROUPS): 0 = auto, 1 = one group of 4 waves per workgroup,
+    2 = two groups that split the KV tiles and merge through LDS."""
+    _lib.call("vl2_set_tuning", 5, int(n))
+
+
 def set_gemm_variant(v):
     """0 auto (per-shape choice), 1 128x128x64, 2 stream-K, 4 128x256x64 ping-pong, 8 256x256x32 ping-pong, 32 64x64 small-M,
     256 128x128 8-wave deep-ring one-round kernel (include/vl2hip.h)."""
