@@ -173,6 +173,14 @@ def test_emu_causal_attention_kv_groups(emu):
                 assert rel(o, ref) < TOL_BF16_OUT, (S, groups)
                 outs.append(o)
             assert rel(outs[0], outs[1]) < 5e-3          # same math, partial sums merged in a different order
+            # rows above the diagonal of the second group's first tile meet only masked keys there: whatever the rounding of
+            # (-1e30 * scale), their weight must come out 0, never 2^(+residue) = inf
+            for scale in (0.05, 0.0713, 0.1, 0.131):
+                o = torch.zeros(S, nh * D, dtype=torch.bfloat16)
+                ops.attn_fwd(q, kc, vc, o, *args, S, S, nh // nkv, scale, True, 0, D)
+                sc2 = (qf @ kf.transpose(1, 2) * scale).masked_fill(torch.triu(torch.ones(S, S, dtype=torch.bool), 1), float("-inf"))
+                ref2 = (torch.softmax(sc2, -1) @ vf).transpose(0, 1).reshape(S, nh * D)
+                assert torch.isfinite(o.float()).all() and rel(o, ref2) < TOL_BF16_OUT, (S, scale)
     finally:
         ops.set_attn_kv_groups(0)
 

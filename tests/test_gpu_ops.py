@@ -231,6 +231,26 @@ def test_attn_causal_gqa(ops, S, nh, nkv, groups):
     assert rel(o, ref) < TOL_BF16_OUT
 
 
+@pytest.mark.parametrize("scale", [0.05, 0.0713, 0.0884, 0.131])
+def test_attn_causal_two_groups_rows_with_only_masked_keys(ops, scale):
+    """Second KV group: rows above the diagonal of its first tile meet only masked keys there; their partial result must carry
+    weight 0 for any rounding of (-1e30 * scale)."""
+    S, nh, nkv, D, smax = 330, 4, 2, 128, 512
+    q, kc, vc = bf(S, nh * D, seed=3), bf(nkv, smax, D, seed=4), bf(nkv, smax, D, seed=5)
+    o = torch.zeros(S, nh * D, dtype=torch.bfloat16, device=DEV)
+    ops.set_attn_kv_groups(2)
+    try:
+        ops.attn_fwd(q.to(DEV), kc.to(DEV), vc.to(DEV), o, (0, D, nh * D), (0, smax * D, D), (0, smax * D, D), (0, D, nh * D),
+                     1, nh, S, S, nh // nkv, scale, True, 0, D)
+    finally:
+        ops.set_attn_kv_groups(0)
+    qf = q.view(S, nh, D).transpose(0, 1).float()
+    kf, vf = kc[:, :S].float().repeat_interleave(2, 0), vc[:, :S].float().repeat_interleave(2, 0)
+    sc = (qf @ kf.transpose(1, 2) * scale).masked_fill(torch.triu(torch.ones(S, S, dtype=torch.bool), 1), float("-inf"))
+    ref = (torch.softmax(sc, -1) @ vf).transpose(0, 1).reshape(S, nh * D)
+    assert torch.isfinite(o.float()).all() and rel(o, ref) < TOL_BF16_OUT
+
+
 def test_attn_softmax_spike(ops):
     """One key dominating one query row at a late tile forces the online-softmax rescale branch (guide rule 26)."""
     B, H, N, D = 1, 1, 300, 64

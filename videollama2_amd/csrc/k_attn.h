@@ -212,7 +212,9 @@ __global__ __launch_bounds__(256 * NG, 2) void attn_fwd_kernel(AttnArgs p) {
         // bounded by 2^THR (fp32 accumulators, bf16 P: fine).  THR = 0 would rescale every tile.
         constexpr float THR = 6.0f;
         if (!__all(mt - m <= THR)) {
-            const float m_new = fmaxf(m, mt);
+            // floor at -1e28: a row that has met only masked keys so far (possible for the second KV group, whose first tile can
+            // lie entirely above the row's diagonal) keeps p = 2^(-1e30 c + 1e28) = 0 instead of 2^(rounding residue of -1e30 c)
+            const float m_new = fmaxf(fmaxf(m, mt), -1e28f);
             const float alpha = __builtin_amdgcn_exp2f(m - m_new);
             m = m_new;
             l *= alpha;

@@ -68,6 +68,10 @@ struct GemvArgs {
 // grid = ceil(N_out / (4*RPW)), block 256; dynamic LDS = K * 2 bytes (x as bf16)
 template <bool SWIGLU, bool OUT_F32, int RPW>
 __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvArgs p) {
+    // The fused RMSNorm must give the SAME bits here and in gemv_mr_bf16_kernel (a row of a batched decode step == the
+    // single-sequence step): under -ffast-math the two instantiations were free to associate "v * rstd * w" and the
+    // sum of squares differently (seen on hardware: one logit row in thousands off by 3e-4).  Fixed order, explicit FMAs.
+#pragma clang fp reassociate(off)
     extern __shared__ __attribute__((aligned(16))) unsigned char vl2_smem[];
     __shared__ float red[8];
     bf16_t* xs = (bf16_t*)vl2_smem;
@@ -102,12 +106,12 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvArgs p) {
             float v[8];
             unpack8(*(const u32x4*)(p.x + k), v);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) ss += v[j] * v[j];
+            for (int j = 0; j < 8; ++j) ss = __builtin_fmaf(v[j], v[j], ss);
         }
         ss = wave_sum(ss);
         if (lane == 0) red[wave] = ss;
         __syncthreads();
-        rstd = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)p.K + p.eps);
+        rstd = rsqrtf(((red[0] + red[1]) + (red[2] + red[3])) / (float)p.K + p.eps);
     }
     for (int k = tid * 8; k < p.K; k += 2048) {
         u32x4 raw = *(const u32x4*)(p.x + k);
@@ -116,7 +120,7 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvArgs p) {
             unpack8(raw, v);
             const f32x4 w0 = *(const f32x4*)(p.norm_w + k), w1 = *(const f32x4*)(p.norm_w + k + 4);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = v[j] * rstd * (j < 4 ? w0[j] : w1[j - 4]);
+            for (int j = 0; j < 8; ++j) v[j] = (v[j] * rstd) * (j < 4 ? w0[j] : w1[j - 4]);
             raw = pack8(v);
         }
         *(u32x4*)(xs + k) = raw;
@@ -162,6 +166,7 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvArgs p) {
 // vector is multiplied against the MB x vectors it meets.  grid = ceil(N_out / 4), block 256.
 template <bool SWIGLU, bool OUT_F32, int MB, int RPW>
 __global__ __launch_bounds__(256) void gemv_mr_bf16_kernel(GemvArgs p) {
+#pragma clang fp reassociate(off)                  // see gemv_bf16_kernel: the norm arithmetic is pinned to one order
     extern __shared__ __attribute__((aligned(16))) unsigned char vl2_smem[];
     __shared__ float red[MB][4];
     bf16_t* xs = (bf16_t*)vl2_smem;
@@ -196,14 +201,14 @@ __global__ __launch_bounds__(256) void gemv_mr_bf16_kernel(GemvArgs p) {
                 float v[8];
                 unpack8(*(const u32x4*)(p.x + (size_t)b * p.ldx + k), v);
 #pragma unroll
-                for (int q = 0; q < 8; ++q) ss += v[q] * v[q];
+                for (int q = 0; q < 8; ++q) ss = __builtin_fmaf(v[q], v[q], ss);
             }
             ss = wave_sum(ss);
             if (lane == 0) red[b][wave] = ss;
         }
         __syncthreads();
 #pragma unroll
-        for (int b = 0; b < MB; ++b) rstd[b] = rsqrtf((red[b][0] + red[b][1] + red[b][2] + red[b][3]) / (float)p.K + p.eps);
+        for (int b = 0; b < MB; ++b) rstd[b] = rsqrtf(((red[b][0] + red[b][1]) + (red[b][2] + red[b][3])) / (float)p.K + p.eps);
     }
 #pragma unroll
     for (int b = 0; b < MB; ++b)
@@ -214,7 +219,7 @@ __global__ __launch_bounds__(256) void gemv_mr_bf16_kernel(GemvArgs p) {
                 unpack8(raw, v);
                 const f32x4 w0 = *(const f32x4*)(p.norm_w + k), w1 = *(const f32x4*)(p.norm_w + k + 4);
 #pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] = v[q] * rstd[b] * (q < 4 ? w0[q] : w1[q - 4]);
+                for (int q = 0; q < 8; ++q) v[q] = (v[q] * rstd[b]) * (q < 4 ? w0[q] : w1[q - 4]);
                 raw = pack8(v);
             }
             *(u32x4*)(xs + (size_t)b * p.K + k) = raw;

@@ -53,6 +53,9 @@ __device__ __forceinline__ int gemm_lds_off(int row, int chunk) {   // byte offs
 // REMAP = the row-remap / residual-row-modulo form (runtime integer divisions) -- only the patch-embed GEMM needs it
 template <int ACT, bool SWIGLU, bool OUT_F32, bool REMAP = false>
 __device__ __forceinline__ void gemm_store_patch(const GemmArgs& p, const float* ep, int m_base, int n_base, int lane) {
+        // every GEMM kernel inlines this epilogue, and a row must come out with the same bits whichever kernel its shape selects
+        // (sharded == unsharded, batched == one by one): (acc + bias) + residual stays in that order in every instantiation
+#pragma clang fp reassociate(off)
         constexpr int LPR = SWIGLU ? 4 : 8;            // lanes per row
         constexpr int RPP = 64 / LPR;                  // rows per pass
 #pragma unroll
