@@ -39,7 +39,7 @@ def import_reference():
     if not reference_available():
         raise RuntimeError("reference tree not present (expected on the GPU box); goldens are in tests/golden/")
     # every other `from transformers import ...` FIRST (lazy-module gotcha, SURVEY 8c shim 3)
-    import transformers
+    import transformers  # noqa: F401  (imported for its side effect: the lazy module must be initialised first)
     from transformers import (CLIPVisionModel, CLIPImageProcessor, CLIPVisionConfig, SiglipVisionModel,  # noqa
                               SiglipImageProcessor, SiglipVisionConfig, MistralConfig, MistralModel,
                               MistralForCausalLM, AutoConfig, AutoModelForCausalLM, PretrainedConfig,

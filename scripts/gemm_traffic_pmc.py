@@ -6,7 +6,6 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from videollama2_amd import ops
 from videollama2_amd.connector import conv3d_k2s2p1_index
-from videollama2_amd.weights import pack_gate_up
 dev = "cuda"
 rnd = lambda *s, scale=1.0: (torch.randn(*s, device=dev) * scale).to(torch.bfloat16)
 SHAPES = [  # M, N, K, count per step, kwargs

@@ -4,7 +4,6 @@ memory side delivers per launch should equal the weight bytes (FETCH_SIZE x 2 on
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from videollama2_amd import ops
-from videollama2_amd.weights import pack_gate_up
 dev = "cuda"
 rnd = lambda *s, scale=1.0: (torch.randn(*s, device=dev) * scale).to(torch.bfloat16)
 x, nw = rnd(4096), torch.ones(4096, device=dev)

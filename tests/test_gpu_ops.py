@@ -1,6 +1,5 @@
 """Per-operator parity on MI355X: every libvl2hip.so kernel, called through the C ABI (videollama2_amd.ops ->
 ctypes), against the fp32 oracle of the same op on identical bf16-rounded inputs.  Tolerances: tests/util.py."""
-import math
 
 import pytest
 import torch

@@ -21,8 +21,13 @@ static int32_t fail(int32_t code, const char* fmt, ...) {
     va_end(ap);
     return code;
 }
+// set-up calls in front of a launch (LDS opt-in, flag re-arming): the first failure is kept and reported by `launched`
+static hipError_t g_setup_err = hipSuccess;
+static inline void check(hipError_t e) { if (e != hipSuccess && g_setup_err == hipSuccess) g_setup_err = e; }
 static int32_t launched(const char* what) {
-    const hipError_t e = hipGetLastError();
+    const hipError_t last = hipGetLastError();
+    const hipError_t e = g_setup_err != hipSuccess ? g_setup_err : last;
+    g_setup_err = hipSuccess;
     if (e != hipSuccess) return fail((int32_t)e, "%s: %s", what, hipGetErrorString(e));
     return 0;
 }
@@ -126,7 +131,7 @@ static void launch_gemm(const GemmArgs& a0, hipStream_t s) {
         if (choose_splitk(a0) <= 1 && want_small_m(a0)) {
             static bool attr_s = false;
             if (!attr_s) {
-                hipFuncSetAttribute((const void*)gemm_s_bf16_kernel<ACT, G>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMMS_LDS_BYTES);
+                check(hipFuncSetAttribute((const void*)gemm_s_bf16_kernel<ACT, G>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMMS_LDS_BYTES));
                 attr_s = true;
             }
             GemmArgs a = a0;
@@ -139,8 +144,8 @@ static void launch_gemm(const GemmArgs& a0, hipStream_t s) {
     if (const int split = choose_splitk(a0); split > 1) {
         static bool attr_k = false;
         if (!attr_k) {
-            hipFuncSetAttribute((const void*)gemm_bf16_kernel<ACT, SW, F32, G, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                GEMM_LDS_BYTES);
+            check(hipFuncSetAttribute((const void*)gemm_bf16_kernel<ACT, SW, F32, G, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                GEMM_LDS_BYTES));
             attr_k = true;
         }
         GemmArgs a = a0;
@@ -154,7 +159,7 @@ static void launch_gemm(const GemmArgs& a0, hipStream_t s) {
         if (g_gemm_variant == 256 || (g_gemm_variant == 0 && (long)a0.tiles_m * a0.tiles_n <= 256 && a0.K >= 4096)) {
             static bool attrl8 = false;
             if (!attrl8) {
-                hipFuncSetAttribute((const void*)gemm_l8_bf16_kernel<ACT, SW, F32>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMML_LDS_BYTES);
+                check(hipFuncSetAttribute((const void*)gemm_l8_bf16_kernel<ACT, SW, F32>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMML_LDS_BYTES));
                 attrl8 = true;
             }
             hipLaunchKernelGGL((gemm_l8_bf16_kernel<ACT, SW, F32>), dim3(a0.tiles_m * a0.tiles_n), dim3(512), GEMML_LDS_BYTES, s, a0);
@@ -164,7 +169,7 @@ static void launch_gemm(const GemmArgs& a0, hipStream_t s) {
         if (kern == 4 && a0.N % GEMM3_BN == 0) {
             static bool attr3 = false;
             if (!attr3) {
-                hipFuncSetAttribute((const void*)gemm3_bf16_kernel<ACT, SW, F32>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM3_LDS_BYTES);
+                check(hipFuncSetAttribute((const void*)gemm3_bf16_kernel<ACT, SW, F32>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM3_LDS_BYTES));
                 attr3 = true;
             }
             GemmArgs a = a0;
@@ -176,8 +181,8 @@ static void launch_gemm(const GemmArgs& a0, hipStream_t s) {
         if (kern == 8 && a0.N % GEMM4_BN == 0) {
             static bool attr4 = false;
             if (!attr4) {
-                hipFuncSetAttribute((const void*)gemm4_bf16_kernel<ACT, SW, F32>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    GEMM4_LDS_BYTES);
+                check(hipFuncSetAttribute((const void*)gemm4_bf16_kernel<ACT, SW, F32>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    GEMM4_LDS_BYTES));
                 attr4 = true;
             }
             GemmArgs a = a0;
@@ -191,8 +196,8 @@ static void launch_gemm(const GemmArgs& a0, hipStream_t s) {
         if (want_stream_k(a0)) {
             static bool attr_sk = false;
             if (!attr_sk) {
-                hipFuncSetAttribute((const void*)gemm_sk_bf16_kernel<ACT, SW, F32>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    GEMM_LDS_BYTES);
+                check(hipFuncSetAttribute((const void*)gemm_sk_bf16_kernel<ACT, SW, F32>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    GEMM_LDS_BYTES));
                 attr_sk = true;
             }
             GemmArgs a = a0;
@@ -200,7 +205,7 @@ static void launch_gemm(const GemmArgs& a0, hipStream_t s) {
             a.sk_ws = (float*)g_ws;
             a.sk_flags = (int*)((char*)g_ws + SK_FLAGS_OFF);
             a.sk_per = (total + SK_GRID - 1) / SK_GRID;
-            hipMemsetAsync(a.sk_flags, 0, (SK_GRID + 1) * 4, s);               // flags re-armed before EVERY launch (guide G16)
+            check(hipMemsetAsync(a.sk_flags, 0, (SK_GRID + 1) * 4, s));               // flags re-armed before EVERY launch (guide G16)
             hipLaunchKernelGGL((gemm_sk_bf16_kernel<ACT, SW, F32>), dim3(SK_GRID), dim3(256), GEMM_LDS_BYTES, s, a);
             return;
         }
@@ -208,8 +213,8 @@ static void launch_gemm(const GemmArgs& a0, hipStream_t s) {
     const GemmArgs& a = a0;
     static bool attr_set = false;   // 64 KiB dynamic LDS needs the opt-in once per kernel instance
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)gemm_bf16_kernel<ACT, SW, F32, G>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            GEMM_LDS_BYTES);
+        check(hipFuncSetAttribute((const void*)gemm_bf16_kernel<ACT, SW, F32, G>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            GEMM_LDS_BYTES));
         attr_set = true;
     }
     hipLaunchKernelGGL((gemm_bf16_kernel<ACT, SW, F32, G>), dim3(a.tiles_m * a.tiles_n), dim3(256), GEMM_LDS_BYTES, s, a);
@@ -235,7 +240,7 @@ extern "C" int32_t vl2_gemm_bf16(const void* A, const void* W, void* C, const fl
         if (sw || g || f32 || act != VL2_ACT_NONE) return fail(VL2_E_UNSUPP, "vl2_gemm_bf16: row remap supports plain bf16 output only");
         static bool attr_r = false;
         if (!attr_r) {
-            hipFuncSetAttribute((const void*)gemm_bf16_kernel<ACT_NONE, false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+            check(hipFuncSetAttribute((const void*)gemm_bf16_kernel<ACT_NONE, false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
             attr_r = true;
         }
         hipLaunchKernelGGL((gemm_bf16_kernel<ACT_NONE, false, false, false, true>), dim3(a.tiles_m * a.tiles_n), dim3(256), GEMM_LDS_BYTES, s, a);
@@ -270,7 +275,7 @@ template <int MT>
 static void launch_skinny(const SkinnyArgs& a, int ks, size_t lds, hipStream_t s) {
     static bool attr = false;
     if (!attr) {
-        hipFuncSetAttribute((const void*)gemm_skinny_kernel<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        check(hipFuncSetAttribute((const void*)gemm_skinny_kernel<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
         attr = true;
     }
     hipLaunchKernelGGL((gemm_skinny_kernel<MT>), dim3(a.N / 64, ks), dim3(256), lds, s, a);
