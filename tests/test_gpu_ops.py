@@ -58,6 +58,21 @@ def test_gemm_pingpong_variant_is_bit_identical(ops, M, N, K):
         ops.set_gemm_variant(0)
 
 
+@pytest.mark.parametrize("M,N,K", [(1621, 28672, 4096), (1100, 16384, 2048)])
+def test_gemm_row_split_swiglu_is_bit_identical(ops, M, N, K):
+    """Wide-N GEMMs whose M leaves the 256-row kernel a nearly empty last row tile run as two launches (256-row kernel on the
+    first floor(M/256)*256 rows, the chooser's pick on the rest): same bits as the 128x128 kernel on the whole matrix."""
+    a, w = bf(M, K).to(DEV), bf(N, K, scale=K ** -0.5).to(DEV)
+    try:
+        ops.set_gemm_variant(1)
+        ref = ops.gemm(a, w, swiglu=True)
+        ops.set_gemm_variant(0)
+        for _ in range(3):
+            assert torch.equal(ops.gemm(a, w, swiglu=True), ref)
+    finally:
+        ops.set_gemm_variant(0)
+
+
 def test_gemm_stream_k_variant(ops):
     """Stream-K form (tuning knob 2): partial tiles cross workgroups through the caller-owned workspace with an
     agent-scope release/acquire hand-off; repeated launches screen for stale reads.  fp32 sums in a different order."""

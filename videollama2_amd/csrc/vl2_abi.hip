@@ -125,8 +125,49 @@ static bool want_small_m(const GemmArgs& a) {
     return a.tiles_m * a.tiles_n <= 128 && a.K >= 512;   // measured crossover: wins at <= 128 tiles, loses at 152-160
 }
 
+template <int ACT, bool SW, bool F32>
+static void launch_gemm4(const GemmArgs& a0, hipStream_t s) {
+    static bool attr4 = false;
+    if (!attr4) {
+        check(hipFuncSetAttribute((const void*)gemm4_bf16_kernel<ACT, SW, F32>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM4_LDS_BYTES));
+        attr4 = true;
+    }
+    GemmArgs a = a0;
+    a.tiles_m = (a.M + GEMM4_BM - 1) / GEMM4_BM;
+    a.tiles_n = a.N / GEMM4_BN;
+    hipLaunchKernelGGL((gemm4_bf16_kernel<ACT, SW, F32>), dim3(a.tiles_m * a.tiles_n), dim3(512), GEMM4_LDS_BYTES, s, a);
+}
+
+// Row split: M = 1621 leaves the 256-row kernel a 7th row tile with 85 live rows (9.5 % of its MFMA work wasted) and the
+// 128-row kernel is slower per FLOP.  When N is wide enough for both parts to fill the chip, the first floor(M/256)*256 rows
+// go to the 256x256 kernel and the remaining rows to whatever the chooser picks for them -- two launches, same stream.  Every
+// kernel accumulates K in the same order and shares one epilogue, so the output bits do not change (asserted in
+// tests/test_gpu_ops.py).  Measured: 1621x28672x4096 + SwiGLU 362 -> 345 us; loses on N <= 6144 and on M % 256 > 128.
+static bool want_m_split(const GemmArgs& a) {
+    if (g_gemm_variant != 0 || a.out_grp > 0 || a.res_row_mod > 0 || a.N % GEMM4_BN || a.K < 2048 || a.M < 1024) return false;
+    const int r = a.M % GEMM4_BM, m1_tiles = a.M / GEMM4_BM, n_tiles = a.N / GEMM4_BN;
+    if (r == 0 || r > 96 || n_tiles < 64) return false;
+    const long t4 = (long)m1_tiles * n_tiles;
+    return (double)t4 / (double)(((t4 + 255) / 256) * 256) >= 0.85;      // the 256-row part fills its rounds
+}
+
 template <int ACT, bool SW, bool F32, bool G>
 static void launch_gemm(const GemmArgs& a0, hipStream_t s) {
+    if constexpr (!G && !F32) {
+        if (want_m_split(a0)) {
+            const int M1 = a0.M / GEMM4_BM * GEMM4_BM;
+            GemmArgs hi = a0, lo = a0;
+            hi.M = M1;
+            launch_gemm4<ACT, SW, F32>(hi, s);
+            lo.M = a0.M - M1;
+            lo.A = a0.A + (size_t)M1 * a0.lda;
+            lo.C = (bf16_t*)a0.C + (size_t)M1 * a0.ldc;
+            if (a0.res) lo.res = a0.res + (size_t)M1 * a0.ldres;
+            lo.tiles_m = (lo.M + GEMM_BM - 1) / GEMM_BM;
+            launch_gemm<ACT, SW, F32, G>(lo, s);
+            return;
+        }
+    }
     if constexpr (!SW && !F32) {
         if (choose_splitk(a0) <= 1 && want_small_m(a0)) {
             static bool attr_s = false;
@@ -179,16 +220,7 @@ static void launch_gemm(const GemmArgs& a0, hipStream_t s) {
             return;
         }
         if (kern == 8 && a0.N % GEMM4_BN == 0) {
-            static bool attr4 = false;
-            if (!attr4) {
-                check(hipFuncSetAttribute((const void*)gemm4_bf16_kernel<ACT, SW, F32>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    GEMM4_LDS_BYTES));
-                attr4 = true;
-            }
-            GemmArgs a = a0;
-            a.tiles_m = (a.M + GEMM4_BM - 1) / GEMM4_BM;
-            a.tiles_n = a.N / GEMM4_BN;
-            hipLaunchKernelGGL((gemm4_bf16_kernel<ACT, SW, F32>), dim3(a.tiles_m * a.tiles_n), dim3(512), GEMM4_LDS_BYTES, s, a);
+            launch_gemm4<ACT, SW, F32>(a0, s);
             return;
         }
     }
