@@ -418,6 +418,9 @@ extern "C" int32_t vl2_attn_fwd(const void* q, const void* k, const void* v, voi
         !ALIGNED16(k) || !ALIGNED16(v) || ((uintptr_t)o & 7))
         return fail(VL2_E_SHAPE, "vl2_attn_fwd: strides must keep 16-byte row alignment");
     if (causal && causal_off < 0) return fail(VL2_E_SHAPE, "vl2_attn_fwd: causal_off must be >= 0");
+    // K / V tiles are fetched through raw buffer resources whose byte offsets and NUM_RECORDS are 32-bit
+    if (((int64_t)(nk - 1) * k_rs + D) * 2 >= (int64_t)1 << 31 || ((int64_t)(nk - 1) * v_rs + D) * 2 >= (int64_t)1 << 31)
+        return fail(VL2_E_SHAPE, "vl2_attn_fwd: one head's K or V rows span >= 2 GiB (nk %d, row strides %d / %d elements)", nk, k_rs, v_rs);
     AttnArgs a{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, q_bs, q_hs, q_rs, k_bs, k_hs, k_rs,
                v_bs, v_hs, v_rs, o_bs, o_hs, o_rs, nq, nk, group, H, B, scale * 1.4426950408889634f, causal_off};
     dim3 g((nq + 127) / 128, H, B), b(256);
