@@ -116,6 +116,21 @@ def test_emu_wide_rmsnorm_and_se_linear(emu):
     assert rel(ops.small_linear(g2, wl2, None, ops.ACT_SIGMOID), torch.sigmoid(F.linear(g2, wl2.float()))) < 1e-5
 
 
+@pytest.mark.parametrize("Fr,H,W,C", [(2, 5, 13, 512), (1, 3, 6, 4096), (1, 2, 1, 256)])
+def test_emu_dwconv_ln_silu_odd_grids(emu, Fr, H, W, C):
+    """Depthwise 3x3 + LayerNorm2d + SiLU on grids other than the square 24x24 / 13x13 of the workload: non-square, a single
+    column, both row edges in every frame."""
+    import torch.nn.functional as F
+    from videollama2_amd import ops
+    x = bf(Fr * H * W, C)
+    wt = (torch.randn(C, 1, 3, 3, generator=torch.Generator().manual_seed(3)) * 0.3).bfloat16().float()
+    lnw, lnb = torch.randn(C, generator=torch.Generator().manual_seed(4)), torch.randn(C, generator=torch.Generator().manual_seed(5))
+    y = ops.dwconv3x3_ln_silu(x, wt.view(C, 9).t().contiguous(), lnw, lnb, Fr, H, W)
+    ref = F.conv2d(x.float().view(Fr, H, W, C).permute(0, 3, 1, 2), wt, padding=1, groups=C).permute(0, 2, 3, 1)
+    ref = F.silu(F.layer_norm(ref, (C,), lnw, lnb, 1e-5)).reshape(Fr * H * W, C)
+    assert rel(y, ref) < TOL_BF16_OUT
+
+
 def test_emu_attention_ragged_and_causal(emu):
     from videollama2_amd import ops
     B, H, N, D = 2, 2, 150, 64

@@ -281,6 +281,18 @@ def test_attn_softmax_spike(ops):
     assert rel(o[17], ref[17]) < 1e-2
 
 
+@pytest.mark.parametrize("Fr,H,W,C", [(2, 13, 13, 4096), (1, 5, 7, 1024), (1, 2, 1, 256)])
+def test_dwconv_odd_grids(ops, Fr, H, W, C):
+    """The 13x13 grid of STC stage s2 at full width, a non-square grid and a single column."""
+    x = bf(Fr * H * W, C)
+    wt = (torch.randn(C, 1, 3, 3) * 0.3).bfloat16().float()
+    lnw, lnb = torch.randn(C), torch.randn(C)
+    y = ops.dwconv3x3_ln_silu(x.to(DEV), wt.view(C, 9).t().contiguous().to(DEV), lnw.to(DEV), lnb.to(DEV), Fr, H, W)
+    ref = F.conv2d(x.float().view(Fr, H, W, C).permute(0, 3, 1, 2), wt, padding=1, groups=C).permute(0, 2, 3, 1)
+    ref = F.silu(F.layer_norm(ref, (C,), lnw, lnb, 1e-5)).reshape(Fr * H * W, C)
+    assert rel(y, ref) < TOL_BF16_OUT
+
+
 @pytest.mark.parametrize("C", [4096, 8192])          # 8192: the STC connector in front of the 72B decoder
 def test_stc_direct_kernels_full_width(ops, C):
     Fr, H = 2, 24
