@@ -181,6 +181,12 @@ extern "C" int32_t vl2_attn_fwd(const void* q, const void* k, const void* v, voi
 extern "C" int32_t vl2_dwconv3x3_ln_silu(const void* x, void* y, const float* wt, const float* lnw, const float* lnb, int32_t F,
                                          int32_t H, int32_t W, int32_t C, float eps, void*) {
     dim3 g(F * H * W), blk(256);
+    if (W >= 16) {
+        dim3 g4(F * H * ((W + DW_P - 1) / DW_P));
+        if (C <= 2048) emu::launch(g4, blk, [=] { dwconv4_ln_silu_kernel<1>((const bf16_t*)x, (bf16_t*)y, wt, lnw, lnb, H, W, C, eps); });
+        else emu::launch(g4, blk, [=] { dwconv4_ln_silu_kernel<2>((const bf16_t*)x, (bf16_t*)y, wt, lnw, lnb, H, W, C, eps); });
+        return 0;
+    }
     if (C <= 2048) emu::launch(g, blk, [=] { dwconv_ln_silu_kernel<1>((const bf16_t*)x, (bf16_t*)y, wt, lnw, lnb, H, W, C, eps); });
     else emu::launch(g, blk, [=] { dwconv_ln_silu_kernel<2>((const bf16_t*)x, (bf16_t*)y, wt, lnw, lnb, H, W, C, eps); });
     return 0;

@@ -281,7 +281,7 @@ def test_attn_softmax_spike(ops):
     assert rel(o[17], ref[17]) < 1e-2
 
 
-@pytest.mark.parametrize("Fr,H,W,C", [(2, 13, 13, 4096), (1, 5, 7, 1024), (1, 2, 1, 256)])
+@pytest.mark.parametrize("Fr,H,W,C", [(2, 13, 13, 4096), (1, 5, 7, 1024), (1, 2, 1, 256), (2, 3, 18, 1024), (1, 24, 24, 8192)])
 def test_dwconv_odd_grids(ops, Fr, H, W, C):
     """The 13x13 grid of STC stage s2 at full width, a non-square grid and a single column."""
     x = bf(Fr * H * W, C)

@@ -79,6 +79,126 @@ __global__ __launch_bounds__(256) void dwconv_ln_silu_kernel(const bf16_t* __res
     }
 }
 
+// The same operator with a workgroup owning DW_P = 4 consecutive output positions of one image row: per input row it loads the
+// 6-position window once (packed bf16 in registers) and each tap's weights once for the 4 outputs -- 73 KB through L2 per
+// output instead of 9 x C x 6 B = 221 KB.  Per output the taps are accumulated in the same (ky, kx) order.  Used for wide
+// rows (the launcher takes it from W >= 16: the 24x24 grid of stage s1, 97 -> 74 us at 16 frames); on the 13x13 grid of
+// stage s2 a quarter of the workgroups would hold one live position.  grid = F * H * ceil(W / DW_P).
+#define DW_P 4
+template <int NVT>
+__global__ __launch_bounds__(256) void dwconv4_ln_silu_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+                                                              const float* __restrict__ wt, const float* __restrict__ lnw,
+                                                              const float* __restrict__ lnb, int H, int W, int C, float eps) {
+#pragma clang fp reassociate(off)
+    __shared__ float red[DW_P][4];
+    const int gpr = (W + DW_P - 1) / DW_P;                        // position groups per image row
+    const int grp = blockIdx.x % gpr, rowid = blockIdx.x / gpr;    // rowid = f * H + h0
+    const int h0 = rowid % H, w0 = grp * DW_P;
+    const size_t fbase = (size_t)(rowid - h0) * W * C;             // frame base (elements)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float acc[DW_P][NVT][8];
+#pragma unroll
+    for (int p = 0; p < DW_P; ++p)
+#pragma unroll
+        for (int i = 0; i < NVT; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[p][i][j] = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int hh = h0 + ky - 1;
+        if (hh < 0 || hh >= H) continue;                           // zero padding: the whole input row contributes nothing
+        u32x4 win[DW_P + 2][NVT];
+#pragma unroll
+        for (int q = 0; q < DW_P + 2; ++q) {
+            const int ww = w0 + q - 1;
+#pragma unroll
+            for (int i = 0; i < NVT; ++i) {
+                const int c = (i * 256 + threadIdx.x) * 8;
+                const u32x4 z = {0u, 0u, 0u, 0u};
+                win[q][i] = (ww >= 0 && ww < W && c < C) ? *(const u32x4*)(x + fbase + (size_t)(hh * W + ww) * C + c) : z;
+            }
+        }
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int i = 0; i < NVT; ++i) {
+                const int c = (i * 256 + threadIdx.x) * 8;
+                if (c >= C) continue;
+                const float* wp = wt + (ky * 3 + kx) * C + c;
+                const f32x4 wa = *(const f32x4*)wp, wb = *(const f32x4*)(wp + 4);
+#pragma unroll
+                for (int p = 0; p < DW_P; ++p) {
+                    const int ww = w0 + p + kx - 1;
+                    if (ww < 0 || ww >= W) continue;               // padded tap: skipped, as in the one-position kernel
+                    float xv[8];
+                    unpack8(win[p + kx][i], xv);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc[p][i][j] = __builtin_fmaf(xv[j], wa[j], acc[p][i][j]);
+                        acc[p][i][4 + j] = __builtin_fmaf(xv[4 + j], wb[j], acc[p][i][4 + j]);
+                    }
+                }
+            }
+    }
+    // LayerNorm statistics of the DW_P rows: one LDS round per statistic for all of them
+    auto block_sums = [&](float (&v)[DW_P]) {
+#pragma unroll
+        for (int p = 0; p < DW_P; ++p) v[p] = wave_sum(v[p]);
+        __syncthreads();                                           // protect `red` against the previous use
+        if (lane == 0) {
+#pragma unroll
+            for (int p = 0; p < DW_P; ++p) red[p][wave] = v[p];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < DW_P; ++p) v[p] = (red[p][0] + red[p][1]) + (red[p][2] + red[p][3]);
+    };
+    float st[DW_P];
+#pragma unroll
+    for (int p = 0; p < DW_P; ++p) {
+        float sm = 0.f;
+#pragma unroll
+        for (int i = 0; i < NVT; ++i)
+            if ((i * 256 + (int)threadIdx.x) * 8 < C) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sm += acc[p][i][j];
+            }
+        st[p] = sm;
+    }
+    block_sums(st);
+    float mean[DW_P];
+#pragma unroll
+    for (int p = 0; p < DW_P; ++p) {
+        mean[p] = st[p] / (float)C;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NVT; ++i)
+            if ((i * 256 + (int)threadIdx.x) * 8 < C) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float d = acc[p][i][j] - mean[p]; q = __builtin_fmaf(d, d, q); }
+            }
+        st[p] = q;
+    }
+    block_sums(st);
+#pragma unroll
+    for (int i = 0; i < NVT; ++i) {
+        const int c = (i * 256 + threadIdx.x) * 8;
+        if (c >= C) continue;
+        const f32x4 g0 = *(const f32x4*)(lnw + c), g1 = *(const f32x4*)(lnw + c + 4);
+        const f32x4 b0 = *(const f32x4*)(lnb + c), b1 = *(const f32x4*)(lnb + c + 4);
+#pragma unroll
+        for (int p = 0; p < DW_P; ++p) {
+            if (w0 + p >= W) continue;
+            const float rstd = rsqrtf(st[p] / (float)C + eps);
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                o[j] = silu_f(((acc[p][i][j] - mean[p]) * rstd) * (j < 4 ? g0[j] : g1[j - 4]) + (j < 4 ? b0[j] : b1[j - 4]));
+            *(u32x4*)(y + ((size_t)rowid * W + w0 + p) * C + c) = pack8(o);
+        }
+    }
+}
+
 // x [F, HW, C] bf16 -> mean [F, C] fp32; grid = (C/64, F), block 256 = 8 channel-vectors x 32 position lanes
 __global__ __launch_bounds__(256) void chan_mean_kernel(const bf16_t* __restrict__ x, float* __restrict__ mean, int HW, int C) {
     __shared__ float part[32][65];

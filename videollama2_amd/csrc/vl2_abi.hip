@@ -450,6 +450,13 @@ extern "C" int32_t vl2_dwconv3x3_ln_silu(const void* x, void* y, const float* w9
     if (!x || !y || !w9c || !lnw || !lnb || F <= 0 || H <= 0 || W <= 0) return fail(VL2_E_BADARG, "vl2_dwconv3x3_ln_silu: bad args");
     if (C % 8 || C > 8192) return fail(VL2_E_SHAPE, "vl2_dwconv3x3_ln_silu: need C%%8==0 and C<=8192");
     dim3 g(F * H * W), b(256);
+    if (W >= 16) {         // wide rows: four positions per workgroup (k_stc.h); the choice depends on W alone
+        dim3 g4(F * H * ((W + DW_P - 1) / DW_P));
+        if (C <= 2048) hipLaunchKernelGGL((dwconv4_ln_silu_kernel<1>), g4, b, 0, ST(stream), (const bf16_t*)x, (bf16_t*)y, w9c, lnw, lnb, H, W, C, eps);
+        else if (C <= 4096) hipLaunchKernelGGL((dwconv4_ln_silu_kernel<2>), g4, b, 0, ST(stream), (const bf16_t*)x, (bf16_t*)y, w9c, lnw, lnb, H, W, C, eps);
+        else hipLaunchKernelGGL((dwconv4_ln_silu_kernel<4>), g4, b, 0, ST(stream), (const bf16_t*)x, (bf16_t*)y, w9c, lnw, lnb, H, W, C, eps);
+        return launched("vl2_dwconv3x3_ln_silu");
+    }
     if (C <= 2048) hipLaunchKernelGGL((dwconv_ln_silu_kernel<1>), g, b, 0, ST(stream), (const bf16_t*)x, (bf16_t*)y, w9c, lnw, lnb, H, W, C, eps);
     else if (C <= 4096) hipLaunchKernelGGL((dwconv_ln_silu_kernel<2>), g, b, 0, ST(stream), (const bf16_t*)x, (bf16_t*)y, w9c, lnw, lnb, H, W, C, eps);
     else hipLaunchKernelGGL((dwconv_ln_silu_kernel<4>), g, b, 0, ST(stream), (const bf16_t*)x, (bf16_t*)y, w9c, lnw, lnb, H, W, C, eps);
