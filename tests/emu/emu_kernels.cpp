@@ -184,11 +184,13 @@ extern "C" int32_t vl2_dwconv3x3_ln_silu(const void* x, void* y, const float* wt
     if (W >= 16) {
         dim3 g4(F * H * ((W + DW_P - 1) / DW_P));
         if (C <= 2048) emu::launch(g4, blk, [=] { dwconv4_ln_silu_kernel<1>((const bf16_t*)x, (bf16_t*)y, wt, lnw, lnb, H, W, C, eps); });
-        else emu::launch(g4, blk, [=] { dwconv4_ln_silu_kernel<2>((const bf16_t*)x, (bf16_t*)y, wt, lnw, lnb, H, W, C, eps); });
+        else if (C <= 4096) emu::launch(g4, blk, [=] { dwconv4_ln_silu_kernel<2>((const bf16_t*)x, (bf16_t*)y, wt, lnw, lnb, H, W, C, eps); });
+        else emu::launch(g4, blk, [=] { dwconv4_ln_silu_kernel<4>((const bf16_t*)x, (bf16_t*)y, wt, lnw, lnb, H, W, C, eps); });
         return 0;
     }
     if (C <= 2048) emu::launch(g, blk, [=] { dwconv_ln_silu_kernel<1>((const bf16_t*)x, (bf16_t*)y, wt, lnw, lnb, H, W, C, eps); });
-    else emu::launch(g, blk, [=] { dwconv_ln_silu_kernel<2>((const bf16_t*)x, (bf16_t*)y, wt, lnw, lnb, H, W, C, eps); });
+    else if (C <= 4096) emu::launch(g, blk, [=] { dwconv_ln_silu_kernel<2>((const bf16_t*)x, (bf16_t*)y, wt, lnw, lnb, H, W, C, eps); });
+    else emu::launch(g, blk, [=] { dwconv_ln_silu_kernel<4>((const bf16_t*)x, (bf16_t*)y, wt, lnw, lnb, H, W, C, eps); });
     return 0;
 }
 extern "C" int32_t vl2_chan_mean(const void* x, float* mean, int32_t F, int32_t HW, int32_t C, void*) {

@@ -116,7 +116,7 @@ def test_emu_wide_rmsnorm_and_se_linear(emu):
     assert rel(ops.small_linear(g2, wl2, None, ops.ACT_SIGMOID), torch.sigmoid(F.linear(g2, wl2.float()))) < 1e-5
 
 
-@pytest.mark.parametrize("Fr,H,W,C", [(2, 5, 13, 512), (1, 3, 6, 4096), (1, 2, 1, 256), (2, 3, 18, 512), (1, 2, 16, 4096)])
+@pytest.mark.parametrize("Fr,H,W,C", [(2, 5, 13, 512), (1, 3, 6, 4096), (1, 2, 1, 256), (2, 3, 18, 512), (1, 2, 16, 4096), (1, 1, 17, 8192), (1, 2, 3, 8192)])
 def test_emu_dwconv_ln_silu_odd_grids(emu, Fr, H, W, C):
     """Depthwise 3x3 + LayerNorm2d + SiLU on grids other than the square 24x24 / 13x13 of the workload: non-square, a single
     column, both row edges in every frame; W >= 16 takes the four-positions-per-workgroup kernel (18 = 4 groups + 2)."""
