@@ -64,33 +64,83 @@ def decode_bytes_per_token(cfg, ctx):
     return 2 * params + l["num_hidden_layers"] * 2 * kvd * 2 * ctx
 
 
-def cpu_baseline(threads):
-    """The CPU restatement of the reference path (oracle/vl2_oracle.py, kind 'port') timed on this box's host cores on
-    a bounded sample: CLIP tower (23 layers) on 1 frame + STC connector on 2 frames, fp32."""
+def cpu_baseline(threads, T=16, S=1621):
+    """The CPU restatement of the reference path (oracle/vl2_oracle.py, kind 'port': /root/reference does not exist on the GPU
+    box) timed on this box's host cores in the three windows of SURVEY.md 8(d), each on a bounded slice of the SAME workload
+    and scaled to it (the scaling is stated in `sample`):
+        encode  : CLIP tower (23 layers) on 2 frames x T/2  +  STC connector on 4 frames x FLOP ratio to T frames
+        prefill : 2 of the 32 decoder layers at the full S x 16  (+ final norm + lm_head on the last position, unscaled)
+        decode  : 4 greedy steps through the same 2 layers x 16 (+ lm_head per step, unscaled)
+    fp32 (the reference's CPU-runnable dtype).  The reference ITSELF was timed in the build container (8 cores,
+    oracle/time_reference.py -> profiles/r02_cpu_reference.json); that record is attached as `reference_build_box`."""
     from oracle import vl2_oracle as O
     torch.set_num_threads(threads)
-    cfg = O.config_videollama2_7b(2)
     g = torch.Generator().manual_seed(0)
-    sd = {}
-    for name, shape in O.state_dict_names(cfg):
-        if "vision_tower" in name or "mm_projector" in name:
+
+    def rnd(names_shapes, keep):
+        sd = {}
+        for name, shape in names_shapes:
+            if not keep(name):
+                continue
             fan = 1
-            for s in shape[1:]:
-                fan *= s
+            for d in shape[1:]:
+                fan *= d
             t = torch.randn(shape, generator=g)
             sd[name] = t * (fan ** -0.5) if len(shape) >= 2 else (1.0 + 0.1 * t if name.endswith("weight") else 0.02 * t)
-    fr = torch.randn(1, 3, 336, 336, generator=g)
-    x = torch.randn(1, 2, 576, 1024, generator=g)
+        return sd
+
+    cfg = O.config_videollama2_7b(4)
+    sd = rnd(O.state_dict_names(cfg), lambda n: "vision_tower" in n or "mm_projector" in n)
+    fr = torch.randn(2, 3, 336, 336, generator=g)
+    x = torch.randn(1, 4, 576, 1024, generator=g)
     with torch.no_grad():
         t0 = time.perf_counter()
         O.clip_tower(sd, cfg, fr)
         t1 = time.perf_counter()
         O.stc_connector(sd, x)
         t2 = time.perf_counter()
-    t_frame = (t1 - t0) + (t2 - t1) / 2.0
-    return dict(value=round(1.0 / t_frame, 4), unit="frames/s", cores=threads, kind="port",
-                sample=f"oracle fp32: CLIP tower 1 frame ({t1 - t0:.2f} s) + STC connector 2 frames ({t2 - t1:.2f} s), "
-                       f"torch {threads} threads; no LLM leg")
+    _, stc4, _, _ = algorithmic_tflop(O.config_videollama2_7b(4), 4)
+    _, stcT, _, _ = algorithmic_tflop(O.config_videollama2_7b(T), T)
+    vit_s, stc_s = t1 - t0, t2 - t1
+    enc_s = vit_s * (T / 2.0) + stc_s * (stcT / stc4)
+    del sd
+    cfg2 = O.config_videollama2_7b(T)
+    nl_full, nl = cfg2["llm"]["num_hidden_layers"], 2
+    cfg2["llm"]["num_hidden_layers"] = nl
+    sd = rnd(O.state_dict_names(cfg2), lambda n: n.startswith(("model.layers.", "model.norm", "model.embed_tokens", "lm_head")))
+    emb = 0.5 * torch.randn(S, cfg2["llm"]["hidden_size"], generator=g)
+    n_dec = 4
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        logits, caches = O.mistral_forward(sd, cfg2, emb, 0, None)
+        t1 = time.perf_counter()
+        O.mistral_forward(sd, cfg2, emb[:1], 0, None, n_layers=0)            # final norm + lm_head alone (not scaled by depth)
+        t_head = time.perf_counter() - t1
+        t2 = time.perf_counter()
+        pos = S
+        for _ in range(n_dec):
+            nxt = int(torch.argmax(logits[0]))
+            xt = torch.nn.functional.embedding(torch.tensor([nxt]), sd["model.embed_tokens.weight"])
+            logits, caches = O.mistral_forward(sd, cfg2, xt, pos, caches)
+            pos += 1
+        t3 = time.perf_counter()
+    scale = nl_full / nl
+    pre_s = max(t1 - t0 - t_head, 0.0) * scale + t_head
+    dec_s = max((t3 - t2) / n_dec - t_head, 0.0) * scale + t_head
+    out = dict(value=round(T / enc_s, 4), unit="frames/s", cores=threads, cores_present=os.cpu_count(), kind="port", where="GPU box host",
+               sample=(f"oracle/vl2_oracle.py fp32, torch {threads} threads: encode = CLIP tower 2 frames ({vit_s:.2f} s) x {T // 2} + STC "
+                       f"4 frames ({stc_s:.2f} s) x {stcT / stc4:.2f} (FLOP ratio to {T} frames); prefill = {nl} of {nl_full} decoder layers at S={S} x {scale:.0f} + lm_head; "
+                       f"decode = {n_dec} greedy steps through {nl} layers x {scale:.0f} + lm_head"),
+               encode=dict(s=round(enc_s, 2), frames_per_s=round(T / enc_s, 4)),
+               prefill=dict(s=round(pre_s, 2), tokens_per_s=round(S / pre_s, 2)),
+               decode=dict(s_per_token=round(dec_s, 3), tokens_per_s=round(1.0 / dec_s, 4)))
+    rpath = os.path.join(ROOT, "profiles", "r02_cpu_reference.json")
+    if os.path.exists(rpath):
+        r = json.load(open(rpath))
+        out["reference_build_box"] = dict(kind="reference", where="build container", source="profiles/r02_cpu_reference.json", cores=r.get("cores"),
+                                          dtype=r.get("dtype"), encode_frames_per_s=r.get("encode_frames_per_s"),
+                                          prefill_tokens_per_s=r.get("prefill_tokens_per_s"), decode_tokens_per_s=r.get("decode_tokens_per_s"))
+    return out
 
 
 def main():
@@ -117,7 +167,7 @@ def main():
                                                       "(BASELINE.json configs[3]); default keeps the decoder replicated like the reference")
     ap.add_argument("--no-graph", action="store_true", help="eager decode loop instead of hipGraph replay")
     ap.add_argument("--vit-streams", type=int, default=None, help="ViT frames as N chunks on N HIP streams (default: the tower's own, 3)")
-    ap.add_argument("--tune", type=str, default="", help="debug: comma list key=value for vl2_set_tuning")
+    ap.add_argument("--tune", type=str, default="", help="debug: comma list of gemm=<variant>, splitk=<0|1>, attn=<variant> (videollama2_amd/ops.py launch controls)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -143,10 +193,9 @@ def main():
     from videollama2_amd.model import VideoLLaMA2Hip
     from videollama2_amd.weights import LazyRandomStateDict, random_state_dict
 
-    from videollama2_amd import _lib
     for kv in filter(None, args.tune.split(",")):
         k, v = kv.split("=")
-        _lib.call("vl2_set_tuning", int(k), int(v))
+        {"gemm": ops.set_gemm_variant, "splitk": lambda x: ops.set_splitk(bool(x)), "attn": ops.set_attn_kv_groups}[k](int(v))
     T, n_new = args.frames, args.new_tokens
     cfg = {"v2": videollama2_7b, "v21": videollama2_1_7b_16f, "72b": videollama2_72b}[args.model](T)
     side = cfg["vision"]["image_size"]
@@ -324,7 +373,7 @@ def main():
             tj = json.load(open(tpath))
             if T == 16 and args.model == "v2" and world == 1 and tj.get("launches_per_step") == ngemm:
                 traffic = tj["hbm_bytes_per_launch"]
-        kernels = ("gemm_bf16_kernel + gemm3_bf16_kernel + gemm4_bf16_kernel + gemm_l8_bf16_kernel (every vl2_gemm_bf16 call of the "
+        kernels = ("gemm_bf16_kernel + gemm3_bf16_kernel + gemm4_bf16_kernel + gemm_l8_bf16_kernel (every vl2_gemm call of the "
                    "step; a row-split call is two kernels back to back)")
         roof = dict(bound="mfma", kernel=kernels, achieved=round(ach, 2), peak=PEAK_MFMA_BF16_TFLOPS,
                     unit="TFLOP/s", frac=round(ach / PEAK_MFMA_BF16_TFLOPS, 4), traffic=traffic,
@@ -364,7 +413,7 @@ def main():
             out["batched_prefill"] = bprefill
         if not args.no_cpu_baseline and world == 1:          # the CPU leg is reported at N=1 only
             try:
-                out["cpu_baseline"] = cpu_baseline(min(os.cpu_count() or 1, 32))   # eager torch oversubscribes badly beyond ~32 threads
+                out["cpu_baseline"] = cpu_baseline(min(os.cpu_count() or 1, 32), T, S)   # eager torch oversubscribes badly beyond ~32 threads
             except Exception as exc:  # the oracle is a checker, never a dependency of the measured path
                 out["cpu_baseline"] = {"value": None, "error": repr(exc)}
         print(json.dumps(out), flush=True)

@@ -12,7 +12,8 @@
  *     (a hipStream_t passed as void*), so every call is hipGraph-capturable.  The caller owns all buffers.
  *   - all pointers are DEVICE pointers unless stated; bf16 tensors are raw uint16 bit patterns; strides (ld*) are in
  *     elements; every row pointer / ld must keep 16-byte alignment (8 bf16).
- *   - thread-safe and re-entrant; the only global state is a thread-local error string.
+ *   - thread-safe and re-entrant: the library holds NO mutable process state.  The only state is thread-local (the error
+ *     string below); kernel variants, split-K and workspaces are per-call arguments.
  */
 #ifndef VL2HIP_H
 #define VL2HIP_H
@@ -21,64 +22,77 @@
 extern "C" {
 #endif
 
-#define VL2_ABI_VERSION 1
+#define VL2_ABI_VERSION 2
 #define VL2_E_BADARG  (-1)   /* null pointer / non-positive size */
 #define VL2_E_SHAPE   (-2)   /* shape not supported by the gfx950 kernels (alignment / multiple-of constraints) */
 #define VL2_E_UNSUPP  (-3)   /* option combination not built */
 
 int32_t vl2_version(void);
-/* Tuning knobs (process-global, for A/B benchmarking; defaults are the shipped heuristics).
- *   key 1 = GEMM kernel variant: 0 = auto (per shape: 128x128x64 two-barrier kernel, 128x256x64 or 256x256x32 ping-pong kernel,
- *           whichever quantises best on 256 CUs), 1 = 128x128x64 always, 2 = its stream-K form (experimental; needs
- *           vl2_set_workspace), 4 = 128x256x64 ping-pong always, 8 = 256x256x32 ping-pong always (4, 8: where N%256==0),
- *           32 = 64x64 small-M kernel always, 256 = 128x128 8-wave deep-ring one-round kernel always.  See profiles/r01_gemm_experiments.md. */
-#define VL2_TUNE_GEMM_VARIANT 1
-#define VL2_TUNE_GEMV_ROWS_PER_WAVE 2   /* 1 (default), 2 or 4 output rows streamed by each wave of the decode GEMV */
-#define VL2_TUNE_GEMV_MR_ROWS_PER_WAVE 4 /* 1, 2 (default) or 4 output rows per wave of the batched (multi-row) decode GEMV */
-#define VL2_TUNE_SPLITK 3               /* 0 (default): never; 1: small-grid GEMMs split K when a workspace is attached */
-#define VL2_TUNE_ATTN_KV_GROUPS 5        /* causal D=128 attention: 0 (default) = two KV groups per workgroup when one sequence has
-                                         * <= 352 (q block, head) pairs, 1 = never, 2 = always */
-int32_t vl2_set_tuning(int32_t key, int32_t value);
-/* Optional caller-owned device workspace (>= vl2_workspace_bytes(), 16-byte aligned; NULL detaches).  With a workspace
- * attached, tuning variant 2 runs GEMMs as stream-K (512 persistent workgroups, partial tiles exchanged through the
- * workspace inside the launch with agent-scope release/acquire), and -- with VL2_TUNE_SPLITK = 1 -- GEMMs whose plain
- * 128x128 grid has <= 192 tiles and K >= 2048 (small M: the per-rank shapes of the frame-sharded encoder; Conv3d with
- * K = 32768) split K over up to 1024 workgroups: fp32 partial tiles go through the workspace, the last arriver of a tile
- * sums them in split order (deterministic for a given shape) and runs the epilogue.  Off by default because it makes a
- * row's result depend on M (the fp32 summation order changes with the split), i.e. a frame-sharded run would no longer
- * reproduce the single-GPU run bit for bit.  The workspace MUST be zero-filled when attached (tile counters live in it and
- * are re-armed by the kernels).  The library still allocates nothing.  One workspace per process: GEMMs sharing it
- * must be ordered on one stream. */
-int64_t vl2_workspace_bytes(void);
-int32_t vl2_set_workspace(void* ws, int64_t bytes);
 const char* vl2_last_error_string(void);      /* host pointer, thread-local, valid until the next failing call */
+/* Size of the caller-owned device workspace that `vl2_gemm` (split-K / stream-K forms) and `vl2_gemm_skinny_bf16` take per
+ * call.  It must be zero-filled once when allocated (split-K tile counters live in it and are re-armed by the kernels) and
+ * calls sharing one workspace must be ordered on one stream; use one workspace per stream for concurrent streams. */
+int64_t vl2_workspace_bytes(void);
 
-/* activation codes for vl2_gemm_bf16 / vl2_small_linear */
+/* activation codes for vl2_gemm / vl2_small_linear */
 #define VL2_ACT_NONE    0
 #define VL2_ACT_QGELU   1   /* x*sigmoid(1.702x)  HF:activations.py QuickGELUActivation (CLIP MLP) */
 #define VL2_ACT_GELU    2   /* exact erf GELU     torch nn.GELU() in projector.py:125-130 build_mlp (STC readout) */
 #define VL2_ACT_SILU    3   /* nn.SiLU            projector.py:164-174 sampler, timm act_layer */
 #define VL2_ACT_SIGMOID 4   /* only vl2_small_linear */
 #define VL2_ACT_GELU_TANH 5 /* nn.GELU(approximate='tanh') = HF gelu_pytorch_tanh (SigLIP MLP, HF:models/siglip/modeling_siglip.py SiglipMLP) */
-/* flags for vl2_gemm_bf16 */
+/* flags for vl2_gemm */
 #define VL2_GEMM_SWIGLU  1  /* W = blocks of 64 rows {32 gate rows, 32 up rows}; C[m, j] = silu(gate_j) * up_j; C has N/2 cols.
                                HF:models/mistral/modeling_mistral.py MistralMLP.forward */
 #define VL2_GEMM_OUT_F32 2  /* C is fp32 (validation / logits) */
+#define VL2_GEMM_SPLITK  4  /* small grids may split K through the workspace (`ws`): trades "a row's bits do not depend on M"
+                               for latency on few-tile shapes (per-rank shapes of the frame-sharded encoder); off by default */
+/* kernel variants (vl2_gemm_desc.variant; 0 = per-shape choice): 1 = 128x128x64 two-barrier kernel, 2 = its stream-K form
+ * (needs `ws`), 4 = 128x256x64 ping-pong, 8 = 256x256x32 ping-pong (4, 8: N%256==0), 32 = 64x64 small-M kernel,
+ * 256 = 128x128 8-wave deep-ring one-round kernel.  profiles/r01_gemm_experiments.md. */
+#define VL2_NORM_NONE 0
+#define VL2_NORM_RMS  1     /* HF:modeling_mistral.py MistralRMSNorm in front of q/k/v and gate/up */
+#define VL2_NORM_LN   2     /* HF:modeling_clip.py layer_norm1 / layer_norm2 in front of q/k/v and fc1 */
 
 /* C[M,N] = epilogue(A[M,K] . W[N,K]^T):  bf16 MFMA GEMM, fp32 accumulate.  Replaces the cuBLAS / cuDNN GEMMs behind
  *   nn.Linear in HF:models/clip/modeling_clip.py CLIPAttention/CLIPMLP, HF:models/mistral/modeling_mistral.py
  *   MistralAttention/MistralMLP/lm_head, and the 1x1 convs / Conv3d / readout of videollama2/model/projector.py:153-187.
- * N % 128 == 0, K % 64 == 0.  bias fp32 [N] or NULL.  res bf16 rows or NULL (added after the activation).
+ * N % 128 == 0, K % 64 == 0.  bias fp32 [N] or NULL.  res bf16 rows or NULL (added after the activation).  Operands of any
+ *   size: rows beyond the kernels' 32-bit buffer offsets (>= 2 GiB of A or W) are covered by splitting the call into row /
+ *   column chunks (e.g. the 2.49 GB lm_head of VideoLLaMA2-72B); the gathered row pool itself must stay below 2 GiB.
  * Gathered-A form (a_idx != NULL): K = nseg*seg_k; the A row of (segment s, output row m) is A[a_idx[s*M+m]] or
- *   zeros when the index is < 0 (an out-of-range buffer offset, which gfx950 reads as zeros; `zero_row` is accepted for
- *   ABI stability and unused) -- this is Conv3d(k=2,s=2,p=1) as a GEMM over the 8 taps (projector.py:164-174).
+ *   zeros when the index is < 0 (an out-of-range buffer offset, which gfx950 reads as zeros) -- this is
+ *   Conv3d(k=2,s=2,p=1) as a GEMM over the 8 taps (projector.py:164-174).
  * Row remap: out_grp > 0 -> output row = m + (m/out_grp)*out_grp_pad + out_row_off; res_row_mod > 0 -> residual row =
  *   m % res_row_mod + res_row_off (else the output row).  Used by the patch-embed GEMM to write torch.cat([cls, patches])
- *   + position_embedding directly (HF:modeling_clip.py CLIPVisionEmbeddings.forward). */
-int32_t vl2_gemm_bf16(const void* A, const void* W, void* C, const float* bias, const void* res, int32_t M, int32_t N,
-                      int32_t K, int32_t lda, int32_t ldw, int32_t ldc, int32_t ldres, int32_t act, int32_t flags,
-                      const int32_t* a_idx, const void* zero_row, int32_t seg_k, int32_t out_grp, int32_t out_grp_pad,
-                      int32_t out_row_off, int32_t res_row_mod, int32_t res_row_off, void* stream);
+ *   + position_embedding directly (HF:modeling_clip.py CLIPVisionEmbeddings.forward).
+ * Norm-carrying chain (csrc/k_gemm.h): `stats_out` != NULL makes the epilogue emit, per output row and 64-column block,
+ *   (sum, sum of squares) of the row as stored -> fp32 [M][N/64][2]; a consumer passes that buffer as `stats_in` (it then
+ *   holds K/64 blocks per A row) with norm = VL2_NORM_RMS / VL2_NORM_LN and computes Norm(A) W^T on the RAW A rows:
+ *   y = rstd*(A W'^T) (RMS) or rstd*(A W'^T - mean*w_colsum) + bias (LN), W' = W*g folded at pack time, bias = W b + c. */
+typedef struct vl2_gemm_desc {
+    uint32_t size;                 /* sizeof(vl2_gemm_desc) -- lets the struct grow without breaking callers */
+    int32_t M, N, K;
+    const void* A;  int32_t lda;
+    const void* W;  int32_t ldw;
+    void* C;        int32_t ldc;
+    const float* bias;
+    const void* res; int32_t ldres;
+    int32_t act, flags;
+    const int32_t* a_idx; int32_t seg_k;
+    int32_t out_grp, out_grp_pad, out_row_off, res_row_mod, res_row_off;
+    float* stats_out;
+    const float* stats_in;
+    int32_t norm;  float norm_eps;
+    const float* w_colsum;
+    void* ws;  int64_t ws_bytes;   /* optional workspace (vl2_workspace_bytes()); NULL = no split-K / stream-K */
+    int32_t variant;               /* 0 = auto */
+} vl2_gemm_desc;
+int32_t vl2_gemm(const vl2_gemm_desc* d, void* stream);
+/* (sum, sum of squares) per row and 64-column block of a bf16 activation x [rows, C] -> stats fp32 [rows][C/64][2], in the
+ * layout / summation order of vl2_gemm's `stats_out`: seeds a norm-carrying chain whose first tensor no GEMM wrote
+ * (inputs_embeds; the CLIP embeddings after pre_layrnorm) or re-derives it after a tensor-parallel all-reduce.  C % 64 == 0. */
+int32_t vl2_row_stats(const void* x, float* stats, int32_t rows, int32_t C, int32_t ldx, void* stream);
 
 /* y = LayerNorm(x)*w + b [+ res] [-> SiLU]; rows x C, fp32 statistics.  HF:modeling_clip.py pre_layrnorm / layer_norm1/2;
  * timm LayerNormAct2d in channels-last form (projector.py:153-184) incl. the Bottleneck tail act3(conv3(x)+shortcut).
@@ -96,20 +110,22 @@ int32_t vl2_patchify(const void* frames, int32_t dtype, void* out, int32_t T, in
                      int32_t Kp, void* stream);
 /* uint8 ingest: frames [T,H,W,3] uint8 (device) -> the same im2col rows, with the image processor's x*rescale, (x-mean)/std
  * (videollama2/mm_utils.py:196-201 -> HF CLIPImageProcessor / SiglipImageProcessor preprocess) done in registers.
- * mean3 / std3 are HOST pointers to 3 floats. */
+ * The per-channel mean / std travel by value. */
 int32_t vl2_patchify_u8(const void* frames_thwc, void* out, int32_t T, int32_t H, int32_t W, int32_t P, int32_t G, int32_t Kp,
-                        float rescale, const float* mean3, const float* std3, void* stream);
+                        float rescale, float mean_r, float mean_g, float mean_b, float std_r, float std_g, float std_b, void* stream);
 /* x[t*rows_per_frame, :] = cls_pos (class_embedding + position_embedding[0]). */
 int32_t vl2_fill_cls(void* x, const void* cls_pos, int32_t T, int32_t D, int32_t rows_per_frame, void* stream);
 
-/* Fused attention forward, softmax in fp32.  D = 64 or 128.  Element strides: *_bs batch, *_hs head, *_rs row.
+/* `variant` (0 = auto): causal D=128: 1 = one group of 4 waves per workgroup, 2 = two groups that split the KV tiles and merge
+ * through LDS (auto: 2 when one sequence has <= 352 (q block, head) pairs).
+ * Fused attention forward, softmax in fp32.  D = 64 or 128.  Element strides: *_bs batch, *_hs head, *_rs row.
  * kv head of q head h = h / group.  causal: key j visible to q row i iff j <= i + causal_off.
  * Replaces flash-attn (videollama2/model/encoder.py:24) / HF eager_attention_forward for CLIP, and HF Mistral
  * attention (repeat_kv + causal softmax) for the prefill. */
 int32_t vl2_attn_fwd(const void* q, const void* k, const void* v, void* o, int64_t q_bs, int64_t q_hs, int32_t q_rs,
                      int64_t k_bs, int64_t k_hs, int32_t k_rs, int64_t v_bs, int64_t v_hs, int32_t v_rs, int64_t o_bs,
                      int64_t o_hs, int32_t o_rs, int32_t B, int32_t H, int32_t nq, int32_t nk, int32_t group, float scale,
-                     int32_t causal, int32_t causal_off, int32_t D, void* stream);
+                     int32_t causal, int32_t causal_off, int32_t D, int32_t variant, void* stream);
 
 /* STC connector direct kernels (channels-last activations [F, H, W, C]); timm Bottleneck.conv2 + LayerNormAct2d, SEModule. */
 int32_t vl2_dwconv3x3_ln_silu(const void* x, void* y, const float* w9c, const float* lnw, const float* lnb, int32_t F,
@@ -130,9 +146,10 @@ int32_t vl2_gemv_bf16(const void* W, const void* x, const float* norm_w, const v
                       int32_t N, int32_t K, int32_t ldw, float eps, int32_t flags, void* stream);
 /* Skinny-M GEMM for batched decode: C[M <= 64, N] = A[M,K] W[N,K]^T (+bias | +res | SwiGLU | fp32 out; flags as vl2_gemm_bf16).
  * The weights stream from HBM straight into the B operand of v_mfma_f32_16x16x32_bf16 (GEMV-style, once for all M rows), K is
- * split over workgroups, fp32 partial sums go through the attached workspace (required) and are reduced in order. */
+ * split over workgroups, fp32 partial sums go through the caller's workspace `ws` (required, >= vl2_workspace_bytes()) and are reduced in order. */
 int32_t vl2_gemm_skinny_bf16(const void* A, const void* W, void* C, const float* bias, const void* res, int32_t M, int32_t N,
-                             int32_t K, int32_t lda, int32_t ldw, int32_t ldc, int32_t ldres, int32_t flags, void* stream);
+                             int32_t K, int32_t lda, int32_t ldw, int32_t ldc, int32_t ldres, int32_t flags, void* ws, int64_t ws_bytes,
+                             void* stream);
 /* Batched decode: y[b][N] = W[N,K] x[b][K] (+ bias) (+ res[b]) for MB sequences in ONE pass over W (up to
  * 4 rows per launch, as many as fit 64 KiB of LDS; larger MB is split).  ldx / ldy / ldres = element strides between rows.
  * Same fused RMSNorm / bias / residual / SwiGLU semantics as vl2_gemv_bf16, applied per row. */

@@ -21,6 +21,59 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+# ------------------------------------------------------------------------------------------ conv lowering switch
+# CONV_AS_GEMM = True computes every convolution of the path through its GEMM form (unfold + F.linear; depthwise 3x3 as nine
+# shifted multiply-adds accumulated in fp32 and rounded once): the same arithmetic a convolution library performs (fp32
+# accumulate, one output rounding), without going through a convolution library.  Only used by the parity tests when they
+# run this restatement in bf16 ON THE GPU (torch-ROCm ops) to measure the reference's own bf16 noise floor: MIOpen's
+# bf16 Conv3d / depthwise paths may JIT-search for minutes on a fresh box.  The fp32 truth runs with the plain F.conv*.
+CONV_AS_GEMM = False
+
+
+def _conv1x1(x_nchw, w):
+    """F.conv2d(x, w[Cout,Cin,1,1]) (no bias)."""
+    if not CONV_AS_GEMM:
+        return F.conv2d(x_nchw, w)
+    return F.linear(x_nchw.permute(0, 2, 3, 1), w.flatten(1)).permute(0, 3, 1, 2)
+
+
+def _patch_conv(x, w, b, stride):
+    """F.conv2d(x, w[Cout,3,P,P], b, stride=P) with P == kernel size (non-overlapping patches)."""
+    if not CONV_AS_GEMM:
+        return F.conv2d(x, w, b, stride=stride)
+    T, C, H, W = x.shape
+    P = stride
+    gh, gw = H // P, W // P
+    cols = x[:, :, :gh * P, :gw * P].reshape(T, C, gh, P, gw, P).permute(0, 2, 4, 1, 3, 5).reshape(T, gh * gw, C * P * P)
+    return F.linear(cols, w.flatten(1), b).transpose(1, 2).reshape(T, -1, gh, gw)
+
+
+def _dwconv3x3(x_nchw, w):
+    """F.conv2d(x, w[C,1,3,3], padding=1, groups=C)."""
+    if not CONV_AS_GEMM:
+        return F.conv2d(x_nchw, w, padding=1, groups=x_nchw.shape[1])
+    xp = F.pad(x_nchw.float(), (1, 1, 1, 1))
+    H, W = x_nchw.shape[2:]
+    acc = torch.zeros_like(x_nchw, dtype=torch.float32)
+    for ky in range(3):
+        for kx in range(3):
+            acc += xp[:, :, ky:ky + H, kx:kx + W] * w[:, 0, ky, kx].float().view(1, -1, 1, 1)
+    return acc.to(x_nchw.dtype)
+
+
+def _conv3d_k2s2(x_ncthw, w, b, padding):
+    """F.conv3d(x, w[Cout,Cin,2,2,2], b, stride=2, padding=p)."""
+    if not CONV_AS_GEMM:
+        return F.conv3d(x_ncthw, w, b, stride=2, padding=padding)
+    p = padding
+    xp = F.pad(x_ncthw, (p, p, p, p, p, p))
+    B, C, T, H, W = xp.shape
+    To, Ho, Wo = (T - 2) // 2 + 1, (H - 2) // 2 + 1, (W - 2) // 2 + 1
+    xp = xp[:, :, :2 * To, :2 * Ho, :2 * Wo].reshape(B, C, To, 2, Ho, 2, Wo, 2)
+    cols = xp.permute(0, 2, 4, 6, 1, 3, 5, 7).reshape(B, To * Ho * Wo, C * 8)          # K order (cin, kt, kh, kw) = w.flatten(1)
+    return F.linear(cols, w.flatten(1), b).transpose(1, 2).reshape(B, -1, To, Ho, Wo)
+
+
 # ------------------------------------------------------------------------------------------------ configs
 
 
@@ -229,7 +282,7 @@ def clip_embeddings(sd, cfg, pixel_values):
     followed by `pre_layrnorm` (CLIPVisionTransformer.forward).  Returns hidden_states[0]  [T, N+1, D]."""
     v = cfg["vision"]
     w = sd[_VT + "embeddings.patch_embedding.weight"]
-    x = F.conv2d(pixel_values.to(w.dtype), w, None, stride=v["patch_size"])
+    x = _patch_conv(pixel_values.to(w.dtype), w, None, v["patch_size"])
     x = x.flatten(2).transpose(1, 2)
     cls = sd[_VT + "embeddings.class_embedding"].expand(x.shape[0], 1, -1)
     x = torch.cat([cls, x], dim=1) + sd[_VT + "embeddings.position_embedding.weight"].unsqueeze(0)
@@ -309,7 +362,7 @@ def siglip_embeddings(sd, cfg, pixel_values):
     """HF:models/siglip/modeling_siglip.py SiglipVisionEmbeddings.forward: biased patch conv (valid padding), flatten,
     + position_embedding (one row per patch, no CLS).  = hidden_states[0]."""
     w = sd[_VT + "embeddings.patch_embedding.weight"]
-    x = F.conv2d(pixel_values.to(w.dtype), w, sd[_VT + "embeddings.patch_embedding.bias"], stride=cfg["vision"]["patch_size"])
+    x = _patch_conv(pixel_values.to(w.dtype), w, sd[_VT + "embeddings.patch_embedding.bias"], cfg["vision"]["patch_size"])
     return x.flatten(2).transpose(1, 2) + sd[_VT + "embeddings.position_embedding.weight"].unsqueeze(0)
 
 
@@ -363,17 +416,17 @@ def stc_bottleneck(sd, p, x):
     in!=out); add; SiLU.  x is NCHW."""
     C = sd[p + "conv1.conv.weight"].shape[0]
     sc = x
-    h = F.conv2d(x, sd[p + "conv1.conv.weight"])
+    h = _conv1x1(x, sd[p + "conv1.conv.weight"])
     h = F.silu(layernorm2d_nchw(h, sd[p + "conv1.bn.weight"], sd[p + "conv1.bn.bias"]))
-    h = F.conv2d(h, sd[p + "conv2.conv.weight"], padding=1, groups=C)
+    h = _dwconv3x3(h, sd[p + "conv2.conv.weight"])
     h = F.silu(layernorm2d_nchw(h, sd[p + "conv2.bn.weight"], sd[p + "conv2.bn.bias"]))
     s = h.mean((2, 3), keepdim=True)
     s = F.conv2d(F.silu(F.conv2d(s, sd[p + "se.fc1.weight"], sd[p + "se.fc1.bias"])),
                  sd[p + "se.fc2.weight"], sd[p + "se.fc2.bias"])
     h = h * torch.sigmoid(s)
-    h = layernorm2d_nchw(F.conv2d(h, sd[p + "conv3.conv.weight"]), sd[p + "conv3.bn.weight"], sd[p + "conv3.bn.bias"])
+    h = layernorm2d_nchw(_conv1x1(h, sd[p + "conv3.conv.weight"]), sd[p + "conv3.bn.weight"], sd[p + "conv3.bn.bias"])
     if (p + "downsample.conv.weight") in sd:
-        sc = layernorm2d_nchw(F.conv2d(sc, sd[p + "downsample.conv.weight"]), sd[p + "downsample.bn.weight"],
+        sc = layernorm2d_nchw(_conv1x1(sc, sd[p + "downsample.conv.weight"]), sd[p + "downsample.bn.weight"],
                               sd[p + "downsample.bn.bias"])
     return F.silu(h + sc)
 
@@ -393,7 +446,7 @@ def stc_connector(sd, x, return_stages=False, padding=1):
     x = x.permute(0, 2, 1, 3, 4).reshape(b * t, d, hw, hw)             # (b t) d h w    (:202)
     s1 = stc_stage(sd, "s1", x)                                        # (:205)
     x = s1.view(b, t, -1, hw, hw).permute(0, 2, 1, 3, 4)               # b d t h w      (:206)
-    samp = F.silu(F.conv3d(x, sd[_MP + "sampler.0.weight"], sd[_MP + "sampler.0.bias"], stride=2, padding=padding))  # (:208)
+    samp = F.silu(_conv3d_k2s2(x, sd[_MP + "sampler.0.weight"], sd[_MP + "sampler.0.bias"], padding))               # (:208)
     nt, nh, nw = samp.shape[2:]
     x = samp.permute(0, 2, 1, 3, 4).reshape(b * nt, -1, nh, nw)        # (:211)
     s2 = stc_stage(sd, "s2", x)                                        # (:212)
@@ -489,8 +542,8 @@ def mistral_layer(sd, cfg, i, x, cos, sin, kv=None):
     kk = k[:, None].expand(nkv, rep, Sk, hd).reshape(nh, Sk, hd)
     vv = v[:, None].expand(nkv, rep, Sk, hd).reshape(nh, Sk, hd)
     a = torch.matmul(q, kk.transpose(1, 2)) * (hd ** -0.5)
-    qpos = torch.arange(Sk - S, Sk)[:, None]
-    mask = torch.arange(Sk)[None, :] > qpos
+    qpos = torch.arange(Sk - S, Sk, device=x.device)[:, None]
+    mask = torch.arange(Sk, device=x.device)[None, :] > qpos
     a = a.masked_fill(mask[None], torch.finfo(a.dtype).min)
     a = F.softmax(a, dim=-1, dtype=torch.float32).to(q.dtype)
     o = torch.matmul(a, vv).transpose(0, 1).reshape(S, nh * hd)
@@ -508,6 +561,7 @@ def mistral_forward(sd, cfg, x, start_pos=0, caches=None, n_layers=None, last_on
     n_layers = l["num_hidden_layers"] if n_layers is None else n_layers
     S = x.shape[0]
     cos, sin = rope_cos_sin(cfg, torch.arange(start_pos, start_pos + S), x.dtype)
+    cos, sin = cos.to(x.device), sin.to(x.device)
     new = []
     for i in range(n_layers):
         x, kv = mistral_layer(sd, cfg, i, x, cos, sin, None if caches is None else caches[i])
@@ -531,7 +585,7 @@ def greedy_generate(sd, cfg, inputs_embeds, max_new_tokens, eos_token_id=None, n
         toks.append(nxt)
         if eos_token_id is not None and nxt == eos_token_id:
             break
-        x = F.embedding(torch.tensor([nxt]), sd["model.embed_tokens.weight"]).to(inputs_embeds.dtype)
+        x = F.embedding(torch.tensor([nxt], device=inputs_embeds.device), sd["model.embed_tokens.weight"]).to(inputs_embeds.dtype)
         logits, caches = mistral_forward(sd, cfg, x, pos, caches, n_layers)
         pos += 1
     return toks, torch.stack(all_logits)

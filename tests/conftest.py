@@ -12,6 +12,21 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `pytest -m gpu` via gpurun)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """A plain `pytest tests` on a box without a GPU skips the `gpu` tests instead of erroring in their fixtures."""
+    try:
+        import torch
+        have_gpu = torch.cuda.is_available()
+    except Exception:
+        have_gpu = False
+    if have_gpu:
+        return
+    skip = pytest.mark.skip(reason="needs a real MI355X (run with `pytest -m gpu` via gpurun)")
+    for it in items:
+        if "gpu" in it.keywords:
+            it.add_marker(skip)
+
+
 @pytest.fixture(scope="session")
 def golden_small():
     import torch

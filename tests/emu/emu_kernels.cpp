@@ -8,26 +8,22 @@ alignas(64) unsigned char vl2_smem[160 * 1024];
 #include "k_norm.h"
 #include "k_vit.h"
 #include "k_attn.h"
+#include "k_attn2.h"
 #include "k_stc.h"
 #include "k_decode.h"
 #include "k_skinny.h"
 #include <cstdint>
 #include <algorithm>
 #include <vector>
+#include "../../include/vl2hip.h"
 
 static char g_err[256] = "emu";
-extern "C" int32_t vl2_version(void) { return 1; }
+extern "C" int32_t vl2_version(void) { return VL2_ABI_VERSION; }
 extern "C" const char* vl2_last_error_string(void) { return g_err; }
-extern "C" int64_t vl2_workspace_bytes(void) { return 0; }
-extern "C" int32_t vl2_set_workspace(void*, int64_t) { return 0; }
+extern "C" int64_t vl2_workspace_bytes(void) { return 64; }
 
+// per-call controls (vl2_gemm_desc.variant, VL2_GEMM_SPLITK, vl2_attn_fwd variant): set by the entry points below
 static int g_gemm_variant = 0;
-static int g_attn_kv_groups = 0;
-extern "C" int32_t vl2_set_tuning(int32_t key, int32_t value) {
-    if (key == 1) { g_gemm_variant = value; return 0; }
-    if (key == 5) { g_attn_kv_groups = value; return 0; }
-    return (key == 2 || key == 3 || key == 4) ? 0 : -1;
-}
 template <int ACT, bool SW, bool F32, bool G>
 static void run_gemm(GemmArgs a) {
     if constexpr (!G) {
@@ -89,16 +85,21 @@ static void run_gemm(GemmArgs a) {
     }
     emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(256), [=] { gemm_bf16_kernel<ACT, SW, F32, G>(a); });
 }
-extern "C" int32_t vl2_gemm_bf16(const void* A, const void* W, void* C, const float* bias, const void* res, int32_t M,
-                                 int32_t N, int32_t K, int32_t lda, int32_t ldw, int32_t ldc, int32_t ldres, int32_t act,
-                                 int32_t flags, const int32_t* a_idx, const void* zero_row, int32_t seg_k, int32_t out_grp,
-                                 int32_t out_grp_pad, int32_t out_row_off, int32_t res_row_mod, int32_t res_row_off, void*) {
+extern "C" int32_t vl2_gemm(const vl2_gemm_desc* d, void*) {
+    if (!d || d->size != sizeof(vl2_gemm_desc)) return -1;
+    const int M = d->M, N = d->N, K = d->K, act = d->act;
     if (N % 128 || K % 64) return -2;
-    GemmArgs a{(const bf16_t*)A, (const bf16_t*)W, C, bias, (const bf16_t*)res, a_idx, (const bf16_t*)zero_row,
-               M, N, K, lda, ldw, ldc, ldres, seg_k, out_grp, out_grp_pad, out_row_off, res_row_mod, res_row_off,
-               (M + 127) / 128, N / 128};
-    const bool sw = flags & 1, f32 = flags & 2, g = a_idx != nullptr;
-    if (out_grp > 0 || res_row_mod > 0) {
+    GemmArgs a{};
+    a.A = (const bf16_t*)d->A; a.W = (const bf16_t*)d->W; a.C = d->C; a.bias = d->bias; a.res = (const bf16_t*)d->res;
+    a.a_idx = d->a_idx; a.M = M; a.N = N; a.K = K; a.lda = d->lda; a.ldw = d->ldw; a.ldc = d->ldc; a.ldres = d->ldres;
+    a.seg_k = d->seg_k; a.out_grp = d->out_grp; a.out_grp_pad = d->out_grp_pad; a.out_row_off = d->out_row_off;
+    a.res_row_mod = d->res_row_mod; a.res_row_off = d->res_row_off; a.tiles_m = (M + 127) / 128; a.tiles_n = N / 128;
+    a.idx_ld = M; a.stats_out = d->stats_out; a.stats_out_np = N / 64; a.stats_in = d->stats_in; a.stats_in_np = K / 64;
+    a.norm = d->norm; a.norm_eps = d->norm_eps; a.w_colsum = d->w_colsum;
+    g_gemm_variant = (d->flags & VL2_GEMM_SPLITK) ? 16 : d->variant;     // 16 = the emulator's split-K form of the 128x128 kernel
+    const bool sw = d->flags & 1, f32 = d->flags & 2, g = a.a_idx != nullptr;
+    if (d->norm && (!d->stats_in || (d->norm == 2 && !d->w_colsum))) return -1;
+    if (d->out_grp > 0 || d->res_row_mod > 0) {
         emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(256), [=] { gemm_bf16_kernel<0, false, false, false, true>(a); });
         return 0;
     }
@@ -113,6 +114,11 @@ extern "C" int32_t vl2_gemm_bf16(const void* A, const void* W, void* C, const fl
         case 5: run_gemm<5, false, false, false>(a); break;
         default: return -3;
     }
+    return 0;
+}
+extern "C" int32_t vl2_row_stats(const void* x, float* stats, int32_t rows, int32_t C, int32_t ldx, void*) {
+    if (C % 64) return -2;
+    emu::launch(dim3((rows + 3) / 4), dim3(256), [=] { row_stats_kernel((const bf16_t*)x, stats, rows, C, ldx); });
     return 0;
 }
 static int32_t run_norm(NormArgs a, bool rms) {
@@ -149,8 +155,8 @@ extern "C" int32_t vl2_patchify(const void* frames, int32_t dtype, void* out, in
     return 0;
 }
 extern "C" int32_t vl2_patchify_u8(const void* frames, void* out, int32_t T, int32_t H, int32_t W, int32_t P, int32_t G, int32_t Kp,
-                                   float rescale, const float* m, const float* sd, void*) {
-    U8Norm n{rescale, {m[0], m[1], m[2]}, {1.0f / sd[0], 1.0f / sd[1], 1.0f / sd[2]}};
+                                   float rescale, float m0, float m1, float m2, float s0, float s1, float s2, void*) {
+    U8Norm n{rescale, {m0, m1, m2}, {1.0f / s0, 1.0f / s1, 1.0f / s2}};
     emu::launch(dim3(G, T), dim3(256), [=] { patchify_u8_kernel((const unsigned char*)frames, (bf16_t*)out, H, W, P, G, Kp, n); });
     return 0;
 }
@@ -161,11 +167,20 @@ extern "C" int32_t vl2_fill_cls(void* x, const void* cls_pos, int32_t T, int32_t
 extern "C" int32_t vl2_attn_fwd(const void* q, const void* k, const void* v, void* o, int64_t q_bs, int64_t q_hs, int32_t q_rs,
                                 int64_t k_bs, int64_t k_hs, int32_t k_rs, int64_t v_bs, int64_t v_hs, int32_t v_rs,
                                 int64_t o_bs, int64_t o_hs, int32_t o_rs, int32_t B, int32_t H, int32_t nq, int32_t nk,
-                                int32_t group, float scale, int32_t causal, int32_t causal_off, int32_t D, void*) {
+                                int32_t group, float scale, int32_t causal, int32_t causal_off, int32_t D, int32_t variant, void*) {
+    const int g_attn_kv_groups = variant;
     AttnArgs a{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, q_bs, q_hs, q_rs, k_bs, k_hs, k_rs,
                v_bs, v_hs, v_rs, o_bs, o_hs, o_rs, nq, nk, group, H, B, scale * 1.4426950408889634f, causal_off};
     dim3 g((nq + 127) / 128, H, B), blk(256);
     if (causal) g = dim3(((nq + 127) / 128) * H * B, 1, 1);
+    if (variant == 3) {                                     // second structure (k_attn2.h): LDS-DMA ring + transpose reads
+        if (D == 64 && !causal) emu::launch(g, blk, [=] { attn2_fwd_kernel<64, false>(a); });
+        else if (D == 64 && causal) emu::launch(g, blk, [=] { attn2_fwd_kernel<64, true>(a); });
+        else if (D == 128 && !causal) emu::launch(g, blk, [=] { attn2_fwd_kernel<128, false>(a); });
+        else if (D == 128 && causal) emu::launch(g, blk, [=] { attn2_fwd_kernel<128, true>(a); });
+        else return -2;
+        return 0;
+    }
     if (D == 64 && !causal) emu::launch(g, blk, [=] { attn_fwd_kernel<64, false>(a); });
     else if (D == 128 && causal) {
         const long per_seq = (long)((nq + 127) / 128) * H;
@@ -226,7 +241,8 @@ extern "C" int32_t vl2_gemv_bf16(const void* W, const void* x, const float* norm
     return 0;
 }
 extern "C" int32_t vl2_gemm_skinny_bf16(const void* A, const void* W, void* C, const float* bias, const void* res, int32_t M, int32_t N,
-                                        int32_t K, int32_t lda, int32_t ldw, int32_t ldc, int32_t ldres, int32_t flags, void*) {
+                                        int32_t K, int32_t lda, int32_t ldw, int32_t ldc, int32_t ldres, int32_t flags, void* ws, int64_t ws_bytes, void*) {
+    if (!ws || ws_bytes <= 0) return -1;
     const bool sw = flags & 1, f32 = flags & 2;
     if (M > 64 || N % 64 || K % 32) return -2;
     const int mt = M <= 16 ? 1 : M <= 32 ? 2 : 4, Mp = 16 * mt, steps = K / 32;

@@ -148,7 +148,29 @@ inline f32x4 mfma_16x16x32_bf16(s16x8 a, s16x8 b, f32x4 c) {
     wave_sync();
     return c;
 }
+// ds_read_b64_tr_b16 (gfx950 LDS transpose read), per 16-lane group: lane m supplies the 8-byte-aligned address of 4 consecutive
+// 16-bit elements; lane i receives element (i & 3) of lanes 4e + (i >> 2), e = 0..3 (guide: with linear addresses lane l, element j
+// = lds[(l & 15) + 16 j + 64 (l >> 4)]).  A misaligned address returns the 8-aligned address's data on hardware: refused here.
+typedef short emu_s16x4 __attribute__((ext_vector_type(4)));
+inline emu_s16x4 ds_read_tr16(const void* p) {
+    if (((uintptr_t)p) & 7) { fprintf(stderr, "EMU: ds_read_b64_tr_b16 address not 8-byte aligned\n"); abort(); }
+    Wave& w = waves[cur->wave];
+    memcpy(w.scratch[cur->lane], p, 8);
+    wave_sync();
+    const int l = cur->lane, g = l >> 4, i = l & 15;
+    emu_s16x4 r;
+    for (int e = 0; e < 4; ++e) {
+        short v;
+        memcpy(&v, w.scratch[16 * g + 4 * e + (i >> 2)] + 2 * (i & 3), 2);
+        r[e] = v;
+    }
+    wave_sync();
+    return r;
+}
 struct Rsrc { const char* p; unsigned bytes; };   // bytes: NUM_RECORDS of a raw buffer (stride 0): loads past it return 0
+}  // namespace emu
+typedef emu::Rsrc __amdgpu_buffer_rsrc_t;
+namespace emu {   // bytes: NUM_RECORDS of a raw buffer (stride 0): loads past it return 0
 typedef unsigned int emu_u32x4 __attribute__((ext_vector_type(4)));
 // buffer_load_dwordx4 of a raw buffer: the range check covers voffset only (the SGPR offset is outside it, gfx9 ISA)
 inline emu_u32x4 buffer_load_b128(Rsrc r, unsigned voff, unsigned soff) {
@@ -195,7 +217,8 @@ inline void global_load_lds(const void* g, void* lds, unsigned size, int offset,
 // raw buffer load to LDS: an offset at or beyond num_records (0x7fffffff here) reads zeros (hardware range check)
 inline void buffer_load_lds(Rsrc r, void* lds, unsigned size, unsigned voff, unsigned soff) {
     static const char zeros[16] = {0};
-    global_load_lds(voff >= 0x7fffffffu ? zeros : r.p + voff + soff, lds, size, 0, 0);
+    const bool oob = (unsigned long long)voff + size > r.bytes;      // raw buffer, stride 0: the range check covers voffset only
+    global_load_lds(oob ? zeros : r.p + voff + soff, lds, size, 0, 0);
 }
 }  // namespace emu
 
@@ -217,6 +240,7 @@ inline void buffer_load_lds(Rsrc r, void* lds, unsigned size, unsigned voff, uns
 #define __builtin_amdgcn_make_buffer_rsrc(p, stride, bytes, flags) emu::Rsrc{(const char*)(p), (unsigned)(bytes)}
 #define __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, aux) emu::buffer_load_b128((r), (unsigned)(voff), (unsigned)(soff))
 #define __builtin_amdgcn_raw_ptr_buffer_load_lds(r, l, sz, voff, soff, off, aux) emu::buffer_load_lds((r), (void*)(l), sz, (unsigned)(voff), (unsigned)(soff))
+#define __builtin_amdgcn_ds_read_tr16_b64_v4i16(p) emu::ds_read_tr16((const void*)(p))
 #define __builtin_amdgcn_readfirstlane(x) emu::shfl_idx((x), 0)
 #define __builtin_amdgcn_fdot2_f32_bf16(a, b, c, cl) emu::dot2((a), (b), (c))
 #define __builtin_amdgcn_s_setprio(x) ((void)0)

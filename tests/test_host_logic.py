@@ -22,17 +22,48 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert _lib.load().vl2_version() == 1
+    assert _lib.load().vl2_version() == 2
 
 
 def test_abi_argument_validation_without_gpu():
     from videollama2_amd import _lib
+    def desc(**kw):
+        d = _lib.GemmDesc()
+        d.size = ctypes.sizeof(_lib.GemmDesc)
+        for k, v in kw.items():
+            setattr(d, k, v)
+        return ctypes.byref(d)
+
     with pytest.raises(_lib.Vl2HipError, match="null pointer"):
-        _lib.call("vl2_gemm_bf16", None, None, None, None, None, 1, 128, 64, 64, 64, 128, 0, 0, 0, None, None, 0, 0, 0, 0, 0, 0, None)
+        _lib.call("vl2_gemm", desc(M=1, N=128, K=64, lda=64, ldw=64, ldc=128), None)
     with pytest.raises(_lib.Vl2HipError, match="N%128"):
-        _lib.call("vl2_gemm_bf16", 16, 16, 16, None, None, 4, 100, 64, 64, 64, 104, 0, 0, 0, None, None, 0, 0, 0, 0, 0, 0, None)
+        _lib.call("vl2_gemm", desc(A=16, W=16, C=16, M=4, N=100, K=64, lda=64, ldw=64, ldc=104), None)
+    with pytest.raises(_lib.Vl2HipError, match="another ABI"):            # a caller built against another struct layout
+        d = _lib.GemmDesc()
+        d.size = 8
+        _lib.call("vl2_gemm", ctypes.byref(d), None)
+    with pytest.raises(_lib.Vl2HipError, match="stats_in"):               # a fused norm without the producer's statistics
+        _lib.call("vl2_gemm", desc(A=16, W=16, C=16, M=4, N=128, K=64, lda=64, ldw=64, ldc=128, norm=1), None)
+    with pytest.raises(_lib.Vl2HipError, match="w_colsum"):
+        _lib.call("vl2_gemm", desc(A=16, W=16, C=16, M=4, N=128, K=64, lda=64, ldw=64, ldc=128, norm=2, stats_in=16), None)
+    with pytest.raises(_lib.Vl2HipError, match="workspace"):
+        _lib.call("vl2_gemm", desc(A=16, W=16, C=16, M=4, N=128, K=64, lda=64, ldw=64, ldc=128, ws=16, ws_bytes=64), None)
+    with pytest.raises(_lib.Vl2HipError, match="workspace"):
+        _lib.call("vl2_gemm_skinny_bf16", 16, 16, 16, None, None, 4, 128, 64, 64, 64, 128, 0, 0, None, 0, None)
     with pytest.raises(_lib.Vl2HipError, match="head_dim"):
-        _lib.call("vl2_attn_fwd", 16, 16, 16, 16, 0, 80, 80, 0, 80, 80, 0, 80, 80, 0, 80, 80, 1, 1, 4, 4, 1, 1.0, 0, 0, 80, None)
+        _lib.call("vl2_attn_fwd", 16, 16, 16, 16, 0, 80, 80, 0, 80, 80, 0, 80, 80, 0, 80, 80, 1, 1, 4, 4, 1, 1.0, 0, 0, 80, 0, None)
+    with pytest.raises(_lib.Vl2HipError, match="C%64"):
+        _lib.call("vl2_row_stats", 16, 16, 4, 100, 104, None)
+
+
+def test_library_keeps_no_mutable_process_state():
+    """'no global mutable state except the error string (thread-local)'.  The header offers no setter, and the
+    translation unit defines no writable namespace-scope object besides thread-locals and the per-kernel LDS-attribute bits."""
+    header = open(os.path.join(ROOT, "include", "vl2hip.h")).read()
+    assert "vl2_set_" not in header
+    src = open(os.path.join(ROOT, "videollama2_amd", "csrc", "vl2_abi.hip")).read()
+    globals_ = re.findall(r"^static\s+(?!thread_local|inline|const|constexpr|int32_t\s+\w+\(|bool\s+\w+\(|void\s+\w+\(|int\s+\w+\(|GemmArgs\s+\w+\()([^;(]+);", src, re.M)
+    assert not globals_, globals_
 
 
 def test_product_never_imports_oracle():

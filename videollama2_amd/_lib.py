@@ -8,26 +8,36 @@ LIB_PATH = os.path.join(_HERE, "libvl2hip.so")
 
 _vp, _i32, _i64, _f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
 
+
+class GemmDesc(ctypes.Structure):
+    """include/vl2hip.h `vl2_gemm_desc` (field for field)."""
+    _fields_ = [("size", ctypes.c_uint32), ("M", _i32), ("N", _i32), ("K", _i32),
+                ("A", _vp), ("lda", _i32), ("W", _vp), ("ldw", _i32), ("C", _vp), ("ldc", _i32),
+                ("bias", _vp), ("res", _vp), ("ldres", _i32), ("act", _i32), ("flags", _i32),
+                ("a_idx", _vp), ("seg_k", _i32),
+                ("out_grp", _i32), ("out_grp_pad", _i32), ("out_row_off", _i32), ("res_row_mod", _i32), ("res_row_off", _i32),
+                ("stats_out", _vp), ("stats_in", _vp), ("norm", _i32), ("norm_eps", _f32), ("w_colsum", _vp),
+                ("ws", _vp), ("ws_bytes", _i64), ("variant", _i32)]
+
+
 # name -> argtypes (all return int32 except the two below)
 SIGNATURES = {
-    "vl2_set_tuning": [_i32, _i32],
-    "vl2_set_workspace": [_vp, _i64],
-    "vl2_gemm_bf16": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _i32,
-                      _i32, _i32, _i32, _i32, _vp],
+    "vl2_gemm": [ctypes.POINTER(GemmDesc), _vp],
+    "vl2_row_stats": [_vp, _vp, _i32, _i32, _i32, _vp],
     "vl2_layernorm": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp],
     "vl2_rmsnorm": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp],
     "vl2_patchify": [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
-    "vl2_patchify_u8": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp],
+    "vl2_patchify_u8": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _vp],
     "vl2_fill_cls": [_vp, _vp, _i32, _i32, _i32, _vp],
     "vl2_attn_fwd": [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _i64, _i64, _i32, _i64, _i64, _i32, _i64, _i64, _i32, _i32, _i32,
-                     _i32, _i32, _i32, _f32, _i32, _i32, _i32, _vp],
+                     _i32, _i32, _i32, _f32, _i32, _i32, _i32, _i32, _vp],
     "vl2_dwconv3x3_ln_silu": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp],
     "vl2_chan_mean": [_vp, _vp, _i32, _i32, _i32, _vp],
     "vl2_small_linear": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
     "vl2_se_scale": [_vp, _vp, _i32, _i32, _i32, _vp],
     "vl2_rope_kv": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "vl2_gemv_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _i32, _vp],
-    "vl2_gemm_skinny_bf16": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
+    "vl2_gemm_skinny_bf16": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp],
     "vl2_gemv_batched_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp],
     "vl2_attn_decode": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _f32, _vp],
     "vl2_attn_decode_batched": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _i64, _i32, _i32, _i32, _vp, _i32, _f32, _vp],
@@ -62,7 +72,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = _i32
         fn.argtypes = args
-    if lib.vl2_version() != 1:
+    if lib.vl2_version() != 2:
         raise Vl2HipError("libvl2hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -301,6 +301,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
     kcache += (size_t)bseq * cache_bs;
     vcache += (size_t)bseq * cache_bs;
     partial += (size_t)bseq * partial_bs;
+    // pos >= smax can only come from a device-side position that ran past the cache (hipGraph replay at the cache end): such a
+    // step must not touch cos/sin row `pos` or cache row `pos`; the host discards its result (decoder.generate `last` step)
+    if (pos >= smax) return;
     const int ctx = pos + 1;
     const int k0 = split * 64;
     if (k0 >= ctx) return;
@@ -394,40 +397,53 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
 }
 
 // grid = nh, block 128: out[h*128 + d] = sum_i o_i[d] 2^(m_i - M) / sum_i l_i 2^(m_i - M) over the ceil(ctx/64) live slices.
-// Wave 0 turns the (m_i, l_i) pairs into weights with two shuffle reductions; then every thread sums its column with
-// independent, coalesced loads (no dependent chain over the slices).
+// Wave 0 turns the (m_i, l_i) pairs into weights (64 slices per pass, any slice count: running max M over the passes first,
+// then the weights against the final M); then every thread sums its column with independent, coalesced loads (no dependent
+// chain over the slices).  The weights live in LDS in chunks of COMBINE_CHUNK slices, so the context length is unbounded.
+#define COMBINE_CHUNK 256
 __global__ __launch_bounds__(128) void attn_decode_combine_kernel(const float* __restrict__ partial, bf16_t* __restrict__ out,
                                                                   int nsplit_cap, int pos_arg, const int* __restrict__ pos_dev,
                                                                   long partial_bs, long out_bs) {
-    __shared__ float wgt[64];
-    __shared__ float inv_l;
+    __shared__ float wgt[COMBINE_CHUNK];
+    __shared__ float red[2];                                  // {M, 1/L}
     const int h = blockIdx.x, d = threadIdx.x, bseq = blockIdx.y;       // grid = (nh, sequences)
     const int pos = pos_dev ? pos_dev[bseq] : pos_arg;
-    const int nsplit = (pos + 64) >> 6;                       // <= 64 (max context 4096)
+    int nsplit = (pos + 64) >> 6;
+    // a position at or beyond the launch's capacity (exhausted cache under hipGraph replay) would index past `partial`:
+    // clamp to the slices the launch produced -- the host never uses the result of such a step (decoder.generate)
+    nsplit = nsplit < nsplit_cap ? nsplit : nsplit_cap;
     const float* src = partial + (size_t)bseq * partial_bs + (size_t)h * nsplit_cap * 130;
     out += (size_t)bseq * out_bs;
-    if (d < 64) {
-        const bool live = d < nsplit;
-        const float m = live ? src[d * 130] : -1e30f;
-        const float l = live ? src[d * 130 + 1] : 0.f;
-        const float M = wave_max(m);
-        const float w = live ? exp2f(m - M) : 0.f;
-        const float L = wave_sum(l * w);
-        wgt[d] = w;
-        if (d == 0) inv_l = 1.0f / L;
+    if (d < 64) {                                             // wave 0: global max M, then L = sum_i l_i 2^(m_i - M)
+        float M = -1e30f;
+        for (int i0 = 0; i0 < nsplit; i0 += 64) M = fmaxf(M, (i0 + d < nsplit) ? src[(i0 + d) * 130] : -1e30f);
+        M = wave_max(M);
+        float L = 0.f;
+        for (int i0 = 0; i0 < nsplit; i0 += 64)
+            if (i0 + d < nsplit) L += src[(i0 + d) * 130 + 1] * exp2f(src[(i0 + d) * 130] - M);
+        L = wave_sum(L);
+        if (d == 0) { red[0] = M; red[1] = 1.0f / L; }
     }
     __syncthreads();
+    const float M = red[0];
     float o = 0.f;
-    int i = 0;
-    for (; i + 8 <= nsplit; i += 8) {
-        float v[8];
+    for (int c0 = 0; c0 < nsplit; c0 += COMBINE_CHUNK) {
+        const int nc = nsplit - c0 < COMBINE_CHUNK ? nsplit - c0 : COMBINE_CHUNK;
+        if (c0 > 0) __syncthreads();                          // the previous chunk's weights have been consumed
+        for (int i = d; i < nc; i += 128) wgt[i] = exp2f(src[(c0 + i) * 130] - M);
+        __syncthreads();
+        const float* s0 = src + (size_t)c0 * 130 + 2 + d;
+        int i = 0;
+        for (; i + 8 <= nc; i += 8) {
+            float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = src[(i + j) * 130 + 2 + d];
+            for (int j = 0; j < 8; ++j) v[j] = s0[(i + j) * 130];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o += v[j] * wgt[i + j];
+            for (int j = 0; j < 8; ++j) o += v[j] * wgt[i + j];
+        }
+        for (; i < nc; ++i) o += s0[i * 130] * wgt[i];
     }
-    for (; i < nsplit; ++i) o += src[i * 130 + 2 + d] * wgt[i];
-    out[h * 128 + d] = f2bf(o * inv_l);
+    out[h * 128 + d] = f2bf(o * red[1]);
 }
 
 // first index of the maximum of logits[V] (fp32) -> *tok (int32) and hist[step]; one block of 1024 threads.

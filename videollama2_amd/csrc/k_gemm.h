@@ -33,7 +33,61 @@ struct GemmArgs {
     float* sk_ws;
     int* sk_flags;
     int sk_per;
+    int idx_ld;              // GATHER: row stride of a_idx (= M of the whole call; a row chunk keeps the full table)
+    // ---- normalisation carried through the GEMM chain (see "norm-carrying GEMMs" below)
+    float* stats_out;        // [rows][stats_out_np][2] fp32 (sum, sum of squares) of the bf16-rounded OUTPUT rows per 64-column block, or null
+    int stats_out_np;        // partial blocks per row of stats_out (= N / 64 of the whole call)
+    const float* stats_in;   // [rows][stats_in_np][2] statistics of the A rows written by the GEMM that produced A, or null
+    int stats_in_np;         // = K / 64
+    int norm;                // 0 none, 1 RMSNorm, 2 LayerNorm of the A rows, applied algebraically in the epilogue
+    float norm_eps;
+    const float* w_colsum;   // LayerNorm: s[n] = sum_k W[n][k] (fp32, of the bf16 weights as packed) [N]
 };
+
+// ---- norm-carrying GEMMs ------------------------------------------------------------------------------------------------
+// y = Norm(x) W^T with the norm's affine part folded into the weights at pack time (W' = W * g per input column, t = W b + c):
+//   RMSNorm:    y[m][n] = rstd_m * (x W'^T)[m][n]                                  (HF:modeling_mistral.py MistralRMSNorm)
+//   LayerNorm:  y[m][n] = rstd_m * ((x W'^T)[m][n] - mean_m * s[n]) + t[n],   s[n] = sum_k W'[n][k]
+//                                                                                  (HF:modeling_clip.py layer_norm1/2 -> q/k/v, fc1)
+// i.e. the MFMA main loop runs on the RAW residual-stream rows and the normalisation is two FMAs per output element in the
+// epilogue: the standalone norm kernels (a full HBM read + write of the activation between every two GEMMs: 1.2 ms of the
+// 39.6 ms T=16 forward, profiles/r01_kernel_stats_bench_default_late.csv) disappear.  The row statistics come from the GEMM
+// that WROTE x (o-proj / down-proj / out_proj / fc2, all with the residual add fused): its epilogue emits, per row and per
+// 64-column patch, (sum, sum of squares) of the values exactly as stored (after the bf16 rounding) -- `stats_out`; the
+// consumer's workgroup reduces the K/64 partials of its BM rows once, in its prologue while the first LDS-DMA slabs are in
+// flight (`gemm_row_stats`), and parks (mean, rstd) in LDS for the epilogue.  Fixed partial layout + fixed reduction order:
+// a row's statistics are the same bits whichever kernel / grid produced them.
+__device__ __forceinline__ f32x2 gemm_row_stats(const GemmArgs& p, int m0, int t, int BM) {
+#pragma clang fp reassociate(off)
+    f32x2 r = {0.f, 1.f};
+    if (p.norm && t < BM) {
+        int m = m0 + t;
+        m = m < p.M ? m : p.M - 1;
+        const float* sp = p.stats_in + (size_t)m * p.stats_in_np * 2;
+        float sum = 0.f, sq = 0.f;
+        int i = 0;
+        for (; i + 2 <= p.stats_in_np; i += 2) {
+            const f32x4 v = *(const f32x4*)(sp + 2 * i);
+            sum = (sum + v[0]) + v[2];
+            sq = (sq + v[1]) + v[3];
+        }
+        if (i < p.stats_in_np) { sum += sp[2 * i]; sq += sp[2 * i + 1]; }
+        const float inv = 1.0f / (float)p.K;
+        if (p.norm == 2) {
+            const float mean = sum * inv;
+            const float var = fmaxf(__builtin_fmaf(-mean, mean, sq * inv), 0.f);
+            r[0] = mean;
+            r[1] = rsqrtf(var + p.norm_eps);
+        } else {
+            r[1] = rsqrtf(sq * inv + p.norm_eps);
+        }
+    }
+    return r;
+}
+// (mean, rstd) of the tile's rows -> LDS table `tab` [BM][2]; call before the barrier that precedes the first gemm_store_patch
+__device__ __forceinline__ void gemm_park_row_stats(const GemmArgs& p, float* tab, const f32x2& r, int t, int BM) {
+    if (p.norm && t < BM) { tab[2 * t] = r[0]; tab[2 * t + 1] = r[1]; }
+}
 
 enum { ACT_NONE = 0, ACT_QGELU = 1, ACT_GELU = 2, ACT_SILU = 3, ACT_GELU_TANH = 5 };
 
@@ -52,9 +106,11 @@ __device__ __forceinline__ int gemm_lds_off(int row, int chunk) {   // byte offs
 // row remap, 16-B stores.  m_base = first row of the patch, n_base = first (un-halved) GEMM column of the patch.
 // REMAP = the row-remap / residual-row-modulo form (runtime integer divisions) -- only the patch-embed GEMM needs it
 template <int ACT, bool SWIGLU, bool OUT_F32, bool REMAP = false>
-__device__ __forceinline__ void gemm_store_patch(const GemmArgs& p, const float* ep, int m_base, int n_base, int lane) {
+__device__ __forceinline__ void gemm_store_patch(const GemmArgs& p, const float* ep, int m_base, int n_base, int lane,
+                                                 const float* rowtab = nullptr, int mt_base = 0) {
         // every GEMM kernel inlines this epilogue, and a row must come out with the same bits whichever kernel its shape selects
-        // (sharded == unsharded, batched == one by one): (acc + bias) + residual stays in that order in every instantiation
+        // (sharded == unsharded, batched == one by one): (acc + bias) + residual stays in that order in every instantiation.
+        // rowtab: LDS table of (mean, rstd) of the tile's rows (p.norm != 0), indexed by the row's offset in the tile.
 #pragma clang fp reassociate(off)
         constexpr int LPR = SWIGLU ? 4 : 8;            // lanes per row
         constexpr int RPP = 64 / LPR;                  // rows per pass
@@ -63,19 +119,33 @@ __device__ __forceinline__ void gemm_store_patch(const GemmArgs& p, const float*
             const int row = pass * RPP + lane / LPR;
             const int cg = (lane % LPR) * 8;
             const int m = m_base + row;
-            if (m < p.M) {
+            const bool live = m < p.M;
+            float st_s = 0.f, st_q = 0.f;
+            int orow = m;
+            if (live) {
                 float v[8];
                 const int nfull = n_base + cg;             // column in the (un-halved) GEMM N space
+                float mu = 0.f, rs = 1.f;
+                if (p.norm) { mu = rowtab[2 * (mt_base + row)]; rs = rowtab[2 * (mt_base + row) + 1]; }
                 if (SWIGLU) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const float g = ep[row * 68 + cg + j], u = ep[row * 68 + 32 + cg + j];
+                        float g = ep[row * 68 + cg + j], u = ep[row * 68 + 32 + cg + j];
+                        if (p.norm) { g *= rs; u *= rs; }                     // RMSNorm only (no mean / shift term)
                         v[j] = silu_f(g) * u;
                     }
                 } else {
                     const f32x4 x0 = *(const f32x4*)(ep + row * 68 + cg), x1 = *(const f32x4*)(ep + row * 68 + cg + 4);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { v[j] = x0[j]; v[4 + j] = x1[j]; }
+                    if (p.norm == 2) {
+                        const f32x4 s0 = *(const f32x4*)(p.w_colsum + nfull), s1 = *(const f32x4*)(p.w_colsum + nfull + 4);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { v[j] = __builtin_fmaf(-mu, s0[j], v[j]) * rs; v[4 + j] = __builtin_fmaf(-mu, s1[j], v[4 + j]) * rs; }
+                    } else if (p.norm == 1) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] *= rs;
+                    }
                     if (p.bias) {
                         const f32x4 b0 = *(const f32x4*)(p.bias + nfull), b1 = *(const f32x4*)(p.bias + nfull + 4);
 #pragma unroll
@@ -90,7 +160,7 @@ __device__ __forceinline__ void gemm_store_patch(const GemmArgs& p, const float*
                     }
                 }
                 const int n = SWIGLU ? (n_base >> 1) + cg : nfull;
-                const int orow = (REMAP && p.out_grp > 0) ? m + (m / p.out_grp) * p.out_grp_pad + p.out_row_off : m;
+                orow = (REMAP && p.out_grp > 0) ? m + (m / p.out_grp) * p.out_grp_pad + p.out_row_off : m;
                 if (p.res) {
                     const int rrow = (REMAP && p.res_row_mod > 0) ? (m % p.res_row_mod) + p.res_row_off : orow;
                     const u32x4 rv = *(const u32x4*)(p.res + (size_t)rrow * p.ldres + n);
@@ -107,7 +177,23 @@ __device__ __forceinline__ void gemm_store_patch(const GemmArgs& p, const float*
                     *(f32x4*)c = o0;
                     *(f32x4*)(c + 4) = o1;
                 } else {
-                    *(u32x4*)((bf16_t*)p.C + (size_t)orow * p.ldc + n) = pack8(v);
+                    const u32x4 packed = pack8(v);
+                    *(u32x4*)((bf16_t*)p.C + (size_t)orow * p.ldc + n) = packed;
+                    if (!SWIGLU && !REMAP && p.stats_out) {       // statistics of the row AS STORED (bf16-rounded)
+                        float rf[8];
+                        unpack8(packed, rf);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) { st_s += rf[j]; st_q = __builtin_fmaf(rf[j], rf[j], st_q); }
+                    }
+                }
+            }
+            if (!SWIGLU && !REMAP && !OUT_F32 && p.stats_out) {   // wave-uniform: the 8 lanes of a row fold their partials
+#pragma unroll
+                for (int msk = 1; msk <= 4; msk <<= 1) { st_s += __shfl_xor(st_s, msk); st_q += __shfl_xor(st_q, msk); }
+                if (live && (lane % LPR) == 0) {
+                    float* dst = p.stats_out + ((size_t)orow * p.stats_out_np + (n_base >> 6)) * 2;
+                    dst[0] = st_s;
+                    dst[1] = st_q;
                 }
             }
         }
@@ -137,6 +223,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
     const int gm = (p.tiles_m - first_m) < 8 ? (p.tiles_m - first_m) : 8;
     const int tm = first_m + (t % grp_sz) % gm, tn = (t % grp_sz) / gm;
     const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
+    const f32x2 rst = gemm_row_stats(p, m0, tid, GEMM_BM);     // (mean, rstd) of A row m0 + tid (norm-carrying GEMMs)
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -252,7 +339,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
             if (kl == 0 || ktl == 0) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const int r = p.a_idx[(size_t)seg * p.M + g_row[i]];
+                    const int r = p.a_idx[(size_t)seg * p.idx_ld + g_row[i]];
                     a_vo[i] = r < 0 ? 0x80000000u : (unsigned)r * (unsigned)p.lda * 2u + g_chk[i];
                 }
             }
@@ -343,6 +430,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
 
     // ---- epilogue: acc (col = lane&31, rows (r&3)+8(r>>2)+4(lane>>5)) -> fp32 LDS patch [32][68] per wave -> rows
     float* ep = (float*)vl2_smem + wave * (32 * 68);
+    float* rowtab = (float*)vl2_smem + 4 * (32 * 68);          // behind the four wave patches
+    gemm_park_row_stats(p, rowtab, rst, tid, GEMM_BM);
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
@@ -353,7 +442,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
                 ep[row * 68 + ni * 32 + (lane & 31)] = acc[mi][ni][r];
             }
         __syncthreads();
-        gemm_store_patch<ACT, SWIGLU, OUT_F32, REMAP>(p, ep, m0 + wm * 64 + mi * 32, n0 + wn * 64, lane);
+        gemm_store_patch<ACT, SWIGLU, OUT_F32, REMAP>(p, ep, m0 + wm * 64 + mi * 32, n0 + wn * 64, lane, rowtab, wm * 64 + mi * 32);
         __syncthreads();
     }
 }
@@ -551,6 +640,7 @@ __global__ __launch_bounds__(512, 2) void gemm4_bf16_kernel(GemmArgs p) {
     const int gm = (p.tiles_m - first_m) < 4 ? (p.tiles_m - first_m) : 4;
     const int tm = first_m + (t0 % grp_sz) % gm, tn = (t0 % grp_sz) / gm;
     const int m0 = tm * GEMM4_BM, n0 = tn * GEMM4_BN;
+    const f32x2 rst = gemm_row_stats(p, m0, tid, GEMM4_BM);
 
     // this wave's LDS-DMA parts of a slab: 2 x A rows [128*grp, +128) and 2 x W rows [128*grp, +128), issue-lean form:
     // `buffer_load_dwordx4 ... offen lds` with loop-invariant VGPR byte offsets, K position in the SGPR soffset
@@ -635,6 +725,8 @@ __global__ __launch_bounds__(512, 2) void gemm4_bf16_kernel(GemmArgs p) {
 
     // ---- epilogue: four 32 x 64 patches per wave (2 row blocks x 2 column halves)
     float* ep = (float*)vl2_smem + wave * (32 * 68);
+    float* rowtab = (float*)vl2_smem + 8 * (32 * 68);
+    gemm_park_row_stats(p, rowtab, rst, tid, GEMM4_BM);
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -647,7 +739,7 @@ __global__ __launch_bounds__(512, 2) void gemm4_bf16_kernel(GemmArgs p) {
                     ep[row * 68 + ni * 32 + (lane & 31)] = acc[mi][nh * 2 + ni][r];
                 }
             __syncthreads();
-            gemm_store_patch<ACT, SWIGLU, OUT_F32>(p, ep, m0 + grp * 128 + wm * 64 + mi * 32, n0 + wn * 128 + nh * 64, lane);
+            gemm_store_patch<ACT, SWIGLU, OUT_F32>(p, ep, m0 + grp * 128 + wm * 64 + mi * 32, n0 + wn * 128 + nh * 64, lane, rowtab, grp * 128 + wm * 64 + mi * 32);
             __syncthreads();
         }
 }
@@ -676,6 +768,7 @@ __global__ __launch_bounds__(512, 2) void gemm3_bf16_kernel(GemmArgs p) {
     const int gm = (p.tiles_m - first_m) < 8 ? (p.tiles_m - first_m) : 8;
     const int tm = first_m + (t0 % grp_sz) % gm, tn = (t0 % grp_sz) / gm;
     const int m0 = tm * GEMM3_BM, n0 = tn * GEMM3_BN;
+    const f32x2 rst = gemm_row_stats(p, m0, tid, GEMM3_BM);
 
     const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x7fffffff, 0x00020000);
     const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0x7fffffff, 0x00020000);
@@ -760,6 +853,8 @@ __global__ __launch_bounds__(512, 2) void gemm3_bf16_kernel(GemmArgs p) {
     if (grp == 0) VL2_PHASE_BARRIER();
 
     float* ep = (float*)vl2_smem + wave * (32 * 68);
+    float* rowtab = (float*)vl2_smem + 8 * (32 * 68);
+    gemm_park_row_stats(p, rowtab, rst, tid, GEMM3_BM);
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
@@ -770,7 +865,7 @@ __global__ __launch_bounds__(512, 2) void gemm3_bf16_kernel(GemmArgs p) {
                 ep[row * 68 + ni * 32 + (lane & 31)] = acc[mi][ni][r];
             }
         __syncthreads();
-        gemm_store_patch<ACT, SWIGLU, OUT_F32>(p, ep, m0 + wm * 64 + mi * 32, n0 + grp * 128 + wn * 64, lane);
+        gemm_store_patch<ACT, SWIGLU, OUT_F32>(p, ep, m0 + wm * 64 + mi * 32, n0 + grp * 128 + wn * 64, lane, rowtab, wm * 64 + mi * 32);
         __syncthreads();
     }
 }
@@ -801,6 +896,7 @@ __global__ __launch_bounds__(128, 2) void gemm_s_bf16_kernel(GemmArgs p) {
     const int tm = t % p.tiles_m, tn = t / p.tiles_m;
     const int m0 = tm * GEMMS_BM, n0 = tn * GEMMS_BN;
     const int nt = p.K / GEMM_BK;
+    const f32x2 rst = gemm_row_stats(p, m0, tid, GEMMS_BM);
 
     f32x16 acc[2];
 #pragma unroll
@@ -842,7 +938,7 @@ __global__ __launch_bounds__(128, 2) void gemm_s_bf16_kernel(GemmArgs p) {
             if (kl == 0) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const int r = p.a_idx[(size_t)seg * p.M + g_row[i]];
+                    const int r = p.a_idx[(size_t)seg * p.idx_ld + g_row[i]];
                     a_vo[i] = r < 0 ? 0x80000000u : (unsigned)r * (unsigned)p.lda * 2u + g_chk[i];
                 }
             }
@@ -889,8 +985,10 @@ __global__ __launch_bounds__(128, 2) void gemm_s_bf16_kernel(GemmArgs p) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             ep[row * 68 + ni * 32 + (lane & 31)] = acc[ni][r];
         }
+    float* rowtab = (float*)vl2_smem + 2 * (32 * 68);
+    gemm_park_row_stats(p, rowtab, rst, tid, GEMMS_BM);
     __syncthreads();
-    gemm_store_patch<ACT, false, false, false>(p, ep, m0 + wave * 32, n0, lane);
+    gemm_store_patch<ACT, false, false, false>(p, ep, m0 + wave * 32, n0, lane, rowtab, wave * 32);
 }
 
 
@@ -916,6 +1014,7 @@ __global__ __launch_bounds__(512, 1) void gemm_l8_bf16_kernel(GemmArgs p) {
     const int tm = t % p.tiles_m, tn = t / p.tiles_m;            // consecutive workgroups share a W panel
     const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
     const int nt = p.K / GEMM_BK;
+    const f32x2 rst = gemm_row_stats(p, m0, tid, GEMM_BM);
 
     f32x16 acc[2];
 #pragma unroll
@@ -983,6 +1082,8 @@ __global__ __launch_bounds__(512, 1) void gemm_l8_bf16_kernel(GemmArgs p) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             ep[row * 68 + ni * 32 + (lane & 31)] = acc[ni][r];
         }
+    float* rowtab = (float*)vl2_smem + 8 * (32 * 68);
+    gemm_park_row_stats(p, rowtab, rst, tid, GEMM_BM);
     __syncthreads();
-    gemm_store_patch<ACT, SWIGLU, OUT_F32>(p, ep, m0 + wm * 32, n0 + wn * 64, lane);
+    gemm_store_patch<ACT, SWIGLU, OUT_F32>(p, ep, m0 + wm * 32, n0 + wn * 64, lane, rowtab, wm * 32);
 }

@@ -165,3 +165,34 @@ __global__ __launch_bounds__(256) void norm_wide_kernel(NormArgs p) {
         }
     }
 }
+
+// (sum, sum of squares) of every 64-column block of every row of x [rows, C] -> stats [rows][C/64][2] fp32: the statistics a
+// norm-carrying GEMM consumes (k_gemm.h `gemm_row_stats`), in the layout AND the summation order of the GEMM epilogue that
+// normally emits them (8 consecutive values per lane in sequence, then the xor-1/2/4 butterfly over the 8 lanes of a block),
+// so a row's statistics are the same bits whether this kernel or a producer GEMM wrote them.  One wave per row; a pass covers
+// 512 columns (8 blocks).  Seeds the chain for tensors no GEMM wrote: inputs_embeds, the CLIP embeddings after pre_layrnorm.
+__global__ __launch_bounds__(256) void row_stats_kernel(const bf16_t* __restrict__ x, float* __restrict__ stats, int rows, int C, int ldx) {
+#pragma clang fp reassociate(off)
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;                               // wave-uniform
+    const bf16_t* xr = x + (size_t)row * ldx;
+    const int np = C >> 6;
+    for (int c0 = 0; c0 < C; c0 += 512) {
+        const int c = c0 + lane * 8;
+        float s = 0.f, q = 0.f;
+        if (c < C) {
+            float v[8];
+            unpack8(*(const u32x4*)(xr + c), v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { s += v[j]; q = __builtin_fmaf(v[j], v[j], q); }
+        }
+#pragma unroll
+        for (int msk = 1; msk <= 4; msk <<= 1) { s += __shfl_xor(s, msk); q += __shfl_xor(q, msk); }
+        if (c < C && (lane & 7) == 0) {
+            float* dst = stats + ((size_t)row * np + (c >> 6)) * 2;
+            dst[0] = s;
+            dst[1] = q;
+        }
+    }
+}

@@ -1,11 +1,13 @@
 // libvl2hip.so: extern "C" launchers (include/vl2hip.h) over the gfx950 kernels in k_*.h.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC vl2_abi.hip -o libvl2hip.so   (see build.py)
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 
 #include "../../include/vl2hip.h"
 #include "k_attn.h"
+#include "k_attn2.h"
 #include "k_decode.h"
 #include "k_gemm.h"
 #include "k_norm.h"
@@ -22,7 +24,7 @@ static int32_t fail(int32_t code, const char* fmt, ...) {
     return code;
 }
 // set-up calls in front of a launch (LDS opt-in, flag re-arming): the first failure is kept and reported by `launched`
-static hipError_t g_setup_err = hipSuccess;
+static thread_local hipError_t g_setup_err = hipSuccess;
 static inline void check(hipError_t e) { if (e != hipSuccess && g_setup_err == hipSuccess) g_setup_err = e; }
 static int32_t launched(const char* what) {
     const hipError_t last = hipGetLastError();
@@ -34,51 +36,51 @@ static int32_t launched(const char* what) {
 #define ST(s) ((hipStream_t)(s))
 #define ALIGNED16(p) ((((uintptr_t)(p)) & 15) == 0)
 
+// Dynamic-LDS opt-in of a kernel instance (> 64 KiB needs hipFuncSetAttribute once per device).  Thread-safe and idempotent:
+// one atomic bit per device ordinal; two threads racing on the first launch both set the same attribute.
+template <auto Kern>
+static void lds_attr(int bytes) {
+    static std::atomic<uint64_t> done{0};
+    int dev = 0;
+    check(hipGetDevice(&dev));
+    const uint64_t bit = 1ull << (dev & 63);
+    if (!(done.load(std::memory_order_acquire) & bit)) {
+        check(hipFuncSetAttribute((const void*)Kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        done.fetch_or(bit, std::memory_order_release);
+    }
+}
+
 extern "C" int32_t vl2_version(void) { return VL2_ABI_VERSION; }
 extern "C" const char* vl2_last_error_string(void) { return g_err; }
 
-static int g_gemm_variant = 0;
-static void* g_ws = nullptr;          // caller-owned device workspace (vl2_set_workspace)
-static int64_t g_ws_bytes = 0;
 #define SK_GRID 512                  // persistent stream-K workgroups: 2 per CU
 #define SPLITK_MAX_WG 1024           // split-K: at most this many (tile, split) workgroups -> 64 MiB of fp32 partials
 #define SPLITK_MAX_TILES 192         // split-K only when the plain grid leaves most of the 512 resident slots empty
 // workspace layout: [SPLITK_MAX_WG][64][256] fp32 partial tiles (stream-K uses the first SK_GRID) | stream-K flags
-// [SK_GRID + 1] | split-K tile counters [SPLITK_MAX_TILES] (zero when attached, re-armed by the kernel itself)
+// [SK_GRID + 1] | split-K tile counters [SPLITK_MAX_TILES] (zero when allocated, re-armed by the kernel itself)
 #define SK_FLAGS_OFF ((int64_t)SPLITK_MAX_WG * 64 * 256 * 4)
 #define SPLITK_CNT_OFF (SK_FLAGS_OFF + (int64_t)(SK_GRID + 1) * 4 + 12)
 #define SK_WS_BYTES (SPLITK_CNT_OFF + (int64_t)SPLITK_MAX_TILES * 4)
-static int g_splitk = 0;             // VL2_TUNE_SPLITK: 0 = never (default: results independent of M), 1 = small grids split K
-static int g_attn_kv_groups = 0; // VL2_TUNE_ATTN_KV_GROUPS
-static int g_gemv_mr_rpw = 2;   // batched GEMV rows per wave (VL2_TUNE_GEMV_MR_ROWS_PER_WAVE); measured at B=4: 5.56 / 5.04 / 5.56 ms per step at 1 / 2 / 4
-static int g_gemv_rpw = 1;   // measured on MI355X: 3.09 / 3.30 / 3.97 ms per 7B decode token at 1 / 2 / 4 rows per wave
-extern "C" int32_t vl2_set_tuning(int32_t key, int32_t value) {
-    if (key == VL2_TUNE_GEMM_VARIANT && (value == 0 || value == 1 || value == 2 || value == 4 || value == 8 || value == 32 || value == 256)) { g_gemm_variant = value; return 0; }
-    if (key == VL2_TUNE_GEMV_ROWS_PER_WAVE && (value == 1 || value == 2 || value == 4)) { g_gemv_rpw = value; return 0; }
-    if (key == VL2_TUNE_SPLITK && (value == 0 || value == 1)) { g_splitk = value; return 0; }
-    if (key == VL2_TUNE_GEMV_MR_ROWS_PER_WAVE && (value == 1 || value == 2 || value == 4)) { g_gemv_mr_rpw = value; return 0; }
-    if (key == VL2_TUNE_ATTN_KV_GROUPS && value >= 0 && value <= 2) { g_attn_kv_groups = value; return 0; }
-    return fail(VL2_E_BADARG, "vl2_set_tuning: unknown key/value %d/%d", key, value);
-}
-
 extern "C" int64_t vl2_workspace_bytes(void) { return SK_WS_BYTES; }
-extern "C" int32_t vl2_set_workspace(void* ws, int64_t bytes) {
-    if (ws && (bytes < SK_WS_BYTES || !ALIGNED16(ws))) return fail(VL2_E_BADARG, "vl2_set_workspace: need >= %lld bytes, 16-byte aligned", (long long)SK_WS_BYTES);
-    g_ws = ws;
-    g_ws_bytes = ws ? bytes : 0;
-    return 0;
-}
+
+// per-call launch controls (vl2_gemm_desc: ws / ws_bytes / variant / VL2_GEMM_SPLITK) -- nothing of this is process state
+struct GemmCtl {
+    void* ws;
+    int64_t ws_bytes;
+    int variant;
+    bool splitk;
+};
 
 // ------------------------------------------------------------------------------------------------ GEMM
 // stream-K form: measured 0.5-0.6x of the plain grid on this workload's shapes (per-tile prologue/epilogue of the persistent
 // workgroups, ~15 us of partial-tile exchange, worse L2 locality of strided tile ownership) -> only on explicit request.
-static bool want_stream_k(const GemmArgs&) { return g_ws && g_gemm_variant == 2; }
+static bool want_stream_k(const GemmArgs& a, const GemmCtl& c) { return c.ws && c.variant == 2 && !a.norm && !a.stats_out; }
 
 // Tile-shape choice (auto): expected efficiency = how full the last round of resident workgroups is x rows wasted by the
 // M edge x the kernel's measured rate on well-quantised shapes (128x128 two-barrier kernel 1.0, 128x256 ping-pong 1.07,
 // 256x256 ping-pong 1.2: profiles/r01_gemm_experiments.md).  Fitted to the measured shapes of the T=16 workload: the LLM
 // o/gate-up/down projections and the STC 4096x4096 convs take 128x256, ViT qkv/wo/fc2 and the LLM qkv take 256x256,
-// short-K GEMMs (ViT fc1, STC b1) stay on 128x128.  Returns 1, 4 (gemm3) or 8 (gemm4).
+// short-K GEMMs (STC b1) stay on 128x128.  Returns 1, 4 (gemm3) or 8 (gemm4).
 static int choose_gemm_kernel(const GemmArgs& a) {
     if (a.N % 256) return 1;
     // at most one 128x128 tile per CU: a bigger tile only halves the CUs in use and doubles the latency of the single round
@@ -100,8 +102,8 @@ static int choose_gemm_kernel(const GemmArgs& a) {
 // workgroup streams its K-tiles at ~0.64 us each (0.95 us when two share a CU), so a 96-tile grid with K = 4096 takes 42 us
 // however idle the chip is (scripts/kernel_bench.py --small).  Cost model in us per launch, d over the divisors of the
 // K-tile count: (K-tiles / d) x per-tile time at the resulting occupancy + partial write/reduce.
-static int choose_splitk(const GemmArgs& a) {
-    if (!g_ws || !g_splitk || (g_gemm_variant != 0 && g_gemm_variant != 1)) return 1;
+static int choose_splitk(const GemmArgs& a, const GemmCtl& c) {
+    if (!c.ws || !c.splitk || (c.variant != 0 && c.variant != 1)) return 1;
     const int tiles = a.tiles_m * a.tiles_n, nt = a.K / GEMM_BK;
     if (tiles > SPLITK_MAX_TILES || nt < 32) return 1;       // measured: K = 1024 GEMMs lose (14.0 -> 19.7 us)
     int best = 1;
@@ -110,8 +112,8 @@ static int choose_splitk(const GemmArgs& a) {
         if (nt % d || nt / d < 4) continue;
         const int wg = tiles * d;
         const double per = wg <= 256 ? 0.64 : 0.95 * ((wg + 511) / 512);
-        const double c = (nt / d) * per + (d > 1 ? 2.0 + 0.3 * d : 0.0);
-        if (c < cb * (d > 1 ? 0.85 : 1.0)) { cb = c; best = d; }
+        const double cst = (nt / d) * per + (d > 1 ? 2.0 + 0.3 * d : 0.0);
+        if (cst < cb * (d > 1 ? 0.85 : 1.0)) { cb = cst; best = d; }
     }
     return best;
 }
@@ -119,19 +121,15 @@ static int choose_splitk(const GemmArgs& a) {
 // Small-M form (64x64 tiles, gemm_s_bf16_kernel): when the 128x128 grid cannot even give every CU one tile, quartering the
 // tile spreads the operand stream over the idle CUs (a workgroup streams at ~55 GB/s whatever the chip does).  Same K order
 // as every other kernel -> same bits.  Measured crossover (scripts/kernel_bench.py --small): see profiles/.
-static bool want_small_m(const GemmArgs& a) {
-    if (g_gemm_variant == 32) return true;
-    if (g_gemm_variant != 0) return false;
+static bool want_small_m(const GemmArgs& a, const GemmCtl& c) {
+    if (c.variant == 32) return true;
+    if (c.variant != 0) return false;
     return a.tiles_m * a.tiles_n <= 128 && a.K >= 512;   // measured crossover: wins at <= 128 tiles, loses at 152-160
 }
 
 template <int ACT, bool SW, bool F32>
 static void launch_gemm4(const GemmArgs& a0, hipStream_t s) {
-    static bool attr4 = false;
-    if (!attr4) {
-        check(hipFuncSetAttribute((const void*)gemm4_bf16_kernel<ACT, SW, F32>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM4_LDS_BYTES));
-        attr4 = true;
-    }
+    lds_attr<gemm4_bf16_kernel<ACT, SW, F32>>(GEMM4_LDS_BYTES);
     GemmArgs a = a0;
     a.tiles_m = (a.M + GEMM4_BM - 1) / GEMM4_BM;
     a.tiles_n = a.N / GEMM4_BN;
@@ -143,38 +141,41 @@ static void launch_gemm4(const GemmArgs& a0, hipStream_t s) {
 // go to the 256x256 kernel and the remaining rows to whatever the chooser picks for them -- two launches, same stream.  Every
 // kernel accumulates K in the same order and shares one epilogue, so the output bits do not change (asserted in
 // tests/test_gpu_ops.py).  Measured: 1621x28672x4096 + SwiGLU 362 -> 345 us; loses on N <= 6144 and on M % 256 > 128.
-static bool want_m_split(const GemmArgs& a) {
-    if (g_gemm_variant != 0 || a.out_grp > 0 || a.res_row_mod > 0 || a.N % GEMM4_BN || a.K < 2048 || a.M < 1024) return false;
+static bool want_m_split(const GemmArgs& a, const GemmCtl& c) {
+    if (c.variant != 0 || a.out_grp > 0 || a.res_row_mod > 0 || a.N % GEMM4_BN || a.K < 2048 || a.M < 1024) return false;
     const int r = a.M % GEMM4_BM, m1_tiles = a.M / GEMM4_BM, n_tiles = a.N / GEMM4_BN;
     if (r == 0 || r > 96 || n_tiles < 64) return false;
     const long t4 = (long)m1_tiles * n_tiles;
     return (double)t4 / (double)(((t4 + 255) / 256) * 256) >= 0.85;      // the 256-row part fills its rounds
 }
 
+// rows [m0, m0 + rows) of a call as a call of its own (A / C / residual / statistics rows shifted; the gather table keeps its
+// row stride idx_ld)
+static GemmArgs gemm_rows(const GemmArgs& a0, int m0, int rows, bool f32) {
+    GemmArgs a = a0;
+    a.M = rows;
+    if (a0.a_idx) a.a_idx = a0.a_idx + m0; else a.A = a0.A + (size_t)m0 * a0.lda;
+    a.C = f32 ? (void*)((float*)a0.C + (size_t)m0 * a0.ldc) : (void*)((bf16_t*)a0.C + (size_t)m0 * a0.ldc);
+    if (a0.res) a.res = a0.res + (size_t)m0 * a0.ldres;
+    if (a0.stats_out) a.stats_out = a0.stats_out + (size_t)m0 * a0.stats_out_np * 2;
+    if (a0.stats_in) a.stats_in = a0.stats_in + (size_t)m0 * a0.stats_in_np * 2;
+    a.tiles_m = (rows + GEMM_BM - 1) / GEMM_BM;
+    return a;
+}
+
 template <int ACT, bool SW, bool F32, bool G>
-static void launch_gemm(const GemmArgs& a0, hipStream_t s) {
+static void launch_gemm(const GemmArgs& a0, const GemmCtl& c, hipStream_t s) {
     if constexpr (!G && !F32) {
-        if (want_m_split(a0)) {
+        if (want_m_split(a0, c)) {
             const int M1 = a0.M / GEMM4_BM * GEMM4_BM;
-            GemmArgs hi = a0, lo = a0;
-            hi.M = M1;
-            launch_gemm4<ACT, SW, F32>(hi, s);
-            lo.M = a0.M - M1;
-            lo.A = a0.A + (size_t)M1 * a0.lda;
-            lo.C = (bf16_t*)a0.C + (size_t)M1 * a0.ldc;
-            if (a0.res) lo.res = a0.res + (size_t)M1 * a0.ldres;
-            lo.tiles_m = (lo.M + GEMM_BM - 1) / GEMM_BM;
-            launch_gemm<ACT, SW, F32, G>(lo, s);
+            launch_gemm4<ACT, SW, F32>(gemm_rows(a0, 0, M1, F32), s);
+            launch_gemm<ACT, SW, F32, G>(gemm_rows(a0, M1, a0.M - M1, F32), c, s);
             return;
         }
     }
     if constexpr (!SW && !F32) {
-        if (choose_splitk(a0) <= 1 && want_small_m(a0)) {
-            static bool attr_s = false;
-            if (!attr_s) {
-                check(hipFuncSetAttribute((const void*)gemm_s_bf16_kernel<ACT, G>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMMS_LDS_BYTES));
-                attr_s = true;
-            }
+        if (choose_splitk(a0, c) <= 1 && want_small_m(a0, c)) {
+            lds_attr<gemm_s_bf16_kernel<ACT, G>>(GEMMS_LDS_BYTES);
             GemmArgs a = a0;
             a.tiles_m = (a.M + GEMMS_BM - 1) / GEMMS_BM;
             a.tiles_n = a.N / GEMMS_BN;
@@ -182,37 +183,24 @@ static void launch_gemm(const GemmArgs& a0, hipStream_t s) {
             return;
         }
     }
-    if (const int split = choose_splitk(a0); split > 1) {
-        static bool attr_k = false;
-        if (!attr_k) {
-            check(hipFuncSetAttribute((const void*)gemm_bf16_kernel<ACT, SW, F32, G, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                GEMM_LDS_BYTES));
-            attr_k = true;
-        }
+    if (const int split = choose_splitk(a0, c); split > 1) {
+        lds_attr<gemm_bf16_kernel<ACT, SW, F32, G, false, true>>(GEMM_LDS_BYTES);
         GemmArgs a = a0;
-        a.sk_ws = (float*)g_ws;
-        a.sk_flags = (int*)((char*)g_ws + SPLITK_CNT_OFF);
+        a.sk_ws = (float*)c.ws;
+        a.sk_flags = (int*)((char*)c.ws + SPLITK_CNT_OFF);
         hipLaunchKernelGGL((gemm_bf16_kernel<ACT, SW, F32, G, false, true>), dim3(a.tiles_m * a.tiles_n, split), dim3(256), GEMM_LDS_BYTES, s, a);
         return;
     }
     if constexpr (!G) {
         // measured (scripts/kernel_bench.py --frames 8): wins 15-20 % at <= 256 tiles with K >= 4096, loses at K = 1024 and beyond one round
-        if (g_gemm_variant == 256 || (g_gemm_variant == 0 && (long)a0.tiles_m * a0.tiles_n <= 256 && a0.K >= 4096)) {
-            static bool attrl8 = false;
-            if (!attrl8) {
-                check(hipFuncSetAttribute((const void*)gemm_l8_bf16_kernel<ACT, SW, F32>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMML_LDS_BYTES));
-                attrl8 = true;
-            }
+        if (c.variant == 256 || (c.variant == 0 && (long)a0.tiles_m * a0.tiles_n <= 256 && a0.K >= 4096)) {
+            lds_attr<gemm_l8_bf16_kernel<ACT, SW, F32>>(GEMML_LDS_BYTES);
             hipLaunchKernelGGL((gemm_l8_bf16_kernel<ACT, SW, F32>), dim3(a0.tiles_m * a0.tiles_n), dim3(512), GEMML_LDS_BYTES, s, a0);
             return;
         }
-        const int kern = g_gemm_variant == 0 ? choose_gemm_kernel(a0) : g_gemm_variant;
+        const int kern = c.variant == 0 ? choose_gemm_kernel(a0) : c.variant;
         if (kern == 4 && a0.N % GEMM3_BN == 0) {
-            static bool attr3 = false;
-            if (!attr3) {
-                check(hipFuncSetAttribute((const void*)gemm3_bf16_kernel<ACT, SW, F32>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM3_LDS_BYTES));
-                attr3 = true;
-            }
+            lds_attr<gemm3_bf16_kernel<ACT, SW, F32>>(GEMM3_LDS_BYTES);
             GemmArgs a = a0;
             a.tiles_m = (a.M + GEMM3_BM - 1) / GEMM3_BM;
             a.tiles_n = a.N / GEMM3_BN;
@@ -225,118 +213,159 @@ static void launch_gemm(const GemmArgs& a0, hipStream_t s) {
         }
     }
     if constexpr (!G) {
-        if (want_stream_k(a0)) {
-            static bool attr_sk = false;
-            if (!attr_sk) {
-                check(hipFuncSetAttribute((const void*)gemm_sk_bf16_kernel<ACT, SW, F32>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    GEMM_LDS_BYTES));
-                attr_sk = true;
-            }
+        if (want_stream_k(a0, c)) {
+            lds_attr<gemm_sk_bf16_kernel<ACT, SW, F32>>(GEMM_LDS_BYTES);
             GemmArgs a = a0;
             const int total = a.tiles_m * a.tiles_n * (a.K / GEMM_BK);
-            a.sk_ws = (float*)g_ws;
-            a.sk_flags = (int*)((char*)g_ws + SK_FLAGS_OFF);
+            a.sk_ws = (float*)c.ws;
+            a.sk_flags = (int*)((char*)c.ws + SK_FLAGS_OFF);
             a.sk_per = (total + SK_GRID - 1) / SK_GRID;
             check(hipMemsetAsync(a.sk_flags, 0, (SK_GRID + 1) * 4, s));               // flags re-armed before EVERY launch (guide G16)
             hipLaunchKernelGGL((gemm_sk_bf16_kernel<ACT, SW, F32>), dim3(SK_GRID), dim3(256), GEMM_LDS_BYTES, s, a);
             return;
         }
     }
-    const GemmArgs& a = a0;
-    static bool attr_set = false;   // 64 KiB dynamic LDS needs the opt-in once per kernel instance
-    if (!attr_set) {
-        check(hipFuncSetAttribute((const void*)gemm_bf16_kernel<ACT, SW, F32, G>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            GEMM_LDS_BYTES));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((gemm_bf16_kernel<ACT, SW, F32, G>), dim3(a.tiles_m * a.tiles_n), dim3(256), GEMM_LDS_BYTES, s, a);
+    lds_attr<gemm_bf16_kernel<ACT, SW, F32, G>>(GEMM_LDS_BYTES);   // 64 KiB dynamic LDS needs the opt-in once per kernel instance
+    hipLaunchKernelGGL((gemm_bf16_kernel<ACT, SW, F32, G>), dim3(a0.tiles_m * a0.tiles_n), dim3(256), GEMM_LDS_BYTES, s, a0);
 }
 
-extern "C" int32_t vl2_gemm_bf16(const void* A, const void* W, void* C, const float* bias, const void* res, int32_t M,
-                                 int32_t N, int32_t K, int32_t lda, int32_t ldw, int32_t ldc, int32_t ldres, int32_t act,
-                                 int32_t flags, const int32_t* a_idx, const void* zero_row, int32_t seg_k, int32_t out_grp,
-                                 int32_t out_grp_pad, int32_t out_row_off, int32_t res_row_mod, int32_t res_row_off,
-                                 void* stream) {
-    if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0) return fail(VL2_E_BADARG, "vl2_gemm_bf16: null pointer or empty shape");
-    if (N % 128 || K % 64) return fail(VL2_E_SHAPE, "vl2_gemm_bf16: need N%%128==0 and K%%64==0 (N=%d K=%d)", N, K);
-    if ((lda % 8) || (ldw % 8) || (ldc % 8) || (res && (ldres % 8)) || !ALIGNED16(A) || !ALIGNED16(W) || !ALIGNED16(C) ||
-        (res && !ALIGNED16(res)) || (bias && !ALIGNED16(bias)))
-        return fail(VL2_E_SHAPE, "vl2_gemm_bf16: pointers / leading dims must be 16-byte aligned");
-    const bool sw = flags & VL2_GEMM_SWIGLU, f32 = flags & VL2_GEMM_OUT_F32, g = a_idx != nullptr;
-    if (g && (seg_k <= 0 || seg_k % 64 || K % seg_k)) return fail(VL2_E_SHAPE, "vl2_gemm_bf16: bad gather segments");
-    GemmArgs a{(const bf16_t*)A, (const bf16_t*)W, C, bias, (const bf16_t*)res, a_idx, (const bf16_t*)zero_row, M, N, K,
-               lda, ldw, ldc, ldres, seg_k, out_grp, out_grp_pad, out_row_off, res_row_mod, res_row_off,
-               (M + GEMM_BM - 1) / GEMM_BM, N / GEMM_BN};
-    hipStream_t s = ST(stream);
-    if (out_grp > 0 || res_row_mod > 0) {                      // row-remap epilogue (patch-embed): dedicated instantiation
-        if (sw || g || f32 || act != VL2_ACT_NONE) return fail(VL2_E_UNSUPP, "vl2_gemm_bf16: row remap supports plain bf16 output only");
-        static bool attr_r = false;
-        if (!attr_r) {
-            check(hipFuncSetAttribute((const void*)gemm_bf16_kernel<ACT_NONE, false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
-            attr_r = true;
-        }
+// one chunk (every operand within the kernels' 32-bit buffer offsets) -> the right instantiation
+static int32_t gemm_dispatch(const GemmArgs& a, const GemmCtl& c, int act, bool sw, bool f32, hipStream_t s) {
+    const bool g = a.a_idx != nullptr;
+    if (a.out_grp > 0 || a.res_row_mod > 0) {                      // row-remap epilogue (patch-embed): dedicated instantiation
+        lds_attr<gemm_bf16_kernel<ACT_NONE, false, false, false, true>>(GEMM_LDS_BYTES);
         hipLaunchKernelGGL((gemm_bf16_kernel<ACT_NONE, false, false, false, true>), dim3(a.tiles_m * a.tiles_n), dim3(256), GEMM_LDS_BYTES, s, a);
-        return launched("vl2_gemm_bf16");
+        return 0;
     }
-    if (sw) {
-        if (f32 || g || act != VL2_ACT_NONE || bias) return fail(VL2_E_UNSUPP, "vl2_gemm_bf16: SWIGLU excludes bias/act/f32/gather");
-        launch_gemm<ACT_NONE, true, false, false>(a, s);
-    } else if (g) {
-        if (f32) return fail(VL2_E_UNSUPP, "vl2_gemm_bf16: gather + f32 not built");
-        if (act == VL2_ACT_SILU) launch_gemm<ACT_SILU, false, false, true>(a, s);
-        else if (act == VL2_ACT_NONE) launch_gemm<ACT_NONE, false, false, true>(a, s);
-        else return fail(VL2_E_UNSUPP, "vl2_gemm_bf16: gather supports act none/silu");
-    } else if (f32) {
-        if (act != VL2_ACT_NONE) return fail(VL2_E_UNSUPP, "vl2_gemm_bf16: f32 output supports act none");
-        launch_gemm<ACT_NONE, false, true, false>(a, s);
-    } else {
+    if (sw) launch_gemm<ACT_NONE, true, false, false>(a, c, s);
+    else if (g) {
+        if (act == VL2_ACT_SILU) launch_gemm<ACT_SILU, false, false, true>(a, c, s);
+        else launch_gemm<ACT_NONE, false, false, true>(a, c, s);
+    } else if (f32) launch_gemm<ACT_NONE, false, true, false>(a, c, s);
+    else {
         switch (act) {
-            case VL2_ACT_NONE: launch_gemm<ACT_NONE, false, false, false>(a, s); break;
-            case VL2_ACT_QGELU: launch_gemm<ACT_QGELU, false, false, false>(a, s); break;
-            case VL2_ACT_GELU: launch_gemm<ACT_GELU, false, false, false>(a, s); break;
-            case VL2_ACT_SILU: launch_gemm<ACT_SILU, false, false, false>(a, s); break;
-            case VL2_ACT_GELU_TANH: launch_gemm<ACT_GELU_TANH, false, false, false>(a, s); break;
-            default: return fail(VL2_E_UNSUPP, "vl2_gemm_bf16: unknown act %d", act);
+            case VL2_ACT_NONE: launch_gemm<ACT_NONE, false, false, false>(a, c, s); break;
+            case VL2_ACT_QGELU: launch_gemm<ACT_QGELU, false, false, false>(a, c, s); break;
+            case VL2_ACT_GELU: launch_gemm<ACT_GELU, false, false, false>(a, c, s); break;
+            case VL2_ACT_SILU: launch_gemm<ACT_SILU, false, false, false>(a, c, s); break;
+            case VL2_ACT_GELU_TANH: launch_gemm<ACT_GELU_TANH, false, false, false>(a, c, s); break;
+            default: return fail(VL2_E_UNSUPP, "vl2_gemm: unknown act %d", act);
         }
     }
-    return launched("vl2_gemm_bf16");
+    return 0;
+}
+
+extern "C" int32_t vl2_gemm(const vl2_gemm_desc* d, void* stream) {
+    if (!d || d->size != sizeof(vl2_gemm_desc)) return fail(VL2_E_BADARG, "vl2_gemm: descriptor missing or of another ABI (size %u, expected %zu)", d ? d->size : 0u, sizeof(vl2_gemm_desc));
+    const int M = d->M, N = d->N, K = d->K, act = d->act;
+    if (!d->A || !d->W || !d->C || M <= 0 || N <= 0 || K <= 0) return fail(VL2_E_BADARG, "vl2_gemm: null pointer or empty shape");
+    if (N % 128 || K % 64) return fail(VL2_E_SHAPE, "vl2_gemm: need N%%128==0 and K%%64==0 (N=%d K=%d)", N, K);
+    if ((d->lda % 8) || (d->ldw % 8) || (d->ldc % 8) || (d->res && (d->ldres % 8)) || !ALIGNED16(d->A) || !ALIGNED16(d->W) || !ALIGNED16(d->C) ||
+        (d->res && !ALIGNED16(d->res)) || (d->bias && !ALIGNED16(d->bias)) || (d->w_colsum && !ALIGNED16(d->w_colsum)) ||
+        (d->stats_in && !ALIGNED16(d->stats_in)))
+        return fail(VL2_E_SHAPE, "vl2_gemm: pointers / leading dims must be 16-byte aligned");
+    const bool sw = d->flags & VL2_GEMM_SWIGLU, f32 = d->flags & VL2_GEMM_OUT_F32, g = d->a_idx != nullptr;
+    if (g && (d->seg_k <= 0 || d->seg_k % 64 || K % d->seg_k)) return fail(VL2_E_SHAPE, "vl2_gemm: bad gather segments");
+    const bool remap = d->out_grp > 0 || d->res_row_mod > 0;
+    if (remap && (sw || g || f32 || act != VL2_ACT_NONE || d->norm || d->stats_out)) return fail(VL2_E_UNSUPP, "vl2_gemm: row remap supports plain bf16 output only");
+    if (sw && (f32 || g || act != VL2_ACT_NONE || d->bias)) return fail(VL2_E_UNSUPP, "vl2_gemm: SWIGLU excludes bias/act/f32/gather");
+    if (g && f32) return fail(VL2_E_UNSUPP, "vl2_gemm: gather + f32 not built");
+    if (g && act != VL2_ACT_NONE && act != VL2_ACT_SILU) return fail(VL2_E_UNSUPP, "vl2_gemm: gather supports act none/silu");
+    if (f32 && act != VL2_ACT_NONE) return fail(VL2_E_UNSUPP, "vl2_gemm: f32 output supports act none");
+    if (d->norm != VL2_NORM_NONE) {
+        if (d->norm != VL2_NORM_RMS && d->norm != VL2_NORM_LN) return fail(VL2_E_BADARG, "vl2_gemm: unknown norm %d", d->norm);
+        if (!d->stats_in || g || remap) return fail(VL2_E_BADARG, "vl2_gemm: a fused norm needs stats_in and plain A rows");
+        if (d->norm == VL2_NORM_LN && (!d->w_colsum || sw)) return fail(VL2_E_BADARG, "vl2_gemm: fused LayerNorm needs w_colsum (and excludes SWIGLU)");
+    }
+    if (d->stats_out && (sw || f32)) return fail(VL2_E_UNSUPP, "vl2_gemm: stats_out needs a plain bf16 output");
+    if (d->ws && (d->ws_bytes < SK_WS_BYTES || !ALIGNED16(d->ws))) return fail(VL2_E_BADARG, "vl2_gemm: workspace needs >= %lld bytes, 16-byte aligned", (long long)SK_WS_BYTES);
+    const int v = d->variant;
+    if (!(v == 0 || v == 1 || v == 2 || v == 4 || v == 8 || v == 32 || v == 256)) return fail(VL2_E_BADARG, "vl2_gemm: unknown variant %d", v);
+    const GemmCtl ctl{d->ws, d->ws_bytes, v, (d->flags & VL2_GEMM_SPLITK) != 0};
+    GemmArgs a{};
+    a.A = (const bf16_t*)d->A; a.W = (const bf16_t*)d->W; a.C = d->C; a.bias = d->bias; a.res = (const bf16_t*)d->res;
+    a.a_idx = d->a_idx; a.zero_row = nullptr;
+    a.M = M; a.N = N; a.K = K; a.lda = d->lda; a.ldw = d->ldw; a.ldc = d->ldc; a.ldres = d->ldres; a.seg_k = d->seg_k;
+    a.out_grp = d->out_grp; a.out_grp_pad = d->out_grp_pad; a.out_row_off = d->out_row_off;
+    a.res_row_mod = d->res_row_mod; a.res_row_off = d->res_row_off;
+    a.tiles_m = (M + GEMM_BM - 1) / GEMM_BM; a.tiles_n = N / GEMM_BN;
+    a.idx_ld = M;
+    a.stats_out = d->stats_out; a.stats_out_np = N / 64;
+    a.stats_in = d->stats_in; a.stats_in_np = K / 64;
+    a.norm = d->norm; a.norm_eps = d->norm_eps; a.w_colsum = d->w_colsum;
+    hipStream_t s = ST(stream);
+    // The kernels address A and W through raw buffer resources: 32-bit byte offsets, NUM_RECORDS 2^31 - 1.  Operands beyond
+    // that are covered in chunks of rows (A, C, residual, statistics) / columns (W, bias, w_colsum, C columns): e.g. the
+    // [152064 x 8192] bf16 lm_head of VideoLLaMA2-72B (2.49 GB) runs as two column chunks.  Chunk sizes are multiples of
+    // 256 (every tile shape, the 64-row SwiGLU blocks).  The gathered row pool cannot be chunked (its extent is unknown here).
+    const int64_t LIM = ((int64_t)1 << 31) - 65536;
+    int64_t rows_a = M, rows_w = N;
+    if (!g && ((int64_t)(M - 1) * d->lda + K) * 2 >= LIM) rows_a = ((LIM / 2 - K) / d->lda + 1) / 256 * 256;
+    if (((int64_t)(N - 1) * d->ldw + K) * 2 >= LIM) rows_w = ((LIM / 2 - K) / d->ldw + 1) / 256 * 256;
+    if (rows_a <= 0 || rows_w <= 0) return fail(VL2_E_SHAPE, "vl2_gemm: a single 256-row block of A or W exceeds 2 GiB (lda %d, ldw %d)", d->lda, d->ldw);
+    if ((rows_a < M || rows_w < N) && remap) return fail(VL2_E_UNSUPP, "vl2_gemm: row remap with >= 2 GiB operands not built");
+    for (int64_t m0 = 0; m0 < M; m0 += rows_a) {
+        const int mr = (int)(M - m0 < rows_a ? M - m0 : rows_a);
+        for (int64_t n0 = 0; n0 < N; n0 += rows_w) {
+            const int nr = (int)(N - n0 < rows_w ? N - n0 : rows_w);
+            GemmArgs c = (mr == M) ? a : gemm_rows(a, (int)m0, mr, f32);
+            if (nr != N) {
+                c.N = nr;
+                c.tiles_n = nr / GEMM_BN;
+                c.W = a.W + (size_t)n0 * a.ldw;
+                if (a.bias) c.bias = a.bias + n0;
+                if (a.w_colsum) c.w_colsum = a.w_colsum + n0;
+                const size_t ccol = sw ? (size_t)n0 / 2 : (size_t)n0;
+                c.C = f32 ? (void*)((float*)c.C + ccol) : (void*)((bf16_t*)c.C + ccol);
+                if (c.res) c.res = c.res + ccol;
+                if (c.stats_out) c.stats_out = c.stats_out + (size_t)(n0 / 64) * 2;
+            }
+            const int32_t rc = gemm_dispatch(c, ctl, act, sw, f32, s);
+            if (rc) return rc;
+        }
+    }
+    return launched("vl2_gemm");
+}
+
+extern "C" int32_t vl2_row_stats(const void* x, float* stats, int32_t rows, int32_t C, int32_t ldx, void* stream) {
+    if (!x || !stats || rows <= 0 || C <= 0) return fail(VL2_E_BADARG, "vl2_row_stats: null pointer or empty shape");
+    if (C % 64 || ldx % 8 || !ALIGNED16(x)) return fail(VL2_E_SHAPE, "vl2_row_stats: need C%%64==0 and 16-byte aligned rows (C=%d)", C);
+    hipLaunchKernelGGL(row_stats_kernel, dim3((rows + 3) / 4), dim3(256), 0, ST(stream), (const bf16_t*)x, stats, rows, C, ldx);
+    return launched("vl2_row_stats");
 }
 
 // ------------------------------------------------------------------------------------------------ skinny-M GEMM (batched decode)
 template <int MT>
 static void launch_skinny(const SkinnyArgs& a, int ks, size_t lds, hipStream_t s) {
-    static bool attr = false;
-    if (!attr) {
-        check(hipFuncSetAttribute((const void*)gemm_skinny_kernel<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
-        attr = true;
-    }
+    lds_attr<gemm_skinny_kernel<MT>>(65536);
     hipLaunchKernelGGL((gemm_skinny_kernel<MT>), dim3(a.N / 64, ks), dim3(256), lds, s, a);
 }
 extern "C" int32_t vl2_gemm_skinny_bf16(const void* A, const void* W, void* C, const float* bias, const void* res, int32_t M,
                                         int32_t N, int32_t K, int32_t lda, int32_t ldw, int32_t ldc, int32_t ldres, int32_t flags,
-                                        void* stream) {
+                                        void* ws, int64_t ws_bytes, void* stream) {
     if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0) return fail(VL2_E_BADARG, "vl2_gemm_skinny_bf16: null pointer or empty shape");
     const bool sw = flags & VL2_GEMM_SWIGLU, f32 = flags & VL2_GEMM_OUT_F32;
     if (M > 64 || N % 64 || (sw && N % 128) || K % 32 || lda % 8 || ldw % 8 || ldc % 4 || (res && ldres % 4))
         return fail(VL2_E_SHAPE, "vl2_gemm_skinny_bf16: need M<=64, N%%64==0, K%%32==0 (M=%d N=%d K=%d)", M, N, K);
     if (sw && (bias || f32)) return fail(VL2_E_UNSUPP, "vl2_gemm_skinny_bf16: SWIGLU excludes bias / f32 output");
-    if (!g_ws) return fail(VL2_E_BADARG, "vl2_gemm_skinny_bf16: needs vl2_set_workspace (fp32 partial sums)");
+    if (!ws || !ALIGNED16(ws) || ws_bytes <= 0) return fail(VL2_E_BADARG, "vl2_gemm_skinny_bf16: needs a 16-byte aligned workspace (fp32 partial sums)");
     const int mt = M <= 16 ? 1 : M <= 32 ? 2 : 4, Mp = 16 * mt;
     const int steps = K / 32;
     // K split: enough (column group, K slice) waves to keep ~4096 in flight, a divisor of the 32-deep steps, partials within
     // the workspace
     int ks = (4096 + N / 16 - 1) / (N / 16);
     ks = ks < 1 ? 1 : ks > 32 ? 32 : ks;
-    while (ks > 1 && (steps % ks || (int64_t)ks * Mp * N * 4 > g_ws_bytes)) --ks;
+    while (ks > 1 && (steps % ks || (int64_t)ks * Mp * N * 4 > ws_bytes)) --ks;
+    if ((int64_t)ks * Mp * N * 4 > ws_bytes) return fail(VL2_E_BADARG, "vl2_gemm_skinny_bf16: workspace too small (%lld bytes)", (long long)ws_bytes);
     const int kslice = K / ks;
     int kchunk = kslice;                                      // largest 32-multiple divisor of the slice whose x chunk fits 64 KiB
     while (kchunk > 32 && (kslice % kchunk || kchunk % 32 || (size_t)Mp * (kchunk + 8) * 2 > 65536)) kchunk -= 32;
     if (kslice % kchunk || (size_t)Mp * (kchunk + 8) * 2 > 65536) return fail(VL2_E_SHAPE, "vl2_gemm_skinny_bf16: no K chunking for K=%d", K);
-    SkinnyArgs a{(const bf16_t*)A, (const bf16_t*)W, (float*)g_ws, M, N, K, lda, ldw, kslice, kchunk};
+    SkinnyArgs a{(const bf16_t*)A, (const bf16_t*)W, (float*)ws, M, N, K, lda, ldw, kslice, kchunk};
     const size_t lds = (size_t)Mp * (kchunk + 8) * 2;
     hipStream_t s = ST(stream);
     if (mt == 1) launch_skinny<1>(a, ks, lds, s); else if (mt == 2) launch_skinny<2>(a, ks, lds, s); else launch_skinny<4>(a, ks, lds, s);
-    SkinnyReduceArgs r{(const float*)g_ws, C, bias, (const bf16_t*)res, M, Mp, N, ks, ldc, ldres};
+    SkinnyReduceArgs r{(const float*)ws, C, bias, (const bf16_t*)res, M, Mp, N, ks, ldc, ldres};
     const int ncol = sw ? N / 2 : N;
     const dim3 g((M * (ncol / 4) + 255) / 256), b(256);
     if (sw) hipLaunchKernelGGL((skinny_reduce_kernel<true, false>), g, b, 0, s, r);
@@ -394,10 +423,11 @@ extern "C" int32_t vl2_patchify(const void* frames, int32_t dtype, void* out, in
     return launched("vl2_patchify");
 }
 extern "C" int32_t vl2_patchify_u8(const void* frames_thwc, void* out, int32_t T, int32_t H, int32_t W, int32_t P, int32_t G, int32_t Kp,
-                                   float rescale, const float* mean3, const float* std3, void* stream) {
-    if (!frames_thwc || !out || !mean3 || !std3 || T <= 0) return fail(VL2_E_BADARG, "vl2_patchify_u8: null pointer or empty shape");
+                                   float rescale, float mean_r, float mean_g, float mean_b, float std_r, float std_g, float std_b,
+                                   void* stream) {
+    if (!frames_thwc || !out || T <= 0 || std_r == 0.f || std_g == 0.f || std_b == 0.f) return fail(VL2_E_BADARG, "vl2_patchify_u8: null pointer, empty shape or zero std");
     if (G * P > H || G * P > W || Kp % 8 || Kp < 3 * P * P) return fail(VL2_E_SHAPE, "vl2_patchify_u8: bad geometry");
-    U8Norm n{rescale, {mean3[0], mean3[1], mean3[2]}, {1.0f / std3[0], 1.0f / std3[1], 1.0f / std3[2]}};   // host pointers
+    U8Norm n{rescale, {mean_r, mean_g, mean_b}, {1.0f / std_r, 1.0f / std_g, 1.0f / std_b}};
     hipLaunchKernelGGL(patchify_u8_kernel, dim3(G, T), dim3(256), 0, ST(stream), (const unsigned char*)frames_thwc, (bf16_t*)out, H, W, P, G, Kp, n);
     return launched("vl2_patchify_u8");
 }
@@ -411,13 +441,15 @@ extern "C" int32_t vl2_fill_cls(void* x, const void* cls_pos, int32_t T, int32_t
 extern "C" int32_t vl2_attn_fwd(const void* q, const void* k, const void* v, void* o, int64_t q_bs, int64_t q_hs, int32_t q_rs,
                                 int64_t k_bs, int64_t k_hs, int32_t k_rs, int64_t v_bs, int64_t v_hs, int32_t v_rs,
                                 int64_t o_bs, int64_t o_hs, int32_t o_rs, int32_t B, int32_t H, int32_t nq, int32_t nk,
-                                int32_t group, float scale, int32_t causal, int32_t causal_off, int32_t D, void* stream) {
+                                int32_t group, float scale, int32_t causal, int32_t causal_off, int32_t D, int32_t variant,
+                                void* stream) {
     if (!q || !k || !v || !o || B <= 0 || H <= 0 || nq <= 0 || nk <= 0 || group <= 0)
         return fail(VL2_E_BADARG, "vl2_attn_fwd: null pointer or empty shape");
     if ((q_rs | k_rs | v_rs | o_rs) % 8 || (q_bs | q_hs | k_bs | k_hs | v_bs | v_hs | o_bs | o_hs) % 4 || !ALIGNED16(q) ||
         !ALIGNED16(k) || !ALIGNED16(v) || ((uintptr_t)o & 7))
         return fail(VL2_E_SHAPE, "vl2_attn_fwd: strides must keep 16-byte row alignment");
     if (causal && causal_off < 0) return fail(VL2_E_SHAPE, "vl2_attn_fwd: causal_off must be >= 0");
+    if (variant < 0 || variant > 3) return fail(VL2_E_BADARG, "vl2_attn_fwd: unknown variant %d", variant);
     // K / V tiles are fetched through raw buffer resources whose byte offsets and NUM_RECORDS are 32-bit
     if (((int64_t)(nk - 1) * k_rs + D) * 2 >= (int64_t)1 << 31 || ((int64_t)(nk - 1) * v_rs + D) * 2 >= (int64_t)1 << 31)
         return fail(VL2_E_SHAPE, "vl2_attn_fwd: one head's K or V rows span >= 2 GiB (nk %d, row strides %d / %d elements)", nk, k_rs, v_rs);
@@ -426,6 +458,14 @@ extern "C" int32_t vl2_attn_fwd(const void* q, const void* k, const void* v, voi
     dim3 g((nq + 127) / 128, H, B), b(256);
     if (causal) g = dim3(((nq + 127) / 128) * H * B, 1, 1);
     hipStream_t s = ST(stream);
+    if (variant == 3) {                                   // second structure (k_attn2.h): LDS-DMA ring + transpose reads
+        if (D == 64 && !causal) hipLaunchKernelGGL((attn2_fwd_kernel<64, false>), g, b, 0, s, a);
+        else if (D == 64 && causal) hipLaunchKernelGGL((attn2_fwd_kernel<64, true>), g, b, 0, s, a);
+        else if (D == 128 && !causal) hipLaunchKernelGGL((attn2_fwd_kernel<128, false>), g, b, 0, s, a);
+        else if (D == 128 && causal) hipLaunchKernelGGL((attn2_fwd_kernel<128, true>), g, b, 0, s, a);
+        else return fail(VL2_E_SHAPE, "vl2_attn_fwd: variant 3 is built for head_dim 64 and 128 (got %d)", D);
+        return launched("vl2_attn_fwd");
+    }
     if (D == 64 && !causal) hipLaunchKernelGGL((attn_fwd_kernel<64, false>), g, b, 0, s, a);
     else if (D == 64 && causal) hipLaunchKernelGGL((attn_fwd_kernel<64, true>), g, b, 0, s, a);
     else if (D == 128 && !causal) hipLaunchKernelGGL((attn_fwd_kernel<128, false>), g, b, 0, s, a);
@@ -435,7 +475,7 @@ extern "C" int32_t vl2_attn_fwd(const void* q, const void* k, const void* v, voi
         // 32 heads) 28.5 -> 27.1 us, 336 (S = 1452, 28 heads) 38.9 -> 35.8; 416 (S = 1621, 32 heads) 47.4 -> 52.2: the SIMD's
         // per-tile throughput, not the length of the dependent tile chain, is the limit once every CU has > 1.4 workgroups.
         const long per_seq = (long)((nq + 127) / 128) * H;
-        const bool two = g_attn_kv_groups == 2 || (g_attn_kv_groups == 0 && per_seq <= 352);
+        const bool two = variant == 2 || (variant == 0 && per_seq <= 352);
         if (two) hipLaunchKernelGGL((attn_fwd_kernel<128, true, 2>), g, dim3(512), 0, s, a);
         else hipLaunchKernelGGL((attn_fwd_kernel<128, true>), g, b, 0, s, a);
     }
@@ -501,12 +541,8 @@ extern "C" int32_t vl2_rope_kv(const void* qkv, void* q_out, void* kcache, void*
 
 template <bool SW, bool F32>
 static void launch_gemv(const GemvArgs& a, int n_out, hipStream_t s) {
-    if (g_gemv_rpw == 2)
-        hipLaunchKernelGGL((gemv_bf16_kernel<SW, F32, 2>), dim3((n_out + 7) / 8), dim3(256), (size_t)a.K * 2, s, a);
-    else if (g_gemv_rpw == 4)
-        hipLaunchKernelGGL((gemv_bf16_kernel<SW, F32, 4>), dim3((n_out + 15) / 16), dim3(256), (size_t)a.K * 2, s, a);
-    else
-        hipLaunchKernelGGL((gemv_bf16_kernel<SW, F32, 1>), dim3((n_out + 3) / 4), dim3(256), (size_t)a.K * 2, s, a);
+    // one output row per wave: measured on MI355X 3.09 / 3.30 / 3.97 ms per 7B decode token at 1 / 2 / 4 rows per wave
+    hipLaunchKernelGGL((gemv_bf16_kernel<SW, F32, 1>), dim3((n_out + 3) / 4), dim3(256), (size_t)a.K * 2, s, a);
 }
 extern "C" int32_t vl2_gemv_bf16(const void* W, const void* x, const float* norm_w, const void* res, const float* bias, void* y,
                                  int32_t N, int32_t K, int32_t ldw, float eps, int32_t flags, void* stream) {
@@ -522,12 +558,11 @@ extern "C" int32_t vl2_gemv_bf16(const void* W, const void* x, const float* norm
 }
 template <bool SW, bool F32>
 static void launch_gemv_mr(const GemvArgs& a, int mb, int n_out, hipStream_t s) {
-    const int rpw = g_gemv_mr_rpw;                    // output rows per wave (amortises staging MB rows of x)
+    // two output rows per wave amortise staging the MB rows of x: measured at B = 4, 5.56 / 5.04 / 5.56 ms per step at 1 / 2 / 4
+    constexpr int rpw = 2;
     const dim3 g((n_out + 4 * rpw - 1) / (4 * rpw)), b(256);
     const size_t lds = (size_t)mb * a.K * 2;
-#define VL2_MR(MBV) do { if (rpw == 1) hipLaunchKernelGGL((gemv_mr_bf16_kernel<SW, F32, MBV, 1>), g, b, lds, s, a); \
-                         else if (rpw == 2) hipLaunchKernelGGL((gemv_mr_bf16_kernel<SW, F32, MBV, 2>), g, b, lds, s, a); \
-                         else hipLaunchKernelGGL((gemv_mr_bf16_kernel<SW, F32, MBV, 4>), g, b, lds, s, a); } while (0)
+#define VL2_MR(MBV) hipLaunchKernelGGL((gemv_mr_bf16_kernel<SW, F32, MBV, 2>), g, b, lds, s, a)
     if (mb == 2) VL2_MR(2); else if (mb == 3) VL2_MR(3); else VL2_MR(4);
 #undef VL2_MR
 }

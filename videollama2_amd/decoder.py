@@ -69,6 +69,16 @@ class HipMistralDecoder(nn.Module):
                 dist.all_reduce(t, group=self.tp_group)
         return t
 
+    def _row_parallel(self, a, w, x, rs):
+        """x + a @ w.T (o_proj / down_proj with the residual fused) and the row statistics of the result in `rs` for the next
+        norm-carrying GEMM.  Single rank: the GEMM's epilogue emits them.  Tensor parallel: the GEMM output is a partial sum, so
+        the statistics are taken after the all-reduce (one extra read of x)."""
+        if self.tp > 1:
+            x = self._reduce(ops.gemm(a, w, res=x if self.tp_rank == 0 else None))
+            ops.row_stats(x, out=rs)
+            return x
+        return ops.gemm(a, w, res=x, stats_out=rs)
+
     # ------------------------------------------------------------------ prefill (M = S tokens, MFMA GEMMs)
     @torch.no_grad()
     def prefill(self, x, return_all_logits=False, cache=None, logits_out=None):
@@ -84,16 +94,15 @@ class HipMistralDecoder(nn.Module):
         q = torch.empty((S, nh * hd), dtype=torch.bfloat16, device=self._dev)
         o = torch.empty((S, nh * hd), dtype=torch.bfloat16, device=self._dev)
         smax = self.max_seq_len
+        rs = ops.row_stats(x)          # RMSNorm rides in the q/k/v and gate/up GEMMs (weights.fold_norm): this seeds the statistics
         for li, lw in enumerate(self.w["layers"]):
-            h = ops.rmsnorm(x, lw["ln1_w"], self.eps)
-            qkv = ops.gemm(h, lw["wqkv"], bias=lw["bqkv"])              # bqkv: Qwen2 only (None for Mistral)
+            qkv = ops.gemm(x, lw["wqkv"], bias=lw["bqkv"], norm=(ops.NORM_RMS, rs, self.eps, None))   # bqkv: Qwen2 only
             ops.rope_kv(qkv, q, kcache[li], vcache[li], self.cos_t, self.sin_t, nh, nkv, 0)
             ops.attn_fwd(q, kcache[li], vcache[li], o, (0, hd, nh * hd), (0, smax * hd, hd), (0, smax * hd, hd),
                          (0, hd, nh * hd), 1, nh, S, S, nh // nkv, hd ** -0.5, True, 0, hd)
-            x = self._reduce(ops.gemm(o, lw["wo"], res=x if self.tp_rank == 0 else None))
-            h = ops.rmsnorm(x, lw["ln2_w"], self.eps)
-            a = ops.gemm(h, lw["wgu"], swiglu=True)
-            x = self._reduce(ops.gemm(a, lw["wd"], res=x if self.tp_rank == 0 else None))
+            x = self._row_parallel(o, lw["wo"], x, rs)
+            a = ops.gemm(x, lw["wgu"], swiglu=True, norm=(ops.NORM_RMS, rs, self.eps, None))
+            x = self._row_parallel(a, lw["wd"], x, rs)
         self.pos = S
         self.last_hidden = x
         if return_all_logits:
@@ -112,12 +121,12 @@ class HipMistralDecoder(nn.Module):
         ops.embed_rows(self.tok, self.w["embed"], b["x0"])
         x = b["x0"][0]
         for li, lw in enumerate(self.w["layers"]):
-            ops.gemv(lw["wqkv"], x, norm_w=lw["ln1_w"], eps=self.eps, out=b["qkv"], bias=lw["bqkv"])
+            ops.gemv(lw["wqkv"], x, norm_w=self.w["ones"], eps=self.eps, out=b["qkv"], bias=lw["bqkv"])   # ln weight folded into wqkv
             ops.attn_decode(b["qkv"], self.kcache[li], self.vcache[li], self.cos_t, self.sin_t, self.partial, b["o"], nh, nkv,
                             self.pos, hd ** -0.5, pos_dev=pos_dev, ctx_cap=self.max_seq_len)
             r0 = self.tp_rank == 0                                              # the residual rides on rank 0's partial sum
             self._reduce(ops.gemv(lw["wo"], b["o"], res=x if r0 else None, out=b["x1"]))          # x1 = x + attn
-            ops.gemv(lw["wgu"], b["x1"], norm_w=lw["ln2_w"], eps=self.eps, swiglu=True, out=b["a"])
+            ops.gemv(lw["wgu"], b["x1"], norm_w=self.w["ones"], eps=self.eps, swiglu=True, out=b["a"])
             self._reduce(ops.gemv(lw["wd"], b["a"], res=b["x1"] if r0 else None, out=x))          # x = x1 + mlp (x's old value is dead)
         ops.gemv(self.w["lm_head"], x, norm_w=self.w["norm_w"], eps=self.eps, out_f32=True, out=self.logits)
 
@@ -178,6 +187,9 @@ class HipMistralDecoder(nn.Module):
         if stopping_criteria is not None:
             crit = stopping_criteria if isinstance(stopping_criteria, (list, tuple)) else [stopping_criteria]
         toks, all_logits = [], []
+        # a prompt that fills the cache leaves no position to decode into: the capture warm-up would run a step at row
+        # max_seq_len (the kernels now ignore such a step, but there is nothing to replay either) -> plain last-step path
+        use_graph = use_graph and self.tp == 1 and self._dev.type == "cuda" and self.pos < self.max_seq_len
         if use_graph:
             g = self.capture_graph()
             self.state.copy_(torch.tensor([self.pos - 1, 0], dtype=torch.int32))
@@ -224,19 +236,17 @@ class HipMistralDecoder(nn.Module):
         nh, nkv, hd, smax = self.nh, self.nkv, self.hd, self.max_seq_len
         q = torch.empty((offs[-1], nh * hd), dtype=torch.bfloat16, device=self._dev)
         o = torch.empty((offs[-1], nh * hd), dtype=torch.bfloat16, device=self._dev)
-        r0 = self.tp_rank == 0
+        rs = ops.row_stats(X)
         for li, lw in enumerate(self.w["layers"]):
-            h = ops.rmsnorm(X, lw["ln1_w"], self.eps)
-            qkv = ops.gemm(h, lw["wqkv"], bias=lw["bqkv"])
+            qkv = ops.gemm(X, lw["wqkv"], bias=lw["bqkv"], norm=(ops.NORM_RMS, rs, self.eps, None))
             for b, (kc, vc) in enumerate(caches):
                 s0, s1, S = offs[b], offs[b + 1], lens[b]
                 ops.rope_kv(qkv[s0:s1], q[s0:s1], kc[li], vc[li], self.cos_t, self.sin_t, nh, nkv, 0)
                 ops.attn_fwd(q[s0:s1], kc[li], vc[li], o[s0:s1], (0, hd, nh * hd), (0, smax * hd, hd), (0, smax * hd, hd),
                              (0, hd, nh * hd), 1, nh, S, S, nh // nkv, hd ** -0.5, True, 0, hd)
-            X = self._reduce(ops.gemm(o, lw["wo"], res=X if r0 else None))
-            h = ops.rmsnorm(X, lw["ln2_w"], self.eps)
-            a = ops.gemm(h, lw["wgu"], swiglu=True)
-            X = self._reduce(ops.gemm(a, lw["wd"], res=X if r0 else None))
+            X = self._row_parallel(o, lw["wo"], X, rs)
+            a = ops.gemm(X, lw["wgu"], swiglu=True, norm=(ops.NORM_RMS, rs, self.eps, None))
+            X = self._row_parallel(a, lw["wd"], X, rs)
         for b in range(len(xs)):
             ops.gemv(self.w["lm_head"], X[offs[b + 1] - 1], norm_w=self.w["norm_w"], eps=self.eps, out_f32=True, out=logits_out[b])
         return lens
@@ -293,12 +303,12 @@ class HipMistralDecoder(nn.Module):
         # up to 64 rows: the skinny-M kernel streams the weights GEMV-style into MFMA; beyond that the tiled GEMMs
         mm = ops.gemm_skinny if nb <= 64 else ops.gemm
         for li, lw in enumerate(self.w["layers"]):
-            h = ops.rmsnorm(x, lw["ln1_w"], self.eps)
+            h = ops.rmsnorm(x, self.w["ones"], self.eps)                  # the norm weights are folded into wqkv / wgu
             mm(h, lw["wqkv"], bias=lw["bqkv"], out=qkv)
             ops.attn_decode_batched(qkv, bb["k"][li][:nb], bb["v"][li][:nb], self.cos_t, self.sin_t, bb["partial"], o, nh, nkv,
                                     bb["pos"][:nb], self.max_seq_len, hd ** -0.5)
             self._reduce(mm(o, lw["wo"], res=x if r0 else None, out=x1))
-            h = ops.rmsnorm(x1, lw["ln2_w"], self.eps)
+            h = ops.rmsnorm(x1, self.w["ones"], self.eps)
             mm(h, lw["wgu"], swiglu=True, out=a)
             self._reduce(mm(a, lw["wd"], res=x1 if r0 else None, out=x))
         h = ops.rmsnorm(x, self.w["norm_w"], self.eps)
@@ -310,11 +320,11 @@ class HipMistralDecoder(nn.Module):
         x, x1, qkv, o, a = bb["x0"][:nb], bb["x1"][:nb], bb["qkv"][:nb], bb["o"][:nb], bb["a"][:nb]
         r0 = self.tp_rank == 0
         for li, lw in enumerate(self.w["layers"]):
-            ops.gemv_batched(lw["wqkv"], x, norm_w=lw["ln1_w"], eps=self.eps, out=qkv, bias=lw["bqkv"])
+            ops.gemv_batched(lw["wqkv"], x, norm_w=self.w["ones"], eps=self.eps, out=qkv, bias=lw["bqkv"])
             ops.attn_decode_batched(qkv, bb["k"][li][:nb], bb["v"][li][:nb], self.cos_t, self.sin_t, bb["partial"], o, nh, nkv,
                                     bb["pos"][:nb], self.max_seq_len, hd ** -0.5)
             self._reduce(ops.gemv_batched(lw["wo"], o, res=x if r0 else None, out=x1))
-            ops.gemv_batched(lw["wgu"], x1, norm_w=lw["ln2_w"], eps=self.eps, swiglu=True, out=a)
+            ops.gemv_batched(lw["wgu"], x1, norm_w=self.w["ones"], eps=self.eps, swiglu=True, out=a)
             self._reduce(ops.gemv_batched(lw["wd"], a, res=x1 if r0 else None, out=x))
         ops.gemv_batched(self.w["lm_head"], x, norm_w=self.w["norm_w"], eps=self.eps, out_f32=True, out=bb["logits"][:nb])
         bb["pos"][:nb] += 1
@@ -388,6 +398,7 @@ class HipMistralDecoder(nn.Module):
         bb["pos"][:nb].copy_(torch.tensor(lens, dtype=torch.int32))
         max_new_tokens = min(max_new_tokens, self.max_seq_len - max(lens) + 1)
         outs, done, all_logits = [[] for _ in range(nb)], [False] * nb, []
+        use_graph = use_graph and max(lens) < self.max_seq_len          # a full cache leaves nothing to replay (see generate)
         graph = self.capture_batch_graph(nb) if use_graph else None
         if graph is not None:                                                # capture clobbered nothing: state was restored
             bb["pos"][:nb].copy_(torch.tensor(lens, dtype=torch.int32))

@@ -69,7 +69,8 @@ class FrameSharder:
         maxc = max(p[1] for p in parts)
         local = tower(frames[s:s + c]) if c > 0 else None
         n, h = (local.shape[1], local.shape[2]) if local is not None else (tower.num_patches, tower.hidden_size)
-        dtype = local.dtype if local is not None else frames.dtype
+        # a rank without frames must send the dtype the other ranks' towers produce (uint8 ingest -> bf16 features)
+        dtype = local.dtype if local is not None else (torch.bfloat16 if frames.dtype == torch.uint8 else frames.dtype)
         dev = local.device if local is not None else tower.device
         send = torch.zeros((maxc, n, h), dtype=dtype, device=dev)          # equal-sized shards (ragged T padded)
         if c > 0:

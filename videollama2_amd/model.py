@@ -80,6 +80,9 @@ class VideoLLaMA2Hip(nn.Module):
         sentinels = torch.tensor(list(MODAL_INDEX_MAP.values()), device=self._dev)
         is_mm = (ids[:, None] == sentinels[None, :]).any(-1)
         mm_pos = torch.nonzero(is_mm).flatten().tolist()
+        if len(mm_pos) != len(mm_features):
+            raise ValueError(f"prompt holds {len(mm_pos)} modal tag(s) but {len(mm_features)} media input(s) were given")
+        self._check_ids(ids[~is_mm])
         D = self.decoder.D
         n_vis = sum(mm_features[k].shape[0] for k in range(len(mm_pos)))
         S = ids.numel() - len(mm_pos) + n_vis
@@ -100,6 +103,14 @@ class VideoLLaMA2Hip(nn.Module):
             attention_mask = torch.cat((pad, attention_mask), dim=1)
         return None, attention_mask, past_key_values, emb.unsqueeze(0), labels
 
+    def _check_ids(self, ids):
+        """embed_rows_kernel indexes the table with the ids unchecked: an id outside [0, vocab) (a leftover modal sentinel, a
+        tokenizer / checkpoint mismatch) must fail here the way torch's embedding lookup does in the reference."""
+        if ids.numel():
+            lo, hi = int(ids.min()), int(ids.max())
+            if lo < 0 or hi >= self.decoder.V:
+                raise IndexError(f"token id out of range: [{lo}, {hi}] vs vocab_size {self.decoder.V}")
+
     # ---------------------------------------------------------------------------------- videollama2_mistral.py:110-144
     @torch.no_grad()
     def generate(self, inputs=None, images=None, **kwargs):
@@ -114,6 +125,7 @@ class VideoLLaMA2Hip(nn.Module):
                 inputs, attention_mask, None, None, images)
             inputs_embeds = inputs_embeds[0]
         else:
+            self._check_ids(inputs[0])
             ids32 = inputs[0].to(self._dev).to(torch.int32).contiguous()
             inputs_embeds = torch.empty((ids32.numel(), self.decoder.D), dtype=torch.bfloat16, device=self._dev)
             ops.embed_rows(ids32, self.decoder.w["embed"], inputs_embeds)
@@ -122,7 +134,10 @@ class VideoLLaMA2Hip(nn.Module):
         return self.decoder.generate(inputs_embeds, max_new_tokens=kwargs.get("max_new_tokens", 2048),
                                      eos_token_id=kwargs.get("eos_token_id", None),
                                      stopping_criteria=kwargs.get("stopping_criteria", None),
-                                     return_logits=kwargs.get("return_logits", False), streamer=kwargs.get("streamer", None))
+                                     return_logits=kwargs.get("return_logits", False), streamer=kwargs.get("streamer", None),
+                                     # one captured hipGraph per token by default (what bench.py measures); `use_graph=False`
+                                     # keeps the eager launch loop
+                                     use_graph=kwargs.get("use_graph", self._dev.type == "cuda" and self.decoder.tp == 1))
 
     @torch.no_grad()
     def generate_batch(self, requests, **kwargs):
@@ -154,6 +169,7 @@ class VideoLLaMA2Hip(nn.Module):
                                                                             mm_features=feats.get(i))
                 embeds.append(emb[0])
             else:
+                self._check_ids(ids[0])
                 ids32 = ids[0].to(self._dev).to(torch.int32).contiguous()
                 emb = torch.empty((ids32.numel(), self.decoder.D), dtype=torch.bfloat16, device=self._dev)
                 ops.embed_rows(ids32, self.decoder.w["embed"], emb)

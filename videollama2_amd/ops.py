@@ -1,6 +1,8 @@
 """Operator-level Python wrappers over the C ABI (include/vl2hip.h).  PyTorch-ROCm tensors are used ONLY as device
 storage: every wrapper passes raw `data_ptr()`s plus the current HIP stream to libvl2hip.so and returns torch tensors
 it allocated.  No torch math happens here and there is no fallback path."""
+import ctypes
+
 import torch
 
 from . import _lib
@@ -30,54 +32,66 @@ def _chk(t, dtype, name):
         raise ValueError(f"{name} must be contiguous in its last dim")
 
 
+GEMM_SPLITK = 4
+NORM_NONE, NORM_RMS, NORM_LN = 0, 1, 2
+
+# Launch controls of the GEMM family.  They are HOST-side settings of this binding layer, handed to libvl2hip.so with every
+# call (vl2_gemm_desc.variant / flags / ws): the library itself holds no mutable state.
 _WORKSPACE = {}
+_CTL = dict(variant=0, splitk=False, attn_variant=0)
 
 
 def attach_workspace(device):
-    """Allocate (once per device, zero-filled) and attach the GEMM workspace (split-K partial tiles + tile counters, stream-K);
-    the library itself never allocates."""
-    key = str(device)
+    """Allocate (once per device, zero-filled) the GEMM workspace (split-K partial tiles + tile counters, stream-K, the skinny-M
+    GEMM's fp32 partial sums); the library itself never allocates.  Calls on one device share it, so they must be ordered on
+    one stream (every path in this package runs its GEMMs on the current stream)."""
+    key = str(torch.device(device))
     if key not in _WORKSPACE:
         n = int(_lib.load().vl2_workspace_bytes())
         _WORKSPACE[key] = torch.zeros((n + 15) // 16 * 16, dtype=torch.uint8, device=device)
-    ws = _WORKSPACE[key]
-    _lib.call("vl2_set_workspace", _p(ws), ws.numel())
-    return ws
+    return _WORKSPACE[key]
+
+
+def _ws(device):
+    return _WORKSPACE.get(str(torch.device(device)))
 
 
 def set_splitk(on):
-    """Split-K for small-grid GEMMs (include/vl2hip.h VL2_TUNE_SPLITK; needs `attach_workspace`).  Off by default: it
-    trades the "same rows -> same bits whatever M" property for latency on small-M shapes (measured on MI355X:
-    1154x1024x4096 45.9 -> 39.7 us, 169x4096x4096 40.8 -> 27.9 us, 338x4096x32768 436 -> 160 us).  Never enable it while
-    GEMMs run concurrently on several streams (they would share the one workspace)."""
-    _lib.call("vl2_set_tuning", 3, 1 if on else 0)
+    """Split-K for small-grid GEMMs (VL2_GEMM_SPLITK; needs `attach_workspace`).  Off by default: it trades the "same rows ->
+    same bits whatever M" property for latency on small-M shapes (measured on MI355X: 1154x1024x4096 45.9 -> 39.7 us,
+    169x4096x4096 40.8 -> 27.9 us, 338x4096x32768 436 -> 160 us).  Never enable it while GEMMs run concurrently on several
+    streams (they would share the one workspace)."""
+    _CTL["splitk"] = bool(on)
 
 
 def set_attn_kv_groups(n):
-    """Causal D=128 attention (include/vl2hip.h VL2_TUNE_ATTN_KV_GROUPS): 0 = auto, 1 = one group of 4 waves per workgroup,
-    2 = two groups that split the KV tiles and merge through LDS."""
-    _lib.call("vl2_set_tuning", 5, int(n))
+    """Causal D=128 attention (vl2_attn_fwd `variant`): 0 = auto, 1 = one group of 4 waves per workgroup, 2 = two groups that
+    split the KV tiles and merge through LDS."""
+    _CTL["attn_variant"] = int(n)
 
 
 def set_gemm_variant(v):
     """0 auto (per-shape choice), 1 128x128x64, 2 stream-K, 4 128x256x64 ping-pong, 8 256x256x32 ping-pong, 32 64x64 small-M,
     256 128x128 8-wave deep-ring one-round kernel (include/vl2hip.h)."""
-    _lib.call("vl2_set_tuning", 1, int(v))
+    _CTL["variant"] = int(v)
 
 
 def gemm(a, w, bias=None, res=None, act=ACT_NONE, swiglu=False, out_f32=False, out=None, M=None,
-         gather=None, out_map=None, res_map=None, flop_k=None):
+         gather=None, out_map=None, res_map=None, flop_k=None, stats_out=None, norm=None):
     """C = epilogue(a @ w.T).  a [M,K] bf16 (or row pool when `gather`), w [N,K] bf16, bias fp32 [N], res bf16 rows.
-    gather = (a_idx int32 [nseg, M], zero_row bf16 [>=seg_k], seg_k).  out_map = (grp, grp_pad, row_off),
-    res_map = (row_mod, row_off) -- see include/vl2hip.h."""
+    gather = (a_idx int32 [nseg, M], zero_row (unused), seg_k).  out_map = (grp, grp_pad, row_off),
+    res_map = (row_mod, row_off) -- see include/vl2hip.h.
+    stats_out: fp32 [M, N/64, 2] buffer the epilogue fills with (sum, sum of squares) per row and 64-column block of the
+    stored output.  norm = (kind, stats_in, eps, w_colsum): Norm(a) @ w.T computed on the raw rows of `a` from the statistics
+    the GEMM that wrote `a` emitted (NORM_RMS / NORM_LN; w must carry the norm weight folded in, bias the folded shift)."""
     _chk(a, BF16, "a"); _chk(w, BF16, "w"); _chk(bias, torch.float32, "bias"); _chk(res, BF16, "res")
     N = w.shape[0]
     if gather is not None:
-        a_idx, zero_row, seg_k = gather
+        a_idx, _zero_row, seg_k = gather
         K = seg_k * a_idx.shape[0]
         M = a_idx.shape[1] if M is None else M
     else:
-        a_idx = zero_row = None
+        a_idx = None
         seg_k = 0
         K = w.shape[1]
         M = a.shape[0] if M is None else M
@@ -88,16 +102,35 @@ def gemm(a, w, bias=None, res=None, act=ACT_NONE, swiglu=False, out_f32=False, o
         out = torch.empty((M, ncol), dtype=torch.float32 if out_f32 else BF16, device=a.device)
     grp, grp_pad, row_off = out_map or (0, 0, 0)
     rmod, roff = res_map or (0, 0)
-    flags = (GEMM_SWIGLU if swiglu else 0) | (GEMM_OUT_F32 if out_f32 else 0)
+    ws = _ws(a.device)
+    flags = (GEMM_SWIGLU if swiglu else 0) | (GEMM_OUT_F32 if out_f32 else 0) | (GEMM_SPLITK if (_CTL["splitk"] and ws is not None) else 0)
+    kind, stats_in, eps, colsum = norm if norm is not None else (NORM_NONE, None, 0.0, None)
+    if stats_out is not None and tuple(stats_out.shape) != (M, N // 64, 2):
+        raise ValueError(f"gemm: stats_out must be [{M}, {N // 64}, 2], got {tuple(stats_out.shape)}")
+    if stats_in is not None and (stats_in.shape[0] < M or tuple(stats_in.shape[1:]) != (K // 64, 2)):
+        raise ValueError(f"gemm: stats_in must be [>={M}, {K // 64}, 2], got {tuple(stats_in.shape)}")
+    _chk(stats_out, torch.float32, "stats_out"); _chk(stats_in, torch.float32, "stats_in"); _chk(colsum, torch.float32, "w_colsum")
+    d = _lib.GemmDesc(ctypes.sizeof(_lib.GemmDesc), M, N, K, _p(a), a.stride(0), _p(w), w.stride(0), _p(out), out.stride(0),
+                      _p(bias), _p(res), res.stride(0) if res is not None else 0, act, flags, _p(a_idx), seg_k,
+                      grp, grp_pad, row_off, rmod, roff, _p(stats_out), _p(stats_in), kind, float(eps), _p(colsum),
+                      _p(ws), ws.numel() if ws is not None else 0, _CTL["variant"])
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _lib.call("vl2_gemm_bf16", _p(a), _p(w), _p(out), _p(bias), _p(res), M, N, K, a.stride(0), w.stride(0), out.stride(0),
-              res.stride(0) if res is not None else 0, act, flags, _p(a_idx), _p(zero_row), seg_k, grp, grp_pad, row_off,
-              rmod, roff, _stream())
+    _lib.call("vl2_gemm", ctypes.byref(d), _stream())
     if PROFILE is not None:
         e1.record()
         PROFILE.append(("gemm", 2.0 * M * N * (flop_k or K), e0, e1, (M, N, K)))
+    return out
+
+
+def row_stats(x, out=None):
+    """(sum, sum of squares) per row and 64-column block of x [rows, C] bf16 -> fp32 [rows, C/64, 2]: seeds a norm-carrying
+    GEMM chain for a tensor no GEMM wrote (same layout and summation order as `gemm(..., stats_out=)`)."""
+    _chk(x, BF16, "x")
+    rows, C = x.shape
+    out = torch.empty((rows, C // 64, 2), dtype=torch.float32, device=x.device) if out is None else out
+    _lib.call("vl2_row_stats", _p(x), _p(out), rows, C, x.stride(0), _stream())
     return out
 
 
@@ -135,7 +168,6 @@ def patchify(frames, patch, kp):
 
 def patchify_u8(frames_thwc, patch, kp, rescale, mean, std):
     """frames [T,H,W,3] uint8 (device) -> [T*G*G, kp] bf16 im2col rows of (x*rescale - mean) / std."""
-    import ctypes
     _chk(frames_thwc, torch.uint8, "frames")
     frames_thwc = frames_thwc.contiguous()
     T, H, W, C = frames_thwc.shape
@@ -143,10 +175,9 @@ def patchify_u8(frames_thwc, patch, kp, rescale, mean, std):
         raise ValueError(f"expected uint8 frames [T,H,W,3], got {tuple(frames_thwc.shape)}")
     G = H // patch
     out = torch.empty((T * G * G, kp), dtype=BF16, device=frames_thwc.device)
-    m3 = (ctypes.c_float * 3)(*[float(v) for v in mean])
-    s3 = (ctypes.c_float * 3)(*[float(v) for v in std])
-    _lib.call("vl2_patchify_u8", _p(frames_thwc), _p(out), T, H, W, patch, G, kp, float(rescale), ctypes.addressof(m3),
-              ctypes.addressof(s3), _stream())
+    m, sd = [float(v) for v in mean], [float(v) for v in std]
+    _lib.call("vl2_patchify_u8", _p(frames_thwc), _p(out), T, H, W, patch, G, kp, float(rescale), m[0], m[1], m[2], sd[0], sd[1], sd[2],
+              _stream())
     return out
 
 
@@ -158,7 +189,7 @@ def attn_fwd(q, k, v, o, q_str, k_str, v_str, o_str, B, H, nq, nk, group, scale,
     """Strided fused attention; *_str = (batch_stride, head_stride, row_stride) in elements; q/k/v/o may be views
     into one fused buffer (pass tensors whose data_ptr is the first element of head 0, batch 0)."""
     _lib.call("vl2_attn_fwd", _p(q), _p(k), _p(v), _p(o), *q_str, *k_str, *v_str, *o_str, B, H, nq, nk, group, float(scale),
-              int(causal), causal_off, D, _stream())
+              int(causal), causal_off, D, _CTL["attn_variant"], _stream())
     return o
 
 
@@ -218,8 +249,9 @@ def gemm_skinny(a, w, bias=None, res=None, swiglu=False, out_f32=False, out=None
     if out is None:
         out = torch.empty((M, ncol), dtype=torch.float32 if out_f32 else BF16, device=a.device)
     flags = (GEMM_SWIGLU if swiglu else 0) | (GEMM_OUT_F32 if out_f32 else 0)
+    ws = attach_workspace(a.device)
     _lib.call("vl2_gemm_skinny_bf16", _p(a), _p(w), _p(out), _p(bias), _p(res), M, N, K, a.stride(0), w.stride(0), out.stride(0),
-              0 if res is None else res.stride(0), flags, _stream())
+              0 if res is None else res.stride(0), flags, _p(ws), ws.numel(), _stream())
     return out
 
 

@@ -140,16 +140,18 @@ class HipCLIPVisionTower(nn.Module):
         ops.fill_cls(x, w["cls_pos"], T, N1)
         x = ops.layernorm(x, w["pre_w"], w["pre_b"], eps)
         o = torch.empty((T * N1, D), dtype=torch.bfloat16, device=self._dev)
+        # layer_norm1 / layer_norm2 never run as kernels: every GEMM that writes the residual stream also emits its row
+        # statistics (`stats_out`), and the q/k/v and fc1 GEMMs normalise in their epilogue (weights.fold_norm, csrc/k_gemm.h)
+        rs = ops.row_stats(x)                                                      # seeds the chain (pre_layrnorm's output)
+        last = len(w["layers"]) - 1
         for li, lw in enumerate(w["layers"]):
-            h = ops.layernorm(x, lw["ln1_w"], lw["ln1_b"], eps)
-            qkv = ops.gemm(h, lw["wqkv"], bias=lw["bqkv"])                         # [T*N1, 3D] = q | k | v
+            qkv = ops.gemm(x, lw["wqkv"], bias=lw["bqkv"], norm=(ops.NORM_LN, rs, eps, lw["sqkv"]))   # [T*N1, 3D] = q | k | v
             st = (N1 * 3 * D, hd, 3 * D)
             ops.attn_fwd(qkv, qkv[:, D:], qkv[:, 2 * D:], o, st, st, st, (N1 * D, hd, D), T, nh, N1, N1, 1,
                          hd ** -0.5, False, 0, hd)
-            x = ops.gemm(o, lw["wo"], bias=lw["bo"], res=x)
-            h = ops.layernorm(x, lw["ln2_w"], lw["ln2_b"], eps)
-            h = ops.gemm(h, lw["w1"], bias=lw["b1"], act=ops.ACT_QGELU)
-            x = ops.gemm(h, lw["w2"], bias=lw["b2"], res=x, out=out if li == len(w["layers"]) - 1 else None)
+            x = ops.gemm(o, lw["wo"], bias=lw["bo"], res=x, stats_out=rs)
+            h = ops.gemm(x, lw["w1"], bias=lw["b1"], act=ops.ACT_QGELU, norm=(ops.NORM_LN, rs, eps, lw["s1"]))
+            x = ops.gemm(h, lw["w2"], bias=lw["b2"], res=x, out=out if li == last else None, stats_out=None if li == last else rs)
         return x, T, N1
 
     @torch.no_grad()
@@ -206,16 +208,16 @@ class HipSiglipVisionTower(HipCLIPVisionTower):
         x = torch.empty((T * N, D), dtype=torch.bfloat16, device=self._dev)
         ops.gemm(a, w["patch_w"], bias=w["patch_b"], res=w["pos"], out=x, res_map=(N, 0), flop_k=3 * P * P)
         o = torch.empty((T * N, Hh), dtype=torch.bfloat16, device=self._dev)
+        rs = ops.row_stats(x)                                                      # norm-carrying chain, as in the CLIP tower
+        last = len(w["layers"]) - 1
         for li, lw in enumerate(w["layers"]):
-            h = ops.layernorm(x, lw["ln1_w"], lw["ln1_b"], eps)
-            qkv = ops.gemm(h, lw["wqkv"], bias=lw["bqkv"])                         # [T*N, 3*Hh] = q | k | v, heads padded to hdp
+            qkv = ops.gemm(x, lw["wqkv"], bias=lw["bqkv"], norm=(ops.NORM_LN, rs, eps, lw["sqkv"]))   # q | k | v, heads padded to hdp
             st = (N * 3 * Hh, hdp, 3 * Hh)
             ops.attn_fwd(qkv, qkv[:, Hh:], qkv[:, 2 * Hh:], o, st, st, st, (N * Hh, hdp, Hh), T, nh, N, N, 1,
                          w["hd"] ** -0.5, False, 0, hdp)
-            x = ops.gemm(o, lw["wo"], bias=lw["bo"], res=x)
-            h = ops.layernorm(x, lw["ln2_w"], lw["ln2_b"], eps)
-            h = ops.gemm(h, lw["w1"], bias=lw["b1"], act=ops.ACT_GELU_TANH)
-            x = ops.gemm(h, lw["w2"], bias=lw["b2"], res=x, out=out if li == len(w["layers"]) - 1 else None)
+            x = ops.gemm(o, lw["wo"], bias=lw["bo"], res=x, stats_out=rs)
+            h = ops.gemm(x, lw["w1"], bias=lw["b1"], act=ops.ACT_GELU_TANH, norm=(ops.NORM_LN, rs, eps, lw["s1"]))
+            x = ops.gemm(h, lw["w2"], bias=lw["b2"], res=x, out=out if li == last else None, stats_out=None if li == last else rs)
         return x, T, N
 
     @torch.no_grad()

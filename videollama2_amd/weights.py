@@ -28,6 +28,26 @@ def _f32(t, dev):
     return _aligned(t.detach().to(dtype=BF16).to(device=dev, dtype=torch.float32).contiguous())
 
 
+def fold_norm(w, g, b=None, c=None, dev=None):
+    """The affine part of a LayerNorm / RMSNorm folded into the linear layer that follows it (csrc/k_gemm.h, "norm-carrying
+    GEMMs"): Norm(x) W^T + c = rstd * (x W'^T - mean * s) + t with
+        W' = bf16(W * g)  (per input column),   s[n] = sum_k W'[n][k]  (fp32, of the ROUNDED W': what the MFMA accumulates),
+        t  = W b + c      (fp32; LayerNorm only -- RMSNorm has no shift).
+    w [N, K], g / b [K], c [N] or None.  Returns (W' bf16 on dev, s fp32, t fp32 or None).  Parameters are taken as the bf16
+    path stores them (rounded to bf16 first), so folding a real checkpoint and folding the oracle's seeded weights agree."""
+    dev = w.device if dev is None else dev
+    wf = w.detach().to(device=dev, dtype=BF16).float()
+    wp = (wf * g.detach().to(device=dev, dtype=BF16).float()[None, :]).to(BF16).contiguous()
+    s = wp.float().sum(1).contiguous()
+    t = None
+    if b is not None:
+        t = wf @ b.detach().to(device=dev, dtype=BF16).float()
+        if c is not None:
+            t = t + c.detach().to(device=dev, dtype=BF16).float()
+        t = t.contiguous()
+    return _aligned(wp), _aligned(s), (None if t is None else _aligned(t))
+
+
 def pack_tower(sd, cfg, dev, prefix="model.vision_tower.vision_tower."):
     """CLIPVisionModel weights (HF:models/clip/modeling_clip.py).  Only the layers feeding hidden_states[select_layer]."""
     sd = normalise_keys(sd)
@@ -48,14 +68,14 @@ def pack_tower(sd, cfg, dev, prefix="model.vision_tower.vision_tower."):
     for i in range(n_run):
         p = f"{prefix}encoder.layers.{i}."
         a = p + "self_attn."
+        # layer_norm1 rides in the q/k/v GEMM, layer_norm2 in the fc1 GEMM (fold_norm): no standalone LayerNorm per layer
+        wqkv, sqkv, bqkv = fold_norm(torch.cat([sd[a + "q_proj.weight"], sd[a + "k_proj.weight"], sd[a + "v_proj.weight"]], 0),
+                                     sd[p + "layer_norm1.weight"], sd[p + "layer_norm1.bias"],
+                                     torch.cat([sd[a + "q_proj.bias"], sd[a + "k_proj.bias"], sd[a + "v_proj.bias"]], 0), dev)
+        w1, s1, b1 = fold_norm(sd[p + "mlp.fc1.weight"], sd[p + "layer_norm2.weight"], sd[p + "layer_norm2.bias"], sd[p + "mlp.fc1.bias"], dev)
         out["layers"].append(dict(
-            ln1_w=_f32(sd[p + "layer_norm1.weight"], dev), ln1_b=_f32(sd[p + "layer_norm1.bias"], dev),
-            wqkv=_bf(torch.cat([sd[a + "q_proj.weight"], sd[a + "k_proj.weight"], sd[a + "v_proj.weight"]], 0), dev),
-            bqkv=_f32(torch.cat([sd[a + "q_proj.bias"], sd[a + "k_proj.bias"], sd[a + "v_proj.bias"]], 0), dev),
-            wo=_bf(sd[a + "out_proj.weight"], dev), bo=_f32(sd[a + "out_proj.bias"], dev),
-            ln2_w=_f32(sd[p + "layer_norm2.weight"], dev), ln2_b=_f32(sd[p + "layer_norm2.bias"], dev),
-            w1=_bf(sd[p + "mlp.fc1.weight"], dev), b1=_f32(sd[p + "mlp.fc1.bias"], dev),
-            w2=_bf(sd[p + "mlp.fc2.weight"], dev), b2=_f32(sd[p + "mlp.fc2.bias"], dev)))
+            wqkv=wqkv, sqkv=sqkv, bqkv=bqkv, wo=_bf(sd[a + "out_proj.weight"], dev), bo=_f32(sd[a + "out_proj.bias"], dev),
+            w1=w1, s1=s1, b1=b1, w2=_bf(sd[p + "mlp.fc2.weight"], dev), b2=_f32(sd[p + "mlp.fc2.bias"], dev)))
     return out
 
 
@@ -101,13 +121,13 @@ def pack_siglip_tower(sd, cfg, dev, prefix="model.vision_tower.vision_tower."):
         w1 = torch.zeros((Ip, D), dtype=BF16); w1[:I] = sd[p + "mlp.fc1.weight"].detach().to(BF16)
         b1 = torch.zeros((Ip,), dtype=BF16); b1[:I] = sd[p + "mlp.fc1.bias"].detach().to(BF16)
         w2 = torch.zeros((D, Ip), dtype=BF16); w2[:, :I] = sd[p + "mlp.fc2.weight"].detach().to(BF16)
+        # layer norms folded into the q/k/v and fc1 GEMMs (fold_norm); the zero padding rows stay zero rows with zero shift
+        wqkv, sqkv, bqkv = fold_norm(torch.cat([pad_rows(sd[a + n + "_proj.weight"]) for n in "qkv"], 0), sd[p + "layer_norm1.weight"],
+                                     sd[p + "layer_norm1.bias"], torch.cat([pad_rows(sd[a + n + "_proj.bias"]) for n in "qkv"], 0), dev)
+        w1f, s1, b1f = fold_norm(w1, sd[p + "layer_norm2.weight"], sd[p + "layer_norm2.bias"], b1, dev)
         out["layers"].append(dict(
-            ln1_w=_f32(sd[p + "layer_norm1.weight"], dev), ln1_b=_f32(sd[p + "layer_norm1.bias"], dev),
-            wqkv=_bf(torch.cat([pad_rows(sd[a + n + "_proj.weight"]) for n in "qkv"], 0), dev),
-            bqkv=_f32(torch.cat([pad_rows(sd[a + n + "_proj.bias"]) for n in "qkv"], 0), dev),
-            wo=_bf(wo.reshape(D, H * hdp), dev), bo=_f32(sd[a + "out_proj.bias"], dev),
-            ln2_w=_f32(sd[p + "layer_norm2.weight"], dev), ln2_b=_f32(sd[p + "layer_norm2.bias"], dev),
-            w1=_bf(w1, dev), b1=_f32(b1, dev), w2=_bf(w2, dev), b2=_f32(sd[p + "mlp.fc2.bias"], dev)))
+            wqkv=wqkv, sqkv=sqkv, bqkv=bqkv, wo=_bf(wo.reshape(D, H * hdp), dev), bo=_f32(sd[a + "out_proj.bias"], dev),
+            w1=w1f, s1=s1, b1=b1f, w2=_bf(w2, dev), b2=_f32(sd[p + "mlp.fc2.bias"], dev)))
     return out
 
 
@@ -182,20 +202,23 @@ def pack_decoder(sd, cfg, dev, n_layers=None, tp_rank=0, tp_size=1):
         return out
 
     out = dict(embed=_bf(sd["model.embed_tokens.weight"], dev), norm_w=_f32(sd["model.norm.weight"], dev),
-               lm_head=_bf(sd["lm_head.weight"], dev), layers=[])
+               lm_head=_bf(sd["lm_head.weight"], dev), layers=[],
+               ones=torch.ones((l["hidden_size"],), dtype=torch.float32, device=dev))   # unit RMSNorm weight: the real ones are folded below
     for i in range(n_layers):
         p = f"model.layers.{i}."
         a = p + "self_attn."
         bqkv = None                                    # Qwen2Attention: bias on q/k/v (HF:models/qwen2/modeling_qwen2.py)
         if (a + "q_proj.bias") in sd:
             bqkv = _f32(torch.cat([sd[a + "q_proj.bias"][q0:q1], sd[a + "k_proj.bias"][k0:k1], sd[a + "v_proj.bias"][k0:k1]], 0), dev)
-        out["layers"].append(dict(
-            ln1_w=_f32(sd[p + "input_layernorm.weight"], dev), ln2_w=_f32(sd[p + "post_attention_layernorm.weight"], dev),
-            bqkv=bqkv,
-            wqkv=_bf(torch.cat([sd[a + "q_proj.weight"][q0:q1], sd[a + "k_proj.weight"][k0:k1], sd[a + "v_proj.weight"][k0:k1]], 0), dev),
-            wo=_bf(sd[a + "o_proj.weight"][:, q0:q1], dev),
-            wgu=_bf(pack_gate_up(rows_padded(sd[p + "mlp.gate_proj.weight"]), rows_padded(sd[p + "mlp.up_proj.weight"])), dev),
-            wd=_bf(cols_padded(sd[p + "mlp.down_proj.weight"]), dev)))
+        # input_layernorm / post_attention_layernorm weights folded into the columns of q/k/v and gate/up (fold_norm): the
+        # prefill GEMMs normalise in their epilogue from the statistics the previous GEMM emitted, the decode GEMVs normalise
+        # x with a unit weight in their prologue
+        wqkv, _, _ = fold_norm(torch.cat([sd[a + "q_proj.weight"][q0:q1], sd[a + "k_proj.weight"][k0:k1], sd[a + "v_proj.weight"][k0:k1]], 0),
+                               sd[p + "input_layernorm.weight"], dev=dev)
+        wgu, _, _ = fold_norm(pack_gate_up(rows_padded(sd[p + "mlp.gate_proj.weight"]), rows_padded(sd[p + "mlp.up_proj.weight"])),
+                              sd[p + "post_attention_layernorm.weight"], dev=dev)
+        out["layers"].append(dict(bqkv=bqkv, wqkv=wqkv, wo=_bf(sd[a + "o_proj.weight"][:, q0:q1], dev), wgu=wgu,
+                                  wd=_bf(cols_padded(sd[p + "mlp.down_proj.weight"]), dev)))
     return out
 
 
