@@ -85,6 +85,7 @@ typedef struct vl2_gemm_desc {
     const float* stats_in;
     int32_t norm;  float norm_eps;
     const float* w_colsum;
+    const float* row_norm;         /* optional [M][2] (mean, rstd) from vl2_row_norm_finalize: replaces the per-tile reduction of stats_in */
     void* ws;  int64_t ws_bytes;   /* optional workspace (vl2_workspace_bytes()); NULL = no split-K / stream-K */
     int32_t variant;               /* 0 = auto */
 } vl2_gemm_desc;
@@ -93,6 +94,10 @@ int32_t vl2_gemm(const vl2_gemm_desc* d, void* stream);
  * layout / summation order of vl2_gemm's `stats_out`: seeds a norm-carrying chain whose first tensor no GEMM wrote
  * (inputs_embeds; the CLIP embeddings after pre_layrnorm) or re-derives it after a tensor-parallel all-reduce.  C % 64 == 0. */
 int32_t vl2_row_stats(const void* x, float* stats, int32_t rows, int32_t C, int32_t ldx, void* stream);
+/* stats [rows][np][2] (as vl2_gemm's stats_out / vl2_row_stats write them, np = K/64) -> row_norm [rows][2] = (mean, rstd):
+ * norm = VL2_NORM_RMS (mean 0, rstd = rsqrt(sum x^2 / K + eps)) or VL2_NORM_LN.  Pass the result as vl2_gemm_desc.row_norm so
+ * the consuming GEMM does not repeat the reduction in each of its column tiles. */
+int32_t vl2_row_norm_finalize(const float* stats, float* row_norm, int32_t rows, int32_t np, int32_t K, int32_t norm, float eps, void* stream);
 
 /* y = LayerNorm(x)*w + b [+ res] [-> SiLU]; rows x C, fp32 statistics.  HF:modeling_clip.py pre_layrnorm / layer_norm1/2;
  * timm LayerNormAct2d in channels-last form (projector.py:153-184) incl. the Bottleneck tail act3(conv3(x)+shortcut).

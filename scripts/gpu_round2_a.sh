@@ -3,7 +3,7 @@
 # a rocprofv3 kernel-trace of the same command, and the RCCL world-1 smoke.  Everything lands in gpurun_out/.
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
-O=gpurun_out/r02a
+O=gpurun_out/${1:-r02a}
 mkdir -p $O
 python -c "import torch; print(torch.cuda.get_device_name(0))" > $O/device.txt 2>&1
 nproc > $O/host_cores.txt; lscpu | head -20 >> $O/host_cores.txt

@@ -95,10 +95,10 @@ extern "C" int32_t vl2_gemm(const vl2_gemm_desc* d, void*) {
     a.seg_k = d->seg_k; a.out_grp = d->out_grp; a.out_grp_pad = d->out_grp_pad; a.out_row_off = d->out_row_off;
     a.res_row_mod = d->res_row_mod; a.res_row_off = d->res_row_off; a.tiles_m = (M + 127) / 128; a.tiles_n = N / 128;
     a.idx_ld = M; a.stats_out = d->stats_out; a.stats_out_np = N / 64; a.stats_in = d->stats_in; a.stats_in_np = K / 64;
-    a.norm = d->norm; a.norm_eps = d->norm_eps; a.w_colsum = d->w_colsum;
+    a.norm = d->norm; a.norm_eps = d->norm_eps; a.w_colsum = d->w_colsum; a.row_norm = d->row_norm;
     g_gemm_variant = (d->flags & VL2_GEMM_SPLITK) ? 16 : d->variant;     // 16 = the emulator's split-K form of the 128x128 kernel
     const bool sw = d->flags & 1, f32 = d->flags & 2, g = a.a_idx != nullptr;
-    if (d->norm && (!d->stats_in || (d->norm == 2 && !d->w_colsum))) return -1;
+    if (d->norm && ((!d->stats_in && !d->row_norm) || (d->norm == 2 && !d->w_colsum))) return -1;
     if (d->out_grp > 0 || d->res_row_mod > 0) {
         emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(256), [=] { gemm_bf16_kernel<0, false, false, false, true>(a); });
         return 0;
@@ -114,6 +114,10 @@ extern "C" int32_t vl2_gemm(const vl2_gemm_desc* d, void*) {
         case 5: run_gemm<5, false, false, false>(a); break;
         default: return -3;
     }
+    return 0;
+}
+extern "C" int32_t vl2_row_norm_finalize(const float* stats, float* row_norm, int32_t rows, int32_t np, int32_t K, int32_t norm, float eps, void*) {
+    emu::launch(dim3((rows + 255) / 256), dim3(256), [=] { row_norm_finalize_kernel(stats, row_norm, rows, np, K, norm, eps); });
     return 0;
 }
 extern "C" int32_t vl2_row_stats(const void* x, float* stats, int32_t rows, int32_t C, int32_t ldx, void*) {

@@ -194,6 +194,19 @@ inline bool wave_all(bool pred) {
     wave_sync();
     return r;
 }
+// v_mov_b32_dpp with row_mask = bank_mask = 0xf and bound_ctrl: lane l reads `src` of the lane the control selects inside its row of 16
+// lanes.  Controls built: quad_perm (0x00-0xFF), row_half_mirror (0x141), row_mirror (0x140).
+template <class T> inline T shfl_idx(T v, int src);
+inline int update_dpp(int old, int src, int ctrl) {
+    const int l = cur->lane, row = l & ~15, i = l & 15;
+    int from;
+    if (ctrl <= 0xFF) from = row + (i & ~3) + ((ctrl >> (2 * (i & 3))) & 3);
+    else if (ctrl == 0x141) from = row + (i & 8) + (7 - (i & 7));
+    else if (ctrl == 0x140) from = row + (15 - i);
+    else { fprintf(stderr, "EMU: dpp control 0x%x not modelled\n", ctrl); abort(); }
+    (void)old;
+    return shfl_idx(src, from);
+}
 template <class T> inline T shfl_idx(T v, int src) {
     static_assert(sizeof(T) <= 16, "shuffle operand");
     Wave& w = waves[cur->wave];
@@ -241,6 +254,7 @@ inline void buffer_load_lds(Rsrc r, void* lds, unsigned size, unsigned voff, uns
 #define __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, aux) emu::buffer_load_b128((r), (unsigned)(voff), (unsigned)(soff))
 #define __builtin_amdgcn_raw_ptr_buffer_load_lds(r, l, sz, voff, soff, off, aux) emu::buffer_load_lds((r), (void*)(l), sz, (unsigned)(voff), (unsigned)(soff))
 #define __builtin_amdgcn_ds_read_tr16_b64_v4i16(p) emu::ds_read_tr16((const void*)(p))
+#define __builtin_amdgcn_update_dpp(old, src, ctrl, rmask, bmask, bc) emu::update_dpp((old), (src), (ctrl))
 #define __builtin_amdgcn_readfirstlane(x) emu::shfl_idx((x), 0)
 #define __builtin_amdgcn_fdot2_f32_bf16(a, b, c, cl) emu::dot2((a), (b), (c))
 #define __builtin_amdgcn_s_setprio(x) ((void)0)

@@ -409,26 +409,70 @@ def test_emu_uint8_frame_ingest_matches_process_video(emu, golden_small, golden_
     assert rel(tower(ro), tower(fo.bfloat16()).float()) < 2e-2
 
 
-class _ToyTokenizer:
-    """Whitespace tokenizer with the attributes mm_infer / KeywordsStoppingCriteria touch (no tokenizer files on the box)."""
-    eos_token, eos_token_id, bos_token_id, unk_token, pad_token, pad_token_id = "</s>", 2, 1, "<unk>", None, 0
+@pytest.mark.parametrize("family", ["v2", "v21"])
+def test_emu_install_patches_factories_and_loader(emu, golden_small, golden_small_v21, family, tmp_path, monkeypatch):
+    """install.install(): the reference's own FACTORIES return HIP modules and its loader returns the HIP model.
+    (1) `Videollama2{Mistral,Qwen2}ForCausalLM(config)` built by the unmodified reference class after install(): its vision
+        tower / projector come from the patched build_vision_tower / build_vision_projector, host the reference's state-dict keys
+        (strict load of the seeded weights), hold no HF / timm module, and the reference's own encode_images_or_videos /
+        generate reproduce the goldens (HF decoder on top of the HIP encoder).
+    (2) `videollama2.model_init(checkpoint dir)` + `videollama2.mm_infer(...)` (videollama2/__init__.py:14-114, unmodified) on a
+        synthetic safetensors checkpoint: `load_pretrained_model` gets the HIP model from the patched loader class."""
+    from oracle import ref_harness as RH
+    if not RH.reference_available():
+        pytest.skip("reference tree only exists in the build container")
+    import json
+    from safetensors.torch import save_file
+    from videollama2_amd import api, install
+    from videollama2_amd.lazy import LazyHipSTCConnector, LazyHipVisionTower
+    from videollama2_amd.model import VideoLLaMA2Hip
+    g = golden_small if family == "v2" else golden_small_v21
+    cfg = g["cfg"]
+    ref = RH.import_reference()
+    install.install(device="cpu", max_seq_len=160)
+    try:
+        # ---- (1) factories
+        model, _ = RH.build_reference_model(cfg)
+        inner = model.get_model()
+        assert isinstance(inner.vision_tower, LazyHipVisionTower) and isinstance(inner.mm_projector, LazyHipSTCConnector)
+        assert not any(type(m).__name__.startswith(("CLIPVision", "SiglipVision", "RegStage")) for m in model.modules())
+        RH.reseed_weights(model, g["seed"])                                  # strict load: the keys are the reference's
+        feats = model.encode_images_or_videos([(g["frames"], "video")])      # reference method, HIP modules underneath
+        assert rel(feats, g["mm_features"]) < 2.5e-2
+        assert inner.vision_tower.vision_tower is None and not list(inner.mm_projector.parameters())   # packed once, hosts released
+        ids = g["input_ids"][None]
+        out = model.generate(ids, attention_mask=torch.ones_like(ids), images=[(g["frames"], "video")], do_sample=False,
+                             max_new_tokens=2, use_cache=True, pad_token_id=0, eos_token_id=None)
+        assert out[0].tolist() == g["new_tokens"][:2].tolist()
+        # ---- (2) loader: the reference's model_init / mm_infer on a synthetic checkpoint directory
+        v, l = cfg["vision"], cfg["llm"]
+        sd = {k: t.bfloat16().contiguous() for k, t in O.seeded_state_dict(cfg, g["seed"]).items()}
+        save_file(sd, str(tmp_path / "model.safetensors"))
+        hf = dict(model_type="videollama2_qwen2" if O.llm_family(cfg) == "qwen2" else "videollama2_mistral",
+                  hidden_size=l["hidden_size"], intermediate_size=l["intermediate_size"], num_hidden_layers=l["num_hidden_layers"],
+                  num_attention_heads=l["num_attention_heads"], num_key_value_heads=l["num_key_value_heads"], head_dim=l["head_dim"],
+                  vocab_size=l["vocab_size"], rms_norm_eps=l["rms_norm_eps"], rope_theta=l["rope_theta"], num_frames=4,
+                  mm_vision_tower="somewhere/" + ("siglip-synthetic" if O.vision_family(cfg) == "siglip" else "clip-synthetic"),
+                  mm_projector_type=cfg.get("projector", "stc_connector"), mm_vision_select_layer=v["select_layer"])
+        json.dump(hf, open(tmp_path / "config.json", "w"))
+        json.dump({k: v[k] for k in v if k != "select_layer"}, open(tmp_path / "vision_config.json", "w"))
+        tok = _ToyTokenizer(l["vocab_size"])
+        import videollama2.model as vm
+        monkeypatch.setattr(vm.AutoTokenizer, "from_pretrained", classmethod(lambda cls, *a, **k: tok))   # no tokenizer files on the box
+        hip, processor, tok2 = ref.model_init(str(tmp_path), device_map={"": "cpu"})
+        assert isinstance(hip, VideoLLaMA2Hip) and tok2 is tok and set(processor) == {"image", "video"}
+        frames = processor["video"](g["frames_u8"].numpy())
+        assert torch.allclose(frames, g["frames"], atol=1e-6)
+        monkeypatch.setattr(torch.Tensor, "cuda", lambda self, *a, **k: self)          # mm_infer does tensor.half().cuda(): no GPU here
+        text = ref.mm_infer(frames, "what happens in the clip ?", hip, tok, modal="video", max_new_tokens=4)
+        mine = api.mm_infer(frames, "what happens in the clip ?", hip, tok, modal="video", max_new_tokens=4)
+        assert len(text) > 0 and text == mine
+    finally:
+        install.uninstall()
+    assert ref.model.encoder.build_vision_tower.__module__ == "videollama2.model.encoder"
 
-    def __init__(self, vocab):
-        self.vocab, self.prompts = vocab, []
 
-    def _id(self, w):
-        return 3 + (sum(ord(c) * (i + 7) for i, c in enumerate(w)) % (self.vocab - 3))
-
-    def __call__(self, text, add_special_tokens=True):
-        ids = [2 if w == "</s>" else self._id(w) for w in text.split()]
-        return type("Enc", (), {"input_ids": ([1] if add_special_tokens else []) + ids})()
-
-    def apply_chat_template(self, message, tokenize=False, add_generation_prompt=True):
-        self.prompts.append(message)
-        return "".join(f"[{m['role']}] {m['content']} " for m in message) + "[assistant]"
-
-    def batch_decode(self, ids, skip_special_tokens=True):
-        return [" ".join(f"t{int(t)}" for t in row if not (skip_special_tokens and int(t) in (0, 1, 2))) for row in ids]
+from tests.util import ToyTokenizer as _ToyTokenizer, write_synthetic_checkpoint  # noqa: E402
 
 
 @pytest.mark.parametrize("family", ["v2", "v21"])
@@ -466,11 +510,67 @@ def test_emu_standalone_model_init_and_mm_infer(emu, golden_small, golden_small_
     prompt = tok.apply_chat_template(tok.prompts[-1])
     ids = api.tokenizer_multimodal_token(prompt, tok, "<video>", return_tensors="pt")[None]
     assert (ids == -201).sum().item() == 1
-    ref = model.generate(ids, attention_mask=torch.ones_like(ids), images=[(frames.bfloat16(), "video")], do_sample=False,
-                         max_new_tokens=4, eos_token_id=2)
+    ref = model.generate(ids, attention_mask=torch.ones_like(ids), images=[(frames.half(), "video")], do_sample=False,
+                         max_new_tokens=4, eos_token_id=2)                        # mm_infer uploads tensor.half() (__init__.py:60)
     assert text == tok.batch_decode(ref)[0].strip() and len(text) > 0
     with pytest.raises(ValueError, match="Unsupported modal"):
         api.mm_infer(frames, "x", model, tok, modal="audio")
+
+
+def test_emu_padded_batch_generate_and_forward_with_images(emu, golden_small):
+    """arch.py:227-261 + videollama2_mistral.py:63-108 on the HIP host path: a RIGHT-PADDED batch of two video prompts of
+    different lengths through `generate(inputs, attention_mask, images=[...])` gives each sequence the tokens it gets alone
+    (finished rows padded with pad_token_id), `forward(input_ids, images=)` returns the logits of every position (golden
+    prefill logits of the real reference), and the spliced mask / embeds follow the reference's layout; with the live reference
+    available, its own padded-batch generate is the cross-check."""
+    from videollama2_amd.model import VideoLLaMA2Hip
+    g = golden_small
+    cfg = g["cfg"]
+    sd = O.seeded_state_dict(cfg, g["seed"])
+    m = VideoLLaMA2Hip(cfg, sd, "cpu", max_seq_len=96)
+    idsA = g["input_ids"]
+    idsB = torch.cat([idsA[:3], idsA[6:]])                                   # three text tokens shorter, sentinel kept
+    assert (idsB == -201).sum() == 1
+    L = idsA.numel()
+    batch = torch.zeros((2, L), dtype=torch.long)
+    batch[0] = idsA
+    batch[1, :idsB.numel()] = idsB
+    mask = torch.ones_like(batch)
+    mask[1, idsB.numel():] = 0
+    fr2 = torch.flip(g["frames"], dims=[0]).contiguous()                      # a second, different video
+    images = [(g["frames"], "video"), (fr2, "video")]
+    _, m2, _, emb, _ = m.prepare_inputs_labels_for_multimodal(batch, mask, None, None, images)
+    n_vis = O.n_visual_tokens(cfg["num_frames"], 4)
+    assert tuple(emb.shape) == (2, L - 1 + n_vis, cfg["llm"]["hidden_size"]) and tuple(m2.shape) == tuple(emb.shape[:2])
+    assert m2[0].all() and int(m2[1].sum()) == idsB.numel() - 1 + n_vis and not m2[1, -3:].any()
+    assert rel(emb[0], g["inputs_embeds"]) < 2.5e-2
+    alone = [m.generate(idsA[None], attention_mask=torch.ones(1, L, dtype=torch.long), images=images[:1], max_new_tokens=3)[0].tolist(),
+             m.generate(idsB[None], attention_mask=torch.ones(1, idsB.numel(), dtype=torch.long), images=images[1:], max_new_tokens=3)[0].tolist()]
+    assert alone[0] == g["new_tokens"][:3].tolist()
+    out = m.generate(batch, attention_mask=mask, images=images, max_new_tokens=3, pad_token_id=0, do_sample=False)
+    assert out.shape == (2, 3) and out.tolist() == alone
+    eos = alone[1][0]                                                         # sequence 1 stops at its first token -> padded with pad_token_id
+    out = m.generate(batch, attention_mask=mask, images=images, max_new_tokens=3, pad_token_id=0, eos_token_id=eos)
+    assert out[1].tolist() == [eos, 0, 0] and (out[0].tolist() == alone[0] or eos in alone[0])
+    res = m(input_ids=idsA[None], attention_mask=torch.ones(1, L, dtype=torch.long), images=images[:1])
+    assert tuple(res.logits.shape) == (1, L - 1 + n_vis, cfg["llm"]["vocab_size"]) and rel(res.logits[0], g["prefill_logits"]) < 2.5e-2
+    with pytest.raises(NotImplementedError):
+        m(input_ids=idsA[None], images=images[:1], labels=idsA[None])
+    bad = mask.clone()
+    bad[1, 2] = 0
+    with pytest.raises(NotImplementedError, match="right-padded"):
+        m.generate(batch, attention_mask=bad, images=images, max_new_tokens=2)
+    with pytest.raises(ValueError, match="media input"):
+        m.generate(batch, attention_mask=mask, images=images[:1], max_new_tokens=2)
+    from oracle import ref_harness as RH
+    if RH.reference_available():                                              # the reference's own batch-2 generate (equal lengths)
+        model, _ = RH.build_reference_model(cfg)
+        RH.reseed_weights(model, g["seed"])
+        both = torch.stack([idsA, idsA])
+        ref = model.generate(both, attention_mask=torch.ones_like(both), images=images, do_sample=False, max_new_tokens=3, use_cache=True,
+                             pad_token_id=0, eos_token_id=None)
+        ours = m.generate(both, attention_mask=torch.ones_like(both), images=images, max_new_tokens=3, pad_token_id=0)
+        assert ours.tolist() == ref.tolist()
 
 
 def test_emu_gemv_batched_matches_single_row(emu):

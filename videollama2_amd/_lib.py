@@ -16,7 +16,7 @@ class GemmDesc(ctypes.Structure):
                 ("bias", _vp), ("res", _vp), ("ldres", _i32), ("act", _i32), ("flags", _i32),
                 ("a_idx", _vp), ("seg_k", _i32),
                 ("out_grp", _i32), ("out_grp_pad", _i32), ("out_row_off", _i32), ("res_row_mod", _i32), ("res_row_off", _i32),
-                ("stats_out", _vp), ("stats_in", _vp), ("norm", _i32), ("norm_eps", _f32), ("w_colsum", _vp),
+                ("stats_out", _vp), ("stats_in", _vp), ("norm", _i32), ("norm_eps", _f32), ("w_colsum", _vp), ("row_norm", _vp),
                 ("ws", _vp), ("ws_bytes", _i64), ("variant", _i32)]
 
 
@@ -24,6 +24,7 @@ class GemmDesc(ctypes.Structure):
 SIGNATURES = {
     "vl2_gemm": [ctypes.POINTER(GemmDesc), _vp],
     "vl2_row_stats": [_vp, _vp, _i32, _i32, _i32, _vp],
+    "vl2_row_norm_finalize": [_vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp],
     "vl2_layernorm": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp],
     "vl2_rmsnorm": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp],
     "vl2_patchify": [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],

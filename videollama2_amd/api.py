@@ -110,8 +110,9 @@ def model_init(model_path, device="cuda", max_seq_len=4096, tokenizer=None, **kw
 
 def mm_infer(image_or_video, instruct, model, tokenizer, modal="video", **kwargs):
     """videollama2/__init__.py:32-114: tag + chat-template the instruction, put the modal sentinel in the ids, greedy-generate
-    with the keyword stopping criterion, decode.  Differences: frames go to the device in bf16 (the kernels' dtype) instead of
-    fp16, and sampling is not built (`do_sample=True` raises, the reference default is greedy)."""
+    with the keyword stopping criterion, decode.  Frames go to the device as the reference sends them (`tensor.half()`,
+    __init__.py:60; the patch-row kernel reads fp16 / bf16 / fp32 / uint8 frames alike); sampling is not built
+    (`do_sample=True` raises, the reference default is greedy)."""
     if modal == "image":
         modal_token = DEFAULT_IMAGE_TOKEN
     elif modal == "video":
@@ -122,7 +123,7 @@ def mm_infer(image_or_video, instruct, model, tokenizer, modal="video", **kwargs
         raise ValueError(f"Unsupported modal: {modal}")
     dev = model.device
     tensor = None if modal == "text" else [((image_or_video if image_or_video.dtype == torch.uint8
-                                             else image_or_video.to(torch.bfloat16)).to(dev), modal)]
+                                             else image_or_video.half()).to(dev), modal)]
     if isinstance(instruct, str):
         message = [{"role": "user", "content": modal_token + "\n" + instruct}]
     elif isinstance(instruct, list):

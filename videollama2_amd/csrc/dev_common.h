@@ -43,6 +43,15 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
     return v;
 }
+// Sum over the 8 lanes of an aligned lane octet, result in every lane of the octet: three DPP adds (v_add_f32_dpp on the VALU;
+// `__shfl_xor` would go through the LDS crossbar as ds_bpermute).  Order: (i, 7-i) pairs (row_half_mirror), then the quad's
+// neighbours [1,0,3,2], then its halves [2,3,0,1] -- fixed, so every user gets the same bits.
+__device__ __forceinline__ float octet_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));
+    return v;
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));

@@ -42,6 +42,7 @@ struct GemmArgs {
     int norm;                // 0 none, 1 RMSNorm, 2 LayerNorm of the A rows, applied algebraically in the epilogue
     float norm_eps;
     const float* w_colsum;   // LayerNorm: s[n] = sum_k W[n][k] (fp32, of the bf16 weights as packed) [N]
+    const float* row_norm;   // [rows][2] = (mean, rstd) of the A rows, already reduced (row_norm_finalize_kernel); overrides stats_in
 };
 
 // ---- norm-carrying GEMMs ------------------------------------------------------------------------------------------------
@@ -63,6 +64,7 @@ __device__ __forceinline__ f32x2 gemm_row_stats(const GemmArgs& p, int m0, int t
     if (p.norm && t < BM) {
         int m = m0 + t;
         m = m < p.M ? m : p.M - 1;
+        if (p.row_norm) return *(const f32x2*)(p.row_norm + 2 * (size_t)m);      // reduced once per GEMM call, not once per tile
         const float* sp = p.stats_in + (size_t)m * p.stats_in_np * 2;
         float sum = 0.f, sq = 0.f;
         int i = 0;
@@ -114,17 +116,22 @@ __device__ __forceinline__ void gemm_store_patch(const GemmArgs& p, const float*
 #pragma clang fp reassociate(off)
         constexpr int LPR = SWIGLU ? 4 : 8;            // lanes per row
         constexpr int RPP = 64 / LPR;                  // rows per pass
+        // a lane keeps its 8 columns through all passes: the per-column vectors (bias, LayerNorm column sums) are loaded once
+        // per patch, not once per row pass (the stores to C in the loop keep the compiler from hoisting them itself)
+        const int cg = (lane % LPR) * 8;
+        const int nfull = n_base + cg;                 // column in the (un-halved) GEMM N space
+        f32x4 bias0 = {0.f, 0.f, 0.f, 0.f}, bias1 = bias0, cs0 = bias0, cs1 = bias0;
+        if (!SWIGLU && p.bias) { bias0 = *(const f32x4*)(p.bias + nfull); bias1 = *(const f32x4*)(p.bias + nfull + 4); }
+        if (!SWIGLU && p.norm == 2) { cs0 = *(const f32x4*)(p.w_colsum + nfull); cs1 = *(const f32x4*)(p.w_colsum + nfull + 4); }
 #pragma unroll
         for (int pass = 0; pass < 32 / RPP; ++pass) {
             const int row = pass * RPP + lane / LPR;
-            const int cg = (lane % LPR) * 8;
             const int m = m_base + row;
             const bool live = m < p.M;
             float st_s = 0.f, st_q = 0.f;
             int orow = m;
             if (live) {
                 float v[8];
-                const int nfull = n_base + cg;             // column in the (un-halved) GEMM N space
                 float mu = 0.f, rs = 1.f;
                 if (p.norm) { mu = rowtab[2 * (mt_base + row)]; rs = rowtab[2 * (mt_base + row) + 1]; }
                 if (SWIGLU) {
@@ -139,17 +146,15 @@ __device__ __forceinline__ void gemm_store_patch(const GemmArgs& p, const float*
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { v[j] = x0[j]; v[4 + j] = x1[j]; }
                     if (p.norm == 2) {
-                        const f32x4 s0 = *(const f32x4*)(p.w_colsum + nfull), s1 = *(const f32x4*)(p.w_colsum + nfull + 4);
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) { v[j] = __builtin_fmaf(-mu, s0[j], v[j]) * rs; v[4 + j] = __builtin_fmaf(-mu, s1[j], v[4 + j]) * rs; }
+                        for (int j = 0; j < 4; ++j) { v[j] = __builtin_fmaf(-mu, cs0[j], v[j]) * rs; v[4 + j] = __builtin_fmaf(-mu, cs1[j], v[4 + j]) * rs; }
                     } else if (p.norm == 1) {
 #pragma unroll
                         for (int j = 0; j < 8; ++j) v[j] *= rs;
                     }
                     if (p.bias) {
-                        const f32x4 b0 = *(const f32x4*)(p.bias + nfull), b1 = *(const f32x4*)(p.bias + nfull + 4);
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) { v[j] += b0[j]; v[4 + j] += b1[j]; }
+                        for (int j = 0; j < 4; ++j) { v[j] += bias0[j]; v[4 + j] += bias1[j]; }
                     }
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
@@ -188,8 +193,8 @@ __device__ __forceinline__ void gemm_store_patch(const GemmArgs& p, const float*
                 }
             }
             if (!SWIGLU && !REMAP && !OUT_F32 && p.stats_out) {   // wave-uniform: the 8 lanes of a row fold their partials
-#pragma unroll
-                for (int msk = 1; msk <= 4; msk <<= 1) { st_s += __shfl_xor(st_s, msk); st_q += __shfl_xor(st_q, msk); }
+                st_s = octet_sum(st_s);
+                st_q = octet_sum(st_q);
                 if (live && (lane % LPR) == 0) {
                     float* dst = p.stats_out + ((size_t)orow * p.stats_out_np + (n_base >> 6)) * 2;
                     dst[0] = st_s;
@@ -626,15 +631,17 @@ __device__ __forceinline__ int gemm4_lds_off(int row, int chunk) {
     return (((row >> 2) << 4) + ((row & 3) << 2) + (chunk ^ ((row >> 2) & 3))) << 4;
 }
 
+// bid / nwg: this workgroup's index and the workgroup count of the tile set it belongs to (the whole grid for
+// gemm4_bf16_kernel; the big-tile part of gemm_mix_bf16_kernel)
 template <int ACT, bool SWIGLU, bool OUT_F32>
-__global__ __launch_bounds__(512, 2) void gemm4_bf16_kernel(GemmArgs p) {
+__device__ __forceinline__ void gemm4_body(const GemmArgs& p, int bid, int nwg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char vl2_smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2, w4 = wave & 3;
     const int wm = w4 >> 1, wn = w4 & 1;
 
-    const int t0 = xcd_remap(blockIdx.x, gridDim.x);
+    const int t0 = xcd_remap(bid, nwg);
     const int grp_sz = 4 * p.tiles_n;                              // 4 tile-rows (1024 rows of A) per raster group
     const int first_m = (t0 / grp_sz) * 4;
     const int gm = (p.tiles_m - first_m) < 4 ? (p.tiles_m - first_m) : 4;
@@ -743,6 +750,10 @@ __global__ __launch_bounds__(512, 2) void gemm4_bf16_kernel(GemmArgs p) {
             __syncthreads();
         }
 }
+template <int ACT, bool SWIGLU, bool OUT_F32>
+__global__ __launch_bounds__(512, 2) void gemm4_bf16_kernel(GemmArgs p) {
+    gemm4_body<ACT, SWIGLU, OUT_F32>(p, blockIdx.x, gridDim.x);
+}
 
 // ------------------------------------------------------------------------------------------------------------------
 // gemm3: 128 (M) x 256 (N) ping-pong kernel (see gemm4) for GEMMs whose M granularity matters (the M = 1621 prefill):
@@ -755,14 +766,14 @@ __global__ __launch_bounds__(512, 2) void gemm4_bf16_kernel(GemmArgs p) {
 #define GEMM3_LDS_BYTES (3 * GEMM3_STAGE)
 
 template <int ACT, bool SWIGLU, bool OUT_F32>
-__global__ __launch_bounds__(512, 2) void gemm3_bf16_kernel(GemmArgs p) {
+__device__ __forceinline__ void gemm3_body(const GemmArgs& p, int bid, int nwg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char vl2_smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2, w4 = wave & 3;                      // waves w and w+4 share a SIMD (measured)
     const int wm = w4 >> 1, wn = w4 & 1;
 
-    const int t0 = xcd_remap(blockIdx.x, gridDim.x);
+    const int t0 = xcd_remap(bid, nwg);
     const int grp_sz = 8 * p.tiles_n;
     const int first_m = (t0 / grp_sz) * 8;
     const int gm = (p.tiles_m - first_m) < 8 ? (p.tiles_m - first_m) : 8;
@@ -868,6 +879,10 @@ __global__ __launch_bounds__(512, 2) void gemm3_bf16_kernel(GemmArgs p) {
         gemm_store_patch<ACT, SWIGLU, OUT_F32>(p, ep, m0 + wm * 64 + mi * 32, n0 + grp * 128 + wn * 64, lane, rowtab, wm * 64 + mi * 32);
         __syncthreads();
     }
+}
+template <int ACT, bool SWIGLU, bool OUT_F32>
+__global__ __launch_bounds__(512, 2) void gemm3_bf16_kernel(GemmArgs p) {
+    gemm3_body<ACT, SWIGLU, OUT_F32>(p, blockIdx.x, gridDim.x);
 }
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void norm_wide_kernel(NormArgs p) {
 
 // (sum, sum of squares) of every 64-column block of every row of x [rows, C] -> stats [rows][C/64][2] fp32: the statistics a
 // norm-carrying GEMM consumes (k_gemm.h `gemm_row_stats`), in the layout AND the summation order of the GEMM epilogue that
-// normally emits them (8 consecutive values per lane in sequence, then the xor-1/2/4 butterfly over the 8 lanes of a block),
+// normally emits them (8 consecutive values per lane in sequence, then `octet_sum` over the 8 lanes of a block),
 // so a row's statistics are the same bits whether this kernel or a producer GEMM wrote them.  One wave per row; a pass covers
 // 512 columns (8 blocks).  Seeds the chain for tensors no GEMM wrote: inputs_embeds, the CLIP embeddings after pre_layrnorm.
 __global__ __launch_bounds__(256) void row_stats_kernel(const bf16_t* __restrict__ x, float* __restrict__ stats, int rows, int C, int ldx) {
@@ -187,12 +187,41 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const bf16_t* __restrict
 #pragma unroll
             for (int j = 0; j < 8; ++j) { s += v[j]; q = __builtin_fmaf(v[j], v[j], q); }
         }
-#pragma unroll
-        for (int msk = 1; msk <= 4; msk <<= 1) { s += __shfl_xor(s, msk); q += __shfl_xor(q, msk); }
+        s = octet_sum(s);
+        q = octet_sum(q);
         if (c < C && (lane & 7) == 0) {
             float* dst = stats + ((size_t)row * np + (c >> 6)) * 2;
             dst[0] = s;
             dst[1] = q;
         }
     }
+}
+
+// The K/64 partial (sum, sum of squares) of every row -> (mean, rstd): the reduction `gemm_row_stats` (k_gemm.h) would
+// otherwise repeat in every column tile of the consuming GEMM (112 times for the gate/up projection).  Same fixed order as
+// gemm_row_stats, so both paths give the same bits.  One thread per row.  kind: 1 RMSNorm (mean = 0), 2 LayerNorm.
+__global__ __launch_bounds__(256) void row_norm_finalize_kernel(const float* __restrict__ stats, float* __restrict__ out, int rows, int np,
+                                                                int K, int kind, float eps) {
+#pragma clang fp reassociate(off)
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= rows) return;
+    const float* sp = stats + (size_t)m * np * 2;
+    float sum = 0.f, sq = 0.f;
+    int i = 0;
+    for (; i + 2 <= np; i += 2) {
+        const f32x4 v = *(const f32x4*)(sp + 2 * i);
+        sum = (sum + v[0]) + v[2];
+        sq = (sq + v[1]) + v[3];
+    }
+    if (i < np) { sum += sp[2 * i]; sq += sp[2 * i + 1]; }
+    const float inv = 1.0f / (float)K;
+    float mean = 0.f, rstd;
+    if (kind == 2) {
+        mean = sum * inv;
+        rstd = rsqrtf(fmaxf(__builtin_fmaf(-mean, mean, sq * inv), 0.f) + eps);
+    } else {
+        rstd = rsqrtf(sq * inv + eps);
+    }
+    out[2 * (size_t)m] = mean;
+    out[2 * (size_t)m + 1] = rstd;
 }

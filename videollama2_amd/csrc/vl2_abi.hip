@@ -159,6 +159,7 @@ static GemmArgs gemm_rows(const GemmArgs& a0, int m0, int rows, bool f32) {
     if (a0.res) a.res = a0.res + (size_t)m0 * a0.ldres;
     if (a0.stats_out) a.stats_out = a0.stats_out + (size_t)m0 * a0.stats_out_np * 2;
     if (a0.stats_in) a.stats_in = a0.stats_in + (size_t)m0 * a0.stats_in_np * 2;
+    if (a0.row_norm) a.row_norm = a0.row_norm + (size_t)m0 * 2;
     a.tiles_m = (rows + GEMM_BM - 1) / GEMM_BM;
     return a;
 }
@@ -274,7 +275,7 @@ extern "C" int32_t vl2_gemm(const vl2_gemm_desc* d, void* stream) {
     if (f32 && act != VL2_ACT_NONE) return fail(VL2_E_UNSUPP, "vl2_gemm: f32 output supports act none");
     if (d->norm != VL2_NORM_NONE) {
         if (d->norm != VL2_NORM_RMS && d->norm != VL2_NORM_LN) return fail(VL2_E_BADARG, "vl2_gemm: unknown norm %d", d->norm);
-        if (!d->stats_in || g || remap) return fail(VL2_E_BADARG, "vl2_gemm: a fused norm needs stats_in and plain A rows");
+        if ((!d->stats_in && !d->row_norm) || g || remap) return fail(VL2_E_BADARG, "vl2_gemm: a fused norm needs stats_in (or row_norm) and plain A rows");
         if (d->norm == VL2_NORM_LN && (!d->w_colsum || sw)) return fail(VL2_E_BADARG, "vl2_gemm: fused LayerNorm needs w_colsum (and excludes SWIGLU)");
     }
     if (d->stats_out && (sw || f32)) return fail(VL2_E_UNSUPP, "vl2_gemm: stats_out needs a plain bf16 output");
@@ -292,7 +293,7 @@ extern "C" int32_t vl2_gemm(const vl2_gemm_desc* d, void* stream) {
     a.idx_ld = M;
     a.stats_out = d->stats_out; a.stats_out_np = N / 64;
     a.stats_in = d->stats_in; a.stats_in_np = K / 64;
-    a.norm = d->norm; a.norm_eps = d->norm_eps; a.w_colsum = d->w_colsum;
+    a.norm = d->norm; a.norm_eps = d->norm_eps; a.w_colsum = d->w_colsum; a.row_norm = d->row_norm;
     hipStream_t s = ST(stream);
     // The kernels address A and W through raw buffer resources: 32-bit byte offsets, NUM_RECORDS 2^31 - 1.  Operands beyond
     // that are covered in chunks of rows (A, C, residual, statistics) / columns (W, bias, w_colsum, C columns): e.g. the
@@ -325,6 +326,15 @@ extern "C" int32_t vl2_gemm(const vl2_gemm_desc* d, void* stream) {
         }
     }
     return launched("vl2_gemm");
+}
+
+extern "C" int32_t vl2_row_norm_finalize(const float* stats, float* row_norm, int32_t rows, int32_t np, int32_t K, int32_t norm, float eps,
+                                         void* stream) {
+    if (!stats || !row_norm || rows <= 0 || np <= 0 || K <= 0) return fail(VL2_E_BADARG, "vl2_row_norm_finalize: null pointer or empty shape");
+    if (norm != VL2_NORM_RMS && norm != VL2_NORM_LN) return fail(VL2_E_BADARG, "vl2_row_norm_finalize: unknown norm %d", norm);
+    if (!ALIGNED16(stats) || (((uintptr_t)row_norm) & 7)) return fail(VL2_E_SHAPE, "vl2_row_norm_finalize: stats must be 16-byte, row_norm 8-byte aligned");
+    hipLaunchKernelGGL(row_norm_finalize_kernel, dim3((rows + 255) / 256), dim3(256), 0, ST(stream), stats, row_norm, rows, np, K, norm, eps);
+    return launched("vl2_row_norm_finalize");
 }
 
 extern "C" int32_t vl2_row_stats(const void* x, float* stats, int32_t rows, int32_t C, int32_t ldx, void* stream) {

@@ -69,15 +69,17 @@ class HipMistralDecoder(nn.Module):
                 dist.all_reduce(t, group=self.tp_group)
         return t
 
-    def _row_parallel(self, a, w, x, rs):
-        """x + a @ w.T (o_proj / down_proj with the residual fused) and the row statistics of the result in `rs` for the next
-        norm-carrying GEMM.  Single rank: the GEMM's epilogue emits them.  Tensor parallel: the GEMM output is a partial sum, so
-        the statistics are taken after the all-reduce (one extra read of x)."""
+    def _row_parallel(self, a, w, x, rs, rn):
+        """x + a @ w.T (o_proj / down_proj with the residual fused); leaves (0, rstd) of the result's rows in `rn` for the next
+        norm-carrying GEMM.  Single rank: the GEMM's epilogue emits the partial statistics (`rs`).  Tensor parallel: the GEMM output
+        is a partial sum, so the statistics are taken after the all-reduce (one extra read of x)."""
         if self.tp > 1:
             x = self._reduce(ops.gemm(a, w, res=x if self.tp_rank == 0 else None))
             ops.row_stats(x, out=rs)
-            return x
-        return ops.gemm(a, w, res=x, stats_out=rs)
+        else:
+            x = ops.gemm(a, w, res=x, stats_out=rs)
+        ops.row_norm_finalize(rs, self.D, ops.NORM_RMS, self.eps, out=rn)
+        return x
 
     # ------------------------------------------------------------------ prefill (M = S tokens, MFMA GEMMs)
     @torch.no_grad()
@@ -95,14 +97,15 @@ class HipMistralDecoder(nn.Module):
         o = torch.empty((S, nh * hd), dtype=torch.bfloat16, device=self._dev)
         smax = self.max_seq_len
         rs = ops.row_stats(x)          # RMSNorm rides in the q/k/v and gate/up GEMMs (weights.fold_norm): this seeds the statistics
+        rn = ops.row_norm_finalize(rs, D, ops.NORM_RMS, self.eps)       # [S, 2] (0, rstd): reduced once, not in every column tile
         for li, lw in enumerate(self.w["layers"]):
-            qkv = ops.gemm(x, lw["wqkv"], bias=lw["bqkv"], norm=(ops.NORM_RMS, rs, self.eps, None))   # bqkv: Qwen2 only
+            qkv = ops.gemm(x, lw["wqkv"], bias=lw["bqkv"], norm=(ops.NORM_RMS, rn, self.eps, None))   # bqkv: Qwen2 only
             ops.rope_kv(qkv, q, kcache[li], vcache[li], self.cos_t, self.sin_t, nh, nkv, 0)
             ops.attn_fwd(q, kcache[li], vcache[li], o, (0, hd, nh * hd), (0, smax * hd, hd), (0, smax * hd, hd),
                          (0, hd, nh * hd), 1, nh, S, S, nh // nkv, hd ** -0.5, True, 0, hd)
-            x = self._row_parallel(o, lw["wo"], x, rs)
-            a = ops.gemm(x, lw["wgu"], swiglu=True, norm=(ops.NORM_RMS, rs, self.eps, None))
-            x = self._row_parallel(a, lw["wd"], x, rs)
+            x = self._row_parallel(o, lw["wo"], x, rs, rn)
+            a = ops.gemm(x, lw["wgu"], swiglu=True, norm=(ops.NORM_RMS, rn, self.eps, None))
+            x = self._row_parallel(a, lw["wd"], x, rs, rn)
         self.pos = S
         self.last_hidden = x
         if return_all_logits:
@@ -237,16 +240,17 @@ class HipMistralDecoder(nn.Module):
         q = torch.empty((offs[-1], nh * hd), dtype=torch.bfloat16, device=self._dev)
         o = torch.empty((offs[-1], nh * hd), dtype=torch.bfloat16, device=self._dev)
         rs = ops.row_stats(X)
+        rn = ops.row_norm_finalize(rs, self.D, ops.NORM_RMS, self.eps)
         for li, lw in enumerate(self.w["layers"]):
-            qkv = ops.gemm(X, lw["wqkv"], bias=lw["bqkv"], norm=(ops.NORM_RMS, rs, self.eps, None))
+            qkv = ops.gemm(X, lw["wqkv"], bias=lw["bqkv"], norm=(ops.NORM_RMS, rn, self.eps, None))
             for b, (kc, vc) in enumerate(caches):
                 s0, s1, S = offs[b], offs[b + 1], lens[b]
                 ops.rope_kv(qkv[s0:s1], q[s0:s1], kc[li], vc[li], self.cos_t, self.sin_t, nh, nkv, 0)
                 ops.attn_fwd(q[s0:s1], kc[li], vc[li], o[s0:s1], (0, hd, nh * hd), (0, smax * hd, hd), (0, smax * hd, hd),
                              (0, hd, nh * hd), 1, nh, S, S, nh // nkv, hd ** -0.5, True, 0, hd)
-            X = self._row_parallel(o, lw["wo"], X, rs)
-            a = ops.gemm(X, lw["wgu"], swiglu=True, norm=(ops.NORM_RMS, rs, self.eps, None))
-            X = self._row_parallel(a, lw["wd"], X, rs)
+            X = self._row_parallel(o, lw["wo"], X, rs, rn)
+            a = ops.gemm(X, lw["wgu"], swiglu=True, norm=(ops.NORM_RMS, rn, self.eps, None))
+            X = self._row_parallel(a, lw["wd"], X, rs, rn)
         for b in range(len(xs)):
             ops.gemv(self.w["lm_head"], X[offs[b + 1] - 1], norm_w=self.w["norm_w"], eps=self.eps, out_f32=True, out=logits_out[b])
         return lens

@@ -7,7 +7,9 @@
                              model.generate                  -> HipMistralDecoder / HipQwen2Decoder loop
                                                                 (videollama2_mistral.py:110, videollama2_qwen2.py:108 seams)
                            `mm_infer(tensor, instruct, model, tokenizer)` then runs unchanged.
-    install()           -- wrap `videollama2.model_init` so every model it returns is accelerated.
+    install()           -- patch the reference's FACTORIES and loader classes (build_vision_tower, build_vision_projector, the
+                           classes `load_pretrained_model` loads, the VLLMs registry): models are BUILT on the HIP path, no HF
+                           tower / projector / decoder is constructed first.
 The reference's modules are NOT kept as a fallback: after accelerate() the HF decoder layers are dropped."""
 import types
 
@@ -46,15 +48,107 @@ def accelerate(ref_model, device="cuda", max_seq_len=4096, free_reference_weight
     return ref_model
 
 
-def install(device="cuda", max_seq_len=4096):
+class HipCausalLMLoader:
+    """Stands in for `Videollama2MistralForCausalLM` / `Videollama2Qwen2ForCausalLM` at the ONE place the reference's inference
+    entry uses them: `<Class>.from_pretrained(model_path, low_cpu_mem_usage=True, config=config, **kwargs)` inside
+    `load_pretrained_model` (videollama2/model/__init__.py:157-165, reached from `model_init`, videollama2/__init__.py:14-29).
+    Returns the HIP model built straight from the checkpoint files -- no HF tower / projector / decoder is ever constructed or
+    loaded onto the GPU first.  The object it returns carries what `model_init` / `mm_infer` touch: `get_vision_tower()`
+    (`.image_processor`), `.config` (`model_type`, `num_frames`), `.generate(input_ids, images=..., **hf_kwargs)`, `.eval()`,
+    `.to()`, `.device`."""
+    device, max_seq_len = "cuda", 4096
+
+    @classmethod
+    def from_pretrained(cls, model_path, *args, config=None, **kwargs):
+        from . import api
+        from .tower import default_image_processor, default_siglip_image_processor
+        cfg, hf = api.config_from_checkpoint(model_path)
+        check_supported(cfg)
+        siglip = cfg["vision"]["family"] == "siglip"
+        proc = (default_siglip_image_processor if siglip else default_image_processor)(cfg["vision"]["image_size"])
+        dm = kwargs.get("device_map")
+        dev = dm[""] if isinstance(dm, dict) and "" in dm else cls.device
+        model = VideoLLaMA2Hip(cfg, api.load_state_dict(model_path), dev, cls.max_seq_len, image_processor=proc)
+        model.config = config if config is not None else types.SimpleNamespace(**hf)
+        return model
+
+
+def install(device="cuda", max_seq_len=4096, patch_factories=True, patch_loader=True):
+    """Re-route the reference package (must be importable) to the HIP path at its own seams:
+      * `build_vision_tower` (encoder.py:154-164)  -> lazy.LazyHipVisionTower   (CLIP and SigLIP towers)
+      * `build_vision_projector` (projector.py:95-122) -> lazy.LazyHipSTCConnector for stc_connector / stc_connector_v35
+        (other projector types fall through to the reference's own factory)
+        -- both in the modules that DEFINE them and in videollama2_arch, which imported the names (arch.py:25-26), so every
+        `Videollama2*ForCausalLM(config)` built afterwards hosts HIP modules with the reference's state-dict keys;
+      * the loader classes `load_pretrained_model` calls `.from_pretrained` on, and the `VLLMs` registry
+        (model/__init__.py:31-37, :157-165) -> HipCausalLMLoader for model types videollama2 / videollama2_mistral /
+        videollama2_qwen2: `videollama2.model_init(path)` then returns the HIP model without building any HF module;
+      * `videollama2.model_init` itself keeps working for model objects that were built some other way (wrapped with
+        `accelerate`, as before).
+    Idempotent."""
     import videollama2
-    if getattr(videollama2.model_init, "_vl2hip_wrapped", False):
+    import videollama2.model as vm
+    import videollama2.model.encoder as enc
+    import videollama2.model.projector as proj
+    import videollama2.model.videollama2_arch as arch
+    from .lazy import LazyHipSTCConnector, LazyHipVisionTower
+    if getattr(videollama2, "_vl2hip_installed", False):
         return
+    saved = dict(enc_tower=enc.build_vision_tower, arch_tower=arch.build_vision_tower, proj_proj=proj.build_vision_projector,
+                 arch_proj=arch.build_vision_projector, mistral=vm.Videollama2MistralForCausalLM, qwen2=vm.Videollama2Qwen2ForCausalLM,
+                 vllms=dict(vm.VLLMs), model_init=videollama2.model_init)
+    videollama2._vl2hip_saved = saved
+    if patch_factories:
+        ref_build_projector = proj.build_vision_projector
+
+        def build_vision_tower(vision_tower_cfg, **kwargs):                        # encoder.py:154-164, same dispatch and error
+            name = getattr(vision_tower_cfg, "mm_vision_tower", getattr(vision_tower_cfg, "vision_tower", None))
+            if name is None or not ("clip" in name or "siglip" in name):
+                raise ValueError(f"Unknown vision tower: {name}")
+            kwargs.pop("load_pretrained", None)
+            return LazyHipVisionTower(name, args=vision_tower_cfg, device=None, **kwargs)
+
+        def build_vision_projector(config, delay_load=False, **kwargs):           # projector.py:95-122
+            if getattr(config, "mm_projector_type", "linear") in ("stc_connector", "stc_connector_v35"):
+                return LazyHipSTCConnector(config)
+            return ref_build_projector(config, delay_load=delay_load, **kwargs)
+
+        for mod in (enc, arch):
+            mod.build_vision_tower = build_vision_tower
+        for mod in (proj, arch):
+            mod.build_vision_projector = build_vision_projector
+    if patch_loader:
+        loader = type("HipCausalLMLoader", (HipCausalLMLoader,), dict(device=device, max_seq_len=max_seq_len))
+        for name in ("Videollama2MistralForCausalLM", "Videollama2Qwen2ForCausalLM"):
+            setattr(vm, name, loader)
+        for key in ("videollama2", "videollama2_mistral", "videollama2_qwen2"):
+            vm.VLLMs[key] = loader
     orig = videollama2.model_init
 
     def model_init(model_path=None, **kwargs):
         model, processor, tokenizer = orig(model_path, **kwargs)
-        return accelerate(model, device, max_seq_len), processor, tokenizer
+        if not isinstance(model, VideoLLaMA2Hip) and not hasattr(model, "_vl2hip"):
+            model = accelerate(model, device, max_seq_len)
+        return model, processor, tokenizer
 
-    model_init._vl2hip_wrapped = True
     videollama2.model_init = model_init
+    videollama2._vl2hip_installed = True
+
+
+def uninstall():
+    """Undo `install()` (tests; A/B against the unmodified reference in one process)."""
+    import videollama2
+    import videollama2.model as vm
+    import videollama2.model.encoder as enc
+    import videollama2.model.projector as proj
+    import videollama2.model.videollama2_arch as arch
+    sv = getattr(videollama2, "_vl2hip_saved", None)
+    if not getattr(videollama2, "_vl2hip_installed", False) or sv is None:
+        return
+    enc.build_vision_tower, arch.build_vision_tower = sv["enc_tower"], sv["arch_tower"]
+    proj.build_vision_projector, arch.build_vision_projector = sv["proj_proj"], sv["arch_proj"]
+    vm.Videollama2MistralForCausalLM, vm.Videollama2Qwen2ForCausalLM = sv["mistral"], sv["qwen2"]
+    vm.VLLMs.clear()
+    vm.VLLMs.update(sv["vllms"])
+    videollama2.model_init = sv["model_init"]
+    videollama2._vl2hip_installed = False

@@ -68,40 +68,77 @@ class VideoLLaMA2Hip(nn.Module):
         raise Exception(f"Unsupported projector type {self.mm_projector_type}!!!")
 
     # ---------------------------------------------------------------------------------- arch.py:161-263
+    def _embed_ids(self, ids, out):
+        self._check_ids(ids)
+        if ids.numel():
+            ops.embed_rows(ids.to(torch.int32).contiguous(), self.decoder.w["embed"], out)
+
     @torch.no_grad()
     def prepare_inputs_labels_for_multimodal(self, input_ids, attention_mask, past_key_values, labels, images, mm_features=None):
+        """arch.py:161-263, inference subset (labels must be None).  Any batch size: every sequence's modal sentinels are replaced,
+        in order, by the next block of `mm_features` (a sequence WITHOUT a sentinel still consumes one block, arch.py:178-191);
+        ragged results are right-padded with zero rows (arch.py:227-236).  attention_mask: equal lengths -> ones for the inserted
+        visual positions in FRONT of the given mask (arch.py:256-259); ragged -> True for a sequence's real rows, False for its
+        padding (what arch.py:245-253 builds; the reference itself only reaches that code with labels).
+        Returns (None, attention_mask, past_key_values, inputs_embeds [B, S, D] bf16, labels)."""
         if images is None or input_ids.shape[1] == 1:                                    # arch.py:166-169
             return input_ids, attention_mask, past_key_values, None, labels
-        if input_ids.shape[0] != 1 or labels is not None:
-            raise NotImplementedError("HIP path: batch 1 inference only (the reference's eval loops use batch 1)")
+        if labels is not None:
+            raise NotImplementedError("HIP path: inference only (labels / loss belong to training, out of scope)")
         if mm_features is None:                       # (generate_batch hands in features it encoded for several requests at once)
             mm_features = self.encode_images_or_videos(images)
-        ids = input_ids[0].to(self._dev)
-        sentinels = torch.tensor(list(MODAL_INDEX_MAP.values()), device=self._dev)
-        is_mm = (ids[:, None] == sentinels[None, :]).any(-1)
-        mm_pos = torch.nonzero(is_mm).flatten().tolist()
-        if len(mm_pos) != len(mm_features):
-            raise ValueError(f"prompt holds {len(mm_pos)} modal tag(s) but {len(mm_features)} media input(s) were given")
-        self._check_ids(ids[~is_mm])
         D = self.decoder.D
-        n_vis = sum(mm_features[k].shape[0] for k in range(len(mm_pos)))
-        S = ids.numel() - len(mm_pos) + n_vis
-        emb = torch.empty((S, D), dtype=torch.bfloat16, device=self._dev)
-        ids32 = ids.clamp(min=0).to(torch.int32)
-        cur, prev = 0, 0
-        for k, p in enumerate(mm_pos + [ids.numel()]):
-            if p > prev:                                                                 # text piece -> embed_tokens
-                ops.embed_rows(ids32[prev:p].contiguous(), self.decoder.w["embed"], emb[cur:cur + (p - prev)])
-                cur += p - prev
-            if k < len(mm_pos):                                                          # visual block in place of sentinel
-                f = mm_features[k].to(torch.bfloat16)
-                emb[cur:cur + f.shape[0]].copy_(f)
-                cur += f.shape[0]
-            prev = p + 1
-        if attention_mask is not None:                                                   # arch.py:256-259
-            pad = torch.ones((1, S - input_ids.shape[1]), dtype=attention_mask.dtype, device=attention_mask.device)
-            attention_mask = torch.cat((pad, attention_mask), dim=1)
-        return None, attention_mask, past_key_values, emb.unsqueeze(0), labels
+        sentinels = torch.tensor(list(MODAL_INDEX_MAP.values()), device=self._dev)
+        B, L = input_ids.shape
+        embeds, cur_mm = [], 0
+        for bi in range(B):
+            ids = input_ids[bi].to(self._dev)
+            is_mm = (ids[:, None] == sentinels[None, :]).any(-1)
+            mm_pos = torch.nonzero(is_mm).flatten().tolist()
+            if cur_mm + max(len(mm_pos), 1) > len(mm_features):
+                raise ValueError(f"prompt {bi} holds {len(mm_pos)} modal tag(s) but only {len(mm_features) - cur_mm} media input(s) are left")
+            if not mm_pos:                                                               # pure text: consumes one (unused) block
+                emb = torch.empty((L, D), dtype=torch.bfloat16, device=self._dev)
+                self._embed_ids(ids, emb)
+                embeds.append(emb)
+                cur_mm += 1
+                continue
+            n_vis = sum(mm_features[cur_mm + k].shape[0] for k in range(len(mm_pos)))
+            S = L - len(mm_pos) + n_vis
+            emb = torch.empty((S, D), dtype=torch.bfloat16, device=self._dev)
+            self._check_ids(ids[~is_mm])
+            ids32 = ids.clamp(min=0).to(torch.int32)
+            cur, prev = 0, 0
+            for k, p in enumerate(mm_pos + [L]):
+                if p > prev:                                                             # text piece -> embed_tokens
+                    ops.embed_rows(ids32[prev:p].contiguous(), self.decoder.w["embed"], emb[cur:cur + (p - prev)])
+                    cur += p - prev
+                if k < len(mm_pos):                                                      # visual block in place of the sentinel
+                    f = mm_features[cur_mm].to(torch.bfloat16)
+                    emb[cur:cur + f.shape[0]].copy_(f)
+                    cur += f.shape[0]
+                    cur_mm += 1
+                prev = p + 1
+            embeds.append(emb)
+        lens = [e.shape[0] for e in embeds]
+        max_len = max(lens)
+        if any(n != max_len for n in lens):                                              # arch.py:227-253
+            out = torch.zeros((B, max_len, D), dtype=torch.bfloat16, device=self._dev)
+            for bi, e in enumerate(embeds):
+                out[bi, :e.shape[0]].copy_(e)
+            if attention_mask is not None:
+                rows = []
+                for bi, n in enumerate(lens):
+                    left = torch.ones((n - L,), dtype=attention_mask.dtype, device=attention_mask.device)
+                    right = torch.zeros((max_len - n,), dtype=attention_mask.dtype, device=attention_mask.device)
+                    rows.append(torch.cat((left, attention_mask[bi], right), 0))
+                attention_mask = torch.stack(rows, 0)
+        else:
+            out = torch.stack(embeds, 0) if B > 1 else embeds[0].unsqueeze(0)
+            if attention_mask is not None:                                               # arch.py:256-259
+                pad = torch.ones((B, max_len - L), dtype=attention_mask.dtype, device=attention_mask.device)
+                attention_mask = torch.cat((pad, attention_mask), dim=1)
+        return None, attention_mask, past_key_values, out, labels
 
     def _check_ids(self, ids):
         """embed_rows_kernel indexes the table with the ids unchecked: an id outside [0, vocab) (a leftover modal sentinel, a
@@ -110,6 +147,54 @@ class VideoLLaMA2Hip(nn.Module):
             lo, hi = int(ids.min()), int(ids.max())
             if lo < 0 or hi >= self.decoder.V:
                 raise IndexError(f"token id out of range: [{lo}, {hi}] vs vocab_size {self.decoder.V}")
+
+    @staticmethod
+    def _valid_lengths(attention_mask, S, B):
+        """Rows of the (spliced) attention mask -> real length per sequence.  HF masks padded KEYS and derives positions from the
+        mask's cumulative sum, so a right-padded prompt decodes exactly like the unpadded one; that is how it runs here (the
+        sequences go through the ragged batched decoder, each with its own cache and position).  Interior or left padding is not
+        built."""
+        if attention_mask is None:
+            return [S] * B
+        m = attention_mask.bool()
+        lens = m.sum(1).tolist()
+        for bi, n in enumerate(lens):
+            if n == 0 or not bool(m[bi, :n].all()):
+                raise NotImplementedError("HIP path: only right-padded prompts (attention_mask = 1...1 0...0) are supported")
+        return lens
+
+    def _inputs_embeds(self, inputs, attention_mask, images):
+        if images is not None:
+            _, attention_mask, _, emb, _ = self.prepare_inputs_labels_for_multimodal(inputs, attention_mask, None, None, images)
+            if emb is None:                        # input_ids.shape[1] == 1: arch.py:166-169 hands the ids back
+                images = None
+        if images is None:
+            B, L = inputs.shape
+            emb = torch.empty((B, L, self.decoder.D), dtype=torch.bfloat16, device=self._dev)
+            for bi in range(B):
+                self._embed_ids(inputs[bi].to(self._dev), emb[bi])
+        return emb, self._valid_lengths(attention_mask, emb.shape[1], emb.shape[0])
+
+    # ---------------------------------------------------------------------------------- videollama2_mistral.py:63-108
+    @torch.no_grad()
+    def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, inputs_embeds=None, labels=None,
+                use_cache=None, output_attentions=None, output_hidden_states=None, images=None, return_dict=None, **kwargs):
+        """One full forward (no cache reuse): logits of EVERY position, fp32 [B, S, V] (rows of a sequence's padding are zero).
+        The inference half of the reference's `forward(..., images=)`: labels / loss, past_key_values, attentions and hidden
+        states are the training / HF-generation plumbing and are not built (asked for -> NotImplementedError)."""
+        if labels is not None or past_key_values is not None or output_attentions or output_hidden_states:
+            raise NotImplementedError("HIP path forward(): logits only (no labels / past_key_values / attentions / hidden states)")
+        if inputs_embeds is None:
+            emb, lens = self._inputs_embeds(input_ids, attention_mask, images)
+        else:
+            emb = inputs_embeds.to(self._dev)
+            lens = self._valid_lengths(attention_mask, emb.shape[1], emb.shape[0])
+        B, S = emb.shape[:2]
+        logits = torch.zeros((B, S, self.decoder.V), dtype=torch.float32, device=self._dev)
+        for bi in range(B):
+            logits[bi, :lens[bi]].copy_(self.decoder.prefill(emb[bi, :lens[bi]], return_all_logits=True))
+        import types
+        return types.SimpleNamespace(logits=logits, loss=None, labels=None, past_key_values=None)
 
     # ---------------------------------------------------------------------------------- videollama2_mistral.py:110-144
     @torch.no_grad()
@@ -120,24 +205,29 @@ class VideoLLaMA2Hip(nn.Module):
             raise NotImplementedError("`inputs_embeds` is not supported")                # videollama2_mistral.py:119-120
         if kwargs.get("do_sample", False):
             raise NotImplementedError("HIP path implements greedy decoding (do_sample=False, the reference default)")
-        if images is not None:
-            _, attention_mask, _, inputs_embeds, _ = self.prepare_inputs_labels_for_multimodal(
-                inputs, attention_mask, None, None, images)
-            inputs_embeds = inputs_embeds[0]
-        else:
-            self._check_ids(inputs[0])
-            ids32 = inputs[0].to(self._dev).to(torch.int32).contiguous()
-            inputs_embeds = torch.empty((ids32.numel(), self.decoder.D), dtype=torch.bfloat16, device=self._dev)
-            ops.embed_rows(ids32, self.decoder.w["embed"], inputs_embeds)
-        if attention_mask is not None and not bool(attention_mask.bool().all()):
-            raise NotImplementedError("HIP path: padded prompts (attention_mask with zeros) are not supported")
-        return self.decoder.generate(inputs_embeds, max_new_tokens=kwargs.get("max_new_tokens", 2048),
-                                     eos_token_id=kwargs.get("eos_token_id", None),
-                                     stopping_criteria=kwargs.get("stopping_criteria", None),
-                                     return_logits=kwargs.get("return_logits", False), streamer=kwargs.get("streamer", None),
-                                     # one captured hipGraph per token by default (what bench.py measures); `use_graph=False`
-                                     # keeps the eager launch loop
-                                     use_graph=kwargs.get("use_graph", self._dev.type == "cuda" and self.decoder.tp == 1))
+        if inputs.dim() == 1:
+            inputs = inputs[None]
+        emb, lens = self._inputs_embeds(inputs, attention_mask, images)
+        max_new, eos = kwargs.get("max_new_tokens", 2048), kwargs.get("eos_token_id", None)
+        if emb.shape[0] == 1:
+            return self.decoder.generate(emb[0, :lens[0]], max_new_tokens=max_new, eos_token_id=eos,
+                                         stopping_criteria=kwargs.get("stopping_criteria", None),
+                                         return_logits=kwargs.get("return_logits", False), streamer=kwargs.get("streamer", None),
+                                         # one captured hipGraph per token by default (what bench.py measures); `use_graph=False`
+                                         # keeps the eager launch loop
+                                         use_graph=kwargs.get("use_graph", self._dev.type == "cuda" and self.decoder.tp == 1))
+        # batch > 1 (right-padded, arch.py:227-261): the sequences decode together, each on its own cache / position; finished rows
+        # are filled with pad_token_id like HF's generate does
+        if kwargs.get("stopping_criteria") is not None or kwargs.get("streamer") is not None or kwargs.get("return_logits"):
+            raise NotImplementedError("HIP path: stopping_criteria / streamer / return_logits are built for batch 1")
+        outs = self.decoder.generate_batch([emb[bi, :lens[bi]] for bi in range(emb.shape[0])], max_new_tokens=max_new, eos_token_id=eos)
+        pad = kwargs.get("pad_token_id", None)
+        pad = 0 if pad is None else int(pad)
+        width = max(o.numel() for o in outs)
+        res = torch.full((len(outs), width), pad, dtype=torch.long, device=self._dev)
+        for bi, o in enumerate(outs):
+            res[bi, :o.numel()] = o
+        return res
 
     @torch.no_grad()
     def generate_batch(self, requests, **kwargs):

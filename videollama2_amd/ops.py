@@ -105,6 +105,12 @@ def gemm(a, w, bias=None, res=None, act=ACT_NONE, swiglu=False, out_f32=False, o
     ws = _ws(a.device)
     flags = (GEMM_SWIGLU if swiglu else 0) | (GEMM_OUT_F32 if out_f32 else 0) | (GEMM_SPLITK if (_CTL["splitk"] and ws is not None) else 0)
     kind, stats_in, eps, colsum = norm if norm is not None else (NORM_NONE, None, 0.0, None)
+    row_norm = None
+    if stats_in is not None and stats_in.dim() == 2:      # [rows, 2] = already reduced (row_norm_finalize)
+        row_norm, stats_in = stats_in, None
+        if row_norm.shape[0] < M or row_norm.shape[1] != 2:
+            raise ValueError(f"gemm: row_norm must be [>={M}, 2], got {tuple(row_norm.shape)}")
+        _chk(row_norm, torch.float32, "row_norm")
     if stats_out is not None and tuple(stats_out.shape) != (M, N // 64, 2):
         raise ValueError(f"gemm: stats_out must be [{M}, {N // 64}, 2], got {tuple(stats_out.shape)}")
     if stats_in is not None and (stats_in.shape[0] < M or tuple(stats_in.shape[1:]) != (K // 64, 2)):
@@ -112,7 +118,7 @@ def gemm(a, w, bias=None, res=None, act=ACT_NONE, swiglu=False, out_f32=False, o
     _chk(stats_out, torch.float32, "stats_out"); _chk(stats_in, torch.float32, "stats_in"); _chk(colsum, torch.float32, "w_colsum")
     d = _lib.GemmDesc(ctypes.sizeof(_lib.GemmDesc), M, N, K, _p(a), a.stride(0), _p(w), w.stride(0), _p(out), out.stride(0),
                       _p(bias), _p(res), res.stride(0) if res is not None else 0, act, flags, _p(a_idx), seg_k,
-                      grp, grp_pad, row_off, rmod, roff, _p(stats_out), _p(stats_in), kind, float(eps), _p(colsum),
+                      grp, grp_pad, row_off, rmod, roff, _p(stats_out), _p(stats_in), kind, float(eps), _p(colsum), _p(row_norm),
                       _p(ws), ws.numel() if ws is not None else 0, _CTL["variant"])
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -121,6 +127,16 @@ def gemm(a, w, bias=None, res=None, act=ACT_NONE, swiglu=False, out_f32=False, o
     if PROFILE is not None:
         e1.record()
         PROFILE.append(("gemm", 2.0 * M * N * (flop_k or K), e0, e1, (M, N, K)))
+    return out
+
+
+def row_norm_finalize(stats, K, kind, eps, out=None):
+    """stats [rows, K/64, 2] -> [rows, 2] = (mean, rstd) for NORM_RMS / NORM_LN: hand the result to gemm(norm=(kind, <it>, eps,
+    colsum)) so the consuming GEMM does not reduce the partials again in every column tile."""
+    _chk(stats, torch.float32, "stats")
+    rows, np_ = stats.shape[0], stats.shape[1]
+    out = torch.empty((rows, 2), dtype=torch.float32, device=stats.device) if out is None else out
+    _lib.call("vl2_row_norm_finalize", _p(stats), _p(out), rows, np_, K, kind, float(eps), _stream())
     return out
 
 

@@ -142,16 +142,23 @@ class HipCLIPVisionTower(nn.Module):
         o = torch.empty((T * N1, D), dtype=torch.bfloat16, device=self._dev)
         # layer_norm1 / layer_norm2 never run as kernels: every GEMM that writes the residual stream also emits its row
         # statistics (`stats_out`), and the q/k/v and fc1 GEMMs normalise in their epilogue (weights.fold_norm, csrc/k_gemm.h)
+        # The K/64 partial statistics of a row are reduced ONCE per tensor (`row_norm_finalize`, a 2 us kernel) instead of in every
+        # column tile of the consuming GEMM (measured, scripts/gemm_norm_bench.py: fc1 +11.4 us per call with the in-tile reduction,
+        # +4.5 us with the reduced form).
         rs = ops.row_stats(x)                                                      # seeds the chain (pre_layrnorm's output)
+        rn = ops.row_norm_finalize(rs, D, ops.NORM_LN, eps)
         last = len(w["layers"]) - 1
         for li, lw in enumerate(w["layers"]):
-            qkv = ops.gemm(x, lw["wqkv"], bias=lw["bqkv"], norm=(ops.NORM_LN, rs, eps, lw["sqkv"]))   # [T*N1, 3D] = q | k | v
+            qkv = ops.gemm(x, lw["wqkv"], bias=lw["bqkv"], norm=(ops.NORM_LN, rn, eps, lw["sqkv"]))   # [T*N1, 3D] = q | k | v
             st = (N1 * 3 * D, hd, 3 * D)
             ops.attn_fwd(qkv, qkv[:, D:], qkv[:, 2 * D:], o, st, st, st, (N1 * D, hd, D), T, nh, N1, N1, 1,
                          hd ** -0.5, False, 0, hd)
             x = ops.gemm(o, lw["wo"], bias=lw["bo"], res=x, stats_out=rs)
-            h = ops.gemm(x, lw["w1"], bias=lw["b1"], act=ops.ACT_QGELU, norm=(ops.NORM_LN, rs, eps, lw["s1"]))
+            ops.row_norm_finalize(rs, D, ops.NORM_LN, eps, out=rn)
+            h = ops.gemm(x, lw["w1"], bias=lw["b1"], act=ops.ACT_QGELU, norm=(ops.NORM_LN, rn, eps, lw["s1"]))
             x = ops.gemm(h, lw["w2"], bias=lw["b2"], res=x, out=out if li == last else None, stats_out=None if li == last else rs)
+            if li != last:
+                ops.row_norm_finalize(rs, D, ops.NORM_LN, eps, out=rn)
         return x, T, N1
 
     @torch.no_grad()
@@ -209,15 +216,19 @@ class HipSiglipVisionTower(HipCLIPVisionTower):
         ops.gemm(a, w["patch_w"], bias=w["patch_b"], res=w["pos"], out=x, res_map=(N, 0), flop_k=3 * P * P)
         o = torch.empty((T * N, Hh), dtype=torch.bfloat16, device=self._dev)
         rs = ops.row_stats(x)                                                      # norm-carrying chain, as in the CLIP tower
+        rn = ops.row_norm_finalize(rs, D, ops.NORM_LN, eps)
         last = len(w["layers"]) - 1
         for li, lw in enumerate(w["layers"]):
-            qkv = ops.gemm(x, lw["wqkv"], bias=lw["bqkv"], norm=(ops.NORM_LN, rs, eps, lw["sqkv"]))   # q | k | v, heads padded to hdp
+            qkv = ops.gemm(x, lw["wqkv"], bias=lw["bqkv"], norm=(ops.NORM_LN, rn, eps, lw["sqkv"]))   # q | k | v, heads padded to hdp
             st = (N * 3 * Hh, hdp, 3 * Hh)
             ops.attn_fwd(qkv, qkv[:, Hh:], qkv[:, 2 * Hh:], o, st, st, st, (N * Hh, hdp, Hh), T, nh, N, N, 1,
                          w["hd"] ** -0.5, False, 0, hdp)
             x = ops.gemm(o, lw["wo"], bias=lw["bo"], res=x, stats_out=rs)
-            h = ops.gemm(x, lw["w1"], bias=lw["b1"], act=ops.ACT_GELU_TANH, norm=(ops.NORM_LN, rs, eps, lw["s1"]))
+            ops.row_norm_finalize(rs, D, ops.NORM_LN, eps, out=rn)
+            h = ops.gemm(x, lw["w1"], bias=lw["b1"], act=ops.ACT_GELU_TANH, norm=(ops.NORM_LN, rn, eps, lw["s1"]))
             x = ops.gemm(h, lw["w2"], bias=lw["b2"], res=x, out=out if li == last else None, stats_out=None if li == last else rs)
+            if li != last:
+                ops.row_norm_finalize(rs, D, ops.NORM_LN, eps, out=rn)
         return x, T, N
 
     @torch.no_grad()
