@@ -333,7 +333,7 @@ extern "C" int32_t vl2_row_norm_finalize(const float* stats, float* row_norm, in
     if (!stats || !row_norm || rows <= 0 || np <= 0 || K <= 0) return fail(VL2_E_BADARG, "vl2_row_norm_finalize: null pointer or empty shape");
     if (norm != VL2_NORM_RMS && norm != VL2_NORM_LN) return fail(VL2_E_BADARG, "vl2_row_norm_finalize: unknown norm %d", norm);
     if (!ALIGNED16(stats) || (((uintptr_t)row_norm) & 7)) return fail(VL2_E_SHAPE, "vl2_row_norm_finalize: stats must be 16-byte, row_norm 8-byte aligned");
-    hipLaunchKernelGGL(row_norm_finalize_kernel, dim3((rows + 255) / 256), dim3(256), 0, ST(stream), stats, row_norm, rows, np, K, norm, eps);
+    hipLaunchKernelGGL(row_norm_finalize_kernel, dim3((rows + 31) / 32), dim3(256), 0, ST(stream), stats, row_norm, rows, np, K, norm, eps);
     return launched("vl2_row_norm_finalize");
 }
 
@@ -459,7 +459,7 @@ extern "C" int32_t vl2_attn_fwd(const void* q, const void* k, const void* v, voi
         !ALIGNED16(k) || !ALIGNED16(v) || ((uintptr_t)o & 7))
         return fail(VL2_E_SHAPE, "vl2_attn_fwd: strides must keep 16-byte row alignment");
     if (causal && causal_off < 0) return fail(VL2_E_SHAPE, "vl2_attn_fwd: causal_off must be >= 0");
-    if (variant < 0 || variant > 3) return fail(VL2_E_BADARG, "vl2_attn_fwd: unknown variant %d", variant);
+    if (variant < 0 || variant > 5) return fail(VL2_E_BADARG, "vl2_attn_fwd: unknown variant %d", variant);
     // K / V tiles are fetched through raw buffer resources whose byte offsets and NUM_RECORDS are 32-bit
     if (((int64_t)(nk - 1) * k_rs + D) * 2 >= (int64_t)1 << 31 || ((int64_t)(nk - 1) * v_rs + D) * 2 >= (int64_t)1 << 31)
         return fail(VL2_E_SHAPE, "vl2_attn_fwd: one head's K or V rows span >= 2 GiB (nk %d, row strides %d / %d elements)", nk, k_rs, v_rs);
@@ -468,6 +468,19 @@ extern "C" int32_t vl2_attn_fwd(const void* q, const void* k, const void* v, voi
     dim3 g((nq + 127) / 128, H, B), b(256);
     if (causal) g = dim3(((nq + 127) / 128) * H * B, 1, 1);
     hipStream_t s = ST(stream);
+    if (variant == 5) {                                   // software-pipelined D = 128 form (k_attn2.h attn2p_fwd_kernel)
+        if (D != 128) return fail(VL2_E_SHAPE, "vl2_attn_fwd: variant 5 is built for head_dim 128 (got %d)", D);
+        if (causal) hipLaunchKernelGGL((attn2p_fwd_kernel<true>), g, b, 0, s, a);
+        else hipLaunchKernelGGL((attn2p_fwd_kernel<false>), g, b, 0, s, a);
+        return launched("vl2_attn_fwd");
+    }
+    if (variant == 4) {                                   // K/V of a (batch, head) resident in LDS (k_attn2.h attn_res64_kernel)
+        if (D != 64 || causal || nk > 64 * ATTN_RES_NT) return fail(VL2_E_SHAPE, "vl2_attn_fwd: variant 4 needs head_dim 64, non-causal, nk <= %d (D %d, nk %d)", 64 * ATTN_RES_NT, D, nk);
+        int qsplit = 1;                                   // fewer (batch, head) pairs than CUs: split the q blocks over workgroups
+        while ((long)H * B * qsplit < 256 && qsplit < 4 && qsplit * 8 * 32 < nq) qsplit *= 2;
+        hipLaunchKernelGGL(attn_res64_kernel, dim3(H, B, qsplit), dim3(512), 0, s, a);
+        return launched("vl2_attn_fwd");
+    }
     if (variant == 3) {                                   // second structure (k_attn2.h): LDS-DMA ring + transpose reads
         if (D == 64 && !causal) hipLaunchKernelGGL((attn2_fwd_kernel<64, false>), g, b, 0, s, a);
         else if (D == 64 && causal) hipLaunchKernelGGL((attn2_fwd_kernel<64, true>), g, b, 0, s, a);
