@@ -121,8 +121,9 @@ int32_t vl2_patchify_u8(const void* frames_thwc, void* out, int32_t T, int32_t H
 /* x[t*rows_per_frame, :] = cls_pos (class_embedding + position_embedding[0]). */
 int32_t vl2_fill_cls(void* x, const void* cls_pos, int32_t T, int32_t D, int32_t rows_per_frame, void* stream);
 
-/* `variant` (0 = auto): causal D=128: 1 = one group of 4 waves per workgroup, 2 = two groups that split the KV tiles and merge
- * through LDS (auto: 2 when one sequence has <= 352 (q block, head) pairs).
+/* `variant`: 0 = auto (3 for head_dim 64 / 128, the register-staged kernel for head_dim 96); 1 = register-staged K/V (k_attn.h), one
+ * group of 4 waves per workgroup; 2 = the same with two groups that split the KV tiles and merge through LDS (causal D=128 only);
+ * 3 = K/V by LDS-DMA into a two-stage ring, V through the transpose read (k_attn2.h).
  * Fused attention forward, softmax in fp32.  D = 64 or 128.  Element strides: *_bs batch, *_hs head, *_rs row.
  * kv head of q head h = h / group.  causal: key j visible to q row i iff j <= i + causal_off.
  * Replaces flash-attn (videollama2/model/encoder.py:24) / HF eager_attention_forward for CLIP, and HF Mistral

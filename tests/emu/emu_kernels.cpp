@@ -177,19 +177,7 @@ extern "C" int32_t vl2_attn_fwd(const void* q, const void* k, const void* v, voi
                v_bs, v_hs, v_rs, o_bs, o_hs, o_rs, nq, nk, group, H, B, scale * 1.4426950408889634f, causal_off};
     dim3 g((nq + 127) / 128, H, B), blk(256);
     if (causal) g = dim3(((nq + 127) / 128) * H * B, 1, 1);
-    if (variant == 5) {
-        if (D != 128) return -2;
-        if (causal) emu::launch(g, blk, [=] { attn2p_fwd_kernel<true>(a); });
-        else emu::launch(g, blk, [=] { attn2p_fwd_kernel<false>(a); });
-        return 0;
-    }
-    if (variant == 4) {
-        if (D != 64 || causal || nk > 64 * ATTN_RES_NT) return -2;
-        int qsplit = 1;
-        while ((long)H * B * qsplit < 8 && qsplit < 4 && qsplit * 8 * 32 < nq) qsplit *= 2;   // a low threshold so that the split form runs here
-        emu::launch(dim3(H, B, qsplit), dim3(512), [=] { attn_res64_kernel(a); });
-        return 0;
-    }
+    if (variant == 0 && (D == 64 || D == 128)) variant = 3;   // auto, as the product launcher
     if (variant == 3) {                                     // second structure (k_attn2.h): LDS-DMA ring + transpose reads
         if (D == 64 && !causal) emu::launch(g, blk, [=] { attn2_fwd_kernel<64, false>(a); });
         else if (D == 64 && causal) emu::launch(g, blk, [=] { attn2_fwd_kernel<64, true>(a); });

@@ -271,75 +271,6 @@ def test_emu_attention_second_structure(emu):
         ops.set_attn_kv_groups(0)
 
 
-def test_emu_attention_pipelined_d128(emu):
-    """csrc/k_attn2.h attn2p_fwd_kernel (variant 5): QK^T of tile t+1 issued before the softmax of tile t, three-stage K/V ring.
-    1..8 KV tiles (every rotation of the three stages, both parities of the score sets), causal GQA from the cache with a
-    chunked-prefill offset, non-causal; against torch and the first structure."""
-    from videollama2_amd import ops
-    nh, nkv, D, smax = 4, 2, 128, 512
-    try:
-        for S in (60, 130, 200, 330, 450):
-            q, kc, vc = bf(S, nh * D, seed=S), bf(nkv, smax, D, seed=S + 1), bf(nkv, smax, D, seed=S + 2)
-            args = ((0, D, nh * D), (0, smax * D, D), (0, smax * D, D), (0, D, nh * D), 1, nh)
-            outs = {}
-            for var in (1, 5):
-                ops.set_attn_kv_groups(var)
-                o = torch.zeros(S, nh * D, dtype=torch.bfloat16)
-                ops.attn_fwd(q, kc, vc, o, *args, S, S, nh // nkv, D ** -0.5, True, 0, D)
-                outs[var] = o
-            qf = q.view(S, nh, D).transpose(0, 1).float()
-            kf, vf = kc[:, :S].float().repeat_interleave(2, 0), vc[:, :S].float().repeat_interleave(2, 0)
-            sc = (qf @ kf.transpose(1, 2) * D ** -0.5).masked_fill(torch.triu(torch.ones(S, S, dtype=torch.bool), 1), float("-inf"))
-            ref = (torch.softmax(sc, -1) @ vf).transpose(0, 1).reshape(S, nh * D)
-            assert rel(outs[5], ref) < TOL_BF16_OUT and rel(outs[5], outs[1]) < 3e-3, S
-            if S == 200:
-                o2 = torch.zeros(40, nh * D, dtype=torch.bfloat16)
-                ops.attn_fwd(q[160:].contiguous(), kc, vc, o2, *args, 40, S, nh // nkv, D ** -0.5, True, 160, D)
-                assert rel(o2, ref[160:]) < TOL_BF16_OUT
-        B, H, N = 1, 2, 130
-        qkv = bf(B * N, 3 * H * D, seed=5)
-        st = (N * 3 * H * D, D, 3 * H * D)
-        o = torch.zeros(B * N, H * D, dtype=torch.bfloat16)
-        ops.attn_fwd(qkv, qkv[:, H * D:], qkv[:, 2 * H * D:], o, st, st, st, (N * H * D, D, H * D), B, H, N, N, 1, D ** -0.5, False, 0, D)
-        q, k, v = [t.view(B, N, H, D).transpose(1, 2).float() for t in qkv.view(B * N, 3, H * D).unbind(1)]
-        assert rel(o, (torch.softmax(q @ k.transpose(-1, -2) * D ** -0.5, -1) @ v).transpose(1, 2).reshape(B * N, H * D)) < TOL_BF16_OUT
-    finally:
-        ops.set_attn_kv_groups(0)
-
-
-def test_emu_attention_lds_resident_vit_shape(emu):
-    """csrc/k_attn2.h attn_res64_kernel (vl2_attn_fwd variant 4): whole K/V of a (frame, head) resident in LDS, 8 waves walking
-    32-row q blocks, software-pipelined tile loop.  1..10 KV tiles, q-block counts below / at / above the wave count (waves
-    without a block must still take part in the first pass's barriers), the q-split form, the 577-token CLIP shape with its
-    one-row last block, a softmax spike; against torch and the first structure."""
-    from videollama2_amd import ops
-    D = 64
-    try:
-        for B, H, N in ((1, 2, 577), (2, 1, 150), (1, 1, 64), (1, 9, 300), (1, 1, 640), (1, 1, 33)):
-            qkv = bf(B * N, 3 * H * D, seed=N)
-            if N == 300:
-                qkv[17, :D] = 6.0
-                qkv[250, H * D:H * D + D] = 6.0
-            st = (N * 3 * H * D, D, 3 * H * D)
-            outs = {}
-            for var in (1, 4):
-                ops.set_attn_kv_groups(var)
-                o = torch.zeros(B * N, H * D, dtype=torch.bfloat16)
-                ops.attn_fwd(qkv, qkv[:, H * D:], qkv[:, 2 * H * D:], o, st, st, st, (N * H * D, D, H * D), B, H, N, N, 1, D ** -0.5, False, 0, D)
-                outs[var] = o
-            q, k, v = [t.view(B, N, H, D).transpose(1, 2).float() for t in qkv.view(B * N, 3, H * D).unbind(1)]
-            ref = (torch.softmax(q @ k.transpose(-1, -2) * D ** -0.5, -1) @ v).transpose(1, 2).reshape(B * N, H * D)
-            assert rel(outs[4], ref) < TOL_BF16_OUT and rel(outs[4], outs[1]) < 3e-3, (B, H, N)
-        from videollama2_amd._lib import Vl2HipError
-        with pytest.raises(Vl2HipError):                                      # nk beyond the resident capacity
-            qkv = bf(700, 3 * D)
-            ops.set_attn_kv_groups(4)
-            ops.attn_fwd(qkv, qkv[:, D:], qkv[:, 2 * D:], torch.zeros(700, D, dtype=torch.bfloat16), (700 * 3 * D, D, 3 * D), (700 * 3 * D, D, 3 * D),
-                         (700 * 3 * D, D, 3 * D), (700 * D, D, D), 1, 1, 700, 700, 1, D ** -0.5, False, 0, D)
-    finally:
-        ops.set_attn_kv_groups(0)
-
-
 def test_emu_causal_attention_kv_groups(emu):
     """Causal D=128 attention with one and with two KV groups per workgroup (the second group takes every other KV tile; the
     partial (m, l, O) are merged through LDS): 1, 3, 4 and 6 KV tiles, so that the second group has none / fewer / as many."""

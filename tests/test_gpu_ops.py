@@ -637,51 +637,3 @@ def test_attn_second_structure_softmax_spike(ops):
     q, k, v = [t.float() for t in qkv.view(N, 3, D).unbind(1)]
     ref = torch.softmax(q @ k.T * D ** -0.5, -1) @ v
     assert rel(o, ref) < TOL_BF16_OUT and rel(o[17], ref[17]) < 1e-2
-
-
-@pytest.mark.parametrize("B,H,N", [(16, 16, 577), (2, 3, 150), (1, 1, 640), (1, 2, 33)])
-def test_attn_lds_resident_vit_shape(ops, B, H, N):
-    """attn_res64_kernel (variant 4): K/V of a (frame, head) resident in LDS; repeated launches screen the counted-vmcnt /
-    barrier schedule of the first pass for races (a ds_read that beats its LDS-DMA returns stale LDS bytes, no fault)."""
-    D = 64
-    qkv = bf(B * N, 3 * H * D, seed=N)
-    g = qkv.to(DEV)
-    st = (N * 3 * H * D, D, 3 * H * D)
-    q, k, v = [t.view(B, N, H, D).transpose(1, 2).float() for t in qkv.view(B * N, 3, H * D).unbind(1)]
-    ref = (torch.softmax(q @ k.transpose(-1, -2) * D ** -0.5, -1) @ v).transpose(1, 2).reshape(B * N, H * D)
-    ops.set_attn_kv_groups(4)
-    try:
-        first = None
-        for it in range(4):
-            o = torch.full((B * N, H * D), float("nan"), dtype=torch.bfloat16, device=DEV)
-            ops.attn_fwd(g, g[:, H * D:], g[:, 2 * H * D:], o, st, st, st, (N * H * D, D, H * D), B, H, N, N, 1, D ** -0.5, False, 0, D)
-            assert rel(o, ref) < TOL_BF16_OUT, it
-            first = o if first is None else first
-            assert torch.equal(o, first), it
-    finally:
-        ops.set_attn_kv_groups(0)
-
-
-@pytest.mark.parametrize("S,nh,nkv", [(1621, 32, 8), (200, 4, 2), (64, 2, 1), (1345, 8, 2), (2973, 32, 8), (450, 28, 4)])
-def test_attn_pipelined_causal_gqa(ops, S, nh, nkv):
-    """attn2p_fwd_kernel (variant 5): software-pipelined tile loop over a three-stage LDS-DMA ring; repeated launches must agree
-    bit for bit (a race between a stage's last reader and its next LDS-DMA would show up as run-to-run differences)."""
-    D, smax = 128, 4096
-    q, kc, vc = bf(S, nh * D), bf(nkv, smax, D), bf(nkv, smax, D, seed=1)
-    qd, kd, vd = q.to(DEV), kc.to(DEV), vc.to(DEV)
-    qf = q.view(S, nh, D).transpose(0, 1).float()
-    kf = kc[:, :S].float().repeat_interleave(nh // nkv, 0)
-    vf = vc[:, :S].float().repeat_interleave(nh // nkv, 0)
-    sc = ((qf @ kf.transpose(1, 2)) * D ** -0.5).masked_fill(torch.triu(torch.ones(S, S, dtype=torch.bool), 1), float("-inf"))
-    ref = (torch.softmax(sc, -1) @ vf).transpose(0, 1).reshape(S, nh * D)
-    ops.set_attn_kv_groups(5)
-    try:
-        first = None
-        for it in range(4):
-            o = torch.full((S, nh * D), float("nan"), dtype=torch.bfloat16, device=DEV)
-            ops.attn_fwd(qd, kd, vd, o, (0, D, nh * D), (0, smax * D, D), (0, smax * D, D), (0, D, nh * D), 1, nh, S, S, nh // nkv, D ** -0.5, True, 0, D)
-            assert rel(o, ref) < TOL_BF16_OUT, it
-            first = o if first is None else first
-            assert torch.equal(o, first), it
-    finally:
-        ops.set_attn_kv_groups(0)

@@ -459,7 +459,11 @@ extern "C" int32_t vl2_attn_fwd(const void* q, const void* k, const void* v, voi
         !ALIGNED16(k) || !ALIGNED16(v) || ((uintptr_t)o & 7))
         return fail(VL2_E_SHAPE, "vl2_attn_fwd: strides must keep 16-byte row alignment");
     if (causal && causal_off < 0) return fail(VL2_E_SHAPE, "vl2_attn_fwd: causal_off must be >= 0");
-    if (variant < 0 || variant > 5) return fail(VL2_E_BADARG, "vl2_attn_fwd: unknown variant %d", variant);
+    if (variant < 0 || variant > 3) return fail(VL2_E_BADARG, "vl2_attn_fwd: unknown variant %d", variant);
+    // auto: the LDS-DMA / transpose-read structure wherever it is built (measured on MI355X, profiles/r02_attn_ab_*.jsonl:
+    // causal D=128 S=945 / 1621 / 2973: 23.3 / 38.1 / 97.7 us vs 26.3 / 43.8 / 106.1 us; ViT D=64 T=8 / 16 / 32: 25.4 / 43.0 / 78.5 vs
+    // 26.9 / 43.8 / 78.1 us); head_dim 96 (SigLIP's padded 72) stays on the register-staged kernel
+    if (variant == 0 && (D == 64 || D == 128)) variant = 3;
     // K / V tiles are fetched through raw buffer resources whose byte offsets and NUM_RECORDS are 32-bit
     if (((int64_t)(nk - 1) * k_rs + D) * 2 >= (int64_t)1 << 31 || ((int64_t)(nk - 1) * v_rs + D) * 2 >= (int64_t)1 << 31)
         return fail(VL2_E_SHAPE, "vl2_attn_fwd: one head's K or V rows span >= 2 GiB (nk %d, row strides %d / %d elements)", nk, k_rs, v_rs);
@@ -468,19 +472,6 @@ extern "C" int32_t vl2_attn_fwd(const void* q, const void* k, const void* v, voi
     dim3 g((nq + 127) / 128, H, B), b(256);
     if (causal) g = dim3(((nq + 127) / 128) * H * B, 1, 1);
     hipStream_t s = ST(stream);
-    if (variant == 5) {                                   // software-pipelined D = 128 form (k_attn2.h attn2p_fwd_kernel)
-        if (D != 128) return fail(VL2_E_SHAPE, "vl2_attn_fwd: variant 5 is built for head_dim 128 (got %d)", D);
-        if (causal) hipLaunchKernelGGL((attn2p_fwd_kernel<true>), g, b, 0, s, a);
-        else hipLaunchKernelGGL((attn2p_fwd_kernel<false>), g, b, 0, s, a);
-        return launched("vl2_attn_fwd");
-    }
-    if (variant == 4) {                                   // K/V of a (batch, head) resident in LDS (k_attn2.h attn_res64_kernel)
-        if (D != 64 || causal || nk > 64 * ATTN_RES_NT) return fail(VL2_E_SHAPE, "vl2_attn_fwd: variant 4 needs head_dim 64, non-causal, nk <= %d (D %d, nk %d)", 64 * ATTN_RES_NT, D, nk);
-        int qsplit = 1;                                   // fewer (batch, head) pairs than CUs: split the q blocks over workgroups
-        while ((long)H * B * qsplit < 256 && qsplit < 4 && qsplit * 8 * 32 < nq) qsplit *= 2;
-        hipLaunchKernelGGL(attn_res64_kernel, dim3(H, B, qsplit), dim3(512), 0, s, a);
-        return launched("vl2_attn_fwd");
-    }
     if (variant == 3) {                                   // second structure (k_attn2.h): LDS-DMA ring + transpose reads
         if (D == 64 && !causal) hipLaunchKernelGGL((attn2_fwd_kernel<64, false>), g, b, 0, s, a);
         else if (D == 64 && causal) hipLaunchKernelGGL((attn2_fwd_kernel<64, true>), g, b, 0, s, a);
