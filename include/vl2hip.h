@@ -184,6 +184,87 @@ int32_t vl2_argmax(const float* logits, int32_t V, int32_t* tok, int32_t* hist, 
 /* out[i,:] = table[ids[i],:]; ids int32 device.  embed_tokens in videollama2/model/videollama2_arch.py:203-220. */
 int32_t vl2_embed_rows(const int32_t* ids, const void* table, void* out, int32_t n, int32_t D, int32_t ldo, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------------------
+ * Stage-level entry points: a whole stage of the hot path in ONE call.  The host loop over the layers runs
+ * inside the library (C++), on the same kernels and through the same argument checks as the per-operator entry points above; a
+ * non-Python host (or a hipGraph capture) drives the path with a handful of calls instead of several hundred.  Same rules: no
+ * allocation, no synchronisation, everything enqueued on `stream`; activations live in a caller-owned workspace whose size the
+ * matching *_workspace_bytes query returns.  The weight structs hold DEVICE pointers to tensors in the packed layouts of
+ * videollama2_amd/weights.py (nn.Linear [N, K] bf16, fused q|k|v, gate/up interleaved for VL2_GEMM_SWIGLU, norm weights folded
+ * into the following projection -- weights.fold_norm); the `layers` arrays themselves are HOST arrays. */
+
+/* CLIP / SigLIP vision tower: frames -> hidden_states[select_layer] (videollama2/model/encoder.py:41-53, :111-123 -> HF
+ * CLIPVisionModel / SiglipVisionModel forward up to the selected layer). */
+typedef struct vl2_vit_layer {
+    const void* wqkv; const float* bqkv; const float* sqkv;      /* layer_norm1 folded: W', W b + c, column sums of W' */
+    const void* wo;   const float* bo;
+    const void* w1;   const float* b1;   const float* s1;        /* layer_norm2 folded into fc1 */
+    const void* w2;   const float* b2;
+} vl2_vit_layer;
+typedef struct vl2_vit_desc {
+    uint32_t size;                 /* sizeof(vl2_vit_desc) */
+    int32_t family;                /* 0 = CLIP (class token + pre_layrnorm, no patch bias), 1 = SigLIP (patch bias, neither) */
+    int32_t image, patch, D, I, heads, head_dim, n_layers, kp;   /* I / head_dim as PACKED (SigLIP: zero-padded), kp = padded 3*patch^2 */
+    int32_t act;                   /* VL2_ACT_QGELU (CLIP) / VL2_ACT_GELU_TANH (SigLIP) */
+    float eps, attn_scale;
+    const void* patch_w; const float* patch_b; const void* pos; const void* cls_pos; const float* pre_w; const float* pre_b;
+    const vl2_vit_layer* layers;   /* host array [n_layers] */
+} vl2_vit_desc;
+int64_t vl2_vit_workspace_bytes(const vl2_vit_desc* w, int32_t T);
+/* frames: frame_dtype 0 fp32 / 1 fp16 / 2 bf16 [T,3,image,image], or 3 = uint8 [T,image,image,3] normalised in the patch-row
+ * kernel with (rescale, mean_rgb[3], std_rgb[3]) (host array of 7 floats, read during the call).  out: bf16
+ * [T * (patches + (family == 0)), D], the class-token row included (the caller drops it for select_feature 'patch'). */
+int32_t vl2_vit_forward(const vl2_vit_desc* w, const void* frames, int32_t frame_dtype, const float* u8_norm7, int32_t T, void* out,
+                        void* ws, int64_t ws_bytes, void* stream);
+
+/* STC connector (videollama2/model/projector.py:189-215; timm RegStage Bottleneck x 4, Conv3d sampler, RegStage x 4, readout MLP):
+ * tower features x [T * hw * hw, cin] bf16 (token-major = channels-last) -> visual tokens out [To * Ho * Wo, C] bf16. */
+typedef struct vl2_stc_block {
+    const void* conv1_w; const float* bn1_w; const float* bn1_b;
+    const float* dw_w;   const float* bn2_w; const float* bn2_b;     /* depthwise 3x3 taps [9][C] fp32 */
+    const void* fc1_w; const float* fc1_b; const void* fc2_w; const float* fc2_b;   /* SE: [rd, C], [C, rd] */
+    const void* conv3_w; const float* bn3_w; const float* bn3_b;
+    const void* ds_w; const float* dsbn_w; const float* dsbn_b;      /* 1x1 shortcut (first block of s1 only) or NULL */
+    int32_t rd;                                                      /* SE reduction width */
+} vl2_stc_block;
+typedef struct vl2_stc_desc {
+    uint32_t size;
+    int32_t cin, C;                /* tower width, connector / LLM width */
+    vl2_stc_block s1[4], s2[4];
+    const void* samp_w; const float* samp_b;                         /* Conv3d as [C, 8*C], K order (kt, kh, kw, cin) */
+    const void* ro0_w; const float* ro0_b; const void* ro2_w; const float* ro2_b;
+} vl2_stc_desc;
+int64_t vl2_stc_workspace_bytes(const vl2_stc_desc* w, int32_t T, int32_t hw, int32_t n_out);
+/* conv3d_idx: device int32 [8][n_out] gather table of the Conv3d(k2, s2, padding 1 | 0) taps (row of the s1 output per tap and
+ * output position, -1 = zero padding; videollama2_amd/connector.py conv3d_k2s2p1_index), n_out = To*Ho*Wo. */
+int32_t vl2_stc_forward(const vl2_stc_desc* w, const void* x, int32_t T, int32_t hw, const int32_t* conv3d_idx, int32_t To, int32_t Ho,
+                        int32_t Wo, void* out, void* ws, int64_t ws_bytes, void* stream);
+
+/* Mistral / Qwen2 decoder (HF:models/mistral/modeling_mistral.py MistralModel.forward + lm_head; Qwen2: q/k/v bias). */
+typedef struct vl2_llm_layer {
+    const void* wqkv; const float* bqkv;     /* input_layernorm folded into the columns; bqkv NULL for Mistral */
+    const void* wo;
+    const void* wgu;                         /* post_attention_layernorm folded; gate/up interleaved (VL2_GEMM_SWIGLU) */
+    const void* wd;
+    void* kcache; void* vcache;              /* [kv_heads][smax][128] bf16 */
+} vl2_llm_layer;
+typedef struct vl2_llm_desc {
+    uint32_t size;
+    int32_t D, I, heads, kv_heads, n_layers, vocab, smax;        /* head_dim is 128; I as packed */
+    float eps;
+    const vl2_llm_layer* layers;   /* host array [n_layers] */
+    const void* embed; const float* norm_w; const float* ones /* [D] of 1.0f */; const void* lm_head;
+    const float* cos_t; const float* sin_t;                      /* fp32 [smax][64] */
+} vl2_llm_desc;
+int64_t vl2_llm_workspace_bytes(const vl2_llm_desc* w, int32_t S);
+/* Prefill: inputs_embeds x [S, D] bf16 -> K/V cache rows 0..S-1 of every layer, fp32 logits of the LAST position [vocab]. */
+int32_t vl2_llm_prefill(const vl2_llm_desc* w, const void* x, int32_t S, float* logits_last, void* ws, int64_t ws_bytes, void* stream);
+/* One greedy decode step, hipGraph-replayable (everything that moves lives on the device): tok = argmax(logits) (also written
+ * to hist[state[1]]; state = {position, step} advance by one), then the token's forward at position state[0] -> logits of the
+ * next step (in place).  partial: fp32 [heads * ceil(smax/64) * 130].  HF:generation/utils.py _sample, do_sample=False. */
+int32_t vl2_llm_decode_step(const vl2_llm_desc* w, float* logits, int32_t* tok, int32_t* state, int32_t* hist, float* partial,
+                            void* ws, int64_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -4,9 +4,11 @@ Times the REAL reference (`Videollama2MistralForCausalLM`, imported in place thr
 shims of SURVEY.md 8c) on this container's host cores on the workload of BASELINE.json configs[1] -- VideoLLaMA2-7B
 architecture, random-init weights, one synthetic 16-frame 336^2 video, S = 1621 prefill, greedy decode -- in the three
 windows SURVEY.md 8(d) names:
-    encode  = model.encode_images_or_videos([(frames, 'video')])          (CLIP tower incl. its discarded 24th layer + STC)
-    prefill = generate(max_new_tokens=1) - encode                          (splice + 32-layer prefill + lm_head + argmax)
-    decode  = (generate(max_new_tokens=1+n) - generate(max_new_tokens=1)) / n
+    encode  = start of generate() .. first call of the decoder stack      (CLIP tower incl. its discarded 24th layer + STC + splice)
+    prefill = first decoder-stack call .. second decoder-stack call       (32-layer prefill + lm_head + argmax + generate's bookkeeping)
+    decode  = (second decoder-stack call .. end of generate()) / n        (n greedy steps)
+all read off ONE `generate(max_new_tokens=1+n)` call through forward hooks on `model.get_model()` (MistralModel.forward): two
+separately timed generate calls differ by more than a decode step on a shared host, hooks do not.
 The result is committed as profiles/r02_cpu_reference.json and cited by bench.py's `cpu_baseline.reference_build_box`
 (the GPU box has no /root/reference, so there bench.py times the port, oracle/vl2_oracle.py, instead).
 

@@ -14,6 +14,12 @@ def emulated_backend():
     lib.vl2_version.restype = ctypes.c_int32
     lib.vl2_last_error_string.restype = ctypes.c_char_p
     lib.vl2_workspace_bytes.restype = ctypes.c_int64
+    lib.vl2_vit_workspace_bytes.restype = ctypes.c_int64
+    lib.vl2_vit_workspace_bytes.argtypes = [ctypes.POINTER(_lib.VitDesc), ctypes.c_int32]
+    lib.vl2_stc_workspace_bytes.restype = ctypes.c_int64
+    lib.vl2_stc_workspace_bytes.argtypes = [ctypes.POINTER(_lib.StcDesc), ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]
+    lib.vl2_llm_workspace_bytes.restype = ctypes.c_int64
+    lib.vl2_llm_workspace_bytes.argtypes = [ctypes.POINTER(_lib.LlmDesc), ctypes.c_int32]
     for name, args in _lib.SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = ctypes.c_int32

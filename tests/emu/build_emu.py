@@ -13,7 +13,7 @@ OUT = os.path.join(HERE, "_emu_kernels.so")
 
 
 def build(force=False):
-    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
     deps = srcs + [os.path.join(HERE, "hip_emu.h"), os.path.join(HERE, "emu_kernels.cpp")]
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) > os.path.getmtime(d) for d in deps):
         return OUT

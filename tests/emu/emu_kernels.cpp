@@ -325,3 +325,14 @@ extern "C" int32_t vl2_embed_rows(const int32_t* ids, const void* table, void* o
     emu::launch(dim3(n), dim3(128), [=] { embed_rows_kernel(ids, (const bf16_t*)table, (bf16_t*)out, D, ldo); });
     return 0;
 }
+
+#include <cstdarg>
+#include <cstdio>
+static int32_t fail(int32_t code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#include "vl2_stage.inc"

@@ -573,6 +573,49 @@ def test_emu_padded_batch_generate_and_forward_with_images(emu, golden_small):
         assert ours.tolist() == ref.tolist()
 
 
+@pytest.mark.parametrize("family", ["v2", "v21"])
+def test_emu_stage_level_entry_points_equal_the_per_operator_path(emu, golden_small, golden_small_v21, family):
+    """include/vl2hip.h stage-level entry points (vl2_vit_forward, vl2_stc_forward, vl2_llm_prefill, vl2_llm_decode_step): the layer loops run
+    inside the library; their results must be bit-identical to the per-operator host loops of tower.py / decoder.py (same kernels,
+    same order), for both families, float and uint8 frames."""
+    from videollama2_amd import ops
+    from videollama2_amd.model import VideoLLaMA2Hip
+    g = golden_small if family == "v2" else golden_small_v21
+    cfg = g["cfg"]
+    m = VideoLLaMA2Hip(cfg, O.seeded_state_dict(cfg, g["seed"]), "cpu", max_seq_len=64)
+    try:
+        outs = {}
+        for stage in (True, False):
+            ops.STAGE_ABI = stage
+            tower = m.vision_tower(g["frames"])
+            tower_u8 = m.vision_tower(g["frames_u8"])
+            vis = m.mm_projector(tower.unsqueeze(0))
+            logits = m.decoder.prefill(g["inputs_embeds"]).clone()
+            m.decoder.state.copy_(torch.tensor([m.decoder.pos - 1, 0], dtype=torch.int32))
+            steps = []
+            for _ in range(3):
+                if stage:
+                    d, _, ws = m.decoder._stage_desc()
+                    ops.llm_decode_step(d, m.decoder.logits, m.decoder.tok, m.decoder.state, m.decoder.hist, m.decoder.partial, ws)
+                else:
+                    ops.argmax(m.decoder.logits, m.decoder.tok, m.decoder.hist, 0, m.decoder.state)
+                    m.decoder._decode_kernels(dyn=True)
+                steps.append((int(m.decoder.tok), m.decoder.logits.clone()))
+            outs[stage] = (tower, tower_u8, logits, steps, m.decoder.state.clone(), m.decoder.hist[:3].clone(), vis)
+        a, b = outs[True], outs[False]
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+        assert [t for t, _ in a[3]] == [t for t, _ in b[3]]         # (the golden step-0 margin is 4e-3: tokens are only compared between the paths)
+        assert all(torch.equal(x[1], y[1]) for x, y in zip(a[3], b[3])) and torch.equal(a[4], b[4]) and torch.equal(a[5], b[5])
+        assert torch.equal(a[6], b[6]) and rel(a[6][0], g["mm_features"]) < 2.5e-2
+        assert rel(a[0], g["tower_out"]) < 1.2e-2
+        from videollama2_amd._lib import Vl2HipError
+        d, _, ws = m.decoder._stage_desc()
+        with pytest.raises(Vl2HipError, match="exceeds the KV cache"):
+            ops.llm_prefill(d, torch.zeros(65, cfg["llm"]["hidden_size"], dtype=torch.bfloat16), m.decoder.logits)
+    finally:
+        ops.STAGE_ABI = True
+
+
 def test_emu_gemv_batched_matches_single_row(emu):
     """Multi-row GEMV (batched decode): every row must equal the single-row kernel's result for that row, with the fused
     RMSNorm / bias / residual / SwiGLU variants, strided rows, and a batch that needs splitting."""

@@ -20,11 +20,52 @@ class GemmDesc(ctypes.Structure):
                 ("ws", _vp), ("ws_bytes", _i64), ("variant", _i32)]
 
 
+class VitLayer(ctypes.Structure):
+    """include/vl2hip.h `vl2_vit_layer`."""
+    _fields_ = [(n, _vp) for n in ("wqkv", "bqkv", "sqkv", "wo", "bo", "w1", "b1", "s1", "w2", "b2")]
+
+
+class VitDesc(ctypes.Structure):
+    """include/vl2hip.h `vl2_vit_desc`."""
+    _fields_ = [("size", ctypes.c_uint32), ("family", _i32), ("image", _i32), ("patch", _i32), ("D", _i32), ("I", _i32), ("heads", _i32),
+                ("head_dim", _i32), ("n_layers", _i32), ("kp", _i32), ("act", _i32), ("eps", _f32), ("attn_scale", _f32),
+                ("patch_w", _vp), ("patch_b", _vp), ("pos", _vp), ("cls_pos", _vp), ("pre_w", _vp), ("pre_b", _vp),
+                ("layers", ctypes.POINTER(VitLayer))]
+
+
+class StcBlock(ctypes.Structure):
+    """include/vl2hip.h `vl2_stc_block`."""
+    _fields_ = [(n, _vp) for n in ("conv1_w", "bn1_w", "bn1_b", "dw_w", "bn2_w", "bn2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b",
+                                   "conv3_w", "bn3_w", "bn3_b", "ds_w", "dsbn_w", "dsbn_b")] + [("rd", _i32)]
+
+
+class StcDesc(ctypes.Structure):
+    """include/vl2hip.h `vl2_stc_desc`."""
+    _fields_ = [("size", ctypes.c_uint32), ("cin", _i32), ("C", _i32), ("s1", StcBlock * 4), ("s2", StcBlock * 4),
+                ("samp_w", _vp), ("samp_b", _vp), ("ro0_w", _vp), ("ro0_b", _vp), ("ro2_w", _vp), ("ro2_b", _vp)]
+
+
+class LlmLayer(ctypes.Structure):
+    """include/vl2hip.h `vl2_llm_layer`."""
+    _fields_ = [(n, _vp) for n in ("wqkv", "bqkv", "wo", "wgu", "wd", "kcache", "vcache")]
+
+
+class LlmDesc(ctypes.Structure):
+    """include/vl2hip.h `vl2_llm_desc`."""
+    _fields_ = [("size", ctypes.c_uint32), ("D", _i32), ("I", _i32), ("heads", _i32), ("kv_heads", _i32), ("n_layers", _i32), ("vocab", _i32),
+                ("smax", _i32), ("eps", _f32), ("layers", ctypes.POINTER(LlmLayer)), ("embed", _vp), ("norm_w", _vp), ("ones", _vp),
+                ("lm_head", _vp), ("cos_t", _vp), ("sin_t", _vp)]
+
+
 # name -> argtypes (all return int32 except the two below)
 SIGNATURES = {
     "vl2_gemm": [ctypes.POINTER(GemmDesc), _vp],
     "vl2_row_stats": [_vp, _vp, _i32, _i32, _i32, _vp],
     "vl2_row_norm_finalize": [_vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp],
+    "vl2_vit_forward": [ctypes.POINTER(VitDesc), _vp, _i32, _vp, _i32, _vp, _vp, _i64, _vp],
+    "vl2_stc_forward": [ctypes.POINTER(StcDesc), _vp, _i32, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _i64, _vp],
+    "vl2_llm_prefill": [ctypes.POINTER(LlmDesc), _vp, _i32, _vp, _vp, _i64, _vp],
+    "vl2_llm_decode_step": [ctypes.POINTER(LlmDesc), _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
     "vl2_layernorm": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp],
     "vl2_rmsnorm": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp],
     "vl2_patchify": [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
@@ -45,7 +86,7 @@ SIGNATURES = {
     "vl2_argmax": [_vp, _i32, _vp, _vp, _i32, _vp, _vp],
     "vl2_embed_rows": [_vp, _vp, _vp, _i32, _i32, _i32, _vp],
 }
-EXPORTS = ["vl2_version", "vl2_last_error_string", "vl2_workspace_bytes"] + list(SIGNATURES)
+EXPORTS = ["vl2_version", "vl2_last_error_string", "vl2_workspace_bytes", "vl2_vit_workspace_bytes", "vl2_stc_workspace_bytes", "vl2_llm_workspace_bytes"] + list(SIGNATURES)
 
 _lib = None
 
@@ -69,6 +110,12 @@ def load():
     lib.vl2_last_error_string.argtypes = []
     lib.vl2_workspace_bytes.restype = _i64
     lib.vl2_workspace_bytes.argtypes = []
+    lib.vl2_vit_workspace_bytes.restype = _i64
+    lib.vl2_vit_workspace_bytes.argtypes = [ctypes.POINTER(VitDesc), _i32]
+    lib.vl2_stc_workspace_bytes.restype = _i64
+    lib.vl2_stc_workspace_bytes.argtypes = [ctypes.POINTER(StcDesc), _i32, _i32, _i32]
+    lib.vl2_llm_workspace_bytes.restype = _i64
+    lib.vl2_llm_workspace_bytes.argtypes = [ctypes.POINTER(LlmDesc), _i32]
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = _i32

@@ -49,6 +49,19 @@ class HipSTCConnector(nn.Module):
         if self._dev.type == "cuda":
             ops.attach_workspace(self._dev)       # split-K (opt-in, ops.set_splitk): Conv3d taps, s2 on few output frames
         self._idx_cache = {}
+        self._stage = None
+
+    def _forward_stage(self, rows, t, hw):
+        """One C call for the whole connector (include/vl2hip.h vl2_stc_forward): the same launches as run_s1 / run_sampler /
+        run_s2_readout, issued inside libvl2hip.so."""
+        if self._stage is None:
+            self._stage = ops.stc_desc(self.w)
+        key = (t, hw, None, 0, None)
+        if key not in self._idx_cache:
+            self._idx_cache[key] = conv3d_k2s2p1_index(t, hw, hw, self._dev, padding=self.padding)
+        idx, dims = self._idx_cache[key]
+        out = torch.empty((dims[0] * dims[1] * dims[2], self.w["ro2_w"].shape[0]), dtype=torch.bfloat16, device=self._dev)
+        return ops.stc_forward(self._stage[0], rows, t, hw, idx, dims, out)
 
     def _bottleneck(self, x, b, F, H, W):
         HW = H * W
@@ -100,6 +113,9 @@ class HipSTCConnector(nn.Module):
         x = x.to(device=self._dev, dtype=torch.bfloat16).contiguous()
         outs, stages = [], {}
         for bi in range(b):
+            if ops.stage_enabled() and not return_stages:
+                outs.append(self._forward_stage(x[bi].reshape(t * l, d), t, hw))
+                continue
             s1 = self.run_s1(x[bi].reshape(t * l, d), t, hw)
             samp, (To, Ho, Wo) = self.run_sampler(s1, t, hw)
             h, s2 = self.run_s2_readout(samp, To, Ho, Wo, return_s2=True)

@@ -11,7 +11,7 @@ SRC = os.path.join(HERE, "vl2_abi.hip")
 
 
 def _deps():
-    return [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith((".h", ".hip"))] + \
+    return [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith((".h", ".hip", ".inc"))] + \
            [os.path.join(os.path.dirname(PKG), "include", "vl2hip.h")]
 
 

@@ -651,3 +651,5 @@ extern "C" int32_t vl2_embed_rows(const int32_t* ids, const void* table, void* o
     hipLaunchKernelGGL(embed_rows_kernel, dim3(n), dim3(128), 0, ST(stream), ids, (const bf16_t*)table, (bf16_t*)out, D, ldo);
     return launched("vl2_embed_rows");
 }
+
+#include "vl2_stage.inc"

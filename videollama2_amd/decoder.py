@@ -56,6 +56,18 @@ class HipMistralDecoder(nn.Module):
         self.logits = torch.empty((self.V,), dtype=torch.float32, device=self._dev)
         self.graph = None
         self.pos = 0
+        self._stage = None                  # (vl2_llm_desc, keepalive, decode workspace): prefill / decode step as ONE C call each
+
+    def _stage_desc(self):
+        if self._stage is None:
+            d, keep = ops.llm_desc(self.w, self.cfg["llm"], self.nh, self.nkv, self.max_seq_len, self.eps, self.kcache, self.vcache,
+                                   self.cos_t, self.sin_t)
+            ws, _ = ops._llm_ws(d, 1, self._dev)
+            self._stage = (d, keep, ws)
+        return self._stage
+
+    def _use_stage(self, cache=None):
+        return ops.stage_enabled() and self.tp == 1 and cache is None
 
     def _reduce(self, t):
         """Sum the row-parallel partial results over the tensor-parallel group (no-op without one).  gloo (CPU tests, debug)
@@ -92,6 +104,12 @@ class HipMistralDecoder(nn.Module):
         if S > self.max_seq_len:
             raise ValueError(f"sequence length {S} exceeds the KV cache ({self.max_seq_len})")
         x = x.to(device=self._dev, dtype=torch.bfloat16).contiguous()
+        if self._use_stage(cache) and not return_all_logits:      # the whole prefill as one call into libvl2hip.so (vl2_llm_prefill)
+            out = self.logits if logits_out is None else logits_out
+            ops.llm_prefill(self._stage_desc()[0], x, out)
+            self.pos = S
+            self.last_hidden = None
+            return out
         nh, nkv, hd, D = self.nh, self.nkv, self.hd, self.D
         q = torch.empty((S, nh * hd), dtype=torch.bfloat16, device=self._dev)
         o = torch.empty((S, nh * hd), dtype=torch.bfloat16, device=self._dev)
@@ -155,16 +173,22 @@ class HipMistralDecoder(nn.Module):
         saved = (self.state.clone(), self.tok.clone(), self.logits.clone(), self.hist[:2].clone())
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
+        def one_step():                                       # argmax + the token's forward: ONE call into libvl2hip.so
+            if self._use_stage():
+                d, _, ws = self._stage_desc()
+                ops.llm_decode_step(d, self.logits, self.tok, self.state, self.hist, self.partial, ws)
+            else:
+                ops.argmax(self.logits, self.tok, self.hist, 0, self.state)
+                self._decode_kernels(dyn=True)
+
         with torch.cuda.stream(side):                       # warm-up outside capture (first-launch attribute calls etc.)
             self.state.copy_(torch.tensor([max(self.pos - 1, 0), 0], dtype=torch.int32))
-            ops.argmax(self.logits, self.tok, self.hist, 0, self.state)
-            self._decode_kernels(dyn=True)
+            one_step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, capture_error_mode="thread_local"):   # a RCCL watchdog thread may be polling events
-            ops.argmax(self.logits, self.tok, self.hist, 0, self.state)
-            self._decode_kernels(dyn=True)
+            one_step()
         self.state.copy_(saved[0]); self.tok.copy_(saved[1]); self.logits.copy_(saved[2]); self.hist[:2].copy_(saved[3])
         torch.cuda.synchronize()
         self.graph = g

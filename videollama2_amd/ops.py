@@ -308,3 +308,101 @@ def argmax(logits, tok, hist=None, step=0, state=None):
 def embed_rows(ids_i32, table, out):
     _lib.call("vl2_embed_rows", _p(ids_i32), _p(table), _p(out), ids_i32.numel(), table.shape[1], out.stride(0), _stream())
     return out
+
+
+# ------------------------------------------------------------------------------------------------ stage-level entry points
+# One C call per stage (include/vl2hip.h vl2_vit_forward / vl2_llm_prefill / vl2_llm_decode_step): the layer loop runs inside
+# libvl2hip.so.  The descriptors hold raw device pointers, so every builder returns (desc, keepalive): the caller keeps
+# `keepalive` (the tensors and the ctypes layer array) referenced for as long as the descriptor is used.
+STAGE_ABI = True        # the towers / connector / decoder use the stage calls ...
+
+
+def stage_enabled():
+    """... unless a per-GEMM profile is being taken (ops.PROFILE) or one of the per-call experiment controls (forced GEMM
+    variant, split-K, forced attention variant: set_gemm_variant / set_splitk / set_attn_kv_groups) is on: those are arguments of
+    the per-operator entry points, the stage calls always use the library's own choice."""
+    return STAGE_ABI and PROFILE is None and not (_CTL["variant"] or _CTL["splitk"] or _CTL["attn_variant"])
+
+
+def vit_desc(w, v, family, act):
+    """weights.pack_tower / pack_siglip_tower dict + vision config -> (_lib.VitDesc, keepalive)."""
+    layers = (_lib.VitLayer * len(w["layers"]))()
+    for i, lw in enumerate(w["layers"]):
+        for n in ("wqkv", "bqkv", "sqkv", "wo", "bo", "w1", "b1", "s1", "w2", "b2"):
+            setattr(layers[i], n, _p(lw[n]))
+    nh = v["num_attention_heads"]
+    hd_real = v["hidden_size"] // nh
+    d = _lib.VitDesc(ctypes.sizeof(_lib.VitDesc), family, v["image_size"], v["patch_size"], v["hidden_size"], w["layers"][0]["w1"].shape[0], nh,
+                     w.get("hdp", hd_real), len(w["layers"]), w["kp"], act, float(v["layer_norm_eps"]), float(hd_real ** -0.5),
+                     _p(w["patch_w"]), _p(w.get("patch_b")), _p(w["pos"]), _p(w.get("cls_pos")), _p(w.get("pre_w")), _p(w.get("pre_b")), layers)
+    return d, (layers, w)
+
+
+def vit_forward(desc, frames, T, out, u8_norm=None):
+    """frames [T,3,S,S] fp32 / fp16 / bf16 or uint8 [T,S,S,3] -> out [T * tokens, D] bf16 (class-token row included)."""
+    code = 3 if frames.dtype == torch.uint8 else {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}[frames.dtype]
+    n = int(_lib.load().vl2_vit_workspace_bytes(ctypes.byref(desc), T))
+    if n < 0:
+        raise _lib.Vl2HipError("vl2_vit_workspace_bytes: bad descriptor")
+    ws = torch.empty((n,), dtype=torch.uint8, device=out.device)
+    nrm = (ctypes.c_float * 7)(*[float(x) for x in u8_norm]) if u8_norm is not None else None
+    _lib.call("vl2_vit_forward", ctypes.byref(desc), _p(frames), code, ctypes.addressof(nrm) if nrm is not None else None, T, _p(out),
+              _p(ws), n, _stream())
+    return out
+
+
+def stc_desc(w):
+    """weights.pack_connector dict -> (_lib.StcDesc, keepalive)."""
+    d = _lib.StcDesc()
+    d.size = ctypes.sizeof(_lib.StcDesc)
+    d.cin, d.C = w["s1"][0]["conv1_w"].shape[1], w["s1"][0]["conv1_w"].shape[0]
+    for stage, blocks in (("s1", d.s1), ("s2", d.s2)):
+        for i, b in enumerate(w[stage]):
+            for n, _t in _lib.StcBlock._fields_[:-1]:
+                setattr(blocks[i], n, _p(b.get(n)))
+            blocks[i].rd = b["fc1_w"].shape[0]
+    for n in ("samp_w", "samp_b", "ro0_w", "ro0_b", "ro2_w", "ro2_b"):
+        setattr(d, n, _p(w[n]))
+    return d, (w,)
+
+
+def stc_forward(desc, x, T, hw, idx, dims, out):
+    """x [T*hw*hw, cin] bf16 tower features -> out [To*Ho*Wo, C] bf16 (idx, dims from connector.conv3d_k2s2p1_index)."""
+    _chk(x, BF16, "x"); _chk(out, BF16, "out"); _chk(idx, torch.int32, "idx")
+    To, Ho, Wo = dims
+    n = int(_lib.load().vl2_stc_workspace_bytes(ctypes.byref(desc), T, hw, To * Ho * Wo))
+    if n < 0:
+        raise _lib.Vl2HipError("vl2_stc_workspace_bytes: bad descriptor")
+    ws = torch.empty((n,), dtype=torch.uint8, device=out.device)
+    _lib.call("vl2_stc_forward", ctypes.byref(desc), _p(x), T, hw, _p(idx), To, Ho, Wo, _p(out), _p(ws), n, _stream())
+    return out
+
+
+def llm_desc(w, cfg_llm, nh, nkv, smax, eps, kcache, vcache, cos_t, sin_t):
+    """weights.pack_decoder dict + this decoder's caches -> (_lib.LlmDesc, keepalive)."""
+    layers = (_lib.LlmLayer * len(w["layers"]))()
+    for i, lw in enumerate(w["layers"]):
+        layers[i].wqkv, layers[i].bqkv, layers[i].wo = _p(lw["wqkv"]), _p(lw["bqkv"]), _p(lw["wo"])
+        layers[i].wgu, layers[i].wd = _p(lw["wgu"]), _p(lw["wd"])
+        layers[i].kcache, layers[i].vcache = _p(kcache[i]), _p(vcache[i])
+    d = _lib.LlmDesc(ctypes.sizeof(_lib.LlmDesc), cfg_llm["hidden_size"], w["layers"][0]["wd"].shape[1], nh, nkv, len(w["layers"]),
+                     w["lm_head"].shape[0], smax, float(eps), layers, _p(w["embed"]), _p(w["norm_w"]), _p(w["ones"]), _p(w["lm_head"]),
+                     _p(cos_t), _p(sin_t))
+    return d, (layers, w, kcache, vcache)
+
+
+def _llm_ws(desc, S, device):
+    n = int(_lib.load().vl2_llm_workspace_bytes(ctypes.byref(desc), S))
+    if n < 0:
+        raise _lib.Vl2HipError("vl2_llm_workspace_bytes: bad descriptor")
+    return torch.empty((n,), dtype=torch.uint8, device=device), n
+
+
+def llm_prefill(desc, x, logits_out):
+    ws, n = _llm_ws(desc, x.shape[0], x.device)
+    _lib.call("vl2_llm_prefill", ctypes.byref(desc), _p(x), x.shape[0], _p(logits_out), _p(ws), n, _stream())
+    return logits_out
+
+
+def llm_decode_step(desc, logits, tok, state, hist, partial, ws):
+    _lib.call("vl2_llm_decode_step", ctypes.byref(desc), _p(logits), _p(tok), _p(state), _p(hist), _p(partial), _p(ws), ws.numel(), _stream())

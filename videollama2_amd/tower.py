@@ -46,9 +46,31 @@ class HipCLIPVisionTower(nn.Module):
         # power-limited, idle CUs in a GEMM's last round already return their power to the busy ones) -> default 1.
         self.streams = 1
         self._side = None
+        self._stage = None                  # (vl2_vit_desc, keepalive): the whole tower as ONE C call (ops.vit_forward)
 
     _pack = staticmethod(pack_tower)
     _cls_tokens = 1                     # rows per frame in front of the patches (CLIP: the CLS token)
+    _stage_family, _stage_act = 0, ops.ACT_QGELU
+
+    def _hidden_stage(self, images, T, u8, out):
+        """The stage-level entry point (include/vl2hip.h vl2_vit_forward): patch embedding + every encoder layer in one call into
+        libvl2hip.so -- the same kernels in the same order as `_hidden` below (asserted bit-identical in the tests)."""
+        v = self.cfg["vision"]
+        if self._stage is None:
+            self._stage = ops.vit_desc(self.w, v, self._stage_family, self._stage_act)
+        N1 = (v["image_size"] // v["patch_size"]) ** 2 + self._cls_tokens
+        if out is None:
+            out = torch.empty((T * N1, v["hidden_size"]), dtype=torch.bfloat16, device=self._dev)
+        nrm = None
+        if u8:
+            ip = self.image_processor
+            rescale, mean, std = self._default_norm
+            if ip is not None:
+                rescale, mean, std = getattr(ip, "rescale_factor", rescale), getattr(ip, "image_mean", mean), getattr(ip, "image_std", std)
+            nrm = [rescale, *mean, *std]
+        ops.vit_forward(self._stage[0], images.contiguous(), T, out, nrm)
+        return out, T, N1
+
     _default_norm = (1 / 255, (0.48145466, 0.4578275, 0.40821073), (0.26862954, 0.26130258, 0.27577711))   # openai/clip preprocessor
 
     @staticmethod
@@ -127,6 +149,8 @@ class HipCLIPVisionTower(nn.Module):
         if H != v["image_size"] or W != v["image_size"]:                          # HF:modeling_clip.py:203-207
             raise ValueError(f"Input image size ({H}*{W}) doesn't match model ({v['image_size']}*{v['image_size']}).")
         images = images.to(self._dev)
+        if ops.stage_enabled() and images.dtype in (torch.float32, torch.float16, torch.bfloat16, torch.uint8):
+            return self._hidden_stage(images, T, u8, out)
         w = self.w
         D, P = v["hidden_size"], v["patch_size"]
         G = H // P
@@ -191,6 +215,7 @@ class HipSiglipVisionTower(HipCLIPVisionTower):
     (weights.pack_siglip_tower)."""
     _pack = staticmethod(pack_siglip_tower)
     _cls_tokens = 0
+    _stage_family, _stage_act = 1, ops.ACT_GELU_TANH
     _default_norm = (1 / 255, (0.5, 0.5, 0.5), (0.5, 0.5, 0.5))                  # google/siglip-so400m-patch14-384 preprocessor
 
     def __init__(self, cfg, state_dict, device="cuda", select_feature="patch", image_processor=None,
@@ -205,6 +230,8 @@ class HipSiglipVisionTower(HipCLIPVisionTower):
         if H != v["image_size"] or W != v["image_size"]:                          # HF:modeling_siglip.py SiglipVisionEmbeddings
             raise ValueError(f"Input image size ({H}*{W}) doesn't match model ({v['image_size']}*{v['image_size']}).")
         images = images.to(self._dev)
+        if ops.stage_enabled() and images.dtype in (torch.float32, torch.float16, torch.bfloat16, torch.uint8):
+            return self._hidden_stage(images, T, u8, out)
         w = self.w
         D, P, nh = v["hidden_size"], v["patch_size"], v["num_attention_heads"]
         G = H // P
