@@ -166,6 +166,8 @@ def main():
     ap.add_argument("--tp", action="store_true", help="with --gpus N > 1: shard the LLM decoder tensor-parallel over the N ranks "
                                                       "(BASELINE.json configs[3]); default keeps the decoder replicated like the reference")
     ap.add_argument("--no-graph", action="store_true", help="eager decode loop instead of hipGraph replay")
+    ap.add_argument("--no-encoder-graph", action="store_true",
+                    help="with --gpus N > 1: launch the rank-local encoder pieces kernel by kernel instead of replaying their two hipGraphs")
     ap.add_argument("--vit-streams", type=int, default=None, help="ViT frames as N chunks on N HIP streams (default: the tower's own, 3)")
     ap.add_argument("--tune", type=str, default="", help="debug: comma list of gemm=<variant>, splitk=<0|1>, attn=<variant> (videollama2_amd/ops.py launch controls)")
     args = ap.parse_args()
@@ -205,10 +207,11 @@ def main():
         sd = random_state_dict(cfg, dev, seed=1234, n_llm_layers=args.llm_layers)
     tp_group = dist.group.WORLD if (args.tp and world > 1) else None
     model = VideoLLaMA2Hip(cfg, sd, dev, max_seq_len=4096, n_llm_layers=args.llm_layers, tp_group=tp_group)
-    if tp_group is not None:
-        args.no_graph = True                       # collectives inside the decode step: eager launches
+    if tp_group is not None and backend != "nccl":
+        args.no_graph = True                       # gloo debug mode: the all-reduces are staged through the host, not capturable
     del sd
     torch.cuda.empty_cache()
+    model.sharder.use_graph = world > 1 and not args.no_encoder_graph     # rank-local ViT + s1 | conv3d + s2 + readout as two graphs
     if args.vit_streams is not None:
         model.vision_tower.streams = args.vit_streams
 
@@ -396,10 +399,10 @@ def main():
                                     f"bf16, S={S} prefill, {n_new} greedy decode tokens (BASELINE.json configs[3] without the TP=8 split)" if args.model == "72b" else
                                     f"VideoLLaMA2.1-7B-16F (SigLIP-so400m-384 + stc_connector_v35 + Qwen2-7B), {T}-frame 384^2 video, bf16, "
                                     f"S={S} prefill, {n_new} greedy decode tokens (SURVEY 8f row 1; not BASELINE.json's metric config)"), "frames": T, "prefill_tokens": S, "new_tokens": n_new,
-                       "parallelism": (f"frames sharded over {world} ranks (ViT + STC s1/conv3d/s2 per rank, halo + RCCL all-gather of visual tokens); "
+                       "parallelism": (f"frames sharded over {world} ranks (ViT + STC s1/conv3d/s2 per rank{' replayed from two hipGraphs' if model.sharder.use_graph else ''}, halo + RCCL all-gather of visual tokens); "
                                        f"LLM {'tensor-parallel over the ranks' if args.tp else 'replicated'}" if world > 1 else "single GPU"),
                        "llm_layers": len(model.decoder.w["layers"]),
-                       "decode": "eager launches" if graph is None else "hipGraph replay (argmax + 32-layer step per token)"},
+                       "decode": "eager launches" if graph is None else ("hipGraph replay (argmax + 32-layer step per token" + (", RCCL all-reduces captured)" if tp_group is not None else ")"))},
             "encode_ms": round(enc_ms, 3), "prefill_ms": round(pre_ms, 3), "decode_ms_per_token": round(dec_ms / n_new, 4),
             "prefill_tokens_per_s": round(S / (pre_ms / 1e3), 1), "decode_tokens_per_s": round(n_new / (dec_ms / 1e3), 2),
             "forward_tflop": round(vit_tf + stc_tf + pre_tf, 3),

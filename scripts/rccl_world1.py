@@ -17,6 +17,7 @@ import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+from videollama2_amd.dist import FrameSharder  # noqa: E402
 
 
 def timed(fn, iters):
@@ -44,7 +45,6 @@ def main():
     out["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else None
     bf = dict(dtype=torch.bfloat16, device=dev)
     # ---- the sharder's collectives, through the product code (force the collective path at world 1)
-    from videollama2_amd.dist import FrameSharder
     sh = FrameSharder()
     send = torch.randn((4, 576, 1024), **bf)
     recv = torch.empty((4, 576, 1024), **bf)
@@ -88,8 +88,52 @@ def main():
         out["graph_capture_of_all_reduce"] = "ok"
     except Exception as exc:
         out["graph_capture_of_all_reduce"] = "failed: " + repr(exc)[:300]
+    # ---- product paths on a small configuration (same code as the 7B model, narrow widths)
+    try:
+        out.update(product_checks(dev))
+    except Exception as exc:
+        out["product_checks_error"] = repr(exc)[:400]
     dist.destroy_process_group()
     print(json.dumps(out), flush=True)
+
+
+def product_checks(dev):
+    """(1) tensor-parallel decode step with its RCCL all-reduces CAPTURED in the decode hipGraph (group of one rank, reduces forced):
+    tokens equal to the plain eager decoder.  (2) the rank-local encoder pieces replayed from their two hipGraphs (every rank's
+    share run in this process): bit-identical to the eager launches, with timings of both."""
+    from videollama2_amd.connector import HipSTCConnector
+    from videollama2_amd.decoder import HipMistralDecoder
+    from videollama2_amd.tower import HipCLIPVisionTower
+    from videollama2_amd.weights import random_state_dict
+    cfg = dict(vision=dict(hidden_size=256, intermediate_size=512, num_hidden_layers=4, num_attention_heads=4, image_size=112,
+                           patch_size=14, layer_norm_eps=1e-5, select_layer=-2),
+               llm=dict(hidden_size=512, intermediate_size=1024, num_hidden_layers=4, num_attention_heads=8, num_key_value_heads=2,
+                        head_dim=128, vocab_size=4096, rms_norm_eps=1e-5, rope_theta=1e6), num_frames=8)
+    cfg["llm"]["hidden_size"] = 1024          # q heads x head_dim = hidden (Mistral layout)
+    sd = random_state_dict(cfg, dev, seed=7)
+    res = {}
+    x = torch.randn((40, cfg["llm"]["hidden_size"]), device=dev, dtype=torch.bfloat16, generator=torch.Generator(device=dev).manual_seed(1))
+    plain = HipMistralDecoder(cfg, sd, dev, max_seq_len=128)
+    want = plain.generate(x, max_new_tokens=12, use_graph=False)[0].tolist()
+    tp = HipMistralDecoder(cfg, sd, dev, max_seq_len=128, tp_group=dist.group.WORLD)
+    tp.tp_always_reduce = True
+    got_eager = tp.generate(x, max_new_tokens=12, use_graph=False)[0].tolist()
+    got_graph = tp.generate(x, max_new_tokens=12, use_graph=True)[0].tolist()
+    res["tp_decode_graph_with_captured_all_reduce"] = "ok" if (tp.graph is not None and got_graph == want and got_eager == want) else \
+        f"MISMATCH graph={got_graph} eager={got_eager} want={want}"
+    tower = HipCLIPVisionTower(cfg, sd, dev)
+    conn = HipSTCConnector(sd, dev)
+    T = 8
+    frames = torch.randn((T, 3, 112, 112), device=dev, dtype=torch.bfloat16, generator=torch.Generator(device=dev).manual_seed(2))
+    for world in (2, 4):
+        eager = FrameSharder.encode_video_all_ranks_locally(tower, conn, frames, world)
+        sh = FrameSharder(use_graph=True)
+        a = FrameSharder.encode_video_all_ranks_locally(tower, conn, frames, world, graphs=sh)
+        b = FrameSharder.encode_video_all_ranks_locally(tower, conn, frames, world, graphs=sh)      # replay of the cached graphs
+        t_e = timed(lambda: FrameSharder.encode_video_all_ranks_locally(tower, conn, frames, world), 5)
+        t_g = timed(lambda: FrameSharder.encode_video_all_ranks_locally(tower, conn, frames, world, graphs=sh), 5)
+        res[f"encoder_graphs_world{world}"] = dict(exact=bool(torch.equal(a, eager) and torch.equal(b, eager)), eager_us=t_e, graph_us=t_g)
+    return res
 
 
 if __name__ == "__main__":

@@ -713,3 +713,54 @@ def test_emu_kv_cache_limits(emu, golden_small):
         dec.decode_step()
     full = dec.generate(bf(16, D, scale=0.5), max_new_tokens=5)
     assert full.shape == (1, 1)
+
+
+def test_emu_continuous_batching_admits_between_decode_steps(emu, golden_small):
+    """serving.ContinuousBatcher (reference worker semantics serve/model_worker.py:263-300,350-352): requests
+    arrive while others decode; each is prefilled into a free slot between two steps, retired at its own stop, and its tokens
+    equal its solo greedy decode whatever else was in flight (multi-row GEMV rows are bit-identical to the single step)."""
+    from videollama2_amd.model import VideoLLaMA2Hip
+    g = golden_small
+    cfg = g["cfg"]
+    m = VideoLLaMA2Hip(cfg, O.seeded_state_dict(cfg, g["seed"]), "cpu", max_seq_len=96)
+    idsA = g["input_ids"]
+    idsB = torch.cat([idsA[:3], idsA[6:]])
+    idsC = torch.cat([idsA[:2], idsA[5:]])
+    fr2 = torch.flip(g["frames"], dims=[0]).contiguous()
+    reqs = [(idsA, [(g["frames"], "video")], 5), (idsB, [(fr2, "video")], 2), (idsC, [(g["frames"], "video")], 4), (idsA[:4], None, 3)]
+    solo = [m.generate(ids[None], attention_mask=torch.ones(1, ids.numel(), dtype=torch.long), images=im, max_new_tokens=n)[0].tolist()
+            for ids, im, n in reqs]
+    assert solo[0] == g["new_tokens"][:5].tolist()
+
+    class Stream:
+        def __init__(self):
+            self.got, self.ended = [], False
+
+        def put(self, t):
+            self.got += t.flatten().tolist()
+
+        def end(self):
+            self.ended = True
+
+    b = m.batcher(max_slots=2)
+    st = [Stream() for _ in reqs]
+    r0 = b.submit(reqs[0][0], reqs[0][1], max_new_tokens=reqs[0][2], streamer=st[0])
+    r1 = b.submit(reqs[1][0], reqs[1][1], max_new_tokens=reqs[1][2], streamer=st[1])
+    first = b.step()
+    assert set(first) == {r0, r1} and first[r0] == solo[0][0] and first[r1] == solo[1][0]
+    r2 = b.submit(reqs[2][0], reqs[2][1], max_new_tokens=reqs[2][2], streamer=st[2])      # both slots busy: waits
+    r3 = b.submit(reqs[3][0], reqs[3][1], max_new_tokens=reqs[3][2], streamer=st[3])
+    second = b.step()                                  # request 1 (2 tokens) finishes here and frees slot 1
+    assert set(second) == {r0, r1} and st[1].ended and not st[0].ended and r1 in b.finished
+    third = b.step()                                   # request 2 was admitted into slot 1 between the steps
+    assert set(third) == {r0, r2} and third[r2] == solo[2][0]
+    done = b.run()
+    assert [done[r].tolist() for r in (r0, r1, r2, r3)] == solo
+    assert [s.got for s in st] == solo and all(s.ended for s in st)
+    assert b.in_flight() == 0 and b.step() == {}
+    # an EOS retires a request early; the slot is reused
+    b2 = m.batcher(max_slots=1, eos_token_id=solo[0][1])
+    ra = b2.submit(reqs[0][0], reqs[0][1], max_new_tokens=5)
+    rb = b2.submit(reqs[3][0], None, max_new_tokens=3)
+    out = b2.run()
+    assert out[ra].tolist() == solo[0][:2] and out[rb].tolist()[:1] == solo[3][:1]

@@ -112,3 +112,30 @@ def test_padded_batch_generate_and_forward_with_images_on_device(golden_small):
     assert out.tolist() == alone
     res = m(input_ids=idsA[None].to(DEV), attention_mask=torch.ones(1, L, dtype=torch.long), images=images[:1])
     assert rel(res.logits[0], g["prefill_logits"]) < 2.5e-2
+
+
+def test_continuous_batching_on_device_equals_solo_decode(golden_small):
+    """serving.ContinuousBatcher on the GPU, one captured hipGraph per occupancy: staggered admission, early retirement and slot
+    reuse; every request's tokens equal its solo greedy decode (hipGraph) -- SURVEY 8f row 4, serve/model_worker.py:263-300."""
+    from videollama2_amd.model import VideoLLaMA2Hip
+    g = golden_small
+    cfg = g["cfg"]
+    m = VideoLLaMA2Hip(cfg, O.seeded_state_dict(cfg, g["seed"]), DEV, max_seq_len=128)
+    idsA = g["input_ids"].to(DEV)
+    variants = [idsA, torch.cat([idsA[:3], idsA[6:]]), torch.cat([idsA[:2], idsA[5:]]), idsA[:4], torch.cat([idsA[:4], idsA[8:]])]
+    fr = [g["frames"].to(DEV), torch.flip(g["frames"], dims=[0]).contiguous().to(DEV)]
+    reqs = [(variants[0], [(fr[0], "video")], 9), (variants[1], [(fr[1], "video")], 3), (variants[2], [(fr[0], "video")], 6),
+            (variants[3], None, 4), (variants[4], [(fr[1], "video")], 7)]
+    solo = [m.generate(ids[None], attention_mask=torch.ones(1, ids.numel(), dtype=torch.long, device=DEV), images=im, max_new_tokens=n)[0].tolist()
+            for ids, im, n in reqs]
+    assert solo[0][:8] == g["new_tokens"][:8].tolist()
+    for use_graph in (True, False):
+        b = m.batcher(max_slots=3, use_graph=use_graph)
+        rid = [b.submit(reqs[i][0], reqs[i][1], max_new_tokens=reqs[i][2]) for i in range(2)]
+        b.step()
+        rid += [b.submit(reqs[i][0], reqs[i][1], max_new_tokens=reqs[i][2]) for i in range(2, 4)]     # one joins now, one waits for a slot
+        b.step(); b.step()
+        rid.append(b.submit(reqs[4][0], reqs[4][1], max_new_tokens=reqs[4][2]))
+        done = b.run()
+        assert [done[r].tolist() for r in rid] == solo, use_graph
+        assert b.inner.steps < sum(n for _, _, n in reqs)          # the steps were shared

@@ -17,7 +17,7 @@ def test_rccl_world1_collectives_on_device():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     try:
         r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "rccl_world1.py"), "--iters", "5", "--port", "29541"],
-                           capture_output=True, text=True, timeout=240, env=env)
+                           capture_output=True, text=True, timeout=420, env=env)
     except subprocess.TimeoutExpired:
         pytest.skip("RCCL world-1 smoke timed out on this box (environment, not the product path)")
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -28,3 +28,10 @@ def test_rccl_world1_collectives_on_device():
     assert out["all_gather_exact"] and out["all_reduce_identity_at_world1"]
     if "halo_exact" in out:
         assert out["halo_exact"]
+    # product paths: TP decode graph with captured all-reduces; rank-local encoder graphs == eager launches
+    assert "product_checks_error" not in out, out["product_checks_error"]
+    if out.get("graph_capture_of_all_reduce") == "ok":
+        assert out["tp_decode_graph_with_captured_all_reduce"] == "ok", out["tp_decode_graph_with_captured_all_reduce"]
+    assert out["encoder_graphs_world2"]["exact"] and out["encoder_graphs_world4"]["exact"]
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r02_rccl_world1.json"), "w"), indent=1)

@@ -57,6 +57,9 @@ class HipMistralDecoder(nn.Module):
         self.graph = None
         self.pos = 0
         self._stage = None                  # (vl2_llm_desc, keepalive, decode workspace): prefill / decode step as ONE C call each
+        # validation hook for 1-GPU boxes: issue the tensor-parallel all-reduces even when the group has ONE rank (the sum over one
+        # rank is the identity), so that the captured-RCCL decode graph can be exercised on hardware without a second GPU
+        self.tp_always_reduce = False
 
     def _stage_desc(self):
         if self._stage is None:
@@ -67,12 +70,12 @@ class HipMistralDecoder(nn.Module):
         return self._stage
 
     def _use_stage(self, cache=None):
-        return ops.stage_enabled() and self.tp == 1 and cache is None
+        return ops.stage_enabled() and self.tp == 1 and cache is None and not self.tp_always_reduce
 
     def _reduce(self, t):
         """Sum the row-parallel partial results over the tensor-parallel group (no-op without one).  gloo (CPU tests, debug)
         takes device tensors through host memory."""
-        if self.tp > 1 and self.tp_group is not None:
+        if (self.tp > 1 or self.tp_always_reduce) and self.tp_group is not None:
             if t.is_cuda and dist.get_backend(self.tp_group) == "gloo":
                 h = t.cpu()
                 dist.all_reduce(h, group=self.tp_group)
@@ -165,9 +168,11 @@ class HipMistralDecoder(nn.Module):
     @torch.no_grad()
     def capture_graph(self):
         """Capture {argmax -> decode step} once as a hipGraph (torch.cuda.CUDAGraph records the launches libvl2hip.so
-        enqueues on the capture stream).  Replays read token / position / step from device memory."""
-        if self.tp > 1:
-            raise NotImplementedError("hipGraph decode is built for the single-GPU decoder (collectives are launched eagerly)")
+        enqueues on the capture stream).  Replays read token / position / step from device memory.
+        Tensor-parallel decoders: the two all-reduces per layer are RCCL kernels on the capture stream and become graph nodes
+        like every other launch (ProcessGroupNCCL supports stream capture); the host-staged gloo debug path cannot be captured."""
+        if (self.tp > 1 or self.tp_always_reduce) and (self.tp_group is None or dist.get_backend(self.tp_group) != "nccl"):
+            raise NotImplementedError("hipGraph decode under tensor parallelism needs the nccl (RCCL) backend: gloo stages through the host")
         if self.graph is not None:
             return self.graph
         saved = (self.state.clone(), self.tok.clone(), self.logits.clone(), self.hist[:2].clone())
@@ -216,7 +221,8 @@ class HipMistralDecoder(nn.Module):
         toks, all_logits = [], []
         # a prompt that fills the cache leaves no position to decode into: the capture warm-up would run a step at row
         # max_seq_len (the kernels now ignore such a step, but there is nothing to replay either) -> plain last-step path
-        use_graph = use_graph and self.tp == 1 and self._dev.type == "cuda" and self.pos < self.max_seq_len
+        tp_ok = self.tp == 1 or (self.tp_group is not None and dist.get_backend(self.tp_group) == "nccl")
+        use_graph = use_graph and tp_ok and self._dev.type == "cuda" and self.pos < self.max_seq_len
         if use_graph:
             g = self.capture_graph()
             self.state.copy_(torch.tensor([self.pos - 1, 0], dtype=torch.int32))

@@ -7,9 +7,56 @@ import torch
 import torch.distributed as dist
 
 
+class RankEncoderGraph:
+    """The rank-local pieces of the sharded-connector cut as two captured hipGraphs (one per side of the halo exchange):
+        A: local frames (static buffer) -> ViT -> STC stage s1            -> `s1` rows (static)
+        B: s1 + halo (static) -> Conv3d + s2 + readout on this rank's output frames -> `tok` (static)
+    At 2 frames per rank the ~330 launches of a rank's share take 3.2 ms on the GPU and 2.4 ms to enqueue one by one
+    (profiles/r01_shard_model.jsonl): replayed from a graph the rank is GPU-bound and a step is 2 replays + 2 collectives.
+    The collectives stay outside the graphs (eager RCCL calls on the same stream).  Same kernels, same order: bit-identical
+    to the eager path (tests/test_gpu_rccl.py)."""
+
+    def __init__(self, tower, connector, local_frames, T, rank, world):
+        self.key = (tuple(local_frames.shape), local_frames.dtype, T, rank, world)
+        self.frames = torch.empty_like(local_frames)
+        self.frames.copy_(local_frames)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                 # eager warm-up: first-launch set-up, gather tables, allocator
+            s1, n, self.in_dtype = FrameSharder.local_s1_of(tower, connector, self.frames)
+            halo = torch.zeros((n, s1.shape[1]), dtype=s1.dtype, device=s1.device)
+            FrameSharder.local_tokens(connector, s1, halo if rank > 0 else None, T, rank, world)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.n, self.halo = n, halo
+        self.graph_a = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph_a, capture_error_mode="thread_local"):
+            self.s1 = FrameSharder.local_s1_of(tower, connector, self.frames)[0]
+        self.graph_b = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph_b, capture_error_mode="thread_local"):
+            self.tok = FrameSharder.local_tokens(connector, self.s1, self.halo if rank > 0 else None, T, rank, world)
+
+    def run_s1(self, local_frames):
+        self.frames.copy_(local_frames)
+        self.graph_a.replay()
+        return self.s1
+
+    def run_tokens(self):
+        self.graph_b.replay()
+        return self.tok
+
+
 class FrameSharder:
-    def __init__(self, group=None):
+    def __init__(self, group=None, use_graph=False):
         self.group = group
+        self.use_graph = use_graph            # hipGraph replay of the rank-local encoder pieces (CUDA tensors only)
+        self._graphs = {}
+
+    def rank_graph(self, tower, connector, local_frames, T, rank, world):
+        key = (id(tower), id(connector), tuple(local_frames.shape), local_frames.dtype, T, rank, world)
+        if key not in self._graphs:
+            self._graphs[key] = RankEncoderGraph(tower, connector, local_frames, T, rank, world)
+        return self._graphs[key]
 
     # ---- collectives.  RCCL takes device tensors directly; with the gloo backend (CPU tests, or the debug mode that lets
     #      several ranks share one GPU) device tensors are staged through host memory.
@@ -102,13 +149,19 @@ class FrameSharder:
             feats = self.encode(tower, frames)
             return connector(feats.view(1, *feats.shape))
         world, rank = self.world, self.rank
-        s1, n, in_dtype = self.local_s1(tower, connector, frames, rank, world)
+        fpr = T // world
+        rg = None
+        if self.use_graph and frames.is_cuda:
+            rg = self.rank_graph(tower, connector, frames[rank * fpr:(rank + 1) * fpr], T, rank, world)
+            s1, n, in_dtype = rg.run_s1(frames[rank * fpr:(rank + 1) * fpr]), rg.n, rg.in_dtype
+        else:
+            s1, n, in_dtype = self.local_s1(tower, connector, frames, rank, world)
         # halo: frame f0-1 comes from rank-1; our last frame goes to rank+1 (padding 1 only: the unpadded v35 sampler pairs
         # frames 2to, 2to+1, which an even frames-per-rank split never separates)
-        halo = torch.empty((n, s1.shape[1]), dtype=s1.dtype, device=s1.device)
+        halo = rg.halo if rg is not None else torch.empty((n, s1.shape[1]), dtype=s1.dtype, device=s1.device)
         if connector.padding == 1:
             self._halo_exchange(s1[s1.shape[0] - n:].contiguous(), halo, rank, world)
-        tok = self.local_tokens(connector, s1, halo if rank > 0 else None, T, rank, world)
+        tok = rg.run_tokens() if rg is not None else self.local_tokens(connector, s1, halo if rank > 0 else None, T, rank, world)
         extra = connector.padding                                  # padding 1: the last rank also owns output frame T/2
         per = tok.shape[0] // (T // world // 2 + (extra if rank == world - 1 else 0))
         max_rows = (T // world // 2 + extra) * per
@@ -124,7 +177,12 @@ class FrameSharder:
     def local_s1(tower, connector, frames, rank, world):
         """ViT + STC stage s1 on this rank's frames -> (s1 rows [fpr*n, C], n tokens per frame, dtype of the tower output)."""
         fpr = frames.shape[0] // world
-        local = tower(frames[rank * fpr:(rank + 1) * fpr])                   # [fpr, n, 1024]
+        return FrameSharder.local_s1_of(tower, connector, frames[rank * fpr:(rank + 1) * fpr])
+
+    @staticmethod
+    def local_s1_of(tower, connector, local_frames):
+        fpr = local_frames.shape[0]
+        local = tower(local_frames)                                          # [fpr, n, 1024]
         n = local.shape[1]
         rows = local.to(torch.bfloat16).reshape(fpr * n, -1).contiguous()
         return connector.run_s1(rows, fpr, int(n ** 0.5)), n, local.dtype
@@ -159,7 +217,7 @@ class FrameSharder:
         return torch.cat(parts, 0).unsqueeze(0)
 
     @classmethod
-    def encode_video_all_ranks_locally(cls, tower, connector, frames, world, timer=None):
+    def encode_video_all_ranks_locally(cls, tower, connector, frames, world, timer=None, graphs=None):
         """Every rank's share of the sharded-connector cut executed one after the other in THIS process (halos passed by
         reference, concatenation instead of the all-gather).  Returns what `encode_video` returns on every rank; with
         `timer` (a callable returning a timestamp object after recording on the current stream) also the per-rank
@@ -169,14 +227,26 @@ class FrameSharder:
         s1s, stamps = [], []
         for r in range(world):
             t0 = timer() if timer else None
-            s1, n, in_dtype = cls.local_s1(tower, connector, frames, r, world)
+            if graphs is not None:                       # a FrameSharder(use_graph=True): every rank's pieces replayed from its graphs
+                fpr = T // world
+                rg = graphs.rank_graph(tower, connector, frames[r * fpr:(r + 1) * fpr], T, r, world)
+                s1, n, in_dtype = rg.run_s1(frames[r * fpr:(r + 1) * fpr]), rg.n, rg.in_dtype
+            else:
+                s1, n, in_dtype = cls.local_s1(tower, connector, frames, r, world)
             s1s.append(s1)
             stamps.append([t0, timer() if timer else None])
         toks = []
         for r in range(world):
             t0 = timer() if timer else None
             halo = s1s[r - 1][s1s[r - 1].shape[0] - n:] if r > 0 else None
-            toks.append(cls.local_tokens(connector, s1s[r], halo, T, r, world))
+            if graphs is not None:
+                fpr = T // world
+                rg = graphs.rank_graph(tower, connector, frames[r * fpr:(r + 1) * fpr], T, r, world)
+                if halo is not None:
+                    rg.halo.copy_(halo)
+                toks.append(rg.run_tokens().clone())
+            else:
+                toks.append(cls.local_tokens(connector, s1s[r], halo, T, r, world))
             stamps[r] += [t0, timer() if timer else None]
         out = torch.cat(toks, 0).unsqueeze(0).to(in_dtype)
         return (out, stamps) if timer else out

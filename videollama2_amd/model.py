@@ -229,6 +229,12 @@ class VideoLLaMA2Hip(nn.Module):
             res[bi, :o.numel()] = o
         return res
 
+    def batcher(self, max_slots=4, eos_token_id=None, use_graph=None):
+        """Continuous batching over this model (serving.ModelBatcher): submit (input_ids, images) requests at any time, `step()`
+        decodes one token for everything in flight, admission / retirement happen between steps."""
+        from .serving import ModelBatcher
+        return ModelBatcher(self, max_slots, eos_token_id, use_graph)
+
     @torch.no_grad()
     def generate_batch(self, requests, **kwargs):
         """Several requests decoded together (the reference serialises requests): `requests` is a list of
