@@ -6,10 +6,21 @@ import csv, json, sys
 COUNTS = [1, 23, 23, 23, 23, 2, 7, 10, 32, 32, 32, 32, 1]     # launches per step of each shape, in driver order
 ALG = None
 def per_shape(path, counter):
-    rows = [r for r in csv.DictReader(open(path)) if "gemm" in r["Kernel_Name"] and r["Counter_Name"] == counter]
-    vals = [float(r["Counter_Value"]) for r in rows]
-    assert len(vals) == 2 * len(COUNTS), (len(vals), counter)
-    return vals[1::2], [r["Kernel_Name"].split("(")[0].replace("void ", "") for r in rows][1::2]
+    """One value per vl2_gemm CALL: the kernels between two separator fills (scripts/gemm_traffic_pmc.py) are summed -- a row-split
+    call is two GEMM kernels back to back.  Calls come in pairs (warm-up, measured): the second of each pair is kept."""
+    rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter]
+    if rows and "Dispatch_Id" in rows[0]:
+        rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    calls, cur, names = [], 0.0, []
+    for r in rows:
+        if "gemm" in r["Kernel_Name"]:
+            cur += float(r["Counter_Value"])
+            names.append(r["Kernel_Name"].split("(")[0].replace("void ", ""))
+        elif "fill" in r["Kernel_Name"].lower() and names:
+            calls.append((cur, " + ".join(names)))
+            cur, names = 0.0, []
+    assert len(calls) == 2 * len(COUNTS), (len(calls), counter)
+    return [c[0] for c in calls[1::2]], [c[1] for c in calls[1::2]]
 fetch, names = per_shape(sys.argv[1], "FETCH_SIZE")
 write, _ = per_shape(sys.argv[2], "WRITE_SIZE")
 tot = sum(c * (2 * f + w) * 1024 for c, f, w in zip(COUNTS, fetch, write))
