@@ -22,5 +22,6 @@ rm -rf $O/traffic_FETCH_SIZE $O/traffic_WRITE_SIZE
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/trace -o bench -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/$O/trace_bench.log 2>&1 )
 rm -f $O/trace/bench_kernel_trace.csv
 find $O/trace -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats_bench.csv \;
+timeout 120 scripts/ubench/conv3d_direct > $O/conv3d_direct.json 2>&1
 timeout 300 python scripts/stc_bench.py > $O/stc_bench.txt 2>&1
 echo done
