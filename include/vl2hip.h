@@ -147,10 +147,10 @@ int32_t vl2_rope_kv(const void* qkv, void* q_out, void* kcache, void* vcache, co
                     int32_t S, int32_t nh, int32_t nkv, int32_t smax, int32_t pos0, void* stream);
 
 /* y[N] = W[N,K] x[K] (+ bias[N]) (+ res[N]) for one token (decode).  norm_w != NULL fuses MistralRMSNorm on x first;
- * bias (fp32, may be NULL) is Qwen2's q/k/v bias (HF:models/qwen2/modeling_qwen2.py Qwen2Attention).  flags as vl2_gemm_bf16. */
+ * bias (fp32, may be NULL) is Qwen2's q/k/v bias (HF:models/qwen2/modeling_qwen2.py Qwen2Attention).  flags as vl2_gemm_desc.flags. */
 int32_t vl2_gemv_bf16(const void* W, const void* x, const float* norm_w, const void* res, const float* bias, void* y,
                       int32_t N, int32_t K, int32_t ldw, float eps, int32_t flags, void* stream);
-/* Skinny-M GEMM for batched decode: C[M <= 64, N] = A[M,K] W[N,K]^T (+bias | +res | SwiGLU | fp32 out; flags as vl2_gemm_bf16).
+/* Skinny-M GEMM for batched decode: C[M <= 64, N] = A[M,K] W[N,K]^T (+bias | +res | SwiGLU | fp32 out; flags as vl2_gemm_desc.flags).
  * The weights stream from HBM straight into the B operand of v_mfma_f32_16x16x32_bf16 (GEMV-style, once for all M rows), K is
  * split over workgroups, fp32 partial sums go through the caller's workspace `ws` (required, >= vl2_workspace_bytes()) and are reduced in order. */
 int32_t vl2_gemm_skinny_bf16(const void* A, const void* W, void* C, const float* bias, const void* res, int32_t M, int32_t N,
