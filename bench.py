@@ -251,6 +251,17 @@ def main():
         return emb.shape[1]
 
     S = step()                                       # eager pass (also performs every first-launch initialisation)
+    shard_check = None
+    if world > 1:                                    # the sharded (+ graph-replayed) encoder must give the unsharded encoder's bits
+        sharded = model.encode_images_or_videos([(frames, "video")])
+        sharded2 = model.encode_images_or_videos([(frames, "video")])          # second call = replay of the cached graphs
+        feats = model.vision_tower(frames)
+        whole = model.mm_projector(feats.view(1, *feats.shape))
+        ok = torch.tensor([int(torch.equal(sharded, whole) and torch.equal(sharded2, whole))], device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN) if backend == "nccl" else None
+        shard_check = bool(ok.item())
+        if not shard_check:
+            raise SystemExit(f"rank {rank}: sharded encoder output differs from the unsharded encoder")
     if not args.no_graph:
         graph = model.decoder.capture_graph()
     for _ in range(args.warmup):
@@ -371,7 +382,7 @@ def main():
         ach = gflop / gms if gms > 0 else 0.0                  # GFLOP/ms = TFLOP/s
         # HBM-side bytes per launch come from a separate rocprofv3 --pmc run (scripts/gpu_traffic.sh; PMC cannot be
         # collected inside this process); only quoted for the workload it was collected on (T=16, 241 GEMM launches).
-        traffic, tpath = None, os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_gemm_traffic.json")
+        traffic, tpath = None, os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_gemm_traffic.json")   # PMC passes of the round-2 kernels (scripts/gpu_round2_e.sh)
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
             if T == 16 and args.model == "v2" and world == 1 and tj.get("launches_per_step") == ngemm:
@@ -410,6 +421,8 @@ def main():
             "decode_hbm_frac": round(decode_bytes_per_token(cfg, S + n_new // 2) / (dec_ms / n_new / 1e3) / 1e9 / PEAK_HBM_GBS, 4),
             "roofline": roof,
         }
+        if shard_check is not None:
+            out["sharded_encoder_equals_unsharded"] = shard_check
         if batched is not None:
             out["batched_decode"] = batched
         if bprefill is not None:

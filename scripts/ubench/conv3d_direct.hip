@@ -19,8 +19,18 @@ typedef __bf16 bf16v2_t __attribute__((ext_vector_type(2)));
 static inline float bf2f(bf16_t v) { uint32_t u = (uint32_t)v << 16; float f; memcpy(&f, &u, 4); return f; }
 static inline bf16_t f2bf(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); return (bf16_t)(u >> 16); }
 
-constexpr int T = 16, H = 24, W = 24, C = 4096, TO = 9, HO = 13, WO = 13, NOUT = TO * HO * WO;
+#ifndef CONV_T          // (smaller values: the host-emulator check of the indexing, see the end of this comment block)
+#define CONV_T 16
+#define CONV_HW 24
+#define CONV_C 4096
+#endif
+constexpr int T = CONV_T, H = CONV_HW, W = CONV_HW, C = CONV_C, TO = T / 2 + 1, HO = H / 2 + 1, WO = W / 2 + 1, NOUT = TO * HO * WO;
 constexpr int TP = 64, TC = 64, KC = 64, LDR = KC + 8;      // tile: 64 positions x 64 output channels, 64 input channels per step
+
+// (by-value uint32 parameters: __builtin_bit_cast applied directly to an ext-vector ELEMENT lvalue is miscompiled by this clang -- zeros)
+__device__ __forceinline__ float dot2_bf16(uint32_t a, uint32_t b, float c) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16v2_t, a), __builtin_bit_cast(bf16v2_t, b), c, false);
+}
 
 // x [T][H][W][C], w [C_out][8 taps][C_in] (tap = kt*4 + kh*2 + kw), y [NOUT][C_out] fp32
 __global__ __launch_bounds__(256) void conv3d_direct_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, float* __restrict__ y) {
@@ -63,7 +73,7 @@ __global__ __launch_bounds__(256) void conv3d_direct_kernel(const bf16_t* __rest
                     for (int j = 0; j < 4; ++j)
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
-                            acc[i][j] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16v2_t, av[i][q]), __builtin_bit_cast(bf16v2_t, wv[j][q]), acc[i][j], false);
+                            acc[i][j] = dot2_bf16(av[i][q], wv[j][q], acc[i][j]);
             }
         }
     }

@@ -83,6 +83,7 @@ def run_tower(cfg, T, check_layers):
     assert len(layers) == check_layers[-1] == len(hs) - 1
     for L in check_layers:
         tower.w["layers"] = layers[:L]
+        tower._stage = None                      # the stage descriptor caches the layer list (raw pointers): rebuild it for the truncated tower
         x, T, N1 = tower.forward_hidden(frames.to(DEV))
         _note(f"vit hidden_states[{L}] (T={T}, with CLS)", rel(x.view(T, N1, -1), hs[L]), rel(hs16[L], hs[L]),
               dict(oracle_fp32_cpu_s=round(t_cpu, 2)) if L == check_layers[0] else None)
