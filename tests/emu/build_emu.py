@@ -24,7 +24,7 @@ def build(force=False):
             txt = txt.replace('asm volatile("s_waitcnt vmcnt(0)" ::: "memory")', "((void)0)")
             open(os.path.join(tmp, os.path.basename(s)), "w").write(txt)
         cxx = CLANG if os.path.exists(CLANG) else "clang++"
-        cmd = [cxx, "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-Wno-everything", "-I", tmp, "-I", HERE,
+        cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-everything", "-I", tmp, "-I", HERE,
                os.path.join(HERE, "emu_kernels.cpp"), "-o", OUT]
         subprocess.run(cmd, check=True)
     finally:

@@ -31,7 +31,8 @@ struct Wave {
 struct Thread {
     dim3 tid;
     int lane = 0, wave = 0, flat = 0, shfl_phase = 0;
-    ucontext_t ctx;
+    ucontext_t ctx;          // portable switch (non-x86-64 hosts)
+    void* sp = nullptr;      // x86-64: saved stack pointer of the parked fiber (emu_ctx_switch)
     char* stack = nullptr;
     bool done = false;
 };
@@ -46,7 +47,58 @@ inline std::function<void()> body;
 inline int nthreads = 0;
 alignas(64) inline unsigned char dyn_smem[160 * 1024];
 
+#if defined(__x86_64__)
+// Fiber switch = push the SysV callee-saved registers, swap stack pointers, pop, ret (~5 ns).  glibc's swapcontext makes two
+// rt_sigprocmask system calls per switch, and the emulated kernels switch at every barrier, shuffle and MFMA: with it the
+// system calls were most of the emulator's run time.
+extern "C" void emu_ctx_switch(void** save_sp, void* load_sp);
+asm(R"(
+    .text
+    .weak emu_ctx_switch
+    .type emu_ctx_switch,@function
+emu_ctx_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+    .size emu_ctx_switch, .-emu_ctx_switch
+)");
+inline void* sched_sp = nullptr;
+inline void yield() { emu_ctx_switch(&cur->sp, sched_sp); }
+inline void resume(Thread& t) { cur = &t; emu_ctx_switch(&sched_sp, t.sp); }
+inline void leave() { emu_ctx_switch(&cur->sp, sched_sp); __builtin_trap(); }
+inline void trampoline();
+inline void prepare(Thread& t, size_t stack_bytes) {
+    // stack image the first resume pops: six zeroed callee-saved registers, then `ret` into trampoline with rsp = 8 mod 16
+    uintptr_t top = ((uintptr_t)t.stack + stack_bytes) & ~(uintptr_t)15;
+    void** sp = (void**)(top - 8 * sizeof(void*));
+    for (int i = 0; i < 6; ++i) sp[i] = nullptr;
+    sp[6] = (void*)&trampoline;
+    sp[7] = nullptr;
+    t.sp = sp;
+}
+#else
 inline void yield() { swapcontext(&cur->ctx, &main_ctx); }
+inline void resume(Thread& t) { cur = &t; swapcontext(&main_ctx, &t.ctx); }
+inline void leave() { swapcontext(&cur->ctx, &main_ctx); }
+inline void trampoline();
+inline void prepare(Thread& t, size_t stack_bytes) {
+    getcontext(&t.ctx);
+    t.ctx.uc_stack.ss_sp = t.stack; t.ctx.uc_stack.ss_size = stack_bytes; t.ctx.uc_link = &main_ctx;
+    makecontext(&t.ctx, (void (*)())trampoline, 0);
+}
+#endif
 
 inline void block_sync() {
     unsigned g = blk_gen;
@@ -65,7 +117,7 @@ inline void wave_sync() {
 inline void trampoline() {
     body();
     cur->done = true;
-    swapcontext(&cur->ctx, &main_ctx);
+    leave();
 }
 // optional explicit workgroup order (1-D grids): used to run stream-K contributors before the workgroups that wait on them
 inline std::vector<unsigned> block_order;
@@ -84,15 +136,12 @@ inline void launch(dim3 grid, dim3 block, std::function<void()> fn, size_t stack
         for (unsigned z = 0; z < block.z; ++z) for (unsigned y = 0; y < block.y; ++y) for (unsigned x = 0; x < block.x; ++x, ++f) {
             Thread& t = threads[f];
             t.tid = dim3(x, y, z); t.flat = f; t.lane = f & 63; t.wave = f >> 6; t.done = false; t.shfl_phase = 0;
-            getcontext(&t.ctx);
-            t.ctx.uc_stack.ss_sp = t.stack; t.ctx.uc_stack.ss_size = stack_bytes; t.ctx.uc_link = &main_ctx;
-            makecontext(&t.ctx, (void (*)())trampoline, 0);
+            prepare(t, stack_bytes);
         }
         int remaining = nthreads;
         while (remaining) {
             for (auto& t : threads) if (!t.done) {
-                cur = &t;
-                swapcontext(&main_ctx, &t.ctx);
+                resume(t);
                 if (t.done) --remaining;
             }
         }

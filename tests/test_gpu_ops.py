@@ -73,6 +73,24 @@ def test_gemm_row_split_swiglu_is_bit_identical(ops, M, N, K):
         ops.set_gemm_variant(0)
 
 
+@pytest.mark.parametrize("M,N,K", [(9216, 4096, 4096), (4608, 4096, 2048)])
+def test_gemm_round_split_is_bit_identical(ops, M, N, K):
+    """Whole rounds + a short tail (the STC s1 convolutions: 576 big tiles = 2.25 rounds): the rows of the whole rounds run on the
+    256x256 kernel, the tail rows on the chooser's pick for them -- same bits as one kernel on the whole matrix, with every
+    epilogue the connector uses (plain, +bias +GELU, +residual and row statistics)."""
+    a, w, res, bias = bf(M, K).to(DEV), bf(N, K, scale=K ** -0.5).to(DEV), bf(M, N).to(DEV), torch.randn(N).to(DEV)
+    st = [torch.zeros((M, N // 64, 2), dtype=torch.float32, device=DEV) for _ in range(2)]
+    try:
+        ops.set_gemm_variant(8)
+        ref = (ops.gemm(a, w), ops.gemm(a, w, bias=bias, act=ops.ACT_GELU), ops.gemm(a, w, res=res, stats_out=st[0]))
+        ops.set_gemm_variant(0)
+        for _ in range(2):
+            got = (ops.gemm(a, w), ops.gemm(a, w, bias=bias, act=ops.ACT_GELU), ops.gemm(a, w, res=res, stats_out=st[1]))
+            assert all(torch.equal(x, y) for x, y in zip(got, ref)) and torch.equal(st[0], st[1])
+    finally:
+        ops.set_gemm_variant(0)
+
+
 def test_gemm_stream_k_variant(ops):
     """Stream-K form (tuning knob 2): partial tiles cross workgroups through the caller-owned workspace with an
     agent-scope release/acquire hand-off; repeated launches screen for stale reads.  fp32 sums in a different order."""

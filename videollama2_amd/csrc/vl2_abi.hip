@@ -136,17 +136,30 @@ static void launch_gemm4(const GemmArgs& a0, hipStream_t s) {
     hipLaunchKernelGGL((gemm4_bf16_kernel<ACT, SW, F32>), dim3(a.tiles_m * a.tiles_n), dim3(512), GEMM4_LDS_BYTES, s, a);
 }
 
-// Row split: M = 1621 leaves the 256-row kernel a 7th row tile with 85 live rows (9.5 % of its MFMA work wasted) and the
-// 128-row kernel is slower per FLOP.  When N is wide enough for both parts to fill the chip, the first floor(M/256)*256 rows
-// go to the 256x256 kernel and the remaining rows to whatever the chooser picks for them -- two launches, same stream.  Every
-// kernel accumulates K in the same order and shares one epilogue, so the output bits do not change (asserted in
-// tests/test_gpu_ops.py).  Measured: 1621x28672x4096 + SwiGLU 362 -> 345 us; loses on N <= 6144 and on M % 256 > 128.
-static bool want_m_split(const GemmArgs& a, const GemmCtl& c) {
-    if (c.variant != 0 || a.out_grp > 0 || a.res_row_mod > 0 || a.N % GEMM4_BN || a.K < 2048 || a.M < 1024) return false;
+// Row split (returns the number of leading rows that go to the 256x256 kernel, 0 = no split).  Two cases, both two launches on the
+// same stream; every kernel accumulates K in the same order and shares one epilogue, so the output bits do not change (asserted
+// in tests/test_gpu_ops.py):
+//  (1) M = 1621 leaves the 256-row kernel a 7th row tile with 85 live rows (9.5 % of its MFMA work wasted) and the 128-row kernel
+//      is slower per FLOP.  When N is wide enough for both parts to fill the chip, the first floor(M/256)*256 rows go to the
+//      256x256 kernel and the remaining rows to whatever the chooser picks for them.  Measured: 1621x28672x4096 + SwiGLU
+//      362 -> 345 us; loses on N <= 6144 and on M % 256 > 128.
+//  (2) whole rounds + a short tail: 9216x4096x4096 (the STC s1 convolutions) is 576 tiles = 2.25 rounds of 256 workgroups; the
+//      quarter round costs most of a full one.  The rows of the whole rounds stay on the 256x256 kernel, the tail rows (at most
+//      half a round of big tiles) go through the chooser, which gives them a finer-tiled one-round kernel
+//      (2 rounds 224 us + 1024 rows on the 8-wave 128x128 kernel ~40 us against 287 us for the single launch).
+static int m_split_rows(const GemmArgs& a, const GemmCtl& c) {
+    if (c.variant != 0 || a.out_grp > 0 || a.res_row_mod > 0 || a.N % GEMM4_BN || a.K < 2048 || a.M < 1024) return 0;
     const int r = a.M % GEMM4_BM, m1_tiles = a.M / GEMM4_BM, n_tiles = a.N / GEMM4_BN;
-    if (r == 0 || r > 96 || n_tiles < 64) return false;
-    const long t4 = (long)m1_tiles * n_tiles;
-    return (double)t4 / (double)(((t4 + 255) / 256) * 256) >= 0.85;      // the 256-row part fills its rounds
+    if (r != 0 && r <= 96 && n_tiles >= 64) {
+        const long t4 = (long)m1_tiles * n_tiles;
+        if ((double)t4 / (double)(((t4 + 255) / 256) * 256) >= 0.85) return m1_tiles * GEMM4_BM;   // the 256-row part fills its rounds
+    }
+    if (256 % n_tiles == 0) {
+        const int per_round = 256 / n_tiles;                       // row tiles in one full round of 256 workgroups
+        const int mt = (a.M + GEMM4_BM - 1) / GEMM4_BM, rounds = mt / per_round, tail = mt - rounds * per_round;
+        if (rounds >= 1 && tail > 0 && tail * n_tiles <= 128) return rounds * per_round * GEMM4_BM;
+    }
+    return 0;
 }
 
 // rows [m0, m0 + rows) of a call as a call of its own (A / C / residual / statistics rows shifted; the gather table keeps its
@@ -167,8 +180,7 @@ static GemmArgs gemm_rows(const GemmArgs& a0, int m0, int rows, bool f32) {
 template <int ACT, bool SW, bool F32, bool G>
 static void launch_gemm(const GemmArgs& a0, const GemmCtl& c, hipStream_t s) {
     if constexpr (!G && !F32) {
-        if (want_m_split(a0, c)) {
-            const int M1 = a0.M / GEMM4_BM * GEMM4_BM;
+        if (const int M1 = m_split_rows(a0, c); M1 > 0) {
             launch_gemm4<ACT, SW, F32>(gemm_rows(a0, 0, M1, F32), s);
             launch_gemm<ACT, SW, F32, G>(gemm_rows(a0, M1, a0.M - M1, F32), c, s);
             return;
