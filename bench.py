@@ -263,7 +263,12 @@ def main():
         if not shard_check:
             raise SystemExit(f"rank {rank}: sharded encoder output differs from the unsharded encoder")
     if not args.no_graph:
-        graph = model.decoder.capture_graph()
+        try:
+            graph = model.decoder.capture_graph()
+        except Exception:                            # a TP decode graph captures RCCL all-reduces: if the capture is refused on this
+            if tp_group is None:                     # RCCL build, measure the eager loop instead of failing the run
+                raise
+            graph = None
     for _ in range(args.warmup):
         S = step()
     torch.cuda.synchronize()
@@ -423,6 +428,7 @@ def main():
         }
         if shard_check is not None:
             out["sharded_encoder_equals_unsharded"] = shard_check
+            out["encoder_graphs"] = "replayed" if model.sharder.use_graph else f"eager ({model.sharder.graph_error or 'disabled'})"
         if batched is not None:
             out["batched_decode"] = batched
         if bprefill is not None:

@@ -51,11 +51,17 @@ class FrameSharder:
         self.group = group
         self.use_graph = use_graph            # hipGraph replay of the rank-local encoder pieces (CUDA tensors only)
         self._graphs = {}
+        self.graph_error = None               # why the graphs were abandoned for eager launches, if they were
 
     def rank_graph(self, tower, connector, local_frames, T, rank, world):
         key = (id(tower), id(connector), tuple(local_frames.shape), local_frames.dtype, T, rank, world)
         if key not in self._graphs:
-            self._graphs[key] = RankEncoderGraph(tower, connector, local_frames, T, rank, world)
+            try:
+                self._graphs[key] = RankEncoderGraph(tower, connector, local_frames, T, rank, world)
+            except Exception as exc:          # a failed capture must not take the step down: same kernels, launched one by one
+                self.use_graph, self.graph_error = False, repr(exc)[:300]
+                torch.cuda.synchronize()
+                return None
         return self._graphs[key]
 
     # ---- collectives.  RCCL takes device tensors directly; with the gloo backend (CPU tests, or the debug mode that lets
@@ -153,6 +159,7 @@ class FrameSharder:
         rg = None
         if self.use_graph and frames.is_cuda:
             rg = self.rank_graph(tower, connector, frames[rank * fpr:(rank + 1) * fpr], T, rank, world)
+        if rg is not None:
             s1, n, in_dtype = rg.run_s1(frames[rank * fpr:(rank + 1) * fpr]), rg.n, rg.in_dtype
         else:
             s1, n, in_dtype = self.local_s1(tower, connector, frames, rank, world)
@@ -227,9 +234,9 @@ class FrameSharder:
         s1s, stamps = [], []
         for r in range(world):
             t0 = timer() if timer else None
-            if graphs is not None:                       # a FrameSharder(use_graph=True): every rank's pieces replayed from its graphs
-                fpr = T // world
-                rg = graphs.rank_graph(tower, connector, frames[r * fpr:(r + 1) * fpr], T, r, world)
+            fpr = T // world
+            rg = graphs.rank_graph(tower, connector, frames[r * fpr:(r + 1) * fpr], T, r, world) if graphs is not None else None
+            if rg is not None:                           # a FrameSharder(use_graph=True): every rank's pieces replayed from its graphs
                 s1, n, in_dtype = rg.run_s1(frames[r * fpr:(r + 1) * fpr]), rg.n, rg.in_dtype
             else:
                 s1, n, in_dtype = cls.local_s1(tower, connector, frames, r, world)
@@ -239,9 +246,8 @@ class FrameSharder:
         for r in range(world):
             t0 = timer() if timer else None
             halo = s1s[r - 1][s1s[r - 1].shape[0] - n:] if r > 0 else None
-            if graphs is not None:
-                fpr = T // world
-                rg = graphs.rank_graph(tower, connector, frames[r * fpr:(r + 1) * fpr], T, r, world)
+            rg = graphs.rank_graph(tower, connector, frames[r * fpr:(r + 1) * fpr], T, r, world) if graphs is not None else None
+            if rg is not None:
                 if halo is not None:
                     rg.halo.copy_(halo)
                 toks.append(rg.run_tokens().clone())
