@@ -220,7 +220,7 @@ extern "C" int32_t vl2_chan_mean(const void* x, float* mean, int32_t F, int32_t 
 extern "C" int32_t vl2_small_linear(const float* x, const void* W, const float* b, float* out, int32_t F, int32_t N, int32_t K,
                                     int32_t act, void*) {
     const int a = act == 3 ? 1 : act == 4 ? 2 : 0;
-    emu::launch(dim3((N + SL_NB - 1) / SL_NB), dim3(256), [=] { small_linear_kernel(x, (const bf16_t*)W, b, out, F, N, K, a); });
+    emu::launch(dim3((N + SL_NB - 1) / SL_NB, (F + 7) / 8), dim3(256), [=] { small_linear_kernel(x, (const bf16_t*)W, b, out, F, N, K, a); });
     return 0;
 }
 extern "C" int32_t vl2_se_scale(void* x, const float* gate, int32_t F, int32_t HW, int32_t C, void*) {

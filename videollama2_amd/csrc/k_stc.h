@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void small_linear_kernel(const float* __restri
     __shared__ float part[4][SL_NB][8];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n0 = blockIdx.x * SL_NB;
-    for (int f0 = 0; f0 < F; f0 += 8) {
+    for (int f0 = (int)blockIdx.y * 8; f0 < F; f0 += 8 * (int)gridDim.y) {      // grid.y = groups of 8 frames (a frame's bits do not depend on it)
         float acc[SL_NB][8];
 #pragma unroll
         for (int j = 0; j < SL_NB; ++j)

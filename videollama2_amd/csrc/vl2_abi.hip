@@ -540,7 +540,7 @@ extern "C" int32_t vl2_small_linear(const float* x, const void* W, const float* 
     if (K % 8) return fail(VL2_E_SHAPE, "vl2_small_linear: need K%%8==0");
     const int a = act == VL2_ACT_SILU ? 1 : act == VL2_ACT_SIGMOID ? 2 : act == VL2_ACT_NONE ? 0 : -1;
     if (a < 0) return fail(VL2_E_UNSUPP, "vl2_small_linear: act %d", act);
-    hipLaunchKernelGGL(small_linear_kernel, dim3((N + SL_NB - 1) / SL_NB), dim3(256), 0, ST(stream), x, (const bf16_t*)W, b, out, F, N, K, a);
+    hipLaunchKernelGGL(small_linear_kernel, dim3((N + SL_NB - 1) / SL_NB, (F + 7) / 8), dim3(256), 0, ST(stream), x, (const bf16_t*)W, b, out, F, N, K, a);
     return launched("vl2_small_linear");
 }
 extern "C" int32_t vl2_se_scale(void* x, const float* gate, int32_t F, int32_t HW, int32_t C, void* stream) {
