@@ -217,6 +217,23 @@ int64_t vl2_vit_workspace_bytes(const vl2_vit_desc* w, int32_t T);
 int32_t vl2_vit_forward(const vl2_vit_desc* w, const void* frames, int32_t frame_dtype, const float* u8_norm7, int32_t T, void* out,
                         void* ws, int64_t ws_bytes, void* stream);
 
+/* ---- one-time weight re-layout (checkpoint tensors, bf16, device memory -> the layouts the entry points above read).  What
+ * videollama2_amd/weights.py does with tensor ops, for hosts without PyTorch; csrc/k_pack.h.  All pointers 16-byte aligned.
+ * vl2_pack_fold_norm: LayerNorm / RMSNorm affine of HF CLIPEncoderLayer.layer_norm1/2, MistralDecoderLayer.input_layernorm /
+ *   post_attention_layernorm folded into the linear layer that follows: Wp = bf16(W * g) per input column, colsum[n] = sum_k Wp[n][k],
+ *   shift[n] = sum_k W[n][k] * beta[k] + bias[n] (beta / bias / shift may be NULL: RMSNorm).  Feeds vl2_gemm_desc.w_colsum / bias.
+ * vl2_pack_gate_up: MistralMLP gate_proj / up_proj [I, D] -> [2I, D], blocks of 64 rows = 32 gate rows then 32 up rows (VL2_GEMM_SWIGLU).
+ * vl2_pack_permute: [A][B][C] -> [A][C][B]; STC sampler Conv3d weight [Co][Ci][2*2*2] -> [Co][tap][Ci] (A=Co, B=Ci, C=8), depthwise
+ *   3x3 [C][9] -> [9][C] with out_f32 = 1 (A=1, B=C, C=9).
+ * vl2_pack_pad_rows: rows x cols_src -> rows x cols_dst, zero filled (patch weight K 588 -> 640; SigLIP head_dim 72 -> 96 and MLP
+ *   4304 -> 4352: a "row" is the block being padded).   vl2_pack_cvt_f32: bf16 -> fp32 (norm weights, biases). */
+int32_t vl2_pack_fold_norm(const void* W, const void* g, const void* beta, const void* bias, void* Wp, float* colsum, float* shift,
+                           int32_t N, int32_t K, int32_t ldw, void* stream);
+int32_t vl2_pack_gate_up(const void* gate, const void* up, void* out, int32_t I, int32_t D, void* stream);
+int32_t vl2_pack_permute(const void* in, void* out, int32_t A, int32_t B, int32_t C, int32_t out_f32, void* stream);
+int32_t vl2_pack_pad_rows(const void* in, void* out, int64_t rows, int64_t cols_src, int64_t cols_dst, void* stream);
+int32_t vl2_pack_cvt_f32(const void* in, float* out, int64_t n, void* stream);
+
 /* STC connector (videollama2/model/projector.py:189-215; timm RegStage Bottleneck x 4, Conv3d sampler, RegStage x 4, readout MLP):
  * tower features x [T * hw * hw, cin] bf16 (token-major = channels-last) -> visual tokens out [To * Ho * Wo, C] bf16. */
 typedef struct vl2_stc_block {

@@ -12,6 +12,7 @@ alignas(64) unsigned char vl2_smem[160 * 1024];
 #include "k_stc.h"
 #include "k_decode.h"
 #include "k_skinny.h"
+#include "k_pack.h"
 #include <cstdint>
 #include <algorithm>
 #include <vector>
@@ -226,6 +227,32 @@ extern "C" int32_t vl2_small_linear(const float* x, const void* W, const float* 
 extern "C" int32_t vl2_se_scale(void* x, const float* gate, int32_t F, int32_t HW, int32_t C, void*) {
     size_t nvec = (size_t)F * HW * C / 8;
     emu::launch(dim3(7), dim3(256), [=] { se_scale_kernel((bf16_t*)x, gate, HW, C, nvec); });
+    return 0;
+}
+extern "C" int32_t vl2_pack_fold_norm(const void* W, const void* g, const void* beta, const void* bias, void* Wp, float* colsum, float* shift,
+                                      int32_t N, int32_t K, int32_t ldw, void*) {
+    if ((beta != nullptr) != (shift != nullptr)) return -1;
+    emu::launch(dim3((N + 3) / 4), dim3(256), [=] { pack_fold_norm_kernel((const bf16_t*)W, (const bf16_t*)g, (const bf16_t*)beta, (const bf16_t*)bias, (bf16_t*)Wp, colsum, shift, N, K, ldw); });
+    return 0;
+}
+extern "C" int32_t vl2_pack_gate_up(const void* gate, const void* up, void* out, int32_t I, int32_t D, void*) {
+    if (I % 32 || D % 8) return -2;
+    emu::launch(dim3(2 * I), dim3(128), [=] { pack_gate_up_kernel((const bf16_t*)gate, (const bf16_t*)up, (bf16_t*)out, D); });
+    return 0;
+}
+extern "C" int32_t vl2_pack_permute(const void* in, void* out, int32_t A, int32_t B, int32_t C, int32_t out_f32, void*) {
+    const dim3 grid((B * C + 255) / 256, A);
+    if (out_f32) emu::launch(grid, dim3(256), [=] { pack_permute_kernel<true>((const bf16_t*)in, out, B, C); });
+    else emu::launch(grid, dim3(256), [=] { pack_permute_kernel<false>((const bf16_t*)in, out, B, C); });
+    return 0;
+}
+extern "C" int32_t vl2_pack_pad_rows(const void* in, void* out, int64_t rows, int64_t cs, int64_t cd, void*) {
+    if (cd < cs) return -1;
+    emu::launch(dim3((unsigned)rows), dim3(256), [=] { pack_pad_rows_kernel((const bf16_t*)in, (bf16_t*)out, (long)cs, (long)cd); });
+    return 0;
+}
+extern "C" int32_t vl2_pack_cvt_f32(const void* in, float* out, int64_t n, void*) {
+    emu::launch(dim3(3), dim3(256), [=] { pack_cvt_f32_kernel((const bf16_t*)in, out, (long)n); });
     return 0;
 }
 extern "C" int32_t vl2_rope_kv(const void* qkv, void* q_out, void* kc, void* vc, const float* cos_t, const float* sin_t,

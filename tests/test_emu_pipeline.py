@@ -764,3 +764,42 @@ def test_emu_continuous_batching_admits_between_decode_steps(emu, golden_small):
     rb = b2.submit(reqs[3][0], None, max_new_tokens=3)
     out = b2.run()
     assert out[ra].tolist() == solo[0][:2] and out[rb].tolist()[:1] == solo[3][:1]
+
+
+def check_pack_entry_points_against_weights_py(ops, dev):
+    """include/vl2hip.h vl2_pack_* vs the tensor-op packing of videollama2_amd/weights.py on the same checkpoint-layout tensors:
+    the re-laid-out weights byte for byte, the fp32 column sums / shifts to summation-order rounding.  Shared by the emulator
+    test here and the GPU test (tests/test_gpu_ops.py)."""
+    from videollama2_amd import weights as Wt
+    g = torch.Generator().manual_seed(3)
+    rb = lambda *s, scale=1.0: (torch.randn(*s, generator=g) * scale).to(torch.bfloat16).to(dev)
+    N, K = 96, 320
+    w, gam, beta, bias = rb(N, K, scale=K ** -0.5), (1 + 0.1 * torch.randn(K, generator=g)).to(torch.bfloat16).to(dev), rb(K, scale=0.1), rb(N, scale=0.1)
+    for b_, c_ in ((beta, bias), (beta, None), (None, None)):
+        wp, s, t = ops.pack_fold_norm(w, gam, b_, c_)
+        wp0, s0, t0 = Wt.fold_norm(w, gam, b_, c_, dev)
+        assert torch.equal(wp, wp0) and torch.allclose(s, s0, rtol=0, atol=2e-5 * K ** 0.5)
+        assert (t is None) == (t0 is None) and (t is None or torch.allclose(t, t0, rtol=0, atol=2e-5 * K ** 0.5))
+    I, D = 128, 64
+    gate, up = rb(I, D), rb(I, D)
+    assert torch.equal(ops.pack_gate_up(gate, up), Wt.pack_gate_up(gate, up))
+    w3 = rb(16, 24, 2, 2, 2)                                                   # Conv3d [Co, Ci, kt, kh, kw] (weights.pack_connector)
+    assert torch.equal(ops.pack_permute(w3.reshape(16, 24, 8)).reshape(16, 8 * 24), w3.permute(0, 2, 3, 4, 1).reshape(16, 8 * 24).contiguous())
+    dw = rb(40, 1, 3, 3)                                                        # depthwise [C, 1, 3, 3] -> [9][C] fp32 (_pack_bottleneck)
+    assert torch.equal(ops.pack_permute(dw.reshape(1, 40, 9), out_f32=True)[0], dw.reshape(40, 9).t().float().contiguous())
+    pw = rb(32, 588)                                                            # patch weight K 588 -> 640
+    ref = torch.zeros((32, 640), dtype=torch.bfloat16, device=dev); ref[:, :588] = pw
+    assert torch.equal(ops.pack_pad_rows(pw, 640), ref)
+    q = rb(4 * 72, 40)                                                          # SigLIP heads 72 -> 96 rows: a "row" = one head's block
+    ref = torch.zeros((4, 96, 40), dtype=torch.bfloat16, device=dev); ref[:, :72] = q.reshape(4, 72, 40)
+    assert torch.equal(ops.pack_pad_rows(q.reshape(4, 72 * 40), 96 * 40).reshape(4 * 96, 40), ref.reshape(4 * 96, 40))
+    v = rb(1000)
+    assert torch.equal(ops.pack_cvt_f32(v), v.float())
+    from videollama2_amd._lib import Vl2HipError
+    with pytest.raises(Vl2HipError):
+        ops.pack_gate_up(rb(48, 64)[:40], rb(48, 64)[:40])                      # I % 32 != 0
+
+
+def test_emu_pack_entry_points_match_weights_py(emu):
+    from videollama2_amd import ops
+    check_pack_entry_points_against_weights_py(ops, "cpu")

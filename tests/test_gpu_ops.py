@@ -655,3 +655,17 @@ def test_attn_second_structure_softmax_spike(ops):
     q, k, v = [t.float() for t in qkv.view(N, 3, D).unbind(1)]
     ref = torch.softmax(q @ k.T * D ** -0.5, -1) @ v
     assert rel(o, ref) < TOL_BF16_OUT and rel(o[17], ref[17]) < 1e-2
+
+
+def test_pack_entry_points_match_weights_py_on_device(ops):
+    """vl2_pack_* (one-time weight re-layout through the C ABI) against weights.py's tensor-op packing, on the device."""
+    from tests.test_emu_pipeline import check_pack_entry_points_against_weights_py
+    check_pack_entry_points_against_weights_py(ops, DEV)
+    # full-width: Mistral gate/up and the layer-norm fold of a ViT q/k/v block
+    from videollama2_amd import weights as Wt
+    gate, up = bf(14336, 4096, scale=0.02).to(DEV), bf(14336, 4096, scale=0.02, seed=1).to(DEV)
+    assert torch.equal(ops.pack_gate_up(gate, up), Wt.pack_gate_up(gate, up))
+    w, g, b, c = bf(3072, 1024, scale=0.03).to(DEV), (1 + 0.1 * torch.randn(1024)).bfloat16().to(DEV), bf(1024, scale=0.1).to(DEV), bf(3072, scale=0.1).to(DEV)
+    wp, s, t = ops.pack_fold_norm(w, g, b, c)
+    wp0, s0, t0 = Wt.fold_norm(w, g, b, c, DEV)
+    assert torch.equal(wp, wp0) and torch.allclose(s, s0, rtol=0, atol=1e-3) and torch.allclose(t, t0, rtol=0, atol=1e-3)

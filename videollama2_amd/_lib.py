@@ -66,6 +66,11 @@ SIGNATURES = {
     "vl2_stc_forward": [ctypes.POINTER(StcDesc), _vp, _i32, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _i64, _vp],
     "vl2_llm_prefill": [ctypes.POINTER(LlmDesc), _vp, _i32, _vp, _vp, _i64, _vp],
     "vl2_llm_decode_step": [ctypes.POINTER(LlmDesc), _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
+    "vl2_pack_fold_norm": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp],
+    "vl2_pack_gate_up": [_vp, _vp, _vp, _i32, _i32, _vp],
+    "vl2_pack_permute": [_vp, _vp, _i32, _i32, _i32, _i32, _vp],
+    "vl2_pack_pad_rows": [_vp, _vp, _i64, _i64, _i64, _vp],
+    "vl2_pack_cvt_f32": [_vp, _vp, _i64, _vp],
     "vl2_layernorm": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp],
     "vl2_rmsnorm": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp],
     "vl2_patchify": [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],

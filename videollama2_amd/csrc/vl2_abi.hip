@@ -11,6 +11,7 @@
 #include "k_decode.h"
 #include "k_gemm.h"
 #include "k_norm.h"
+#include "k_pack.h"
 #include "k_skinny.h"
 #include "k_stc.h"
 #include "k_vit.h"
@@ -550,6 +551,43 @@ extern "C" int32_t vl2_se_scale(void* x, const float* gate, int32_t F, int32_t H
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(se_scale_kernel, dim3((unsigned)blocks), dim3(256), 0, ST(stream), (bf16_t*)x, gate, HW, C, nvec);
     return launched("vl2_se_scale");
+}
+
+// ------------------------------------------------------------------------------------------------ one-time weight re-layout
+extern "C" int32_t vl2_pack_fold_norm(const void* W, const void* g, const void* beta, const void* bias, void* Wp, float* colsum, float* shift,
+                                      int32_t N, int32_t K, int32_t ldw, void* stream) {
+    if (!W || !g || !Wp || !colsum || N <= 0 || K <= 0 || ldw < K) return fail(VL2_E_BADARG, "vl2_pack_fold_norm: bad args");
+    if ((beta != nullptr) != (shift != nullptr)) return fail(VL2_E_BADARG, "vl2_pack_fold_norm: beta and shift go together");
+    if (bias && !beta) return fail(VL2_E_BADARG, "vl2_pack_fold_norm: a bias without a norm shift needs no folding");
+    hipLaunchKernelGGL(pack_fold_norm_kernel, dim3((N + 3) / 4), dim3(256), 0, ST(stream), (const bf16_t*)W, (const bf16_t*)g, (const bf16_t*)beta,
+                       (const bf16_t*)bias, (bf16_t*)Wp, colsum, shift, N, K, ldw);
+    return launched("vl2_pack_fold_norm");
+}
+extern "C" int32_t vl2_pack_gate_up(const void* gate, const void* up, void* out, int32_t I, int32_t D, void* stream) {
+    if (!gate || !up || !out || I <= 0 || D <= 0) return fail(VL2_E_BADARG, "vl2_pack_gate_up: bad args");
+    if (I % 32 || D % 8) return fail(VL2_E_SHAPE, "vl2_pack_gate_up: need I%%32==0 and D%%8==0");
+    hipLaunchKernelGGL(pack_gate_up_kernel, dim3(2 * I), dim3(128), 0, ST(stream), (const bf16_t*)gate, (const bf16_t*)up, (bf16_t*)out, D);
+    return launched("vl2_pack_gate_up");
+}
+extern "C" int32_t vl2_pack_permute(const void* in, void* out, int32_t A, int32_t B, int32_t C, int32_t out_f32, void* stream) {
+    if (!in || !out || A <= 0 || B <= 0 || C <= 0 || A > 65535) return fail(VL2_E_BADARG, "vl2_pack_permute: bad args");
+    if ((int64_t)B * C > 0x7fffffffLL) return fail(VL2_E_SHAPE, "vl2_pack_permute: plane too large");
+    const dim3 grid((unsigned)(((int64_t)B * C + 255) / 256), A);
+    if (out_f32) hipLaunchKernelGGL((pack_permute_kernel<true>), grid, dim3(256), 0, ST(stream), (const bf16_t*)in, out, B, C);
+    else hipLaunchKernelGGL((pack_permute_kernel<false>), grid, dim3(256), 0, ST(stream), (const bf16_t*)in, out, B, C);
+    return launched("vl2_pack_permute");
+}
+extern "C" int32_t vl2_pack_pad_rows(const void* in, void* out, int64_t rows, int64_t cols_src, int64_t cols_dst, void* stream) {
+    if (!in || !out || rows <= 0 || cols_src <= 0 || cols_dst < cols_src || rows > 0x7fffffffLL) return fail(VL2_E_BADARG, "vl2_pack_pad_rows: bad args");
+    hipLaunchKernelGGL(pack_pad_rows_kernel, dim3((unsigned)rows), dim3(256), 0, ST(stream), (const bf16_t*)in, (bf16_t*)out, (long)cols_src, (long)cols_dst);
+    return launched("vl2_pack_pad_rows");
+}
+extern "C" int32_t vl2_pack_cvt_f32(const void* in, float* out, int64_t n, void* stream) {
+    if (!in || !out || n <= 0) return fail(VL2_E_BADARG, "vl2_pack_cvt_f32: bad args");
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pack_cvt_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, ST(stream), (const bf16_t*)in, out, (long)n);
+    return launched("vl2_pack_cvt_f32");
 }
 
 // ------------------------------------------------------------------------------------------------ decoder glue / decode

@@ -310,6 +310,53 @@ def embed_rows(ids_i32, table, out):
     return out
 
 
+# ------------------------------------------------------------------------------------------------ one-time weight re-layout
+# The C-ABI forms of what weights.py does with tensor ops (include/vl2hip.h vl2_pack_*): for hosts without PyTorch; here they are
+# bound so that the tests can hold them against weights.py byte for byte.
+def pack_fold_norm(w, g, beta=None, bias=None):
+    """(W' bf16 [N,K], colsum fp32 [N], shift fp32 [N] or None) = weights.fold_norm(w, g, beta, bias)."""
+    for t, n in ((w, "w"), (g, "g"), (beta, "beta"), (bias, "bias")):
+        _chk(t, BF16, n)
+    N, K = w.shape
+    wp = torch.empty((N, K), dtype=BF16, device=w.device)
+    s = torch.empty((N,), dtype=torch.float32, device=w.device)
+    t = torch.empty((N,), dtype=torch.float32, device=w.device) if beta is not None else None
+    _lib.call("vl2_pack_fold_norm", _p(w), _p(g), _p(beta), _p(bias), _p(wp), _p(s), _p(t), N, K, w.stride(0), _stream())
+    return wp, s, t
+
+
+def pack_gate_up(gate, up):
+    _chk(gate, BF16, "gate"); _chk(up, BF16, "up")
+    I, D = gate.shape
+    out = torch.empty((2 * I, D), dtype=BF16, device=gate.device)
+    _lib.call("vl2_pack_gate_up", _p(gate), _p(up), _p(out), I, D, _stream())
+    return out
+
+
+def pack_permute(x, out_f32=False):
+    """[A, B, C] bf16 -> [A, C, B] (bf16, or fp32 with out_f32)."""
+    _chk(x, BF16, "x")
+    A, B, C = x.shape
+    out = torch.empty((A, C, B), dtype=torch.float32 if out_f32 else BF16, device=x.device)
+    _lib.call("vl2_pack_permute", _p(x), _p(out), A, B, C, int(out_f32), _stream())
+    return out
+
+
+def pack_pad_rows(x, cols_dst):
+    _chk(x, BF16, "x")
+    rows, cs = x.shape
+    out = torch.empty((rows, cols_dst), dtype=BF16, device=x.device)
+    _lib.call("vl2_pack_pad_rows", _p(x), _p(out), rows, cs, cols_dst, _stream())
+    return out
+
+
+def pack_cvt_f32(x):
+    _chk(x, BF16, "x")
+    out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    _lib.call("vl2_pack_cvt_f32", _p(x), _p(out), x.numel(), _stream())
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ stage-level entry points
 # One C call per stage (include/vl2hip.h vl2_vit_forward / vl2_llm_prefill / vl2_llm_decode_step): the layer loop runs inside
 # libvl2hip.so.  The descriptors hold raw device pointers, so every builder returns (desc, keepalive): the caller keeps
