@@ -85,29 +85,41 @@ class VideoLLaMA2Hip(nn.Module):
             return input_ids, attention_mask, past_key_values, None, labels
         if labels is not None:
             raise NotImplementedError("HIP path: inference only (labels / loss belong to training, out of scope)")
+        # Everything that needs the token ids on the HOST (sentinel positions, range check, media count) happens first, on one small
+        # D2H copy, while the device queue is still empty: once the encoder is enqueued nothing below synchronises, so the
+        # encoder, the embedding gathers and the prefill run back to back on the device.
+        D = self.decoder.D
+        B, L = input_ids.shape
+        ids_host = input_ids.detach().cpu()
+        sent = set(MODAL_INDEX_MAP.values())
+        plans, need = [], 0
+        n_media = len(mm_features) if mm_features is not None else len(images)
+        for bi in range(B):
+            row = ids_host[bi].tolist()
+            mm_pos = [i for i, t in enumerate(row) if t in sent]
+            text = [t for t in row if t not in sent]
+            if need + max(len(mm_pos), 1) > n_media:
+                raise ValueError(f"prompt {bi} holds {len(mm_pos)} modal tag(s) but only {n_media - need} media input(s) are left")
+            if text and (min(text) < 0 or max(text) >= self.decoder.V):                    # what torch's embedding lookup raises in the reference
+                raise IndexError(f"token id out of range: [{min(text)}, {max(text)}] vs vocab_size {self.decoder.V}")
+            plans.append(mm_pos)
+            need += max(len(mm_pos), 1)
         if mm_features is None:                       # (generate_batch hands in features it encoded for several requests at once)
             mm_features = self.encode_images_or_videos(images)
-        D = self.decoder.D
-        sentinels = torch.tensor(list(MODAL_INDEX_MAP.values()), device=self._dev)
-        B, L = input_ids.shape
         embeds, cur_mm = [], 0
         for bi in range(B):
-            ids = input_ids[bi].to(self._dev)
-            is_mm = (ids[:, None] == sentinels[None, :]).any(-1)
-            mm_pos = torch.nonzero(is_mm).flatten().tolist()
-            if cur_mm + max(len(mm_pos), 1) > len(mm_features):
-                raise ValueError(f"prompt {bi} holds {len(mm_pos)} modal tag(s) but only {len(mm_features) - cur_mm} media input(s) are left")
+            mm_pos = plans[bi]
+            ids32 = input_ids[bi].to(self._dev).clamp(min=0).to(torch.int32)
             if not mm_pos:                                                               # pure text: consumes one (unused) block
                 emb = torch.empty((L, D), dtype=torch.bfloat16, device=self._dev)
-                self._embed_ids(ids, emb)
+                if L:
+                    ops.embed_rows(ids32.contiguous(), self.decoder.w["embed"], emb)
                 embeds.append(emb)
                 cur_mm += 1
                 continue
             n_vis = sum(mm_features[cur_mm + k].shape[0] for k in range(len(mm_pos)))
             S = L - len(mm_pos) + n_vis
             emb = torch.empty((S, D), dtype=torch.bfloat16, device=self._dev)
-            self._check_ids(ids[~is_mm])
-            ids32 = ids.clamp(min=0).to(torch.int32)
             cur, prev = 0, 0
             for k, p in enumerate(mm_pos + [L]):
                 if p > prev:                                                             # text piece -> embed_tokens
@@ -121,6 +133,7 @@ class VideoLLaMA2Hip(nn.Module):
                 prev = p + 1
             embeds.append(emb)
         lens = [e.shape[0] for e in embeds]
+        self._splice_lens = lens                     # unpadded spliced length of every row (host-side; see _inputs_embeds)
         max_len = max(lens)
         if any(n != max_len for n in lens):                                              # arch.py:227-253
             out = torch.zeros((B, max_len, D), dtype=torch.bfloat16, device=self._dev)
@@ -164,16 +177,29 @@ class VideoLLaMA2Hip(nn.Module):
         return lens
 
     def _inputs_embeds(self, inputs, attention_mask, images):
+        """(inputs_embeds [B, S, D], real length of every row).  The attention mask is validated on the host BEFORE anything is
+        enqueued (one small D2H while the queue is empty), so that encoder, splice and prefill run back to back on the device."""
+        B, L = inputs.shape
+        msum = None
+        if attention_mask is not None:
+            m = attention_mask.detach().cpu().bool()
+            msum = m.sum(1).tolist()
+            for bi, n in enumerate(msum):
+                if n == 0 or not bool(m[bi, :n].all()):
+                    raise NotImplementedError("HIP path: only right-padded prompts (attention_mask = 1...1 0...0) are supported")
+        emb = None
         if images is not None:
-            _, attention_mask, _, emb, _ = self.prepare_inputs_labels_for_multimodal(inputs, attention_mask, None, None, images)
-            if emb is None:                        # input_ids.shape[1] == 1: arch.py:166-169 hands the ids back
-                images = None
-        if images is None:
-            B, L = inputs.shape
+            _, _, _, emb, _ = self.prepare_inputs_labels_for_multimodal(inputs, attention_mask, None, None, images)
+        if emb is None:                            # no media, or input_ids.shape[1] == 1 (arch.py:166-169 hands the ids back)
             emb = torch.empty((B, L, self.decoder.D), dtype=torch.bfloat16, device=self._dev)
             for bi in range(B):
                 self._embed_ids(inputs[bi].to(self._dev), emb[bi])
-        return emb, self._valid_lengths(attention_mask, emb.shape[1], emb.shape[0])
+            rows = [L] * B
+        else:
+            rows = self._splice_lens
+        if msum is None:
+            return emb, [emb.shape[1]] * B
+        return emb, [rows[bi] - L + msum[bi] for bi in range(B)]        # the inserted visual rows + the row's real text tokens
 
     # ---------------------------------------------------------------------------------- videollama2_mistral.py:63-108
     @torch.no_grad()
