@@ -85,8 +85,10 @@ __global__ __launch_bounds__(256) void dwconv_ln_silu_kernel(const bf16_t* __res
 // rows (the launcher takes it from W >= 16: the 24x24 grid of stage s1, 97 -> 74 us at 16 frames); on the 13x13 grid of
 // stage s2 a quarter of the workgroups would hold one live position.  grid = F * H * ceil(W / DW_P).
 #define DW_P 4
+// (NVT <= 2 is held to 128 VGPRs = four waves per SIMD: 130 -> 128 registers with 12 B/lane of scratch outside the tap loop,
+// 72.3 -> 69.0 us on the s1 grid, scripts/stc_bench.py)
 template <int NVT>
-__global__ __launch_bounds__(256) void dwconv4_ln_silu_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+__global__ __launch_bounds__(256, NVT <= 2 ? 4 : 2) void dwconv4_ln_silu_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
                                                               const float* __restrict__ wt, const float* __restrict__ lnw,
                                                               const float* __restrict__ lnb, int H, int W, int C, float eps) {
 #pragma clang fp reassociate(off)
