@@ -77,6 +77,9 @@ class ContinuousBatcher:
     @torch.no_grad()
     def step(self):
         """Admit, run one step, retire.  Returns {request id: new token} for the requests that produced a token."""
+        if self.dec._bb is not self.bb:       # a larger generate_batch() on the same decoder reallocated the slot buffers (and caches)
+            raise RuntimeError("the decoder's batch buffers were reallocated while requests were in flight: use one batcher per decoder "
+                               "and do not call generate_batch() with more sequences than max_slots on it")
         self._admit()
         occupied = [s for s, r in enumerate(self.slots) if r is not None]
         if not occupied:
