@@ -212,17 +212,20 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(AttnArgs p) {
     // ---- main loop: tile t lives in stage t & 1.  Top of tile t: this wave's pieces of tile t have landed (its only
     //      outstanding VMEM), the barrier makes everyone's pieces visible AND proves every wave is done reading the other stage
     //      (tile t-1), which the DMA of tile t+1 may therefore overwrite while tile t is computed.  One barrier per tile.
+    // a wave whose 32 query rows all lie past nq (the last query block of a 577-row ViT frame: rows 65..127 of it) still moves its
+    // share of every K/V tile and meets every barrier, but skips the arithmetic: its issue slots go to the waves it shares a SIMD with
+    const bool live = q0 + wave * 32 < p.nq;
     dma_tile(0, 0);
     for (int t = 0; t < ntiles; t += 2) {
         VL2_WAIT_VMCNT(0);
         VL2_ATTN2_BARRIER();
         if (t + 1 < ntiles) dma_tile(t + 1, STAGE);
-        compute_tile(t, 0);
+        if (live) compute_tile(t, 0);
         if (t + 1 >= ntiles) break;
         VL2_WAIT_VMCNT(0);
         VL2_ATTN2_BARRIER();
         if (t + 2 < ntiles) dma_tile(t + 2, 0);
-        compute_tile(t + 1, STAGE);
+        if (live) compute_tile(t + 1, STAGE);
     }
 
     if (qrow < p.nq) {
