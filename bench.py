@@ -156,7 +156,14 @@ def main():
     ap.add_argument("--new-tokens", type=int, default=32)
     ap.add_argument("--llm-layers", type=int, default=None, help="debug only: fewer decoder layers (INVALID as a result)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--u8-frames", action="store_true", help="feed raw uint8 [T,S,S,3] frames (normalised in the patch-row kernel) instead of bf16 [T,3,S,S]")
+    ap.add_argument("--u8-frames", action="store_true", help="(default since round 3; kept for old command lines) raw uint8 [T,S,S,3] frames")
+    ap.add_argument("--bf16-frames", action="store_true",
+                    help="feed randn bf16 [T,3,S,S] frames (rounds 1-2) instead of SURVEY 8d's recipe: np.random.default_rng(0) uint8 "
+                         "[T,S,S,3] frames, resident in HBM, rescaled + normalised (the image processor's arithmetic tail, mm_utils.py:196-201) "
+                         "in the patch-row kernel")
+    ap.add_argument("--cut", choices=["north_star", "sharded_connector"], default="north_star",
+                    help="with --gpus N > 1: the frame-parallel cut `value` is measured on (SURVEY 8e: north_star = BASELINE.json's own cut is "
+                         "the default; the other cut and the ViT-only rate are reported beside it as extra keys)")
     ap.add_argument("--decode-batch", type=int, default=0,
                     help="extra measurement: after the timed steps, decode this many copies of the request TOGETHER (batched decode, "
                          "SURVEY 8f row 4) and report aggregate decode tokens/s as `batched_decode`")
@@ -215,10 +222,13 @@ def main():
     if args.vit_streams is not None:
         model.vision_tower.streams = args.vit_streams
 
-    g = torch.Generator(device=dev).manual_seed(0)
-    frames = torch.randn((T, 3, side, side), generator=g, device=dev, dtype=torch.float32).to(torch.bfloat16)
-    if args.u8_frames:
-        frames = torch.randint(0, 256, (T, side, side, 3), generator=g, device=dev, dtype=torch.uint8)
+    model.sharder.cut = args.cut
+    if args.bf16_frames:
+        g = torch.Generator(device=dev).manual_seed(0)
+        frames = torch.randn((T, 3, side, side), generator=g, device=dev, dtype=torch.float32).to(torch.bfloat16)
+    else:        # SURVEY.md 8(d) synthetic input: seeded uint8 video frames (what process_video decodes / resizes to), uploaded ONCE
+        import numpy as np
+        frames = torch.from_numpy(np.random.default_rng(0).integers(0, 256, (T, side, side, 3), dtype=np.uint8)).to(dev)
     V = cfg["llm"]["vocab_size"]
     cg = torch.Generator().manual_seed(1)
     ids = torch.cat([torch.tensor([1]), torch.randint(3, V, (31,), generator=cg), torch.tensor([-201]),
@@ -292,6 +302,42 @@ def main():
     enc_ms = sum(e[0].elapsed_time(e[1]) for e in rec) / len(rec)
     pre_ms = sum(e[1].elapsed_time(e[2]) for e in rec) / len(rec)
     dec_ms = sum(e[2].elapsed_time(e[3]) for e in rec) / len(rec)
+
+    # ---- the encoder alone: ViT-only frames/s (no collective, no connector) and, with N > 1 ranks, BOTH frame-parallel cuts
+    #      (SURVEY 8e), each timed like the main loop (barrier + synchronize on both sides, max over ranks)
+    def timed(fn, iters):
+        fn()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        d = time.perf_counter() - t
+        if world > 1:
+            tt = torch.tensor([d], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            d = tt.item()
+        return d * 1e3 / iters
+
+    enc_iters = max(args.steps, 3)
+    parts = model.sharder.split(T, world)
+    s0, c0 = parts[rank]
+    vit_ms = timed(lambda: model.vision_tower(frames[s0:s0 + c0]) if c0 > 0 else None, enc_iters)
+    cuts = {}
+    if world > 1:
+        keep = model.sharder.cut
+        for cut in model.sharder.CUTS:
+            model.sharder.cut = cut
+            ms = timed(lambda: model.encode_images_or_videos([(frames, "video")]), enc_iters)
+            cuts[cut] = dict(encode_ms=round(ms, 3), frames_per_s=round(T / (ms / 1e3), 1),
+                             taken=("sharded_connector" if cut == "sharded_connector" and model.sharder.can_shard_connector(T) else "north_star"))
+        model.sharder.cut = keep
 
     # ---- roofline of the dominant kernel (gemm_bf16_kernel, MFMA-bound): one extra profiled pass, every GEMM launch
     #      bracketed by HIP events on the launch stream; achieved = sum(algorithmic FLOPs) / sum(kernel time)
@@ -387,21 +433,47 @@ def main():
         ach = gflop / gms if gms > 0 else 0.0                  # GFLOP/ms = TFLOP/s
         # HBM-side bytes per launch come from a separate rocprofv3 --pmc run (scripts/gpu_traffic.sh; PMC cannot be
         # collected inside this process); only quoted for the workload it was collected on (T=16, 241 GEMM launches).
-        traffic, tpath = None, os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_gemm_traffic.json")   # PMC passes of the round-2 kernels (scripts/gpu_round2_e.sh)
-        if os.path.exists(tpath):
-            tj = json.load(open(tpath))
-            if T == 16 and args.model == "v2" and world == 1 and tj.get("launches_per_step") == ngemm:
-                traffic = tj["hbm_bytes_per_launch"]
+        traffic, tsrc = None, None
+        for tname in ("r03_gemm_traffic.json", "r02_gemm_traffic.json"):     # PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs) of this round's kernels first
+            tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", tname)
+            if os.path.exists(tpath):
+                tj = json.load(open(tpath))
+                if T == 16 and args.model == "v2" and world == 1 and tj.get("launches_per_step") == ngemm:
+                    traffic, tsrc = tj["hbm_bytes_per_launch"], "profiles/" + tname
+                    break
+        # the single dominant GEMM shape of the step (most total time): its own rate against the same peak
+        by_shape = {}
+        for pr in prof:
+            if pr[0] == "gemm":
+                e = by_shape.setdefault(pr[4], [0, 0.0, 0.0])
+                e[0] += 1; e[1] += pr[1] / 1e9; e[2] += pr[2].elapsed_time(pr[3])
+        dom = max(by_shape.items(), key=lambda kv: kv[1][2]) if by_shape else None
         kernels = ("gemm_bf16_kernel + gemm3_bf16_kernel + gemm4_bf16_kernel + gemm_l8_bf16_kernel (every vl2_gemm call of the "
                    "step; a row-split call is two kernels back to back)")
         roof = dict(bound="mfma", kernel=kernels, achieved=round(ach, 2), peak=PEAK_MFMA_BF16_TFLOPS,
                     unit="TFLOP/s", frac=round(ach / PEAK_MFMA_BF16_TFLOPS, 4), traffic=traffic,
                     launches=ngemm, avg_launch_us=round(1e3 * gms / max(ngemm, 1), 2),
-                    flop_per_launch_avg=round(1e9 * gflop / max(ngemm, 1), 0))
+                    flop_per_launch_avg=round(1e9 * gflop / max(ngemm, 1), 0), traffic_source=tsrc)
+        if dom is not None:
+            (dM, dN, dK), (dn, dgf, dms) = dom
+            roof["dominant"] = dict(gemm=f"M={dM} N={dN} K={dK}" + (" (gate/up + SwiGLU: 256x256 ping-pong kernel on the first 1536 rows + one-round 128x128 kernel on the last 85)"
+                                                                     if (dN, dK) == (2 * cfg["llm"]["intermediate_size"], cfg["llm"]["hidden_size"]) else ""),
+                                    launches=dn, avg_launch_us=round(1e3 * dms / dn, 2), gflop_per_launch=round(dgf / dn, 1),
+                                    achieved=round(dgf / dms, 2), frac=round(dgf / dms / PEAK_MFMA_BF16_TFLOPS, 4), share_of_gemm_time=round(dms / gms, 3))
 
     if rank == 0:
         vit_tf, stc_tf, pre_tf, S_alg = algorithmic_tflop(cfg, T)
         fwd_ms = enc_ms + pre_ms
+        if world == 1:
+            par = "single GPU"
+        else:
+            if model.sharder.cut == "north_star" or not model.sharder.can_shard_connector(T):
+                par = (f"frames sharded over {world} ranks, north_star cut: ViT per rank, ONE RCCL all-gather of [T/R,576,1024] visual tokens, "
+                       f"connector replicated; ")
+            else:
+                par = (f"frames sharded over {world} ranks, sharded-connector cut (ViT + STC s1/conv3d/s2 per rank"
+                       f"{' replayed from two hipGraphs' if model.sharder.use_graph else ''}, halo + RCCL all-gather of visual tokens); ")
+            par += f"LLM {'tensor-parallel over the ranks' if args.tp else 'replicated'}"
         out = {
             "metric": {"v2": "video-frames/sec encoded (CLIP-ViT + STC), VideoLLaMA2-7B 16f@336^2; prefill/decode tokens/sec as extra keys",
                        "v21": "video-frames/sec encoded (SigLIP + STC v35), VideoLLaMA2.1-7B-16F 16f@384^2; prefill/decode tokens/sec as extra keys",
@@ -415,8 +487,7 @@ def main():
                                     f"bf16, S={S} prefill, {n_new} greedy decode tokens (BASELINE.json configs[3] without the TP=8 split)" if args.model == "72b" else
                                     f"VideoLLaMA2.1-7B-16F (SigLIP-so400m-384 + stc_connector_v35 + Qwen2-7B), {T}-frame 384^2 video, bf16, "
                                     f"S={S} prefill, {n_new} greedy decode tokens (SURVEY 8f row 1; not BASELINE.json's metric config)"), "frames": T, "prefill_tokens": S, "new_tokens": n_new,
-                       "parallelism": (f"frames sharded over {world} ranks (ViT + STC s1/conv3d/s2 per rank{' replayed from two hipGraphs' if model.sharder.use_graph else ''}, halo + RCCL all-gather of visual tokens); "
-                                       f"LLM {'tensor-parallel over the ranks' if args.tp else 'replicated'}" if world > 1 else "single GPU"),
+                       "parallelism": par,
                        "llm_layers": len(model.decoder.w["layers"]),
                        "decode": "eager launches" if graph is None else ("hipGraph replay (argmax + 32-layer step per token" + (", RCCL all-reduces captured)" if tp_group is not None else ")"))},
             "encode_ms": round(enc_ms, 3), "prefill_ms": round(pre_ms, 3), "decode_ms_per_token": round(dec_ms / n_new, 4),
@@ -425,7 +496,14 @@ def main():
             "forward_mfma_frac": round((vit_tf + stc_tf + pre_tf) / (fwd_ms / 1e3) / PEAK_MFMA_BF16_TFLOPS, 4),
             "decode_hbm_frac": round(decode_bytes_per_token(cfg, S + n_new // 2) / (dec_ms / n_new / 1e3) / 1e9 / PEAK_HBM_GBS, 4),
             "roofline": roof,
+            "frames_input": "bf16 randn [T,3,S,S]" if args.bf16_frames else "uint8 [T,S,S,3] (np.random.default_rng(0)), normalised on the GPU in the patch-row kernel",
+            "vit_only": {"ms": round(vit_ms, 3), "frames_per_s": round(T / (vit_ms / 1e3), 1),
+                         "what": f"CLIP tower alone on the rank's {c0} of {T} frames (no collective, no connector), max over ranks"},
         }
+        if world > 1:
+            out["cut"] = model.sharder.cut
+            out["north_star_cut"] = cuts["north_star"]
+            out["sharded_connector_cut"] = cuts["sharded_connector"]
         if shard_check is not None:
             out["sharded_encoder_equals_unsharded"] = shard_check
             out["encoder_graphs"] = "replayed" if model.sharder.use_graph else f"eager ({model.sharder.graph_error or 'disabled'})"

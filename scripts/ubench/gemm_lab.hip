@@ -1,0 +1,133 @@
+// GEMM kernel lab (diagnostic, not part of the library): A/B of the library's GEMM kernels straight from C++ -- no Python, no
+// torch -- so a kernel edit is one hipcc of this file and a few seconds on the GPU box.
+//   build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffast-math -fno-finite-math-only -I videollama2_amd/csrc scripts/ubench/gemm_lab.hip -o scripts/ubench/gemm_lab
+//   run:   scripts/ubench/gemm_lab [rounds]          (prints one line per shape and variant: us, TFLOP/s, bitwise == gemm4)
+// Operands: N(0,1) bf16 activations, N(0,1)/sqrt(K) weights (random data: the chip is power-limited, zero-filled operands
+// flatter every kernel by 15-20 %).  Variants are run in interleaved rounds inside ONE process; min over rounds is reported.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <vector>
+#include <string>
+#include "k_gemm5.h"
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1); } } while (0)
+
+template <typename K> static void lds_attr(K k, int bytes) { CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)); }
+
+struct Shape { const char* name; int M, N, K; bool swiglu, bias, res; int act; };
+
+static void fill_bf16(std::vector<uint16_t>& h, float scale, unsigned seed) {
+    srand(seed);
+    for (size_t i = 0; i < h.size(); ++i) {
+        float u1 = (rand() + 1.f) / (RAND_MAX + 2.f), u2 = rand() / (float)RAND_MAX;
+        float g = scale * sqrtf(-2.f * logf(u1)) * cosf(6.2831853f * u2);
+        unsigned u; memcpy(&u, &g, 4); h[i] = (uint16_t)((u + 0x7fff + ((u >> 16) & 1)) >> 16);
+    }
+}
+
+template <int ACT, bool SW>
+static void launch(int variant, GemmArgs a, hipStream_t s) {
+    if (variant == 8) {
+        lds_attr(gemm4_bf16_kernel<ACT, SW, false>, GEMM4_LDS_BYTES);
+        a.tiles_m = (a.M + 255) / 256; a.tiles_n = a.N / 256;
+        hipLaunchKernelGGL((gemm4_bf16_kernel<ACT, SW, false>), dim3(a.tiles_m * a.tiles_n), dim3(512), GEMM4_LDS_BYTES, s, a);
+    } else if (variant == 4) {
+        lds_attr(gemm3_bf16_kernel<ACT, SW, false>, GEMM3_LDS_BYTES);
+        a.tiles_m = (a.M + 127) / 128; a.tiles_n = a.N / 256;
+        hipLaunchKernelGGL((gemm3_bf16_kernel<ACT, SW, false>), dim3(a.tiles_m * a.tiles_n), dim3(512), GEMM3_LDS_BYTES, s, a);
+    } else if (variant == 1) {
+        lds_attr(gemm_bf16_kernel<ACT, SW, false, false>, GEMM_LDS_BYTES);
+        a.tiles_m = (a.M + 127) / 128; a.tiles_n = a.N / 128;
+        hipLaunchKernelGGL((gemm_bf16_kernel<ACT, SW, false, false>), dim3(a.tiles_m * a.tiles_n), dim3(256), GEMM_LDS_BYTES, s, a);
+    } else if (variant == 22) {
+        using G = Gemm5Geo<2, 2>;
+        lds_attr(gemm5_bf16_kernel<ACT, SW, false, 2, 2>, G::LDS);
+        a.tiles_m = (a.M + G::BM - 1) / G::BM; a.tiles_n = a.N / G::BN;
+        hipLaunchKernelGGL((gemm5_bf16_kernel<ACT, SW, false, 2, 2>), dim3(a.tiles_m * a.tiles_n), dim3(256), G::LDS, s, a);
+    } else if (variant == 14) {
+        using G = Gemm5Geo<1, 4>;
+        lds_attr(gemm5_bf16_kernel<ACT, SW, false, 1, 4>, G::LDS);
+        a.tiles_m = (a.M + G::BM - 1) / G::BM; a.tiles_n = a.N / G::BN;
+        hipLaunchKernelGGL((gemm5_bf16_kernel<ACT, SW, false, 1, 4>), dim3(a.tiles_m * a.tiles_n), dim3(256), G::LDS, s, a);
+    } else if (variant == 41) {
+        using G = Gemm5Geo<4, 1>;
+        lds_attr(gemm5_bf16_kernel<ACT, SW, false, 4, 1>, G::LDS);
+        a.tiles_m = (a.M + G::BM - 1) / G::BM; a.tiles_n = a.N / G::BN;
+        hipLaunchKernelGGL((gemm5_bf16_kernel<ACT, SW, false, 4, 1>), dim3(a.tiles_m * a.tiles_n), dim3(256), G::LDS, s, a);
+    }
+}
+
+int main(int argc, char** argv) {
+    const int rounds = argc > 1 ? atoi(argv[1]) : 3;
+    const std::vector<Shape> shapes = {
+        {"sq_8192x4096x4096", 8192, 4096, 4096, false, false, false, 0},
+        {"sq_8192", 8192, 8192, 8192, false, false, false, 0},
+        {"sq_4096", 4096, 4096, 4096, false, false, false, 0},
+        {"vit_qkv", 9232, 3072, 1024, false, true, false, 0},
+        {"vit_wo", 9232, 1024, 1024, false, true, true, 0},
+        {"vit_fc1", 9232, 4096, 1024, false, true, false, 1},
+        {"vit_fc2", 9232, 1024, 4096, false, true, true, 0},
+        {"stc_s1_conv", 9216, 4096, 4096, false, false, false, 0},
+        {"stc_s1_b1", 9216, 4096, 1024, false, false, false, 0},
+        {"llm_qkv", 1621, 6144, 4096, false, false, false, 0},
+        {"llm_wo", 1621, 4096, 4096, false, false, true, 0},
+        {"llm_gateup", 1621, 28672, 4096, true, false, false, 0},
+        {"llm_down", 1621, 4096, 14336, false, false, true, 0},
+    };
+    const std::vector<int> variants = {8, 4, 22, 14, 41};
+    hipStream_t s; CK(hipStreamCreate(&s));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (const Shape& sh : shapes) {
+        const size_t na = (size_t)sh.M * sh.K, nw = (size_t)sh.N * sh.K, ncol = sh.swiglu ? sh.N / 2 : sh.N, nc = (size_t)sh.M * ncol;
+        std::vector<uint16_t> ha(na), hw(nw), hr(nc);
+        fill_bf16(ha, 1.f, 1); fill_bf16(hw, 1.f / sqrtf((float)sh.K), 2); fill_bf16(hr, 1.f, 3);
+        std::vector<float> hb(sh.N);
+        for (int i = 0; i < sh.N; ++i) hb[i] = 0.01f * (float)((i * 37) % 101 - 50);
+        uint16_t *dA, *dW, *dR, *dC, *dRef; float* dB;
+        CK(hipMalloc(&dA, na * 2)); CK(hipMalloc(&dW, nw * 2)); CK(hipMalloc(&dR, nc * 2)); CK(hipMalloc(&dC, nc * 2)); CK(hipMalloc(&dRef, nc * 2)); CK(hipMalloc(&dB, sh.N * 4));
+        CK(hipMemcpy(dA, ha.data(), na * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dW, hw.data(), nw * 2, hipMemcpyHostToDevice));
+        CK(hipMemcpy(dR, hr.data(), nc * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dB, hb.data(), sh.N * 4, hipMemcpyHostToDevice));
+        GemmArgs a{};
+        a.A = dA; a.W = dW; a.C = dC; a.bias = sh.bias ? dB : nullptr; a.res = sh.res ? dR : nullptr;
+        a.M = sh.M; a.N = sh.N; a.K = sh.K; a.lda = sh.K; a.ldw = sh.K; a.ldc = (int)ncol; a.ldres = (int)ncol;
+        auto go = [&](int v, GemmArgs x) {
+            if (sh.swiglu) launch<ACT_NONE, true>(v, x, s);
+            else if (sh.act == 1) launch<ACT_QGELU, false>(v, x, s);
+            else launch<ACT_NONE, false>(v, x, s);
+        };
+        std::vector<double> best(variants.size(), 1e30);
+        std::vector<int> same(variants.size(), -1);
+        std::vector<uint16_t> href(nc), hc(nc);
+        for (int r = 0; r < rounds; ++r)
+            for (size_t vi = 0; vi < variants.size(); ++vi) {
+                const int v = variants[vi];
+                if ((v == 14 && sh.N % 512) || (v == 8 && sh.N % 256) || (v == 4 && sh.N % 256) || (v == 22 && sh.N % 256)) continue;
+                if (r == 0) {
+                    CK(hipMemsetAsync(dC, 0xff, nc * 2, s));
+                    go(v, a);
+                    CK(hipStreamSynchronize(s));
+                    CK(hipGetLastError());
+                    CK(hipMemcpy(hc.data(), dC, nc * 2, hipMemcpyDeviceToHost));
+                    if (v == 8) href = hc;
+                    else { size_t bad = 0; for (size_t i = 0; i < nc; ++i) bad += hc[i] != href[i]; same[vi] = bad == 0 ? 1 : 0; if (bad) fprintf(stderr, "  %s v%d: %zu of %zu elements differ from v8\n", sh.name, v, bad, nc); }
+                }
+                for (int w = 0; w < 2; ++w) go(v, a);
+                const int iters = 10;
+                CK(hipEventRecord(e0, s));
+                for (int i = 0; i < iters; ++i) go(v, a);
+                CK(hipEventRecord(e1, s));
+                CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                best[vi] = std::min(best[vi], (double)ms * 1e3 / iters);
+            }
+        printf("%-18s %5d %5d %5d ", sh.name, sh.M, sh.N, sh.K);
+        for (size_t vi = 0; vi < variants.size(); ++vi)
+            if (best[vi] < 1e29) printf("| v%-2d %7.1f us %6.0f TF %s ", variants[vi], best[vi], 2.0 * sh.M * sh.N * sh.K / best[vi] / 1e6, same[vi] == 1 ? "==" : (same[vi] == 0 ? "!=" : "  "));
+        printf("\n"); fflush(stdout);
+        CK(hipFree(dA)); CK(hipFree(dW)); CK(hipFree(dR)); CK(hipFree(dC)); CK(hipFree(dRef)); CK(hipFree(dB));
+    }
+    return 0;
+}

@@ -69,9 +69,13 @@ def _worker_sharded(rank, world, port, q, fixture):
         siglip = O.vision_family(cfg) == "siglip"
         tower = (HipSiglipVisionTower if siglip else HipCLIPVisionTower)(cfg, sd, "cpu")
         conn = HipSTCConnector(sd, "cpu", padding=O.conv3d_padding(cfg))
-        sh = FrameSharder()
+        sh = FrameSharder(cut="sharded_connector")
         assert sh.can_shard_connector(4)
         out = sh.encode_video(tower, conn, g["frames"])                     # sharded ViT + s1 + halo + conv3d/s2/readout
+        ns = FrameSharder()                                                 # default cut = BASELINE.json's north_star
+        assert ns.cut == "north_star"
+        out_ns = ns.encode_video(tower, conn, g["frames"])                  # ViT sharded, all-gather of tower tokens, connector replicated
+        assert torch.equal(out_ns, out)
         feats = tower(g["frames"])
         ref = conn(feats.view(1, *feats.shape))                             # single-process path, same kernels
     q.put((rank, torch.equal(out, ref), tuple(out.shape), ((out - g["mm_features"]).norm() / g["mm_features"].norm()).item()))

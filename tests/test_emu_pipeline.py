@@ -803,3 +803,33 @@ def check_pack_entry_points_against_weights_py(ops, dev):
 def test_emu_pack_entry_points_match_weights_py(emu):
     from videollama2_amd import ops
     check_pack_entry_points_against_weights_py(ops, "cpu")
+
+
+def test_emu_parity_full_end_to_end_dry_run(emu):
+    """CPU dry run of tests/test_gpu_parity_full.py::run_end_to_end (the configs[1] end-to-end chain: frames -> tower -> STC ->
+    splice -> prefill -> teacher-forced decode + the free-running product generate) on the small config through the emulator, so
+    that the GPU test's host logic is exercised where no GPU exists."""
+    from tests import test_gpu_parity_full as PF
+    saved = PF.DEV
+    PF.DEV = "cpu"
+    try:
+        PF.run_end_to_end(O.config_small(4), 4, 3, 256)
+        assert any(r.get("stage", "").startswith("e2e greedy tokens") for r in PF.RECORD)
+    finally:
+        PF.DEV = saved
+        del PF.RECORD[:]
+
+
+def test_emu_tensor_parallel_real_shards_in_one_process(emu):
+    """dist.LocalTensorParallel (both ranks' shards in this process, partial sums added where the all-reduce sits) on the small
+    decoder through the emulator: the CPU dry run of tests/test_gpu_tp.py."""
+    from tests import test_gpu_tp as TP
+    cfg = O.config_small(4)
+    cfg["llm"].update(hidden_size=512, num_attention_heads=4, num_key_value_heads=2, intermediate_size=512)   # 2 kv heads: TP = 2
+    keep = lambda n: n.startswith(("model.layers.", "model.norm", "model.embed_tokens", "lm_head"))
+    sd = O.seeded_state_dict(cfg, 21, only=keep)
+    x = (torch.randn(37, 512, generator=torch.Generator().manual_seed(3)) * 0.5).bfloat16().float()
+    with torch.no_grad():
+        toks, lg = O.greedy_generate(sd, cfg, x, 3)
+    rows = TP.run_local_tp(cfg, sd, x, toks, lg, 2, 64, "cpu")
+    assert len(rows) == 3

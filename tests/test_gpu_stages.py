@@ -12,7 +12,7 @@ import pytest
 import torch
 
 from oracle import vl2_oracle as O
-from tests.util import rel, sd_to
+from tests.util import rel, sd_to, token_tie_ok
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -155,8 +155,9 @@ def test_full_width_mistral_layers_prefill_and_decode():
             stage_ok(f"full-width decode logits {s}", mine[s], lg[s], lg16[s], rec)
     else:
         print("[parity] greedy path diverged on a near-tie:", out[0].tolist(), toks)
-        top2 = lg[0].topk(2).values
-        assert out[0, 0].item() == toks[0] or (top2[0] - top2[1]).item() < 0.05
+        s_div = next(i for i, (a, b) in enumerate(zip(out[0].tolist(), toks)) if a != b)       # first step that differs
+        ok, margin, dmax = token_tie_ok(mine[s_div], lg[s_div])
+        assert ok, f"step {s_div}: token differs although fp32 top-2 margin {margin:.3e} >= 2 x max|dlogit| {dmax:.3e}"
 
 
 def test_hipgraph_decode_matches_eager(small):

@@ -10,7 +10,7 @@ import torch
 
 from oracle import vl2_oracle as O
 from tests.test_gpu_stages import FULL_TOL, stage_ok
-from tests.util import rel, sd_to
+from tests.util import rel, sd_to, token_tie_ok
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -50,8 +50,8 @@ def test_small_golden_v21_tower_connector_generate(small21):
         got = toks[0].tolist()
         for i, (a, b) in enumerate(zip(got, ref)):                    # tokens must agree while the fp32 top-2 margin is clear
             if a != b:
-                top2 = g["step_logits"][i].topk(2).values
-                assert (top2[0] - top2[1]).item() < 0.05, (use_graph, i, got, ref)
+                ok, margin, dmax = token_tie_ok(logits[i], g["step_logits"][i])
+                assert ok, (use_graph, i, got, ref, margin, dmax)
                 break
 
 
@@ -112,8 +112,9 @@ def test_full_width_qwen2_layers_prefill_and_decode():
             stage_ok(f"qwen2 full-width decode logits {s}", mine[s], lg[s], FULL_TOL["logits"], rec)
     else:
         print("[parity] greedy path diverged on a near-tie:", out[0].tolist(), toks)
-        top2 = lg[0].topk(2).values
-        assert out[0, 0].item() == toks[0] or (top2[0] - top2[1]).item() < 0.05
+        s_div = next(i for i, (a, b) in enumerate(zip(out[0].tolist(), toks)) if a != b)
+        ok, margin, dmax = token_tie_ok(mine[s_div], lg[s_div])
+        assert ok, f"step {s_div}: token differs although fp32 top-2 margin {margin:.3e} >= 2 x max|dlogit| {dmax:.3e}"
     graph = dec.generate(x.to(DEV), max_new_tokens=4, use_graph=True)
     assert graph.tolist() == out.tolist()
 
@@ -191,8 +192,9 @@ def test_batched_decode_gemm_path_matches_sequential_to_rounding():
             if outs[b][:s].tolist() != toks[0, :s].tolist():
                 break                                                         # diverged on a near-tie earlier: later steps differ
             assert rel(blogits[s, b], logits[s]) < 2e-2, (b, s)
-            top2 = logits[s].topk(2).values
-            assert outs[b][s].item() == toks[0, s].item() or (top2[0] - top2[1]).item() < 0.05, (b, s)
+            if outs[b][s].item() != toks[0, s].item():                        # batched (skinny-MFMA) vs single-request arithmetic
+                ok, margin, dmax = token_tie_ok(blogits[s, b], logits[s])
+                assert ok, (b, s, margin, dmax)
 
 
 def test_full_width_72b_connector():

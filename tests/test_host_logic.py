@@ -201,3 +201,67 @@ def test_checkpoint_config_uses_public_tower_values(tmp_path):
     json.dump(dict(base, model_type="videollama2_mixtral"), open(tmp_path / "config.json", "w"))
     with pytest.raises(ValueError, match="not built"):
         api.config_from_checkpoint(str(tmp_path))
+
+
+def test_lazy_tower_key_layouts_and_never_loaded_guard(tmp_path):
+    """(1) a local tower directory whose config.json nests the vision hyper-parameters under `vision_config`
+    (the standard openai/clip-vit-large-patch14-336 layout) is read; (2) a `vision_model.`-prefixed (transformers 4.x era) checkpoint
+    loads through HF `from_pretrained(low_cpu_mem_usage=True)` -- which matches keys by NAME and runs no load_state_dict hook --
+    when the tower hosts that layout; (3) with the mismatching layout the parameters are materialised uninitialised and
+    `check_loaded()` (called by `pack()`) refuses to run instead of encoding frames with garbage; (4) a plain `load_state_dict`
+    accepts either layout."""
+    import json
+    import types
+    from safetensors.torch import save_file
+    from transformers import PretrainedConfig, PreTrainedModel
+    from videollama2_amd.lazy import LazyHipVisionTower, default_key_layout, tower_config
+    tdir = tmp_path / "clip-tiny"
+    tdir.mkdir()
+    vis = dict(hidden_size=64, intermediate_size=128, num_hidden_layers=3, num_attention_heads=2, image_size=28, patch_size=14)
+    json.dump({"model_type": "clip", "text_config": {}, "vision_config": vis}, open(tdir / "config.json", "w"))
+    v = tower_config(str(tdir))
+    assert v["family"] == "clip" and all(v[k] == vis[k] for k in vis)
+    assert default_key_layout() in ("vision_model", "flat")
+    args = types.SimpleNamespace(mm_vision_select_layer=-2)
+
+    class Cfg(PretrainedConfig):
+        model_type = "vl2_lazy_probe"
+
+        def __init__(self, key_layout="vision_model", **kw):
+            super().__init__(**kw)
+            self.key_layout = key_layout
+
+    class Host(PreTrainedModel):
+        config_class = Cfg
+
+        def __init__(self, config):
+            super().__init__(config)
+            self.vision_tower = LazyHipVisionTower(str(tdir), args, key_layout=config.key_layout)
+            self.post_init()
+
+        def _init_weights(self, module):
+            pass
+
+    ref = LazyHipVisionTower(str(tdir), args, key_layout="vision_model")
+    with pytest.raises(RuntimeError, match="never loaded"):
+        ref.check_loaded()                                                         # fresh torch.empty storage is not a tower
+    g = torch.Generator().manual_seed(0)
+    sd = {"vision_tower." + k: torch.randn(p.shape, generator=g).bfloat16() for k, p in ref.state_dict().items()}
+    assert all(".vision_model." in k for k in sd)
+    ck = tmp_path / "ckpt"
+    ck.mkdir()
+    save_file(sd, str(ck / "model.safetensors"))
+    Cfg(key_layout="vision_model").save_pretrained(str(ck))
+    m = Host.from_pretrained(str(ck), low_cpu_mem_usage=True)
+    m.vision_tower.check_loaded()
+    for k, p in m.vision_tower.state_dict().items():
+        assert torch.equal(p.bfloat16(), sd["vision_tower." + k]), k
+    Cfg(key_layout="flat").save_pretrained(str(ck))
+    m2 = Host.from_pretrained(str(ck), low_cpu_mem_usage=True)                      # every tower key is reported missing
+    with pytest.raises(RuntimeError, match="key_layout='vision_model'"):
+        m2.vision_tower.check_loaded()
+    flat = LazyHipVisionTower(str(tdir), args, key_layout="flat")
+    flat.load_state_dict({k[len("vision_tower."):]: t for k, t in sd.items()}, strict=True)     # 4.x keys into the 5.x host
+    flat.check_loaded()
+    ref.load_state_dict({k: p for k, p in flat.state_dict().items()}, strict=True)                  # 5.x keys into the 4.x host
+    ref.check_loaded()

@@ -12,6 +12,17 @@ TOL_F32_OUT = 1e-3     # fp32-accumulate kernels with fp32 output
 TOL_BF16_OUT = 3e-3    # same + one bf16 output rounding (floor 2^-9/sqrt(3) = 1.1e-3) and bf16 P in attention
 
 
+def token_tie_ok(ours_logits, ref_logits):
+    """The ONLY excuse for a greedy token that differs from the reference's: the reference's own top-2 margin at that step is
+    smaller than twice the largest logit error of the path under test (a tie the bf16 floor cannot resolve).  Returns
+    (ok, margin, dmax)."""
+    a, b = ours_logits.detach().float().cpu(), ref_logits.detach().float().cpu()
+    top2 = b.topk(2).values
+    margin = (top2[0] - top2[1]).item()
+    dmax = (a - b).abs().max().item()
+    return margin < 2.0 * dmax, margin, dmax
+
+
 def bf16_round(t):
     return t.bfloat16().float()
 

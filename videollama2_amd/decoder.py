@@ -19,7 +19,7 @@ class HipMistralDecoder(nn.Module):
     all-reduced (RCCL over xGMI; 2 x [S, D] bf16 per layer in the prefill, 2 x [D] per layer per token in the decode loop).
     The residual is folded into rank 0's partial so the sum needs no extra pass."""
 
-    def __init__(self, cfg, state_dict, device="cuda", max_seq_len=4096, n_layers=None, tp_group=None, tp_shard=None):
+    def __init__(self, cfg, state_dict, device="cuda", max_seq_len=4096, n_layers=None, tp_group=None, tp_shard=None, tp_local=None):
         super().__init__()
         self.cfg = cfg
         l = cfg["llm"]
@@ -29,6 +29,9 @@ class HipMistralDecoder(nn.Module):
         self.tp_rank = dist.get_rank(tp_group) if tp_group is not None else 0
         if tp_shard is not None:                 # (rank, size) WITHOUT a group: one rank's shard run alone, no collectives --
             self.tp_rank, self.tp = tp_shard     # timing model only (scripts/tp_model.py); the numbers it produces are partial sums
+        # ... unless `tp_local` (dist.LocalTensorParallel) stands in for the group: every rank's shard in ONE process, the all-reduce
+        # a rendezvous of host threads -- how >= 2 REAL shards are summed and checked on a 1-GPU box (tests/test_gpu_tp.py)
+        self.tp_local = tp_local
         self.w = pack_decoder(state_dict, cfg, self._dev, n_layers, self.tp_rank, self.tp)
         self.n_layers = len(self.w["layers"])
         self.nh, self.nkv, self.hd = l["num_attention_heads"] // self.tp, l["num_key_value_heads"] // self.tp, l["head_dim"]
@@ -75,6 +78,8 @@ class HipMistralDecoder(nn.Module):
     def _reduce(self, t):
         """Sum the row-parallel partial results over the tensor-parallel group (no-op without one).  gloo (CPU tests, debug)
         takes device tensors through host memory."""
+        if self.tp > 1 and self.tp_local is not None:
+            return self.tp_local.reduce(self.tp_rank, t)
         if (self.tp > 1 or self.tp_always_reduce) and self.tp_group is not None:
             if t.is_cuda and dist.get_backend(self.tp_group) == "gloo":
                 h = t.cpu()

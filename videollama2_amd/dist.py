@@ -46,9 +46,87 @@ class RankEncoderGraph:
         return self.tok
 
 
+class LocalTensorParallel:
+    """Every rank of a tensor-parallel decoder in ONE process, for boxes that reach one GPU (the decoder-side counterpart of
+    `FrameSharder.encode_video_all_ranks_locally`): rank r's shard is a `HipMistralDecoder(..., tp_shard=(r, R), tp_local=self)` that
+    runs in its own host thread, all of them on the same device and stream.  `reduce(rank, t)` is the all-reduce of the row-parallel
+    projections (o_proj / down_proj partial sums): the ranks rendezvous, the partials are summed in RANK ORDER in fp32 and rounded
+    once to the tensor's dtype, and every rank receives the same bits (what an RCCL all-reduce guarantees, though its ring adds in
+    another order).  Validation only: the collectives of a real run are RCCL calls (`tp_group`)."""
+
+    def __init__(self, size):
+        import threading
+        self.size = size
+        self._bar = threading.Barrier(size)
+        self._turn = threading.Lock()         # ONE rank enqueues at a time (the ranks hand the turn over at every reduction): the
+        self._slots = [None] * size           # launch order on the shared stream is deterministic, and a host-side backend that is
+        self._sum = None                      # not thread-safe (the CPU emulator of the tests) can sit underneath
+        self._holds = [False] * size          # which rank's thread owns the turn right now
+        self.reductions = 0
+
+    def reduce(self, rank, t):
+        self._slots[rank] = t
+        self._holds[rank] = False
+        self._turn.release()
+        self._bar.wait()                      # every rank's partial is enqueued; nobody holds the turn
+        if rank == 0:
+            with self._turn:
+                acc = self._slots[0].float().clone()
+                for r in range(1, self.size):
+                    acc += self._slots[r].float()
+                self._sum = acc.to(t.dtype)
+                self.reductions += 1
+        self._bar.wait()
+        self._turn.acquire()                  # keeps the turn until its next reduction (or the end of its program)
+        self._holds[rank] = True
+        t.copy_(self._sum)
+        return t
+
+    def run(self, fns):
+        """fns[r]() is rank r's program (every rank must reach the same reductions); returns [fns[r]() for r], re-raises the first error."""
+        import threading
+        out, err = [None] * self.size, [None] * self.size
+
+        def body(r):
+            self._turn.acquire()
+            self._holds[r] = True
+            try:
+                out[r] = fns[r]()
+            except BaseException as exc:          # noqa: BLE001 -- a failed rank must not leave the others waiting forever
+                err[r] = exc
+                self._bar.abort()
+            finally:
+                if self._holds[r]:
+                    self._holds[r] = False
+                    self._turn.release()
+
+        th = [threading.Thread(target=body, args=(r,)) for r in range(self.size)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        errs = [e for e in err if e is not None]
+        if errs:
+            real = [e for e in errs if type(e).__name__ != "BrokenBarrierError"]
+            raise (real or errs)[0]
+        return out
+
+
 class FrameSharder:
-    def __init__(self, group=None, use_graph=False):
+    """cut: which of the two frame-parallel cuts `encode_video` takes ("keep the north_star cut as the default /
+    baseline and report the alternative"):
+        "north_star"        (default) BASELINE.json's own: ViT on the rank's frames, ONE all-gather of [T/R, 576, 1024] visual
+                            tokens in front of the connector, connector replicated on every rank;
+        "sharded_connector" everything per-frame stays sharded (ViT + STC s1, one-frame halo, Conv3d / s2 / readout on the rank's
+                            output frames, all-gather of the final tokens); falls back to north_star when T does not split into an
+                            even number of frames per rank."""
+    CUTS = ("north_star", "sharded_connector")
+
+    def __init__(self, group=None, use_graph=False, cut="north_star"):
+        if cut not in self.CUTS:
+            raise ValueError(f"cut {cut!r}: expected one of {self.CUTS}")
         self.group = group
+        self.cut = cut
         self.use_graph = use_graph            # hipGraph replay of the rank-local encoder pieces (CUDA tensors only)
         self._graphs = {}
         self.graph_error = None               # why the graphs were abandoned for eager launches, if they were
@@ -144,14 +222,14 @@ class FrameSharder:
     def encode_video(self, tower, connector, frames):
         """frames [T,3,H,W] -> visual tokens [1, N_vis, D] on every rank.
 
-        world 1, or a frame count that does not split evenly: the north-star cut -- ViT on the local frames, ONE
-        all-gather of [T/R, 576, 1024] tokens, connector replicated (`encode` above + connector).
-        Otherwise the "better cut" of SURVEY.md 8(e): everything per-frame stays sharded -- ViT and STC stage s1 on the
+        cut "north_star" (default), world 1, or a frame count that does not split evenly: the north-star cut -- ViT on the local
+        frames, ONE all-gather of [T/R, 576, 1024] tokens, connector replicated (`encode` above + connector).
+        cut "sharded_connector": the "better cut" of SURVEY.md 8(e): everything per-frame stays sharded -- ViT and STC stage s1 on the
         local frames, a one-frame halo (the last s1 frame goes to the next rank: Conv3d output `to` reads frames
         2to-1 and 2to), Conv3d + s2 + readout on this rank's output frames, then ONE all-gather of the final visual
         tokens (1.4 MB per rank at T=16).  Same arithmetic, same row order, bit-identical output."""
         T = frames.shape[0]
-        if not self.can_shard_connector(T):
+        if self.cut != "sharded_connector" or not self.can_shard_connector(T):
             feats = self.encode(tower, frames)
             return connector(feats.view(1, *feats.shape))
         world, rank = self.world, self.rank

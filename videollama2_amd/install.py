@@ -62,6 +62,9 @@ class HipCausalLMLoader:
     def from_pretrained(cls, model_path, *args, config=None, **kwargs):
         from . import api
         from .tower import default_image_processor, default_siglip_image_processor
+        for k in ("load_in_4bit", "load_in_8bit", "quantization_config"):          # model/__init__.py:57-69: bitsandbytes loading
+            if kwargs.get(k):
+                raise NotImplementedError(f"HIP path: `{k}` (bitsandbytes quantised loading) is not built; load the bf16 checkpoint")
         cfg, hf = api.config_from_checkpoint(model_path)
         check_supported(cfg)
         siglip = cfg["vision"]["family"] == "siglip"

@@ -40,10 +40,17 @@ def tower_config(name, select_layer=-2):
     """Vision hyper-parameters from a local tower directory (config.json) or the public values keyed by the tower's name."""
     import json
     import os
+    need = ("hidden_size", "intermediate_size", "num_hidden_layers", "num_attention_heads", "image_size", "patch_size")
+    v, fam = None, None
     if os.path.isfile(os.path.join(str(name), "config.json")):
-        v = json.load(open(os.path.join(str(name), "config.json")))
-        fam = "siglip" if "siglip" in (str(v.get("model_type", "")) + str(name)).lower() else "clip"
-    else:
+        top = json.load(open(os.path.join(str(name), "config.json")))
+        # the standard tower directories (openai/clip-vit-large-patch14-336, google/siglip-so400m-patch14-384) ship a CLIPConfig /
+        # SiglipConfig whose vision hyper-parameters sit under `vision_config`; CLIPVisionConfig.from_pretrained reads that level
+        v = top.get("vision_config", top)
+        fam = "siglip" if "siglip" in (str(top.get("model_type", "")) + str(v.get("model_type", "")) + str(name)).lower() else "clip"
+        if not all(k in v for k in need):
+            v = None                                                                   # partial config: fall back to the public values
+    if v is None:
         key = str(name).strip("/").split("/")[-1]
         if key not in PUBLIC_TOWERS:
             raise ValueError(f"Unknown vision tower: {name}")                          # encoder.py:162
@@ -54,9 +61,21 @@ def tower_config(name, select_layer=-2):
                 layer_norm_eps=v.get("layer_norm_eps", 1e-5), select_layer=select_layer)
 
 
+def default_key_layout():
+    """Key layout of HF CLIPVisionModel / SiglipVisionModel in the INSTALLED transformers: releases before 5.0 (the reference pins
+    4.40.0, and the released checkpoints were written by it) keep the encoder under a `vision_model.` level, 5.x does not.  The
+    hosting module must use the layout `from_pretrained(low_cpu_mem_usage=True)` will match by name (load_state_dict hooks do not
+    run on that path)."""
+    try:
+        import transformers
+        return "vision_model" if int(transformers.__version__.split(".")[0]) < 5 else "flat"
+    except Exception:
+        return "flat"
+
+
 def _tower_names(v):
     """State-dict names of HF CLIPVisionModel / SiglipVisionModel below the reference tower's `vision_tower` attribute
-    (transformers 5.x naming; weights.normalise_keys maps the 4.40-era `vision_model.` level)."""
+    (transformers 5.x naming, no `vision_model.` level; LazyHipVisionTower adds the level for the 4.x layout)."""
     from .weights import state_dict_names
     cfg = dict(vision=v, llm=dict(hidden_size=128, intermediate_size=128, num_hidden_layers=0, num_attention_heads=1,
                                   num_key_value_heads=1, head_dim=128, vocab_size=128))
@@ -77,7 +96,10 @@ def _tower_names(v):
 class LazyHipVisionTower(nn.Module):
     """What the patched `build_vision_tower` returns (reference: CLIPVisionTower / SiglipVisionTower, encoder.py:12-151)."""
 
-    def __init__(self, vision_tower, args, device=None, keep_parameters=False, **_unused):
+    def __init__(self, vision_tower, args, device=None, keep_parameters=False, key_layout="auto", **_unused):
+        """key_layout: "vision_model" = transformers 4.x names (`vision_tower.vision_model.encoder...`, the released checkpoints),
+        "flat" = transformers 5.x names, "auto" = whatever the installed transformers uses (`default_key_layout`).  A plain
+        `load_state_dict` accepts either layout (pre-hook); `from_pretrained(low_cpu_mem_usage=True)` matches by name only."""
         super().__init__()
         self.vision_tower_name = vision_tower
         self.select_layer = getattr(args, "mm_vision_select_layer", -2)
@@ -94,24 +116,60 @@ class LazyHipVisionTower(nn.Module):
             self.image_processor = cls.from_pretrained(vision_tower)
         except Exception:
             self.image_processor = (default_siglip_image_processor if v["family"] == "siglip" else default_image_processor)(v["image_size"])
-        host = ParamHost(_tower_names(v))
+        self.key_layout = default_key_layout() if key_layout == "auto" else key_layout
+        if self.key_layout not in ("vision_model", "flat"):
+            raise ValueError(f"key_layout {key_layout!r}: expected 'auto', 'vision_model' or 'flat'")
+        names = _tower_names(v)
+        if self.key_layout == "vision_model":
+            names = [("vision_tower.vision_model." + n[len("vision_tower."):], s) for n, s in names]
+        host = ParamHost(names)
         self.vision_tower = host._modules["vision_tower"]       # same attribute name as the reference -> same state-dict keys
         self.config = types.SimpleNamespace(**v)
-        self._register_load_state_dict_pre_hook(self._rename_4_40_keys)
+        self._register_load_state_dict_pre_hook(self._rename_other_layout)
 
-    @staticmethod
-    def _rename_4_40_keys(state_dict, prefix, *_):
-        for k in [k for k in state_dict if k.startswith(prefix + "vision_tower.vision_model.")]:
-            state_dict[prefix + "vision_tower." + k[len(prefix + "vision_tower.vision_model."):]] = state_dict.pop(k)
+    def _rename_other_layout(self, state_dict, prefix, *_):
+        """`load_state_dict` of a checkpoint written in the OTHER key layout (4.x <-> 5.x): rename its keys to the hosted ones."""
+        old = prefix + "vision_tower.vision_model."
+        if self.key_layout == "flat":
+            for k in [k for k in state_dict if k.startswith(old)]:
+                state_dict[prefix + "vision_tower." + k[len(old):]] = state_dict.pop(k)
+        elif not any(k.startswith(old) for k in state_dict):
+            for k in [k for k in state_dict if k.startswith(prefix + "vision_tower.")]:
+                state_dict[old + k[len(prefix + "vision_tower."):]] = state_dict.pop(k)
+
+    def check_loaded(self):
+        """Refuse to run on weights that were never loaded.  `from_pretrained(low_cpu_mem_usage=True)` matches checkpoint keys to
+        parameter names and materialises every UNMATCHED parameter with uninitialised memory (a warning, not an error); a key-layout
+        mismatch would therefore run the tower on garbage.  Signature of uninitialised / never-written storage: non-finite values,
+        or a weight matrix / LayerNorm scale that is constant (fresh pages are zero).  A trained tower has neither."""
+        bad = []
+        for k, p in self.vision_tower.state_dict().items():
+            if p.device.type == "meta":
+                bad.append(k + " (meta)")
+                continue
+            if "post_layernorm" in k or ".head." in k:               # hosted for strict loading only, never read
+                continue
+            t = p.detach().float()
+            if not bool(torch.isfinite(t).all()):
+                bad.append(k + " (non-finite)")
+            elif (t.dim() >= 2 or k.endswith("norm1.weight") or k.endswith("norm2.weight") or "layrnorm.weight" in k) and t.numel() > 1 \
+                    and float(t.max() - t.min()) == 0.0:
+                bad.append(k + " (constant)")
+        if bad:
+            raise RuntimeError(f"vision tower parameters were never loaded ({len(bad)} tensors, e.g. {bad[:4]}): the checkpoint's key "
+                               f"layout does not match the hosted one ('{self.key_layout}'); build the tower with "
+                               f"key_layout='{'flat' if self.key_layout == 'vision_model' else 'vision_model'}' or load with load_state_dict")
 
     def pack(self, device=None):
         if not self._hip:
             dev = torch.device(device or self._device or next(self.vision_tower.parameters()).device)
             if dev.type == "meta":
                 raise RuntimeError("vision tower parameters were never loaded (still on the meta device)")
+            self.check_loaded()
             cfg = dict(vision=self._v)
             cls = HipSiglipVisionTower if self._v["family"] == "siglip" else HipCLIPVisionTower
-            sd = {"vision_tower." + k: p for k, p in self.vision_tower.state_dict().items()}
+            strip = "vision_model." if self.key_layout == "vision_model" else ""
+            sd = {"vision_tower." + (k[len(strip):] if k.startswith(strip) else k): p for k, p in self.vision_tower.state_dict().items()}
             self._hip.append(cls(cfg, sd, dev, select_feature=self.select_feature, image_processor=self.image_processor, prefix="vision_tower."))
             if not self._keep:
                 self.vision_tower = None                         # the packed copies are the weights now

@@ -197,8 +197,8 @@ class VideoLLaMA2Hip(nn.Module):
             rows = [L] * B
         else:
             rows = self._splice_lens
-        if msum is None:
-            return emb, [emb.shape[1]] * B
+        if msum is None:                           # no mask = every text token is real: the row's length is its own splice length
+            return emb, list(rows)                 # (ragged media token counts pad the shorter rows with zeros: not prompt tokens)
         return emb, [rows[bi] - L + msum[bi] for bi in range(B)]        # the inserted visual rows + the row's real text tokens
 
     # ---------------------------------------------------------------------------------- videollama2_mistral.py:63-108
