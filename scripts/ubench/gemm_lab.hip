@@ -34,6 +34,10 @@ static void launch(int variant, GemmArgs a, hipStream_t s) {
         lds_attr(gemm4_bf16_kernel<ACT, SW, false>, GEMM4_LDS_BYTES);
         a.tiles_m = (a.M + 255) / 256; a.tiles_n = a.N / 256;
         hipLaunchKernelGGL((gemm4_bf16_kernel<ACT, SW, false>), dim3(a.tiles_m * a.tiles_n), dim3(512), GEMM4_LDS_BYTES, s, a);
+    } else if (variant == 9) {                          // gemm4 with the register-resident (C^T) epilogue
+        lds_attr(gemm4_bf16_kernel<ACT, SW, false, true>, GEMM4_LDS_BYTES);
+        a.tiles_m = (a.M + 255) / 256; a.tiles_n = a.N / 256;
+        hipLaunchKernelGGL((gemm4_bf16_kernel<ACT, SW, false, true>), dim3(a.tiles_m * a.tiles_n), dim3(512), GEMM4_LDS_BYTES, s, a);
     } else if (variant == 4) {
         lds_attr(gemm3_bf16_kernel<ACT, SW, false>, GEMM3_LDS_BYTES);
         a.tiles_m = (a.M + 127) / 128; a.tiles_n = a.N / 256;
@@ -63,6 +67,7 @@ static void launch(int variant, GemmArgs a, hipStream_t s) {
 int main(int argc, char** argv) {
     const int rounds = argc > 1 ? atoi(argv[1]) : 3;
     const std::vector<Shape> shapes = {
+        {"tiny", 256, 256, 64, false, false, false, 0},
         {"sq_8192x4096x4096", 8192, 4096, 4096, false, false, false, 0},
         {"sq_8192", 8192, 8192, 8192, false, false, false, 0},
         {"sq_4096", 4096, 4096, 4096, false, false, false, 0},
@@ -77,7 +82,11 @@ int main(int argc, char** argv) {
         {"llm_gateup", 1621, 28672, 4096, true, false, false, 0},
         {"llm_down", 1621, 4096, 14336, false, false, true, 0},
     };
-    const std::vector<int> variants = {8, 4, 22, 14, 41};
+    std::vector<int> variants = {8, 4, 22, 14, 41};
+    if (argc > 2) {                                     // e.g. "8,4": only these variants (v8 is the bit reference, keep it first)
+        variants.clear();
+        for (char* tok = strtok(argv[2], ","); tok; tok = strtok(nullptr, ",")) variants.push_back(atoi(tok));
+    }
     hipStream_t s; CK(hipStreamCreate(&s));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (const Shape& sh : shapes) {
@@ -104,15 +113,18 @@ int main(int argc, char** argv) {
         for (int r = 0; r < rounds; ++r)
             for (size_t vi = 0; vi < variants.size(); ++vi) {
                 const int v = variants[vi];
-                if ((v == 14 && sh.N % 512) || (v == 8 && sh.N % 256) || (v == 4 && sh.N % 256) || (v == 22 && sh.N % 256)) continue;
+                if ((v == 14 && sh.N % 512) || ((v == 8 || v == 9) && sh.N % 256) || (v == 4 && sh.N % 256) || (v == 22 && sh.N % 256)) continue;
                 if (r == 0) {
                     CK(hipMemsetAsync(dC, 0xff, nc * 2, s));
                     go(v, a);
                     CK(hipStreamSynchronize(s));
                     CK(hipGetLastError());
                     CK(hipMemcpy(hc.data(), dC, nc * 2, hipMemcpyDeviceToHost));
+                    { unsigned long long hsh = 1469598103934665603ull; for (size_t i = 0; i < nc; ++i) { hsh ^= hc[i]; hsh *= 1099511628211ull; }
+                      fprintf(stderr, "  hash %s v%d %016llx\n", sh.name, v, hsh); }
                     if (v == 8) href = hc;
-                    else { size_t bad = 0; for (size_t i = 0; i < nc; ++i) bad += hc[i] != href[i]; same[vi] = bad == 0 ? 1 : 0; if (bad) fprintf(stderr, "  %s v%d: %zu of %zu elements differ from v8\n", sh.name, v, bad, nc); }
+                    else { size_t bad = 0; for (size_t i = 0; i < nc; ++i) { if (hc[i] != href[i] && bad < 12 && getenv("LAB_DIFF")) { fprintf(stderr, "    diff at row %zu col %zu: %04x vs %04x; ref holds that value at:", i / ncol, i % ncol, hc[i], href[i]);
+                                   int shown = 0; for (size_t q = 0; q < nc && shown < 4; ++q) if (href[q] == hc[i]) { fprintf(stderr, " (%zu,%zu)", q / ncol, q % ncol); ++shown; } fprintf(stderr, "\n"); } bad += hc[i] != href[i]; } same[vi] = bad == 0 ? 1 : 0; if (bad) fprintf(stderr, "  %s v%d: %zu of %zu elements differ from v8\n", sh.name, v, bad, nc); }
                 }
                 for (int w = 0; w < 2; ++w) go(v, a);
                 const int iters = 10;

@@ -296,6 +296,7 @@ inline void buffer_load_lds(Rsrc r, void* lds, unsigned size, unsigned voff, uns
 #define gridDim (emu::g_gdim)
 #define __syncthreads() emu::block_sync()
 #define __builtin_amdgcn_s_barrier() emu::block_sync()
+#define __builtin_amdgcn_wave_barrier() emu::wave_sync()     /* hardware: no instruction (lanes of a wave run in lockstep); here the wave's fibers meet */
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) emu::mfma_32x32x16_bf16(a, b, c)
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) emu::mfma_16x16x32_bf16(a, b, c)
 #define __builtin_amdgcn_global_load_lds(g, l, sz, off, aux) emu::global_load_lds((const void*)(g), (void*)(l), sz, off, aux)

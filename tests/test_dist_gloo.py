@@ -75,7 +75,7 @@ def _worker_sharded(rank, world, port, q, fixture):
         ns = FrameSharder()                                                 # default cut = BASELINE.json's north_star
         assert ns.cut == "north_star"
         out_ns = ns.encode_video(tower, conn, g["frames"])                  # ViT sharded, all-gather of tower tokens, connector replicated
-        assert torch.equal(out_ns, out)
+        assert out_ns.dtype == out.dtype and torch.equal(out_ns, out), (out_ns.dtype, out.dtype, (out_ns.float() - out.float()).abs().max().item())
         feats = tower(g["frames"])
         ref = conn(feats.view(1, *feats.shape))                             # single-process path, same kernels
     q.put((rank, torch.equal(out, ref), tuple(out.shape), ((out - g["mm_features"]).norm() / g["mm_features"].norm()).item()))

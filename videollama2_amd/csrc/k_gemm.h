@@ -116,20 +116,41 @@ __device__ __forceinline__ void gemm_store_patch(const GemmArgs& p, const float*
 #pragma clang fp reassociate(off)
         constexpr int LPR = SWIGLU ? 4 : 8;            // lanes per row
         constexpr int RPP = 64 / LPR;                  // rows per pass
+        constexpr int NP = 32 / RPP;                   // row passes per patch (4, SwiGLU 2)
         // a lane keeps its 8 columns through all passes: the per-column vectors (bias, LayerNorm column sums) are loaded once
         // per patch, not once per row pass (the stores to C in the loop keep the compiler from hoisting them itself)
         const int cg = (lane % LPR) * 8;
         const int nfull = n_base + cg;                 // column in the (un-halved) GEMM N space
+        const int n = SWIGLU ? (n_base >> 1) + cg : nfull;
         f32x4 bias0 = {0.f, 0.f, 0.f, 0.f}, bias1 = bias0, cs0 = bias0, cs1 = bias0;
         if (!SWIGLU && p.bias) { bias0 = *(const f32x4*)(p.bias + nfull); bias1 = *(const f32x4*)(p.bias + nfull + 4); }
         if (!SWIGLU && p.norm == 2) { cs0 = *(const f32x4*)(p.w_colsum + nfull); cs1 = *(const f32x4*)(p.w_colsum + nfull + 4); }
+        // Round 3 (profiles/r03_experiments.md): the epilogue was 7-12 us of every tile (22-36 % of a K = 1024 GEMM), a chain of
+        // LDS write -> read -> RESIDUAL LOAD (an L2 / HBM round trip under `if (live)`, so never hoisted) -> store per row pass.
+        // The residual rows of all passes are now requested up front, unconditionally (rows past M clamp to M - 1 and are dropped
+        // by the store predicate): one memory round trip per patch instead of one per pass.  Same arithmetic, same bits.
+        int orow_[NP];
+        u32x4 rv_[NP];
 #pragma unroll
-        for (int pass = 0; pass < 32 / RPP; ++pass) {
+        for (int pass = 0; pass < NP; ++pass) {
+            const int m = m_base + pass * RPP + lane / LPR;
+            const int mc = m < p.M ? m : p.M - 1;
+            orow_[pass] = (REMAP && p.out_grp > 0) ? mc + (mc / p.out_grp) * p.out_grp_pad + p.out_row_off : mc;
+#ifdef VL2_LAB_STORE_WRAP                  // scripts/ubench/gemm_lab.hip ablation only: every tile stores into the same 256 rows (no HBM writes)
+            orow_[pass] &= 255;
+#endif
+            if (p.res) {
+                const int rrow = (REMAP && p.res_row_mod > 0) ? (mc % p.res_row_mod) + p.res_row_off : orow_[pass];
+                rv_[pass] = *(const u32x4*)(p.res + (size_t)rrow * p.ldres + n);
+            }
+        }
+#pragma unroll
+        for (int pass = 0; pass < NP; ++pass) {
             const int row = pass * RPP + lane / LPR;
             const int m = m_base + row;
             const bool live = m < p.M;
             float st_s = 0.f, st_q = 0.f;
-            int orow = m;
+            const int orow = orow_[pass];
             if (live) {
                 float v[8];
                 float mu = 0.f, rs = 1.f;
@@ -164,13 +185,9 @@ __device__ __forceinline__ void gemm_store_patch(const GemmArgs& p, const float*
                         if (ACT == ACT_GELU_TANH) v[j] = gelu_tanh_f(v[j]);
                     }
                 }
-                const int n = SWIGLU ? (n_base >> 1) + cg : nfull;
-                orow = (REMAP && p.out_grp > 0) ? m + (m / p.out_grp) * p.out_grp_pad + p.out_row_off : m;
                 if (p.res) {
-                    const int rrow = (REMAP && p.res_row_mod > 0) ? (m % p.res_row_mod) + p.res_row_off : orow;
-                    const u32x4 rv = *(const u32x4*)(p.res + (size_t)rrow * p.ldres + n);
                     float rf[8];
-                    unpack8(rv, rf);
+                    unpack8(rv_[pass], rf);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] += rf[j];
                 }
@@ -183,7 +200,12 @@ __device__ __forceinline__ void gemm_store_patch(const GemmArgs& p, const float*
                     *(f32x4*)(c + 4) = o1;
                 } else {
                     const u32x4 packed = pack8(v);
+#ifdef VL2_LAB_NO_GSTORE                   // scripts/ubench/gemm_lab.hip ablation only: the whole epilogue except the global store itself
+                    if (p.ldc == -12345) *(u32x4*)((bf16_t*)p.C + (size_t)orow * p.ldc + n) = packed;
+                    asm volatile("" :: "v"(packed));
+#else
                     *(u32x4*)((bf16_t*)p.C + (size_t)orow * p.ldc + n) = packed;
+#endif
                     if (!SWIGLU && !REMAP && p.stats_out) {       // statistics of the row AS STORED (bf16-rounded)
                         float rf[8];
                         unpack8(packed, rf);
@@ -202,6 +224,131 @@ __device__ __forceinline__ void gemm_store_patch(const GemmArgs& p, const float*
                 }
             }
         }
+}
+
+// ---- register-resident epilogue for kernels whose MFMAs were issued with the operands SWAPPED (acc = mfma(w_frag, a_frag, acc)):
+// the accumulator block then holds C^T -- lane (l & 31) owns ROW m of the 32 x 32 block and its 16 registers are columns
+// (r & 3) + 8 (r >> 2) + 4 (l >> 5) -- so the row-major image needs no trip through LDS.  Round 3 measurement
+// (profiles/r03_experiments.md): the LDS-transposing epilogue (gemm_store_patch: 128 ds_write_b32 + 32 ds_read_b128 per lane of
+// a 64 x 128 wave tile, LDS writes run at 64 B/clk/CU) costs 7-12 us of every 256 x 256 tile -- 22-36 % of a K = 1024 GEMM.
+// Here one v_permlane32_swap per register pair (guide T21) turns two 4-column groups of the two half-waves into 8 contiguous
+// columns per lane, i.e. exactly the (row, 8 columns) unit gemm_store_patch works on; from there the arithmetic is the same code
+// path in the same order -- (acc [norm] + bias) -> activation -> + residual -> bf16 -- so a row's bits do not depend on which
+// epilogue stored it (checked on hardware: output hashes of both forms agree, scripts/ubench/gemm_lab.hip).
+// acc[mi][nj]: 32-row blocks mi (rows m_w0 + 32 mi + (lane & 31)), 32-column blocks nj (columns n_w0 + 32 nj + ...), NJ even.
+template <int ACT, bool SWIGLU, int MI, int NJ>
+__device__ __forceinline__ void gemm_store_tr(const GemmArgs& p, f32x16 (&acc)[MI][NJ], int m_w0, int n_w0, int lane) {
+#pragma clang fp reassociate(off)
+    const int hi = lane >> 5, l31 = lane & 31;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int m = m_w0 + mi * 32 + l31;
+        const bool live = m < p.M;
+        const int mc = live ? m : p.M - 1;
+        const f32x2 st = gemm_row_stats(p, m_w0 + mi * 32, l31, 32);       // (mean, rstd) of this lane's row (norm-carrying GEMMs)
+        const float mu = st[0], rs = st[1];
+#pragma unroll
+        for (int cb = 0; cb < NJ / 2; ++cb) {                                // 64 GEMM columns = one statistics block / SwiGLU block
+            float s8[4], q8[4];                                              // statistics of this lane's four 8-column groups
+#pragma unroll
+            for (int half = 0; half < (SWIGLU ? 1 : 2); ++half) {
+                const int nj = cb * 2 + half;
+                float x[16];
+                if (SWIGLU) {                                                // columns [64 cb, +32) gate, [64 cb + 32, +32) up
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float g = acc[mi][nj][r], u = acc[mi][nj + 1][r];
+                        if (p.norm) { g *= rs; u *= rs; }
+                        x[r] = silu_f(g) * u;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) x[r] = acc[mi][nj][r];
+                }
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {                             // register groups (2 pr, 2 pr + 1) -> 8 contiguous columns
+                    float v[8];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        // inline asm, not __builtin_amdgcn_permlane32_swap: in this function hipcc (ROCm 7.2) folded the builtin's
+                        // SECOND result into a copy of the first (v_mov of the swapped register over it; seen in the .s and as
+                        // wrong columns 4..7 of every 8 on hardware).  The two v_nop are the wait states a VALU write of either
+                        // operand needs before the swap reads it (guide T21).
+                        float a_ = x[8 * pr + c], b_ = x[8 * pr + 4 + c];
+                        asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a_), "+v"(b_));
+                        v[c] = a_;
+                        v[4 + c] = b_;
+                    }
+                    const int nfull = n_w0 + nj * 32 + 16 * pr + 8 * hi;     // un-halved GEMM column of v[0]
+                    const int n = SWIGLU ? (n_w0 >> 1) + cb * 32 + 16 * pr + 8 * hi : nfull;
+                    u32x4 rv;
+                    if (p.res) rv = *(const u32x4*)(p.res + (size_t)mc * p.ldres + n);
+                    if (!SWIGLU) {
+                        if (p.norm == 2) {
+                            const f32x4 cs0 = *(const f32x4*)(p.w_colsum + nfull), cs1 = *(const f32x4*)(p.w_colsum + nfull + 4);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) { v[j] = __builtin_fmaf(-mu, cs0[j], v[j]) * rs; v[4 + j] = __builtin_fmaf(-mu, cs1[j], v[4 + j]) * rs; }
+                        } else if (p.norm == 1) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) v[j] *= rs;
+                        }
+                        if (p.bias) {
+                            const f32x4 b0 = *(const f32x4*)(p.bias + nfull), b1 = *(const f32x4*)(p.bias + nfull + 4);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) { v[j] += b0[j]; v[4 + j] += b1[j]; }
+                        }
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            if (ACT == ACT_QGELU) v[j] = quick_gelu_f(v[j]);
+                            if (ACT == ACT_GELU) v[j] = gelu_erf_f(v[j]);
+                            if (ACT == ACT_SILU) v[j] = silu_f(v[j]);
+                            if (ACT == ACT_GELU_TANH) v[j] = gelu_tanh_f(v[j]);
+                        }
+                    }
+                    if (p.res) {
+                        float rf[8];
+                        unpack8(rv, rf);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] += rf[j];
+                    }
+                    const u32x4 packed = pack8(v);
+                    if (live) *(u32x4*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = packed;
+                    if (!SWIGLU && p.stats_out) {                            // statistics of the row AS STORED, per 8-column group
+                        float rf[8], ss = 0.f, qq = 0.f;
+                        unpack8(packed, rf);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) { ss += rf[j]; qq = __builtin_fmaf(rf[j], rf[j], qq); }
+                        s8[half * 2 + pr] = ss;
+                        q8[half * 2 + pr] = qq;
+                    }
+                }
+            }
+            if (!SWIGLU && p.stats_out) {
+                // the 64-column block's eight 8-column groups: this lane holds groups 2 i + hi (i = 0..3), its half-wave partner the
+                // other four.  gemm_store_patch folds them with octet_sum = ((s0 + s7) + (s1 + s6)) + ((s2 + s5) + (s3 + s4)):
+                // the same tree here (fp32 addition is commutative, so the operand order inside a pair does not matter).
+                float os[4], oq[4];                                          // the partner's four groups
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    os[i] = __shfl_xor(s8[i], 32);
+                    oq[i] = __shfl_xor(q8[i], 32);
+                }
+                // group index of s8[i] is 2 i + hi, of os[i] is 2 i + (1 - hi); pair (g, 7 - g): own 2 i + hi pairs with partner's 3 - i
+                float ts[4], tq[4];                                          // t_g for g = own groups
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { ts[i] = s8[i] + os[3 - i]; tq[i] = q8[i] + oq[3 - i]; }
+                // t_g == t_{7-g}; u_g = t_g + t_{g^1}: own group g = 2 i + hi, g ^ 1 = 2 i + (1 - hi) = 7 - (2 (3 - i) + hi) -> ts[3 - i]
+                const float u0s = ts[0] + ts[3], u0q = tq[0] + tq[3];                          // u of groups {0,1} (== {6,7})
+                const float u2s = ts[1] + ts[2], u2q = tq[1] + tq[2];                          // u of groups {2,3} (== {4,5})
+                const float tot_s = u0s + u2s, tot_q = u0q + u2q;
+                if (live && hi == 0) {
+                    float* dst = p.stats_out + ((size_t)m * p.stats_out_np + ((n_w0 + cb * 64) >> 6)) * 2;
+                    dst[0] = tot_s;
+                    dst[1] = tot_q;
+                }
+            }
+        }
+    }
 }
 
 #define VL2_DRAIN_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
@@ -437,6 +584,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
     float* ep = (float*)vl2_smem + wave * (32 * 68);
     float* rowtab = (float*)vl2_smem + 4 * (32 * 68);          // behind the four wave patches
     gemm_park_row_stats(p, rowtab, rst, tid, GEMM_BM);
+    __syncthreads();                       // the row table is visible; from here on every wave works on its OWN patch: the LDS
+    // operations of one wave execute in issue order, so the patch writes of pass k+1 cannot overtake the reads of pass k and no
+    // workgroup barrier separates the passes -- the waves' store chains (LDS -> residual load -> store) overlap freely
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
@@ -446,9 +596,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 ep[row * 68 + ni * 32 + (lane & 31)] = acc[mi][ni][r];
             }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();    // no instruction on the hardware (a wave's lanes run in lockstep and its LDS operations
         gemm_store_patch<ACT, SWIGLU, OUT_F32, REMAP>(p, ep, m0 + wm * 64 + mi * 32, n0 + wn * 64, lane, rowtab, wm * 64 + mi * 32);
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();    // complete in order); pins the write / read order for the compiler and the CPU emulator
     }
 }
 
@@ -633,8 +783,10 @@ __device__ __forceinline__ int gemm4_lds_off(int row, int chunk) {
 
 // bid / nwg: this workgroup's index and the workgroup count of the tile set it belongs to (the whole grid for
 // gemm4_bf16_kernel; the big-tile part of gemm_mix_bf16_kernel)
-template <int ACT, bool SWIGLU, bool OUT_F32>
+// TR: accumulate C^T (MFMA operands swapped) and store through gemm_store_tr (no LDS in the epilogue); bf16 output only
+template <int ACT, bool SWIGLU, bool OUT_F32, bool TR = false>
 __device__ __forceinline__ void gemm4_body(const GemmArgs& p, int bid, int nwg) {
+    static_assert(!(TR && OUT_F32), "gemm_store_tr writes bf16");
     extern __shared__ __attribute__((aligned(16))) unsigned char vl2_smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -647,7 +799,8 @@ __device__ __forceinline__ void gemm4_body(const GemmArgs& p, int bid, int nwg) 
     const int gm = (p.tiles_m - first_m) < 4 ? (p.tiles_m - first_m) : 4;
     const int tm = first_m + (t0 % grp_sz) % gm, tn = (t0 % grp_sz) / gm;
     const int m0 = tm * GEMM4_BM, n0 = tn * GEMM4_BN;
-    const f32x2 rst = gemm_row_stats(p, m0, tid, GEMM4_BM);
+    f32x2 rst = {0.f, 1.f};
+    if constexpr (!TR) rst = gemm_row_stats(p, m0, tid, GEMM4_BM);
 
     // this wave's LDS-DMA parts of a slab: 2 x A rows [128*grp, +128) and 2 x W rows [128*grp, +128), issue-lean form:
     // `buffer_load_dwordx4 ... offen lds` with loop-invariant VGPR byte offsets, K position in the SGPR soffset
@@ -725,15 +878,28 @@ __device__ __forceinline__ void gemm4_body(const GemmArgs& p, int bid, int nwg) 
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = TR ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks][j], fa[ks][i], acc[i][j], 0, 0, 0)
+                                   : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
         VL2_PHASE_BARRIER();
     }
     if (grp == 0) VL2_PHASE_BARRIER();
 
+    if constexpr (TR) {       // ---- register-resident epilogue: the accumulators hold C^T, rows are lane-local
+        gemm_store_tr<ACT, SWIGLU, 2, 4>(p, acc, m0 + grp * 128 + wm * 64, n0 + wn * 128, lane);
+        return;
+    }
     // ---- epilogue: four 32 x 64 patches per wave (2 row blocks x 2 column halves)
+#ifdef VL2_LAB_NO_EPILOGUE          // scripts/ubench/gemm_lab.hip ablation only: main loop without the store path (accumulators kept alive)
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(acc[mi][j]));
+    return;
+#endif
     float* ep = (float*)vl2_smem + wave * (32 * 68);
     float* rowtab = (float*)vl2_smem + 8 * (32 * 68);
     gemm_park_row_stats(p, rowtab, rst, tid, GEMM4_BM);
+    __syncthreads();                       // row table visible; the passes below are wave-private (see gemm_bf16_kernel)
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -745,14 +911,14 @@ __device__ __forceinline__ void gemm4_body(const GemmArgs& p, int bid, int nwg) 
                     const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                     ep[row * 68 + ni * 32 + (lane & 31)] = acc[mi][nh * 2 + ni][r];
                 }
-            __syncthreads();
+            __builtin_amdgcn_wave_barrier();
             gemm_store_patch<ACT, SWIGLU, OUT_F32>(p, ep, m0 + grp * 128 + wm * 64 + mi * 32, n0 + wn * 128 + nh * 64, lane, rowtab, grp * 128 + wm * 64 + mi * 32);
-            __syncthreads();
+            __builtin_amdgcn_wave_barrier();
         }
 }
-template <int ACT, bool SWIGLU, bool OUT_F32>
+template <int ACT, bool SWIGLU, bool OUT_F32, bool TR = false>
 __global__ __launch_bounds__(512, 2) void gemm4_bf16_kernel(GemmArgs p) {
-    gemm4_body<ACT, SWIGLU, OUT_F32>(p, blockIdx.x, gridDim.x);
+    gemm4_body<ACT, SWIGLU, OUT_F32, TR>(p, blockIdx.x, gridDim.x);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -866,6 +1032,7 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs& p, int bid, int nwg) 
     float* ep = (float*)vl2_smem + wave * (32 * 68);
     float* rowtab = (float*)vl2_smem + 8 * (32 * 68);
     gemm_park_row_stats(p, rowtab, rst, tid, GEMM3_BM);
+    __syncthreads();                       // row table visible; the passes below are wave-private (see gemm_bf16_kernel)
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
@@ -875,9 +1042,9 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs& p, int bid, int nwg) 
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 ep[row * 68 + ni * 32 + (lane & 31)] = acc[mi][ni][r];
             }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
         gemm_store_patch<ACT, SWIGLU, OUT_F32>(p, ep, m0 + wm * 64 + mi * 32, n0 + grp * 128 + wn * 64, lane, rowtab, wm * 64 + mi * 32);
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
     }
 }
 template <int ACT, bool SWIGLU, bool OUT_F32>
