@@ -38,6 +38,20 @@ static void launch(int variant, GemmArgs a, hipStream_t s) {
         lds_attr(gemm4_bf16_kernel<ACT, SW, false, true>, GEMM4_LDS_BYTES);
         a.tiles_m = (a.M + 255) / 256; a.tiles_n = a.N / 256;
         hipLaunchKernelGGL((gemm4_bf16_kernel<ACT, SW, false, true>), dim3(a.tiles_m * a.tiles_n), dim3(512), GEMM4_LDS_BYTES, s, a);
+    } else if (variant == 10) {                         // ... with the epilogue flags compiled in (EF)
+        a.tiles_m = (a.M + 255) / 256; a.tiles_n = a.N / 256;
+        const int ef = (a.bias ? EF_BIAS : 0) | (a.res ? EF_RES : 0);
+#define LAB_EF(E) case E: lds_attr(gemm4_bf16_kernel<ACT, SW, false, true, E>, GEMM4_LDS_BYTES); \
+        hipLaunchKernelGGL((gemm4_bf16_kernel<ACT, SW, false, true, E>), dim3(a.tiles_m * a.tiles_n), dim3(512), GEMM4_LDS_BYTES, s, a); break;
+        switch (ef) { LAB_EF(0) LAB_EF(1) LAB_EF(8) LAB_EF(9) }
+#undef LAB_EF
+    } else if (variant == 5) {                          // gemm3 (128 x 256) with the register-resident epilogue, flags compiled in
+        a.tiles_m = (a.M + 127) / 128; a.tiles_n = a.N / 256;
+        const int ef = (a.bias ? EF_BIAS : 0) | (a.res ? EF_RES : 0);
+#define LAB_EF(E) case E: lds_attr(gemm3_bf16_kernel<ACT, SW, false, true, E>, GEMM3_LDS_BYTES); \
+        hipLaunchKernelGGL((gemm3_bf16_kernel<ACT, SW, false, true, E>), dim3(a.tiles_m * a.tiles_n), dim3(512), GEMM3_LDS_BYTES, s, a); break;
+        switch (ef) { LAB_EF(0) LAB_EF(1) LAB_EF(8) LAB_EF(9) }
+#undef LAB_EF
     } else if (variant == 4) {
         lds_attr(gemm3_bf16_kernel<ACT, SW, false>, GEMM3_LDS_BYTES);
         a.tiles_m = (a.M + 127) / 128; a.tiles_n = a.N / 256;
@@ -113,7 +127,7 @@ int main(int argc, char** argv) {
         for (int r = 0; r < rounds; ++r)
             for (size_t vi = 0; vi < variants.size(); ++vi) {
                 const int v = variants[vi];
-                if ((v == 14 && sh.N % 512) || ((v == 8 || v == 9) && sh.N % 256) || (v == 4 && sh.N % 256) || (v == 22 && sh.N % 256)) continue;
+                if ((v == 14 && sh.N % 512) || ((v == 8 || v == 9 || v == 10) && sh.N % 256) || ((v == 4 || v == 5) && sh.N % 256) || (v == 22 && sh.N % 256)) continue;
                 if (r == 0) {
                     CK(hipMemsetAsync(dC, 0xff, nc * 2, s));
                     go(v, a);

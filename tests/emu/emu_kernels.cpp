@@ -30,6 +30,9 @@ static void run_gemm(GemmArgs a) {
     if constexpr (!G) {
         if (g_gemm_variant == 4 && a.N % 256 == 0) {
             a.tiles_m = (a.M + 127) / 128; a.tiles_n = a.N / 256;
+            if constexpr (!F32) {        // vl2_abi.hip want_tr_epilogue: no residual -> register-resident C^T epilogue
+                if (a.res == nullptr) { emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(512), [=] { gemm3_bf16_kernel<ACT, SW, false, true>(a); }); return; }
+            }
             emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(512), [=] { gemm3_bf16_kernel<ACT, SW, F32>(a); });
             return;
         }
@@ -39,6 +42,9 @@ static void run_gemm(GemmArgs a) {
         }
         if (g_gemm_variant == 8 && a.N % 256 == 0) {
             a.tiles_m = (a.M + 255) / 256; a.tiles_n = a.N / 256;
+            if constexpr (!F32) {
+                if (a.res == nullptr) { emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(512), [=] { gemm4_bf16_kernel<ACT, SW, false, true>(a); }); return; }
+            }
             emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(512), [=] { gemm4_bf16_kernel<ACT, SW, F32>(a); });
             return;
         }

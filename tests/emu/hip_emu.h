@@ -328,6 +328,14 @@ inline void buffer_load_lds(Rsrc r, void* lds, unsigned size, unsigned voff, uns
 #define __fdividef(a, b) ((a) / (b))
 #define __frcp_rn(x) (1.0f / (x))
 #define VL2_EMU 1
+// v_permlane32_swap_b32 vdst, src (k_gemm.h gemm_store_tr): lanes 32-63 of vdst trade places with lanes 0-31 of src
+template <class T> static inline void emu_permlane32_swap(T& vdst, T& src) {
+    const int lane = emu::cur->lane;
+    const T from_src = emu::shfl_idx(src, lane & 31), from_dst = emu::shfl_idx(vdst, (lane & 31) + 32);
+    if (lane >= 32) vdst = from_src; else src = from_dst;
+}
+#define VL2_PERMLANE32_SWAP_8(pk) do { emu_permlane32_swap(pk[0], pk[2]); emu_permlane32_swap(pk[1], pk[3]); \
+                                       emu_permlane32_swap(pk[4], pk[6]); emu_permlane32_swap(pk[5], pk[7]); } while (0)
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 static inline int emu_fetch_add(int* p, int v) { int o = *p; *p = o + v; return o; }
 static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }

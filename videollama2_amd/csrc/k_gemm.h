@@ -108,12 +108,18 @@ __device__ __forceinline__ int gemm_lds_off(int row, int chunk) {   // byte offs
 // row remap, 16-B stores.  m_base = first row of the patch, n_base = first (un-halved) GEMM column of the patch.
 // REMAP = the row-remap / residual-row-modulo form (runtime integer divisions) -- only the patch-embed GEMM needs it
 template <int ACT, bool SWIGLU, bool OUT_F32, bool REMAP = false>
-__device__ __forceinline__ void gemm_store_patch(const GemmArgs& p, const float* ep, int m_base, int n_base, int lane,
+__device__ __forceinline__ void gemm_store_patch(const GemmArgs& p0, const float* ep, int m_base, int n_base, int lane,
                                                  const float* rowtab = nullptr, int mt_base = 0) {
         // every GEMM kernel inlines this epilogue, and a row must come out with the same bits whichever kernel its shape selects
         // (sharded == unsharded, batched == one by one): (acc + bias) + residual stays in that order in every instantiation.
         // rowtab: LDS table of (mean, rstd) of the tile's rows (p.norm != 0), indexed by the row's offset in the tile.
 #pragma clang fp reassociate(off)
+#ifdef VL2_LAB_PLAIN                       // scripts/ubench/gemm_lab.hip ablation only: norm / residual / statistics compiled out
+        GemmArgs p = p0;
+        p.norm = 0; p.res = nullptr; p.stats_out = nullptr;
+#else
+        const GemmArgs& p = p0;
+#endif
         constexpr int LPR = SWIGLU ? 4 : 8;            // lanes per row
         constexpr int RPP = 64 / LPR;                  // rows per pass
         constexpr int NP = 32 / RPP;                   // row passes per patch (4, SwiGLU 2)
@@ -228,92 +234,129 @@ __device__ __forceinline__ void gemm_store_patch(const GemmArgs& p, const float*
 
 // ---- register-resident epilogue for kernels whose MFMAs were issued with the operands SWAPPED (acc = mfma(w_frag, a_frag, acc)):
 // the accumulator block then holds C^T -- lane (l & 31) owns ROW m of the 32 x 32 block and its 16 registers are columns
-// (r & 3) + 8 (r >> 2) + 4 (l >> 5) -- so the row-major image needs no trip through LDS.  Round 3 measurement
-// (profiles/r03_experiments.md): the LDS-transposing epilogue (gemm_store_patch: 128 ds_write_b32 + 32 ds_read_b128 per lane of
-// a 64 x 128 wave tile, LDS writes run at 64 B/clk/CU) costs 7-12 us of every 256 x 256 tile -- 22-36 % of a K = 1024 GEMM.
-// Here one v_permlane32_swap per register pair (guide T21) turns two 4-column groups of the two half-waves into 8 contiguous
-// columns per lane, i.e. exactly the (row, 8 columns) unit gemm_store_patch works on; from there the arithmetic is the same code
-// path in the same order -- (acc [norm] + bias) -> activation -> + residual -> bf16 -- so a row's bits do not depend on which
-// epilogue stored it (checked on hardware: output hashes of both forms agree, scripts/ubench/gemm_lab.hip).
+// (r & 3) + 8 (r >> 2) + 4 (l >> 5) -- so the row-major image needs no trip through LDS.
+// Round 3 measurements (profiles/r03_experiments.md): the epilogue of a 256 x 256 tile costs 7-12 us (22-36 % of a K = 1024 GEMM).
+// It is NOT the stores (ablated: -1.6 us), not HBM (all tiles storing into one L2-resident window: -0.7 us), not the LDS
+// bandwidth as such (a first register-resident form with fp32 swaps measured the same): with two waves per SIMD and 128
+// outputs per lane it is instruction ISSUE -- every per-element instruction of the epilogue costs ~0.5 us per tile.  So this form
+// minimises instructions per element: all arithmetic runs on the accumulator registers where they are (bias / LayerNorm column
+// sums are fetched in this lane's column pattern, the residual as 8-byte pieces), the results are packed to bf16 FIRST and one
+// v_permlane32_swap per packed register pair (guide T21) then turns the two half-waves' 4-column groups into 8 contiguous columns
+// = one 16-B store.  Per 32 x 32 block: 8 cvt_pk + 4 swaps + 2 stores instead of 16 ds_write + 4 ds_read + 8 cvt_pk + 2 stores,
+// and no row table, no barrier.  EF >= 0 compiles the runtime flags in (bit 0 bias, 1 RMSNorm, 2 LayerNorm, 3 residual,
+// 4 row statistics); EF < 0 tests them at run time.  Arithmetic per element = gemm_store_patch's, same order:
+// ((acc [norm]) + bias) -> activation -> + residual -> bf16; statistics from the stored bf16 values in the same association --
+// a row's bits do not depend on which epilogue stored it (hash-checked on hardware, scripts/ubench/gemm_lab.hip).
 // acc[mi][nj]: 32-row blocks mi (rows m_w0 + 32 mi + (lane & 31)), 32-column blocks nj (columns n_w0 + 32 nj + ...), NJ even.
-template <int ACT, bool SWIGLU, int MI, int NJ>
+// four v_permlane32_swap on pk[0..7]: (pk[0], pk[2]), (pk[1], pk[3]), (pk[4], pk[6]), (pk[5], pk[7]) as (vdst, src) -- lanes 32-63 of vdst
+// trade places with lanes 0-31 of src.  (tests/emu/hip_emu.h supplies the host-side equivalent for the CPU emulator.)
+#ifndef VL2_PERMLANE32_SWAP_8
+#define VL2_PERMLANE32_SWAP_8(pk)                                                                                              \
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\t"                                 \
+                 "v_permlane32_swap_b32 %4, %6\n\tv_permlane32_swap_b32 %5, %7"                                                 \
+                 : "+v"(pk[0]), "+v"(pk[1]), "+v"(pk[2]), "+v"(pk[3]), "+v"(pk[4]), "+v"(pk[5]), "+v"(pk[6]), "+v"(pk[7]))
+#endif
+enum { EF_BIAS = 1, EF_RMS = 2, EF_LN = 4, EF_RES = 8, EF_STATS = 16 };
+__device__ __forceinline__ int gemm_ef_code(const GemmArgs& p) {
+    return (p.bias ? EF_BIAS : 0) | (p.norm == 1 ? EF_RMS : 0) | (p.norm == 2 ? EF_LN : 0) | (p.res ? EF_RES : 0) | (p.stats_out ? EF_STATS : 0);
+}
+template <int ACT, bool SWIGLU, int MI, int NJ, int EF = -1>
 __device__ __forceinline__ void gemm_store_tr(const GemmArgs& p, f32x16 (&acc)[MI][NJ], int m_w0, int n_w0, int lane) {
 #pragma clang fp reassociate(off)
+    const bool has_bias = EF < 0 ? (!SWIGLU && p.bias != nullptr) : (!SWIGLU && (EF & EF_BIAS) != 0);
+    const bool norm_rms = EF < 0 ? p.norm == 1 : (EF & EF_RMS) != 0;
+    const bool norm_ln = EF < 0 ? (!SWIGLU && p.norm == 2) : (!SWIGLU && (EF & EF_LN) != 0);
+    const bool has_res = EF < 0 ? p.res != nullptr : (EF & EF_RES) != 0;
+    const bool has_stats = EF < 0 ? (!SWIGLU && p.stats_out != nullptr) : (!SWIGLU && (EF & EF_STATS) != 0);
     const int hi = lane >> 5, l31 = lane & 31;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         const int m = m_w0 + mi * 32 + l31;
         const bool live = m < p.M;
         const int mc = live ? m : p.M - 1;
-        const f32x2 st = gemm_row_stats(p, m_w0 + mi * 32, l31, 32);       // (mean, rstd) of this lane's row (norm-carrying GEMMs)
-        const float mu = st[0], rs = st[1];
+        float mu = 0.f, rs = 1.f;
+        if (norm_rms || norm_ln) {
+            const f32x2 st = gemm_row_stats(p, m_w0 + mi * 32, l31, 32);   // (mean, rstd) of this lane's row (norm-carrying GEMMs)
+            mu = st[0];
+            rs = st[1];
+        }
+        bf16_t* crow = (bf16_t*)p.C + (size_t)m * p.ldc;
+        const bf16_t* rrow = has_res ? p.res + (size_t)mc * p.ldres : nullptr;
 #pragma unroll
         for (int cb = 0; cb < NJ / 2; ++cb) {                                // 64 GEMM columns = one statistics block / SwiGLU block
             float s8[4], q8[4];                                              // statistics of this lane's four 8-column groups
 #pragma unroll
             for (int half = 0; half < (SWIGLU ? 1 : 2); ++half) {
                 const int nj = cb * 2 + half;
+                // un-halved GEMM column / output column of this lane's group g = 0: + 8 g + 4 hi + c
+                const int ncol = n_w0 + nj * 32 + 4 * hi;
+                const int ocol = SWIGLU ? (n_w0 >> 1) + cb * 32 + 4 * hi : ncol;
                 float x[16];
                 if (SWIGLU) {                                                // columns [64 cb, +32) gate, [64 cb + 32, +32) up
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         float g = acc[mi][nj][r], u = acc[mi][nj + 1][r];
-                        if (p.norm) { g *= rs; u *= rs; }
+                        if (norm_rms) { g *= rs; u *= rs; }
                         x[r] = silu_f(g) * u;
                     }
                 } else {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) x[r] = acc[mi][nj][r];
+                    if (norm_ln) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const f32x4 cs = *(const f32x4*)(p.w_colsum + ncol + 8 * g);
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) x[4 * g + c] = __builtin_fmaf(-mu, cs[c], x[4 * g + c]) * rs;
+                        }
+                    } else if (norm_rms) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) x[r] *= rs;
+                    }
+                    if (has_bias) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const f32x4 bv = *(const f32x4*)(p.bias + ncol + 8 * g);
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) x[4 * g + c] += bv[c];
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        if (ACT == ACT_QGELU) x[r] = quick_gelu_f(x[r]);
+                        if (ACT == ACT_GELU) x[r] = gelu_erf_f(x[r]);
+                        if (ACT == ACT_SILU) x[r] = silu_f(x[r]);
+                        if (ACT == ACT_GELU_TANH) x[r] = gelu_tanh_f(x[r]);
+                    }
                 }
+                if (has_res) {
 #pragma unroll
-                for (int pr = 0; pr < 2; ++pr) {                             // register groups (2 pr, 2 pr + 1) -> 8 contiguous columns
-                    float v[8];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        // inline asm, not __builtin_amdgcn_permlane32_swap: in this function hipcc (ROCm 7.2) folded the builtin's
-                        // SECOND result into a copy of the first (v_mov of the swapped register over it; seen in the .s and as
-                        // wrong columns 4..7 of every 8 on hardware).  The two v_nop are the wait states a VALU write of either
-                        // operand needs before the swap reads it (guide T21).
-                        float a_ = x[8 * pr + c], b_ = x[8 * pr + 4 + c];
-                        asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a_), "+v"(b_));
-                        v[c] = a_;
-                        v[4 + c] = b_;
+                    for (int g = 0; g < 4; ++g) {
+                        const u32x2 rv = *(const u32x2*)(rrow + ocol + 8 * g);
+                        x[4 * g + 0] += __builtin_bit_cast(float, rv[0] << 16);
+                        x[4 * g + 1] += __builtin_bit_cast(float, rv[0] & 0xffff0000u);
+                        x[4 * g + 2] += __builtin_bit_cast(float, rv[1] << 16);
+                        x[4 * g + 3] += __builtin_bit_cast(float, rv[1] & 0xffff0000u);
                     }
-                    const int nfull = n_w0 + nj * 32 + 16 * pr + 8 * hi;     // un-halved GEMM column of v[0]
-                    const int n = SWIGLU ? (n_w0 >> 1) + cb * 32 + 16 * pr + 8 * hi : nfull;
-                    u32x4 rv;
-                    if (p.res) rv = *(const u32x4*)(p.res + (size_t)mc * p.ldres + n);
-                    if (!SWIGLU) {
-                        if (p.norm == 2) {
-                            const f32x4 cs0 = *(const f32x4*)(p.w_colsum + nfull), cs1 = *(const f32x4*)(p.w_colsum + nfull + 4);
+                }
+                uint32_t pk[8];                                              // pk[2 g + h] = columns 8 g + 4 hi + 2 h, + 1 (bf16 pair)
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) { v[j] = __builtin_fmaf(-mu, cs0[j], v[j]) * rs; v[4 + j] = __builtin_fmaf(-mu, cs1[j], v[4 + j]) * rs; }
-                        } else if (p.norm == 1) {
+                for (int g = 0; g < 4; ++g) {
+                    pk[2 * g] = pack2bf(x[4 * g], x[4 * g + 1]);
+                    pk[2 * g + 1] = pack2bf(x[4 * g + 2], x[4 * g + 3]);
+                }
+                // register groups (g, g + 1), g = 0, 2: afterwards lanes 0-31 hold columns 8 g .. 8 g + 7 (own group g | the upper
+                // half-wave's group g), lanes 32-63 columns 8 (g + 1) .. + 7 (the lower half-wave's group g + 1 | own).  Inline asm, not
+                // __builtin_amdgcn_permlane32_swap: inside this function hipcc (ROCm 7.2) folded the builtin's SECOND result into a
+                // copy of the first (seen in the .s; wrong columns 4..7 of every 8 on hardware).  s_nop 1 = the two wait states a VALU
+                // write of an operand needs before the swap reads it (guide T21).
+                VL2_PERMLANE32_SWAP_8(pk);
 #pragma unroll
-                            for (int j = 0; j < 8; ++j) v[j] *= rs;
-                        }
-                        if (p.bias) {
-                            const f32x4 b0 = *(const f32x4*)(p.bias + nfull), b1 = *(const f32x4*)(p.bias + nfull + 4);
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) { v[j] += b0[j]; v[4 + j] += b1[j]; }
-                        }
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            if (ACT == ACT_QGELU) v[j] = quick_gelu_f(v[j]);
-                            if (ACT == ACT_GELU) v[j] = gelu_erf_f(v[j]);
-                            if (ACT == ACT_SILU) v[j] = silu_f(v[j]);
-                            if (ACT == ACT_GELU_TANH) v[j] = gelu_tanh_f(v[j]);
-                        }
-                    }
-                    if (p.res) {
-                        float rf[8];
-                        unpack8(rv, rf);
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) v[j] += rf[j];
-                    }
-                    const u32x4 packed = pack8(v);
-                    if (live) *(u32x4*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = packed;
-                    if (!SWIGLU && p.stats_out) {                            // statistics of the row AS STORED, per 8-column group
+                for (int pr = 0; pr < 2; ++pr) {
+                    const u32x4 packed = {pk[4 * pr], pk[4 * pr + 1], pk[4 * pr + 2], pk[4 * pr + 3]};
+                    const int oc8 = (SWIGLU ? (n_w0 >> 1) + cb * 32 : n_w0 + nj * 32) + 16 * pr + 8 * hi;      // first of the 8 columns
+                    if (live) *(u32x4*)(crow + oc8) = packed;
+                    if (has_stats) {                                         // statistics of the row AS STORED, per 8-column group
                         float rf[8], ss = 0.f, qq = 0.f;
                         unpack8(packed, rf);
 #pragma unroll
@@ -323,24 +366,18 @@ __device__ __forceinline__ void gemm_store_tr(const GemmArgs& p, f32x16 (&acc)[M
                     }
                 }
             }
-            if (!SWIGLU && p.stats_out) {
+            if (has_stats) {
                 // the 64-column block's eight 8-column groups: this lane holds groups 2 i + hi (i = 0..3), its half-wave partner the
                 // other four.  gemm_store_patch folds them with octet_sum = ((s0 + s7) + (s1 + s6)) + ((s2 + s5) + (s3 + s4)):
                 // the same tree here (fp32 addition is commutative, so the operand order inside a pair does not matter).
-                float os[4], oq[4];                                          // the partner's four groups
+                float ts[4], tq[4];                                          // t_g = s_g + s_{7-g} for the own groups g = 2 i + hi
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    os[i] = __shfl_xor(s8[i], 32);
-                    oq[i] = __shfl_xor(q8[i], 32);
+                for (int i = 0; i < 4; ++i) {                                // 7 - (2 i + hi) = 2 (3 - i) + (1 - hi): the partner's slot 3 - i
+                    ts[i] = s8[i] + __shfl_xor(s8[3 - i], 32);
+                    tq[i] = q8[i] + __shfl_xor(q8[3 - i], 32);
                 }
-                // group index of s8[i] is 2 i + hi, of os[i] is 2 i + (1 - hi); pair (g, 7 - g): own 2 i + hi pairs with partner's 3 - i
-                float ts[4], tq[4];                                          // t_g for g = own groups
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { ts[i] = s8[i] + os[3 - i]; tq[i] = q8[i] + oq[3 - i]; }
-                // t_g == t_{7-g}; u_g = t_g + t_{g^1}: own group g = 2 i + hi, g ^ 1 = 2 i + (1 - hi) = 7 - (2 (3 - i) + hi) -> ts[3 - i]
-                const float u0s = ts[0] + ts[3], u0q = tq[0] + tq[3];                          // u of groups {0,1} (== {6,7})
-                const float u2s = ts[1] + ts[2], u2q = tq[1] + tq[2];                          // u of groups {2,3} (== {4,5})
-                const float tot_s = u0s + u2s, tot_q = u0q + u2q;
+                // lane hi = 0: ts = (t0, t2, t4, t6) with t4 = t3, t6 = t1  ->  (t0 + t1) + (t2 + t3) = (ts0 + ts3) + (ts1 + ts2)
+                const float tot_s = (ts[0] + ts[3]) + (ts[1] + ts[2]), tot_q = (tq[0] + tq[3]) + (tq[1] + tq[2]);
                 if (live && hi == 0) {
                     float* dst = p.stats_out + ((size_t)m * p.stats_out_np + ((n_w0 + cb * 64) >> 6)) * 2;
                     dst[0] = tot_s;
@@ -784,7 +821,7 @@ __device__ __forceinline__ int gemm4_lds_off(int row, int chunk) {
 // bid / nwg: this workgroup's index and the workgroup count of the tile set it belongs to (the whole grid for
 // gemm4_bf16_kernel; the big-tile part of gemm_mix_bf16_kernel)
 // TR: accumulate C^T (MFMA operands swapped) and store through gemm_store_tr (no LDS in the epilogue); bf16 output only
-template <int ACT, bool SWIGLU, bool OUT_F32, bool TR = false>
+template <int ACT, bool SWIGLU, bool OUT_F32, bool TR = false, int EF = -1>
 __device__ __forceinline__ void gemm4_body(const GemmArgs& p, int bid, int nwg) {
     static_assert(!(TR && OUT_F32), "gemm_store_tr writes bf16");
     extern __shared__ __attribute__((aligned(16))) unsigned char vl2_smem[];
@@ -885,7 +922,7 @@ __device__ __forceinline__ void gemm4_body(const GemmArgs& p, int bid, int nwg) 
     if (grp == 0) VL2_PHASE_BARRIER();
 
     if constexpr (TR) {       // ---- register-resident epilogue: the accumulators hold C^T, rows are lane-local
-        gemm_store_tr<ACT, SWIGLU, 2, 4>(p, acc, m0 + grp * 128 + wm * 64, n0 + wn * 128, lane);
+        gemm_store_tr<ACT, SWIGLU, 2, 4, EF>(p, acc, m0 + grp * 128 + wm * 64, n0 + wn * 128, lane);
         return;
     }
     // ---- epilogue: four 32 x 64 patches per wave (2 row blocks x 2 column halves)
@@ -916,9 +953,9 @@ __device__ __forceinline__ void gemm4_body(const GemmArgs& p, int bid, int nwg) 
             __builtin_amdgcn_wave_barrier();
         }
 }
-template <int ACT, bool SWIGLU, bool OUT_F32, bool TR = false>
+template <int ACT, bool SWIGLU, bool OUT_F32, bool TR = false, int EF = -1>
 __global__ __launch_bounds__(512, 2) void gemm4_bf16_kernel(GemmArgs p) {
-    gemm4_body<ACT, SWIGLU, OUT_F32, TR>(p, blockIdx.x, gridDim.x);
+    gemm4_body<ACT, SWIGLU, OUT_F32, TR, EF>(p, blockIdx.x, gridDim.x);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -931,8 +968,9 @@ __global__ __launch_bounds__(512, 2) void gemm4_bf16_kernel(GemmArgs p) {
 #define GEMM3_STAGE 49152
 #define GEMM3_LDS_BYTES (3 * GEMM3_STAGE)
 
-template <int ACT, bool SWIGLU, bool OUT_F32>
+template <int ACT, bool SWIGLU, bool OUT_F32, bool TR = false, int EF = -1>
 __device__ __forceinline__ void gemm3_body(const GemmArgs& p, int bid, int nwg) {
+    static_assert(!(TR && OUT_F32), "gemm_store_tr writes bf16");
     extern __shared__ __attribute__((aligned(16))) unsigned char vl2_smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -945,7 +983,8 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs& p, int bid, int nwg) 
     const int gm = (p.tiles_m - first_m) < 8 ? (p.tiles_m - first_m) : 8;
     const int tm = first_m + (t0 % grp_sz) % gm, tn = (t0 % grp_sz) / gm;
     const int m0 = tm * GEMM3_BM, n0 = tn * GEMM3_BN;
-    const f32x2 rst = gemm_row_stats(p, m0, tid, GEMM3_BM);
+    f32x2 rst = {0.f, 1.f};
+    if constexpr (!TR) rst = gemm_row_stats(p, m0, tid, GEMM3_BM);
 
     const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x7fffffff, 0x00020000);
     const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0x7fffffff, 0x00020000);
@@ -1024,11 +1063,16 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs& p, int bid, int nwg) 
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = TR ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks][j], fa[ks][i], acc[i][j], 0, 0, 0)
+                                   : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
         VL2_PHASE_BARRIER();
     }
     if (grp == 0) VL2_PHASE_BARRIER();
 
+    if constexpr (TR) {       // register-resident epilogue (the accumulators hold C^T)
+        gemm_store_tr<ACT, SWIGLU, 2, 2, EF>(p, acc, m0 + wm * 64, n0 + grp * 128 + wn * 64, lane);
+        return;
+    }
     float* ep = (float*)vl2_smem + wave * (32 * 68);
     float* rowtab = (float*)vl2_smem + 8 * (32 * 68);
     gemm_park_row_stats(p, rowtab, rst, tid, GEMM3_BM);
@@ -1047,9 +1091,9 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs& p, int bid, int nwg) 
         __builtin_amdgcn_wave_barrier();
     }
 }
-template <int ACT, bool SWIGLU, bool OUT_F32>
+template <int ACT, bool SWIGLU, bool OUT_F32, bool TR = false, int EF = -1>
 __global__ __launch_bounds__(512, 2) void gemm3_bf16_kernel(GemmArgs p) {
-    gemm3_body<ACT, SWIGLU, OUT_F32>(p, blockIdx.x, gridDim.x);
+    gemm3_body<ACT, SWIGLU, OUT_F32, TR, EF>(p, blockIdx.x, gridDim.x);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
