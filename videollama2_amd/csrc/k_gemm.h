@@ -58,30 +58,50 @@ struct GemmArgs {
 // consumer's workgroup reduces the K/64 partials of its BM rows once, in its prologue while the first LDS-DMA slabs are in
 // flight (`gemm_row_stats`), and parks (mean, rstd) in LDS for the epilogue.  Fixed partial layout + fixed reduction order:
 // a row's statistics are the same bits whichever kernel / grid produced them.
+// (sum, sum of squares) of a row from its `np` per-64-column partials, in the association of row_norm_finalize_kernel (k_norm.h:
+// eight strided sums -- accumulator i takes partials i, i + 8, ... in increasing order -- folded like octet_sum), so a GEMM that
+// reduces the partials itself normalises with the same (mean, rstd) bits as one that is handed the finalize kernel's table.
+// The loads go out in batches of eight 16-B vectors (one memory round trip per 16 partials), not one per loop trip.
+__device__ __forceinline__ f32x2 row_partials_reduce(const float* sp, int np) {
+#pragma clang fp reassociate(off)
+    float s[8], q[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s[i] = q[i] = 0.f;
+    const int nv = np >> 1;                                       // 16-B vectors (two partials each); np is even (K % 128 == 0)
+    for (int c0 = 0; c0 < nv; c0 += 8) {
+        f32x4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (c0 + k < nv) ? *(const f32x4*)(sp + 4 * (c0 + k)) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (c0 + k < nv) {                                    // partials 2 (c0 + k), + 1  ->  accumulators (2 k) & 7, + 1
+                s[(2 * k) & 7] += v[k][0];
+                q[(2 * k) & 7] += v[k][1];
+                s[(2 * k + 1) & 7] += v[k][2];
+                q[(2 * k + 1) & 7] += v[k][3];
+            }
+    }
+    if (np & 1) { s[(np - 1) & 7] += sp[2 * (np - 1)]; q[(np - 1) & 7] += sp[2 * (np - 1) + 1]; }
+    f32x2 r;
+    r[0] = ((s[0] + s[7]) + (s[1] + s[6])) + ((s[2] + s[5]) + (s[3] + s[4]));
+    r[1] = ((q[0] + q[7]) + (q[1] + q[6])) + ((q[2] + q[5]) + (q[3] + q[4]));
+    return r;
+}
 __device__ __forceinline__ f32x2 gemm_row_stats(const GemmArgs& p, int m0, int t, int BM) {
 #pragma clang fp reassociate(off)
     f32x2 r = {0.f, 1.f};
     if (p.norm && t < BM) {
         int m = m0 + t;
         m = m < p.M ? m : p.M - 1;
-        if (p.row_norm) return *(const f32x2*)(p.row_norm + 2 * (size_t)m);      // reduced once per GEMM call, not once per tile
-        const float* sp = p.stats_in + (size_t)m * p.stats_in_np * 2;
-        float sum = 0.f, sq = 0.f;
-        int i = 0;
-        for (; i + 2 <= p.stats_in_np; i += 2) {
-            const f32x4 v = *(const f32x4*)(sp + 2 * i);
-            sum = (sum + v[0]) + v[2];
-            sq = (sq + v[1]) + v[3];
-        }
-        if (i < p.stats_in_np) { sum += sp[2 * i]; sq += sp[2 * i + 1]; }
-        const float inv = 1.0f / (float)p.K;
+        if (p.row_norm) return *(const f32x2*)(p.row_norm + 2 * (size_t)m);      // reduced once per GEMM call (row_norm_finalize_kernel)
+        const f32x2 sq = row_partials_reduce(p.stats_in + (size_t)m * p.stats_in_np * 2, p.stats_in_np);
+        const float inv = 1.0f / (float)p.K;                                     // same expressions as row_norm_finalize_kernel
         if (p.norm == 2) {
-            const float mean = sum * inv;
-            const float var = fmaxf(__builtin_fmaf(-mean, mean, sq * inv), 0.f);
+            const float mean = sq[0] * inv;
             r[0] = mean;
-            r[1] = rsqrtf(var + p.norm_eps);
+            r[1] = rsqrtf(fmaxf(__builtin_fmaf(-mean, mean, sq[1] * inv), 0.f) + p.norm_eps);
         } else {
-            r[1] = rsqrtf(sq * inv + p.norm_eps);
+            r[1] = rsqrtf(sq[1] * inv + p.norm_eps);
         }
     }
     return r;
@@ -260,8 +280,15 @@ enum { EF_BIAS = 1, EF_RMS = 2, EF_LN = 4, EF_RES = 8, EF_STATS = 16 };
 __device__ __forceinline__ int gemm_ef_code(const GemmArgs& p) {
     return (p.bias ? EF_BIAS : 0) | (p.norm == 1 ? EF_RMS : 0) | (p.norm == 2 ? EF_LN : 0) | (p.res ? EF_RES : 0) | (p.stats_out ? EF_STATS : 0);
 }
+// rowst[mi] = (mean, rstd) of row m_w0 + 32 mi + (lane & 31) (gemm_tr_row_stats, computed in the kernel's PROLOGUE so that the loads
+// of the statistics hide behind the first LDS-DMA slabs)
+template <int MI>
+__device__ __forceinline__ void gemm_tr_row_stats(const GemmArgs& p, int m_w0, int lane, f32x2 (&rowst)[MI]) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) rowst[mi] = gemm_row_stats(p, m_w0 + mi * 32, lane & 31, 32);
+}
 template <int ACT, bool SWIGLU, int MI, int NJ, int EF = -1>
-__device__ __forceinline__ void gemm_store_tr(const GemmArgs& p, f32x16 (&acc)[MI][NJ], int m_w0, int n_w0, int lane) {
+__device__ __forceinline__ void gemm_store_tr(const GemmArgs& p, f32x16 (&acc)[MI][NJ], int m_w0, int n_w0, int lane, const f32x2 (&rowst)[MI]) {
 #pragma clang fp reassociate(off)
     const bool has_bias = EF < 0 ? (!SWIGLU && p.bias != nullptr) : (!SWIGLU && (EF & EF_BIAS) != 0);
     const bool norm_rms = EF < 0 ? p.norm == 1 : (EF & EF_RMS) != 0;
@@ -274,12 +301,7 @@ __device__ __forceinline__ void gemm_store_tr(const GemmArgs& p, f32x16 (&acc)[M
         const int m = m_w0 + mi * 32 + l31;
         const bool live = m < p.M;
         const int mc = live ? m : p.M - 1;
-        float mu = 0.f, rs = 1.f;
-        if (norm_rms || norm_ln) {
-            const f32x2 st = gemm_row_stats(p, m_w0 + mi * 32, l31, 32);   // (mean, rstd) of this lane's row (norm-carrying GEMMs)
-            mu = st[0];
-            rs = st[1];
-        }
+        const float mu = rowst[mi][0], rs = rowst[mi][1];                  // (mean, rstd) of this lane's row (norm-carrying GEMMs)
         bf16_t* crow = (bf16_t*)p.C + (size_t)m * p.ldc;
         const bf16_t* rrow = has_res ? p.res + (size_t)mc * p.ldres : nullptr;
 #pragma unroll
@@ -836,8 +858,9 @@ __device__ __forceinline__ void gemm4_body(const GemmArgs& p, int bid, int nwg) 
     const int gm = (p.tiles_m - first_m) < 4 ? (p.tiles_m - first_m) : 4;
     const int tm = first_m + (t0 % grp_sz) % gm, tn = (t0 % grp_sz) / gm;
     const int m0 = tm * GEMM4_BM, n0 = tn * GEMM4_BN;
-    f32x2 rst = {0.f, 1.f};
+    f32x2 rst = {0.f, 1.f}, rowst[2] = {{0.f, 1.f}, {0.f, 1.f}};
     if constexpr (!TR) rst = gemm_row_stats(p, m0, tid, GEMM4_BM);
+    else gemm_tr_row_stats<2>(p, m0 + grp * 128 + wm * 64, lane, rowst);
 
     // this wave's LDS-DMA parts of a slab: 2 x A rows [128*grp, +128) and 2 x W rows [128*grp, +128), issue-lean form:
     // `buffer_load_dwordx4 ... offen lds` with loop-invariant VGPR byte offsets, K position in the SGPR soffset
@@ -922,7 +945,7 @@ __device__ __forceinline__ void gemm4_body(const GemmArgs& p, int bid, int nwg) 
     if (grp == 0) VL2_PHASE_BARRIER();
 
     if constexpr (TR) {       // ---- register-resident epilogue: the accumulators hold C^T, rows are lane-local
-        gemm_store_tr<ACT, SWIGLU, 2, 4, EF>(p, acc, m0 + grp * 128 + wm * 64, n0 + wn * 128, lane);
+        gemm_store_tr<ACT, SWIGLU, 2, 4, EF>(p, acc, m0 + grp * 128 + wm * 64, n0 + wn * 128, lane, rowst);
         return;
     }
     // ---- epilogue: four 32 x 64 patches per wave (2 row blocks x 2 column halves)
@@ -983,8 +1006,9 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs& p, int bid, int nwg) 
     const int gm = (p.tiles_m - first_m) < 8 ? (p.tiles_m - first_m) : 8;
     const int tm = first_m + (t0 % grp_sz) % gm, tn = (t0 % grp_sz) / gm;
     const int m0 = tm * GEMM3_BM, n0 = tn * GEMM3_BN;
-    f32x2 rst = {0.f, 1.f};
+    f32x2 rst = {0.f, 1.f}, rowst[2] = {{0.f, 1.f}, {0.f, 1.f}};
     if constexpr (!TR) rst = gemm_row_stats(p, m0, tid, GEMM3_BM);
+    else gemm_tr_row_stats<2>(p, m0 + wm * 64, lane, rowst);
 
     const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x7fffffff, 0x00020000);
     const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0x7fffffff, 0x00020000);
@@ -1070,7 +1094,7 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs& p, int bid, int nwg) 
     if (grp == 0) VL2_PHASE_BARRIER();
 
     if constexpr (TR) {       // register-resident epilogue (the accumulators hold C^T)
-        gemm_store_tr<ACT, SWIGLU, 2, 2, EF>(p, acc, m0 + wm * 64, n0 + grp * 128 + wn * 64, lane);
+        gemm_store_tr<ACT, SWIGLU, 2, 2, EF>(p, acc, m0 + wm * 64, n0 + grp * 128 + wn * 64, lane, rowst);
         return;
     }
     float* ep = (float*)vl2_smem + wave * (32 * 68);
