@@ -168,6 +168,14 @@ int32_t vl2_gemv_batched_bf16(const void* W, const void* x, const float* norm_w,
  *   split in 64-key slices (flash-decoding), and combines the slices into out [nh*128] bf16.
  *   pos_dev != NULL: the position is read from device memory (*pos_dev) so a captured hipGraph replays as it moves; the
  *   launch then covers positions < ctx_cap.  partial: fp32 workspace >= nh*ceil(cap/64)*130 floats (cap = ctx_cap or pos+1). */
+/* The same attention + combine in ONE launch (the workgroup that finishes a kv head's last slice combines its q heads): position from
+ * device memory only, partial sized for smax (nh*ceil(smax/64)*130 floats), cnt = nkv int32 ticket counters that must be ZERO when the
+ * launch starts (the caller clears them; NOT with a hipMemsetAsync node of a few bytes inside a captured hipGraph -- that did not replay
+ * on ROCm 7.2).  Same bits as vl2_attn_decode; measured slower than it on MI355X (profiles/r03_experiments.md section 5), so nothing in
+ * the product takes it by default. */
+int32_t vl2_attn_decode_fused(const void* qkv, void* kcache, void* vcache, const float* cos_t, const float* sin_t, float* partial,
+                              void* out, int32_t nh, int32_t nkv, int32_t smax, const int32_t* pos_dev, float scale, int32_t* cnt,
+                              void* stream);
 int32_t vl2_attn_decode(const void* qkv, void* kcache, void* vcache, const float* cos_t, const float* sin_t, float* partial,
                         void* out, int32_t nh, int32_t nkv, int32_t smax, int32_t pos, const int32_t* pos_dev,
                         int32_t ctx_cap, float scale, void* stream);

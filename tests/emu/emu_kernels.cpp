@@ -336,22 +336,40 @@ extern "C" int32_t vl2_attn_decode(const void* qkv, void* kc, void* vc, const fl
     const int group = nh / nkv, cap = pos_dev ? ctx_cap : pos + 1, nsplit = (cap + 63) / 64;
     if (cap <= 0 || cap > smax) return -2;
     emu::launch(dim3(nsplit, nkv, (group + 3) / 4), dim3(256), [=] {
-        attn_decode_kernel((const bf16_t*)qkv, (bf16_t*)kc, (bf16_t*)vc, cos_t, sin_t, partial, nh, group, nkv, smax, pos, pos_dev, scale * 1.4426950408889634f, 0L, 0L, 0L); });
+        attn_decode_kernel<false>((const bf16_t*)qkv, (bf16_t*)kc, (bf16_t*)vc, cos_t, sin_t, partial, nh, group, nkv, smax, pos, pos_dev, scale * 1.4426950408889634f, 0L, 0L, 0L, (int*)nullptr, (bf16_t*)nullptr); });
     emu::launch(dim3(nh), dim3(128), [=] { attn_decode_combine_kernel(partial, (bf16_t*)out, nsplit, pos, pos_dev, 0L, 0L); });
     return 0;
 }
+// vl2_abi.hip attn_decode_fused (attention + combine in one launch; the emulator runs the workgroups one after the other, so the
+// last one in launch order of every kv head draws the last ticket)
+static int32_t attn_decode_fused(const void* qkv, void* kc, void* vc, const float* cos_t, const float* sin_t, float* partial, void* out,
+                                 int32_t nh, int32_t nkv, int32_t smax, const int32_t* pos_dev, float scale, int32_t* cnt, void*) {
+    const int group = nh / nkv, nsplit = (smax + 63) / 64;
+    emu::launch(dim3(nsplit, nkv, (group + 3) / 4), dim3(256), [=] {
+        attn_decode_kernel<true>((const bf16_t*)qkv, (bf16_t*)kc, (bf16_t*)vc, cos_t, sin_t, partial, nh, group, nkv, smax, 0, pos_dev, scale * 1.4426950408889634f, 0L, 0L, 0L, (int*)cnt, (bf16_t*)out); });
+    return 0;
+}
+static int32_t argmax_and_clear(const float* logits, int32_t V, int32_t* tok, int32_t* hist, int32_t* state, int32_t* zero, int32_t nzero, void*) {
+    emu::launch(dim3(1), dim3(1024), [=] { argmax_kernel(logits, V, tok, hist, 0, state, (int*)zero, nzero); });
+    return 0;
+}
+extern "C" int32_t vl2_attn_decode_fused(const void* qkv, void* kc, void* vc, const float* cos_t, const float* sin_t, float* partial, void* out,
+                                         int32_t nh, int32_t nkv, int32_t smax, const int32_t* pos_dev, float scale, int32_t* cnt, void* st) {
+    return attn_decode_fused(qkv, kc, vc, cos_t, sin_t, partial, out, nh, nkv, smax, pos_dev, scale, cnt, st);
+}
+
 extern "C" int32_t vl2_attn_decode_batched(const void* qkv, void* kc, void* vc, const float* cos_t, const float* sin_t, float* partial,
                                            void* out, int32_t B, int64_t qkv_bs, int64_t cache_bs, int64_t out_bs, int32_t nh, int32_t nkv,
                                            int32_t smax, const int32_t* pos_dev, int32_t ctx_cap, float scale, void*) {
     const int group = nh / nkv, nsplit = (ctx_cap + 63) / 64;
     const long pbs = (long)nh * nsplit * 130;
     emu::launch(dim3(nsplit, nkv * B, (group + 3) / 4), dim3(256), [=] {
-        attn_decode_kernel((const bf16_t*)qkv, (bf16_t*)kc, (bf16_t*)vc, cos_t, sin_t, partial, nh, group, nkv, smax, 0, pos_dev, scale * 1.4426950408889634f, (long)qkv_bs, (long)cache_bs, pbs); });
+        attn_decode_kernel<false>((const bf16_t*)qkv, (bf16_t*)kc, (bf16_t*)vc, cos_t, sin_t, partial, nh, group, nkv, smax, 0, pos_dev, scale * 1.4426950408889634f, (long)qkv_bs, (long)cache_bs, pbs, (int*)nullptr, (bf16_t*)nullptr); });
     emu::launch(dim3(nh, B), dim3(128), [=] { attn_decode_combine_kernel(partial, (bf16_t*)out, nsplit, 0, pos_dev, pbs, (long)out_bs); });
     return 0;
 }
 extern "C" int32_t vl2_argmax(const float* logits, int32_t V, int32_t* tok, int32_t* hist, int32_t step, int32_t* state, void*) {
-    emu::launch(dim3(1), dim3(1024), [=] { argmax_kernel(logits, V, tok, hist, step, state); });
+    emu::launch(dim3(1), dim3(1024), [=] { argmax_kernel(logits, V, tok, hist, step, state, (int*)nullptr, 0); });
     return 0;
 }
 extern "C" int32_t vl2_embed_rows(const int32_t* ids, const void* table, void* out, int32_t n, int32_t D, int32_t ldo, void*) {

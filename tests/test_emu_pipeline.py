@@ -754,10 +754,18 @@ def test_emu_continuous_batching_admits_between_decode_steps(emu, golden_small):
     assert set(second) == {r0, r1} and st[1].ended and not st[0].ended and r1 in b.finished
     third = b.step()                                   # request 2 was admitted into slot 1 between the steps
     assert set(third) == {r0, r2} and third[r2] == solo[2][0]
+    # the slot buffers are shared with generate_batch / a second batcher: while this batcher holds requests both are refused
+    # (they would overwrite the caches and positions of the requests in flight), and allowed again once it has drained
+    with pytest.raises(RuntimeError, match="in use by a ContinuousBatcher"):
+        m.generate_batch([(reqs[0][0], reqs[0][1]), (reqs[1][0], reqs[1][1])], max_new_tokens=2)
+    with pytest.raises(RuntimeError, match="in use by a ContinuousBatcher"):
+        m.batcher(max_slots=2)
     done = b.run()
     assert [done[r].tolist() for r in (r0, r1, r2, r3)] == solo
     assert [s.got for s in st] == solo and all(s.ended for s in st)
     assert b.in_flight() == 0 and b.step() == {}
+    again = m.generate_batch([(reqs[0][0], reqs[0][1]), (reqs[1][0], reqs[1][1])], max_new_tokens=2)     # drained: free again
+    assert [o.tolist() for o in again] == [solo[0][:2], solo[1][:2]]
     # an EOS retires a request early; the slot is reused
     b2 = m.batcher(max_slots=1, eos_token_id=solo[0][1])
     ra = b2.submit(reqs[0][0], reqs[0][1], max_new_tokens=5)
@@ -833,3 +841,24 @@ def test_emu_tensor_parallel_real_shards_in_one_process(emu):
         toks, lg = O.greedy_generate(sd, cfg, x, 3)
     rows = TP.run_local_tp(cfg, sd, x, toks, lg, 2, 64, "cpu")
     assert len(rows) == 3
+
+
+def test_emu_attn_decode_fused_equals_two_kernels(emu):
+    """CPU dry run of tests/test_gpu_ops.py::test_attn_decode_fused_combine_equals_two_kernels on the emulator (group 4 and group 7)."""
+    from videollama2_amd import ops
+    HD = 128
+    for nh, nkv, smax, pos in ((8, 2, 256, 130), (7, 1, 128, 70)):
+        qkv, kc, vc = bf((nh + 2 * nkv) * HD, seed=pos), bf(nkv, smax, HD, seed=2), bf(nkv, smax, HD, seed=3)
+        inv = 1.0 / (1e6 ** (torch.arange(0, HD, 2).float() / HD))
+        fr = torch.arange(smax).float()[:, None] * inv[None]
+        cos_t, sin_t = fr.cos().contiguous(), fr.sin().contiguous()
+        nsp, group = (smax + 63) // 64, nh // nkv
+        pos_dev = torch.tensor([pos], dtype=torch.int32)
+        k1, v1, k2, v2 = kc.clone(), vc.clone(), kc.clone(), vc.clone()
+        p1, p2 = torch.full((nh * nsp * 130,), 7.0), torch.full((nh * nsp * 130,), -3.0)
+        o1, o2 = torch.zeros(nh * HD, dtype=torch.bfloat16), torch.ones(nh * HD, dtype=torch.bfloat16)
+        ops.attn_decode(qkv, k1, v1, cos_t, sin_t, p1, o1, nh, nkv, pos, HD ** -0.5, pos_dev=pos_dev, ctx_cap=smax)
+        cnt = torch.zeros(nkv, dtype=torch.int32)
+        ops.attn_decode_fused(qkv, k2, v2, cos_t, sin_t, p2, o2, nh, nkv, pos_dev, HD ** -0.5, cnt)
+        assert torch.equal(o1, o2) and torch.equal(k1, k2) and torch.equal(v1, v2)
+        assert cnt.tolist() == [((pos + 64) // 64) * ((group + 3) // 4)] * nkv

@@ -406,6 +406,32 @@ def test_attn_decode_fused_rope_append(ops, pos):
         assert rel(out, torch.einsum("hk,hkd->hd", a, vf).reshape(-1)) < TOL_BF16_OUT
 
 
+@pytest.mark.parametrize("nh,nkv,smax,pos", [(32, 8, 2048, 300), (32, 8, 2048, 1650), (28, 4, 512, 300), (32, 8, 2048, 63), (32, 8, 2048, 64),
+                                             (32, 8, 512, 511), (64, 8, 1024, 700)])
+def test_attn_decode_fused_combine_equals_two_kernels(ops, nh, nkv, smax, pos):
+    """vl2_attn_decode_fused (the kv head's last-finishing slice combines its q heads inside the attention launch; what
+    vl2_llm_decode_step enqueues) must give the bits of vl2_attn_decode (attention + combine kernels): same output, same appended
+    cache rows, every ticket counter at the number of live slices -- Mistral (group 4), Qwen2-7B (group 7 = two head blocks per kv
+    head), 72B (group 8), slice boundaries and the last cache row, repeated launches."""
+    HD = 128
+    qkv, kc, vc = bf((nh + 2 * nkv) * HD, seed=pos), bf(nkv, smax, HD, seed=2), bf(nkv, smax, HD, seed=3)
+    inv = 1.0 / (1e6 ** (torch.arange(0, HD, 2).float() / HD))
+    fr = torch.arange(smax).float()[:, None] * inv[None]
+    cos_t, sin_t = fr.cos().contiguous().to(DEV), fr.sin().contiguous().to(DEV)
+    nsp, group = (smax + 63) // 64, nh // nkv
+    pos_dev = torch.tensor([pos], dtype=torch.int32, device=DEV)
+    for rep in range(3):
+        k1, v1, k2, v2 = kc.to(DEV), vc.to(DEV), kc.to(DEV), vc.to(DEV)
+        p1, p2 = torch.full((nh * nsp * 130,), 7.0, device=DEV), torch.full((nh * nsp * 130,), -3.0, device=DEV)   # stale garbage
+        o1, o2 = torch.zeros(nh * HD, dtype=torch.bfloat16, device=DEV), torch.ones(nh * HD, dtype=torch.bfloat16, device=DEV)
+        ops.attn_decode(qkv.to(DEV), k1, v1, cos_t, sin_t, p1, o1, nh, nkv, pos, HD ** -0.5, pos_dev=pos_dev, ctx_cap=smax)
+        cnt = torch.zeros(nkv, dtype=torch.int32, device=DEV)
+        ops.attn_decode_fused(qkv.to(DEV), k2, v2, cos_t, sin_t, p2, o2, nh, nkv, pos_dev, HD ** -0.5, cnt)
+        assert torch.equal(o1, o2), (rep, int((o1 != o2).sum()))
+        assert torch.equal(k1, k2) and torch.equal(v1, v2)
+        assert cnt.tolist() == [((pos + 64) // 64) * ((group + 3) // 4)] * nkv
+
+
 def test_argmax_embed(ops):
     lg = torch.randn(32000)
     lg[1234] = 9.0

@@ -87,6 +87,7 @@ SIGNATURES = {
     "vl2_gemm_skinny_bf16": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp],
     "vl2_gemv_batched_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp],
     "vl2_attn_decode": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _f32, _vp],
+    "vl2_attn_decode_fused": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _f32, _vp, _vp],
     "vl2_attn_decode_batched": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _i64, _i32, _i32, _i32, _vp, _i32, _f32, _vp],
     "vl2_argmax": [_vp, _i32, _vp, _vp, _i32, _vp, _vp],
     "vl2_embed_rows": [_vp, _vp, _vp, _i32, _i32, _i32, _vp],

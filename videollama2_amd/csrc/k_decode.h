@@ -268,6 +268,66 @@ __global__ __launch_bounds__(256) void gemv_mr_bf16_kernel(GemvArgs p) {
     }
 }
 
+// ---- the combine of the flash-decoding partials (shared by attn_decode_combine_kernel and the fused form of attn_decode_kernel)
+#define COMBINE_CHUNK 256
+// One head's combine, 128 threads (d = 0..127 = the output dimension; the threads with d < 64 are one wave and turn the (m_i, l_i)
+// pairs into weights).  ACQ = the partials were written by OTHER workgroups of the same launch (attn_decode_kernel<true>): they are
+// read with agent-scope relaxed atomic loads (global_load ... sc1: bypass this CU's vector L1, the producer stored write-through).
+// Every thread of the workgroup must call this the same number of times (it contains workgroup barriers).  The arithmetic -- and
+// so the bits -- is the same whichever kernel runs it.
+template <bool ACQ>
+__device__ __forceinline__ float attn_ld(const float* p) {
+    if (ACQ) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+template <bool ACQ, int TPH = 128>
+__device__ __forceinline__ void attn_combine_head(const float* __restrict__ src, int nsplit, int d, float* wgt, float* red,
+                                                  bf16_t* outp, bool store) {
+    // TPH threads work on one head (d = 0 .. TPH-1; the first 64 of them are one wave and turn the (m_i, l_i) pairs into weights);
+    // thread d sums the 128 / TPH output columns d, d + TPH, ... one after the other -- every output element is the same fixed-order
+    // sum whatever TPH is.  Two instantiations (plain / agent-scope loads) must give the same bits: under -ffast-math the compiler
+    // is otherwise free to contract or re-associate them differently (seen on hardware: one bf16 output element in 4096 off by an
+    // ulp) -> the sums are explicit FMAs in a fixed order
+#pragma clang fp reassociate(off)
+    if (d < 64) {                                             // one wave: global max M, then L = sum_i l_i 2^(m_i - M)
+        float M = -1e30f;
+        for (int i0 = 0; i0 < nsplit; i0 += 64) M = fmaxf(M, (i0 + d < nsplit) ? attn_ld<ACQ>(src + (i0 + d) * 130) : -1e30f);
+        M = wave_max(M);
+        float L = 0.f;
+        for (int i0 = 0; i0 < nsplit; i0 += 64)
+            if (i0 + d < nsplit) L = __builtin_fmaf(attn_ld<ACQ>(src + (i0 + d) * 130 + 1), exp2f(attn_ld<ACQ>(src + (i0 + d) * 130) - M), L);
+        L = wave_sum(L);
+        if (d == 0) { red[0] = M; red[1] = 1.0f / L; }
+    }
+    __syncthreads();
+    const float M = red[0];
+    float o[128 / TPH];
+#pragma unroll
+    for (int c = 0; c < 128 / TPH; ++c) o[c] = 0.f;
+    for (int c0 = 0; c0 < nsplit; c0 += COMBINE_CHUNK) {
+        const int nc = nsplit - c0 < COMBINE_CHUNK ? nsplit - c0 : COMBINE_CHUNK;
+        if (c0 > 0) __syncthreads();                          // the previous chunk's weights have been consumed
+        for (int i = d; i < nc; i += TPH) wgt[i] = exp2f(attn_ld<ACQ>(src + (c0 + i) * 130) - M);
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 128 / TPH; ++c) {
+            const float* s0 = src + (size_t)c0 * 130 + 2 + d + c * TPH;
+            int i = 0;
+            for (; i + 8 <= nc; i += 8) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = attn_ld<ACQ>(s0 + (i + j) * 130);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[c] = __builtin_fmaf(v[j], wgt[i + j], o[c]);
+            }
+            for (; i < nc; ++i) o[c] = __builtin_fmaf(attn_ld<ACQ>(s0 + i * 130), wgt[i], o[c]);
+        }
+    }
+    if (store) {
+#pragma unroll
+        for (int c = 0; c < 128 / TPH; ++c) outp[d + c * TPH] = f2bf(o[c] * red[1]);
+    }
+}
 // ---- decode attention (flash-decoding) fused with RoPE and the KV-cache append of the new token.
 // qkv [(nh+2*nkv)*128] = the un-roped fused projection of the ONE new token at position pos (pos = *pos_dev when pos_dev
 // is non-null, so a captured hipGraph replays with a moving position).  grid = (nsplit_cap, nkv, ceil(group/4)), 256
@@ -278,12 +338,21 @@ __global__ __launch_bounds__(256) void gemv_mr_bf16_kernel(GemvArgs p) {
 // The workgroup(s) whose slice contains pos rope k_new and append k_new / v_new to the cache (DynamicCache.update) first
 // (with two head blocks both write the same bytes, and each reads the row back only after its own barrier).
 // partial: fp32 [nh][nsplit_cap][130] = {m (exp2 domain), l, o[128]}
+// FUSED (single sequence, the stage-level decode step): the combine runs inside this launch -- every workgroup stores its partials
+// write-through (agent-scope relaxed atomic stores = `global_store ... sc1`), drains them, and takes a ticket on its kv head's
+// counter `cnt[hk]` (zeroed by the caller before the launch); the workgroup that draws the last ticket of the head combines the
+// `group` q heads of that kv head (attn_combine_head<true>: the same arithmetic as attn_decode_combine_kernel, partials read past
+// the vector L1) and writes `out`.  One launch and one kernel boundary less per layer and token than attn + combine
+// (7.6 + 4.7 us + a boundary -> measured in profiles/r03_experiments.md).  Round 1 tried the same election with an agent-scope
+// RELEASE fence in every slice (buffer_wbl2) and lost; write-through stores need no fence (guide G16 R1).
+template <bool FUSED>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ kcache,
                                                           bf16_t* __restrict__ vcache, const float* __restrict__ cos_t,
                                                           const float* __restrict__ sin_t, float* __restrict__ partial,
                                                           int nh, int group, int nkv, int smax, int pos_arg,
                                                           const int* __restrict__ pos_dev, float scale_log2e,
-                                                          long qkv_bs, long cache_bs, long partial_bs) {
+                                                          long qkv_bs, long cache_bs, long partial_bs,
+                                                          int* __restrict__ cnt, bf16_t* __restrict__ out) {
     // batched decode: blockIdx.y = kv head + nkv * sequence; sequence b uses qkv + b*qkv_bs, caches + b*cache_bs,
     // partial + b*partial_bs and position pos_dev[b] (single sequence: strides 0, b = 0)
     constexpr int HD = 128, HALF = 64;
@@ -385,13 +454,42 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
 #pragma unroll
     for (int h = 0; h < 4; ++h) { oacc[wave][h][lane * 2] = o[h][0]; oacc[wave][h][lane * 2 + 1] = o[h][1]; }
     __syncthreads();
+    auto put = [](float* p, float v) {
+        if (FUSED) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // write-through (sc1)
+        else *p = v;
+    };
     for (int t = tid; t < ng * HD; t += 256) {
         const int h = t / HD, d = t % HD;
         float* dst = partial + ((size_t)(hk * group + h0 + h) * nsplit + split) * 130;
-        dst[2 + d] = oacc[0][h][d] + oacc[1][h][d] + oacc[2][h][d] + oacc[3][h][d];
+        put(dst + 2 + d, oacc[0][h][d] + oacc[1][h][d] + oacc[2][h][d] + oacc[3][h][d]);
         if (d == 0) {
-            dst[0] = fmaxf(fmaxf(wred[0][0][h], wred[0][1][h]), fmaxf(wred[0][2][h], wred[0][3][h]));
-            dst[1] = wred[1][0][h] + wred[1][1][h] + wred[1][2][h] + wred[1][3][h];
+            put(dst, fmaxf(fmaxf(wred[0][0][h], wred[0][1][h]), fmaxf(wred[0][2][h], wred[0][3][h])));
+            put(dst + 1, wred[1][0][h] + wred[1][1][h] + wred[1][2][h] + wred[1][3][h]);
+        }
+    }
+    if constexpr (FUSED) {
+        __shared__ float wgtf[4][COMBINE_CHUNK];
+        __shared__ float redf[4][2];
+        __shared__ int s_last;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // EVERY storing wave drains its write-through stores (guide G16 R1)
+        __syncthreads();
+        const int nlive = (ctx + 63) >> 6;                          // slices that reach this point, per head block
+        if (tid == 0) {
+            const int ticket = __hip_atomic_fetch_add(cnt + hk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = ticket == nlive * (int)gridDim.z - 1;
+        }
+        __syncthreads();
+        if (!s_last) return;
+        // the elected workgroup: four heads at a time, one wave each.  The partial buffer is reused by every layer and token, so this
+        // CU's vector L1 may hold stale lines of it: the combine reads with agent-scope atomic loads (sc1: past the L1; the producers
+        // stored write-through), which is the "sc1 both sides" form of guide G16 -- no fence.
+        const int q4 = tid >> 6, d = tid & 63;
+        for (int hp = 0; hp < group; hp += 4) {
+            const bool act = hp + q4 < group;
+            const int head = hk * group + (act ? hp + q4 : group - 1);
+            attn_combine_head<true, 64>(partial + (size_t)head * nsplit * 130, nlive < nsplit ? nlive : nsplit, d, wgtf[q4], redf[q4],
+                                        out + (size_t)head * HD, act);
+            __syncthreads();                                        // the weights / (M, 1/L) slots are reused by the next four
         }
     }
 }
@@ -400,7 +498,6 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
 // Wave 0 turns the (m_i, l_i) pairs into weights (64 slices per pass, any slice count: running max M over the passes first,
 // then the weights against the final M); then every thread sums its column with independent, coalesced loads (no dependent
 // chain over the slices).  The weights live in LDS in chunks of COMBINE_CHUNK slices, so the context length is unbounded.
-#define COMBINE_CHUNK 256
 __global__ __launch_bounds__(128) void attn_decode_combine_kernel(const float* __restrict__ partial, bf16_t* __restrict__ out,
                                                                   int nsplit_cap, int pos_arg, const int* __restrict__ pos_dev,
                                                                   long partial_bs, long out_bs) {
@@ -413,45 +510,19 @@ __global__ __launch_bounds__(128) void attn_decode_combine_kernel(const float* _
     // clamp to the slices the launch produced -- the host never uses the result of such a step (decoder.generate)
     nsplit = nsplit < nsplit_cap ? nsplit : nsplit_cap;
     const float* src = partial + (size_t)bseq * partial_bs + (size_t)h * nsplit_cap * 130;
-    out += (size_t)bseq * out_bs;
-    if (d < 64) {                                             // wave 0: global max M, then L = sum_i l_i 2^(m_i - M)
-        float M = -1e30f;
-        for (int i0 = 0; i0 < nsplit; i0 += 64) M = fmaxf(M, (i0 + d < nsplit) ? src[(i0 + d) * 130] : -1e30f);
-        M = wave_max(M);
-        float L = 0.f;
-        for (int i0 = 0; i0 < nsplit; i0 += 64)
-            if (i0 + d < nsplit) L += src[(i0 + d) * 130 + 1] * exp2f(src[(i0 + d) * 130] - M);
-        L = wave_sum(L);
-        if (d == 0) { red[0] = M; red[1] = 1.0f / L; }
-    }
-    __syncthreads();
-    const float M = red[0];
-    float o = 0.f;
-    for (int c0 = 0; c0 < nsplit; c0 += COMBINE_CHUNK) {
-        const int nc = nsplit - c0 < COMBINE_CHUNK ? nsplit - c0 : COMBINE_CHUNK;
-        if (c0 > 0) __syncthreads();                          // the previous chunk's weights have been consumed
-        for (int i = d; i < nc; i += 128) wgt[i] = exp2f(src[(c0 + i) * 130] - M);
-        __syncthreads();
-        const float* s0 = src + (size_t)c0 * 130 + 2 + d;
-        int i = 0;
-        for (; i + 8 <= nc; i += 8) {
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = s0[(i + j) * 130];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o += v[j] * wgt[i + j];
-        }
-        for (; i < nc; ++i) o += s0[i * 130] * wgt[i];
-    }
-    out[h * 128 + d] = f2bf(o * red[1]);
+    attn_combine_head<false>(src, nsplit, d, wgt, red, out + (size_t)bseq * out_bs + h * 128, true);
 }
 
 // first index of the maximum of logits[V] (fp32) -> *tok (int32) and hist[step]; one block of 1024 threads.
 // state != null (hipGraph-replayable decode): step = state[1]; afterwards state[0] (position) and state[1] advance by one.
+// zero / nzero: int32 words this launch clears first (the ticket counters of the fused attention launches of the step that follows:
+// a kernel-side clear instead of a memset node, which replayed wrongly from a captured hipGraph for a 32-byte range on ROCm 7.2).
 __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ logits, int V, int* __restrict__ tok,
-                                                      int* __restrict__ hist, int step, int* __restrict__ state) {
+                                                      int* __restrict__ hist, int step, int* __restrict__ state,
+                                                      int* __restrict__ zero, int nzero) {
     __shared__ float bv[16];
     __shared__ int bi[16];
+    for (int i = threadIdx.x; i < nzero; i += 1024) zero[i] = 0;
     float best = -3.4e38f;
     int idx = 0x7fffffff;
     for (int i = threadIdx.x; i < V; i += 1024) {

@@ -269,7 +269,7 @@ __device__ __forceinline__ void gemm_store_patch(const GemmArgs& p0, const float
 // a row's bits do not depend on which epilogue stored it (hash-checked on hardware, scripts/ubench/gemm_lab.hip).
 // acc[mi][nj]: 32-row blocks mi (rows m_w0 + 32 mi + (lane & 31)), 32-column blocks nj (columns n_w0 + 32 nj + ...), NJ even.
 // four v_permlane32_swap on pk[0..7]: (pk[0], pk[2]), (pk[1], pk[3]), (pk[4], pk[6]), (pk[5], pk[7]) as (vdst, src) -- lanes 32-63 of vdst
-// trade places with lanes 0-31 of src.  (tests/emu/hip_emu.h supplies the host-side equivalent for the CPU emulator.)
+// trade places with lanes 0-31 of src.  (The CPU test build defines the macro itself.)
 #ifndef VL2_PERMLANE32_SWAP_8
 #define VL2_PERMLANE32_SWAP_8(pk)                                                                                              \
     asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\t"                                 \

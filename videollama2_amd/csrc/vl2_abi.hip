@@ -688,10 +688,30 @@ extern "C" int32_t vl2_attn_decode(const void* qkv, void* kcache, void* vcache, 
     const int cap = pos_dev ? ctx_cap : pos + 1;                 // positions the launch must be able to cover
     if (cap <= 0 || cap > smax || (!pos_dev && pos < 0)) return fail(VL2_E_SHAPE, "vl2_attn_decode: position %d outside the cache (%d)", cap - 1, smax);
     const int nsplit = (cap + 63) / 64;
-    hipLaunchKernelGGL(attn_decode_kernel, dim3(nsplit, nkv, (group + 3) / 4), dim3(256), 0, ST(stream), (const bf16_t*)qkv, (bf16_t*)kcache,
-                       (bf16_t*)vcache, cos_t, sin_t, partial, nh, group, nkv, smax, pos, pos_dev, scale * 1.4426950408889634f, 0L, 0L, 0L);
+    hipLaunchKernelGGL(attn_decode_kernel<false>, dim3(nsplit, nkv, (group + 3) / 4), dim3(256), 0, ST(stream), (const bf16_t*)qkv, (bf16_t*)kcache,
+                       (bf16_t*)vcache, cos_t, sin_t, partial, nh, group, nkv, smax, pos, pos_dev, scale * 1.4426950408889634f, 0L, 0L, 0L,
+                       (int*)nullptr, (bf16_t*)nullptr);
     hipLaunchKernelGGL(attn_decode_combine_kernel, dim3(nh), dim3(128), 0, ST(stream), partial, (bf16_t*)out, nsplit, pos, pos_dev, 0L, 0L);
     return launched("vl2_attn_decode");
+}
+// attention + combine of ONE decode token in one launch (k_decode.h attn_decode_kernel<true>): `cnt` = nkv int32 ticket counters,
+// zero when the launch starts (vl2_llm_decode_step clears the counters of all layers in its argmax launch).  Same bits as
+// vl2_attn_decode.  Measured 2.4 us per layer SLOWER than the two launches (profiles/r03_experiments.md section 5), so the stage-level
+// decode step takes it only under VL2_DECODE_FUSED_ATTN=1; exported as vl2_attn_decode_fused and kept under test.
+static int32_t attn_decode_fused(const void* qkv, void* kcache, void* vcache, const float* cos_t, const float* sin_t, float* partial, void* out,
+                                 int32_t nh, int32_t nkv, int32_t smax, const int32_t* pos_dev, float scale, int32_t* cnt, void* stream) {
+    const int group = nh / nkv, nsplit = (smax + 63) / 64;
+    hipLaunchKernelGGL(attn_decode_kernel<true>, dim3(nsplit, nkv, (group + 3) / 4), dim3(256), 0, ST(stream), (const bf16_t*)qkv, (bf16_t*)kcache,
+                       (bf16_t*)vcache, cos_t, sin_t, partial, nh, group, nkv, smax, 0, pos_dev, scale * 1.4426950408889634f, 0L, 0L, 0L,
+                       cnt, (bf16_t*)out);
+    return launched("vl2_llm_decode_step (attention)");
+}
+extern "C" int32_t vl2_attn_decode_fused(const void* qkv, void* kcache, void* vcache, const float* cos_t, const float* sin_t, float* partial,
+                                         void* out, int32_t nh, int32_t nkv, int32_t smax, const int32_t* pos_dev, float scale, int32_t* cnt,
+                                         void* stream) {
+    if (!qkv || !kcache || !vcache || !cos_t || !sin_t || !partial || !out || !pos_dev || !cnt || nh <= 0 || nkv <= 0 || smax <= 0 || nh % nkv)
+        return fail(VL2_E_BADARG, "vl2_attn_decode_fused: bad args");
+    return attn_decode_fused(qkv, kcache, vcache, cos_t, sin_t, partial, out, nh, nkv, smax, pos_dev, scale, cnt, stream);
 }
 extern "C" int32_t vl2_attn_decode_batched(const void* qkv, void* kcache, void* vcache, const float* cos_t, const float* sin_t,
                                            float* partial, void* out, int32_t B, int64_t qkv_bs, int64_t cache_bs, int64_t out_bs,
@@ -704,9 +724,9 @@ extern "C" int32_t vl2_attn_decode_batched(const void* qkv, void* kcache, void* 
     if (ctx_cap <= 0 || ctx_cap > smax) return fail(VL2_E_SHAPE, "vl2_attn_decode_batched: ctx_cap %d outside the cache (%d)", ctx_cap, smax);
     const int nsplit = (ctx_cap + 63) / 64;
     const long partial_bs = (long)nh * nsplit * 130;
-    hipLaunchKernelGGL(attn_decode_kernel, dim3(nsplit, nkv * B, (group + 3) / 4), dim3(256), 0, ST(stream), (const bf16_t*)qkv,
+    hipLaunchKernelGGL(attn_decode_kernel<false>, dim3(nsplit, nkv * B, (group + 3) / 4), dim3(256), 0, ST(stream), (const bf16_t*)qkv,
                        (bf16_t*)kcache, (bf16_t*)vcache, cos_t, sin_t, partial, nh, group, nkv, smax, 0, pos_dev,
-                       scale * 1.4426950408889634f, (long)qkv_bs, (long)cache_bs, partial_bs);
+                       scale * 1.4426950408889634f, (long)qkv_bs, (long)cache_bs, partial_bs, (int*)nullptr, (bf16_t*)nullptr);
     hipLaunchKernelGGL(attn_decode_combine_kernel, dim3(nh, B), dim3(128), 0, ST(stream), partial, (bf16_t*)out, nsplit, 0, pos_dev,
                        partial_bs, (long)out_bs);
     return launched("vl2_attn_decode_batched");
@@ -714,8 +734,13 @@ extern "C" int32_t vl2_attn_decode_batched(const void* qkv, void* kcache, void* 
 extern "C" int32_t vl2_argmax(const float* logits, int32_t V, int32_t* tok, int32_t* hist, int32_t step, int32_t* state,
                               void* stream) {
     if (!logits || !tok || V <= 0) return fail(VL2_E_BADARG, "vl2_argmax: bad args");
-    hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(1024), 0, ST(stream), logits, V, tok, hist, step, state);
+    hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(1024), 0, ST(stream), logits, V, tok, hist, step, state, (int*)nullptr, 0);
     return launched("vl2_argmax");
+}
+// the decode step's argmax, which also clears `nzero` int32 words (the fused attention launches' ticket counters)
+static int32_t argmax_and_clear(const float* logits, int32_t V, int32_t* tok, int32_t* hist, int32_t* state, int32_t* zero, int32_t nzero, void* stream) {
+    hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(1024), 0, ST(stream), logits, V, tok, hist, 0, state, (int*)zero, nzero);
+    return launched("vl2_llm_decode_step (argmax)");
 }
 extern "C" int32_t vl2_embed_rows(const int32_t* ids, const void* table, void* out, int32_t n, int32_t D, int32_t ldo, void* stream) {
     if (!ids || !table || !out || n <= 0 || D % 8 || ldo % 8) return fail(VL2_E_BADARG, "vl2_embed_rows: bad args");

@@ -290,7 +290,16 @@ class HipMistralDecoder(nn.Module):
             ops.gemv(self.w["lm_head"], X[offs[b + 1] - 1], norm_w=self.w["norm_w"], eps=self.eps, out_f32=True, out=logits_out[b])
         return lens
 
-    def _ensure_batch(self, B):
+    def _ensure_batch(self, B, owner=None):
+        """Slot buffers (KV caches, positions, tokens, logits) of the batched decode paths.  They are SHARED by `generate_batch`,
+        `model.generate(batch > 1)` and `serving.ContinuousBatcher`; a batcher with requests in flight marks them busy
+        (`_bb_busy` = the batcher) and every other user is refused until it drains, instead of silently overwriting the caches and
+        positions of the requests in flight."""
+        busy = getattr(self, "_bb_busy", None)
+        if busy is not None and busy is not owner and busy.in_flight():
+            raise RuntimeError("the decoder's batch slots are in use by a ContinuousBatcher with requests in flight: drain it "
+                               "(run()) or use a second decoder -- generate_batch / batched generate / another batcher would "
+                               "overwrite their KV caches")
         if getattr(self, "_bb", None) is not None and self._bb["B"] >= B:
             return self._bb
         self._batch_graphs = {}                      # captured graphs point into the buffers replaced below

@@ -57,11 +57,22 @@ class HipCausalLMLoader:
     (`.image_processor`), `.config` (`model_type`, `num_frames`), `.generate(input_ids, images=..., **hf_kwargs)`, `.eval()`,
     `.to()`, `.device`."""
     device, max_seq_len = "cuda", 4096
+    _orig = None          # the reference class this loader replaced (install() sets it): plain-LLM checkpoints are handed back to it
 
     @classmethod
     def from_pretrained(cls, model_path, *args, config=None, **kwargs):
         from . import api
         from .tower import default_image_processor, default_siglip_image_processor
+        # The LoRA / `model_base` / pretrain-projector branches of load_pretrained_model (model/__init__.py:70-156) call
+        # `<Class>.from_pretrained(model_base, ...)` on a PLAIN language-model checkpoint, then touch `model.lm_head`, load
+        # `mm_projector` weights into it and wrap it with PeftModel: that is the reference class's job.  A checkpoint without the
+        # multimodal config keys goes back to the class this loader replaced; `model_init` accelerates the finished model afterwards.
+        import json
+        import os
+        cj = os.path.join(str(model_path), "config.json")
+        hfj = json.load(open(cj)) if os.path.isfile(cj) else {}
+        if cls._orig is not None and not (hfj.get("mm_vision_tower") and hfj.get("mm_projector_type")):
+            return cls._orig.from_pretrained(model_path, *args, config=config, **kwargs)
         for k in ("load_in_4bit", "load_in_8bit", "quantization_config"):          # model/__init__.py:57-69: bitsandbytes loading
             if kwargs.get(k):
                 raise NotImplementedError(f"HIP path: `{k}` (bitsandbytes quantised loading) is not built; load the bf16 checkpoint")
@@ -121,11 +132,13 @@ def install(device="cuda", max_seq_len=4096, patch_factories=True, patch_loader=
         for mod in (proj, arch):
             mod.build_vision_projector = build_vision_projector
     if patch_loader:
-        loader = type("HipCausalLMLoader", (HipCausalLMLoader,), dict(device=device, max_seq_len=max_seq_len))
+        loaders = {}
         for name in ("Videollama2MistralForCausalLM", "Videollama2Qwen2ForCausalLM"):
-            setattr(vm, name, loader)
-        for key in ("videollama2", "videollama2_mistral", "videollama2_qwen2"):
-            vm.VLLMs[key] = loader
+            loaders[name] = type("HipCausalLMLoader", (HipCausalLMLoader,), dict(device=device, max_seq_len=max_seq_len, _orig=getattr(vm, name)))
+            setattr(vm, name, loaders[name])
+        for key, name in (("videollama2", "Videollama2MistralForCausalLM"), ("videollama2_mistral", "Videollama2MistralForCausalLM"),
+                          ("videollama2_qwen2", "Videollama2Qwen2ForCausalLM")):
+            vm.VLLMs[key] = loaders[name]
     orig = videollama2.model_init
 
     def model_init(model_path=None, **kwargs):

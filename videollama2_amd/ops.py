@@ -293,6 +293,15 @@ def attn_decode(qkv, kcache, vcache, cos_t, sin_t, partial, out, nh, nkv, pos, s
     return out
 
 
+def attn_decode_fused(qkv, kcache, vcache, cos_t, sin_t, partial, out, nh, nkv, pos_dev, scale, cnt):
+    """attention + combine of one decode token in ONE launch (vl2_attn_decode_fused): position from device memory, `partial` sized for
+    the whole cache, `cnt` = nkv zeroed int32 ticket counters (re-zero before every call).  Same bits as `attn_decode`."""
+    smax = kcache.shape[-2]
+    _lib.call("vl2_attn_decode_fused", _p(qkv), _p(kcache), _p(vcache), _p(cos_t), _p(sin_t), _p(partial), _p(out), nh, nkv, smax,
+              _p(pos_dev), float(scale), _p(cnt), _stream())
+    return out
+
+
 def attn_decode_batched(qkv, kcache, vcache, cos_t, sin_t, partial, out, nh, nkv, pos_dev, ctx_cap, scale):
     """Batched decode attention: qkv [B, (nh+2nkv)*128], caches [B, nkv, smax, 128], out [B, nh*128], pos_dev int32 [B]."""
     B = qkv.shape[0]

@@ -41,7 +41,7 @@ class ContinuousBatcher:
         self.finished = {}
         self._ids = itertools.count()
         self.steps = 0
-        self.bb = decoder._ensure_batch(self.max_slots)
+        self.bb = decoder._ensure_batch(self.max_slots, owner=self)
 
     # ---- admission
     def submit(self, inputs_embeds, max_new_tokens=2048, streamer=None, stopping_criteria=None):
@@ -77,6 +77,8 @@ class ContinuousBatcher:
     @torch.no_grad()
     def step(self):
         """Admit, run one step, retire.  Returns {request id: new token} for the requests that produced a token."""
+        self.dec._ensure_batch(self.max_slots, owner=self)     # raises if ANOTHER batcher owns the slots with requests in flight
+        self.dec._bb_busy = self                               # from here on generate_batch / a second batcher are refused while we hold requests
         if self.dec._bb is not self.bb:       # a larger generate_batch() on the same decoder reallocated the slot buffers (and caches)
             raise RuntimeError("the decoder's batch buffers were reallocated while requests were in flight: use one batcher per decoder "
                                "and do not call generate_batch() with more sequences than max_slots on it")
