@@ -48,7 +48,8 @@ int64_t vl2_workspace_bytes(void);
 #define VL2_GEMM_SPLITK  4  /* small grids may split K through the workspace (`ws`): trades "a row's bits do not depend on M"
                                for latency on few-tile shapes (per-rank shapes of the frame-sharded encoder); off by default */
 /* kernel variants (vl2_gemm_desc.variant; 0 = per-shape choice): 1 = 128x128x64 two-barrier kernel, 2 = its stream-K form
- * (needs `ws`), 4 = 128x256x64 ping-pong, 8 = 256x256x32 ping-pong (4, 8: N%256==0), 32 = 64x64 small-M kernel,
+ * (needs `ws`), 4 = 128x256x64 ping-pong, 8 = 256x256x32 ping-pong, 12 = the same on 192x256 tiles (4, 8, 12: N%256==0; 12: bf16
+ * output), 32 = 64x64 small-M kernel,
  * 256 = 128x128 8-wave deep-ring one-round kernel.  profiles/r01_gemm_experiments.md. */
 #define VL2_NORM_NONE 0
 #define VL2_NORM_RMS  1     /* HF:modeling_mistral.py MistralRMSNorm in front of q/k/v and gate/up */

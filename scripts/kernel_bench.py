@@ -77,7 +77,7 @@ def main():
     out = {}
     ops.attach_workspace(dev)
     if "--frames" in sys.argv:
-        SHAPES, VARIANTS = shapes_for(int(sys.argv[sys.argv.index("--frames") + 1])), (1, 0, 4, 8, 256)
+        SHAPES, VARIANTS = shapes_for(int(sys.argv[sys.argv.index("--frames") + 1])), (1, 0, 4, 8, 12, 256)
     if "--small" in sys.argv:
         SHAPES, VARIANTS = SMALL, (1, 0, 32, 256)   # 0 = auto, 1 = 128x128, 32 = 64x64 small-M kernel, 's' = 128x128 + split-K
     rounds = 2 if "--quick" in sys.argv else 3
@@ -90,7 +90,7 @@ def main():
         best = {}
         for r in range(rounds):
             for v in VARIANTS:
-                if v in (4, 8) and N % 256:
+                if v in (4, 8, 12) and N % 256:
                     continue
                 ops.set_gemm_variant(1 if v == 's' else v)
                 ops.set_splitk(v == 's')

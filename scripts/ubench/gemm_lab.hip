@@ -38,6 +38,14 @@ static void launch(int variant, GemmArgs a, hipStream_t s) {
         lds_attr(gemm4_bf16_kernel<ACT, SW, false, true>, GEMM4_LDS_BYTES);
         a.tiles_m = (a.M + 255) / 256; a.tiles_n = a.N / 256;
         hipLaunchKernelGGL((gemm4_bf16_kernel<ACT, SW, false, true>), dim3(a.tiles_m * a.tiles_n), dim3(512), GEMM4_LDS_BYTES, s, a);
+    } else if (variant == 16) {                         // gemm4 on 192 x 256 tiles, LDS epilogue
+        lds_attr(gemm4_bf16_kernel<ACT, SW, false, false, -1, 192>, GEMM4_LDS_BYTES);
+        a.tiles_m = (a.M + 191) / 192; a.tiles_n = a.N / 256;
+        hipLaunchKernelGGL((gemm4_bf16_kernel<ACT, SW, false, false, -1, 192>), dim3(a.tiles_m * a.tiles_n), dim3(512), GEMM4_LDS_BYTES, s, a);
+    } else if (variant == 17) {                         // ... with the register-resident (C^T) epilogue
+        lds_attr(gemm4_bf16_kernel<ACT, SW, false, true, -1, 192>, GEMM4_LDS_BYTES);
+        a.tiles_m = (a.M + 191) / 192; a.tiles_n = a.N / 256;
+        hipLaunchKernelGGL((gemm4_bf16_kernel<ACT, SW, false, true, -1, 192>), dim3(a.tiles_m * a.tiles_n), dim3(512), GEMM4_LDS_BYTES, s, a);
     } else if (variant == 10) {                         // ... with the epilogue flags compiled in (EF)
         a.tiles_m = (a.M + 255) / 256; a.tiles_n = a.N / 256;
         const int ef = (a.bias ? EF_BIAS : 0) | (a.res ? EF_RES : 0);
@@ -96,7 +104,7 @@ int main(int argc, char** argv) {
         {"llm_gateup", 1621, 28672, 4096, true, false, false, 0},
         {"llm_down", 1621, 4096, 14336, false, false, true, 0},
     };
-    std::vector<int> variants = {8, 4, 22, 14, 41};
+    std::vector<int> variants = {8, 4, 16, 17};
     if (argc > 2) {                                     // e.g. "8,4": only these variants (v8 is the bit reference, keep it first)
         variants.clear();
         for (char* tok = strtok(argv[2], ","); tok; tok = strtok(nullptr, ",")) variants.push_back(atoi(tok));
@@ -127,7 +135,7 @@ int main(int argc, char** argv) {
         for (int r = 0; r < rounds; ++r)
             for (size_t vi = 0; vi < variants.size(); ++vi) {
                 const int v = variants[vi];
-                if ((v == 14 && sh.N % 512) || ((v == 8 || v == 9 || v == 10) && sh.N % 256) || ((v == 4 || v == 5) && sh.N % 256) || (v == 22 && sh.N % 256)) continue;
+                if ((v == 14 && sh.N % 512) || ((v == 8 || v == 9 || v == 10 || v == 16 || v == 17) && sh.N % 256) || ((v == 4 || v == 5) && sh.N % 256) || (v == 22 && sh.N % 256)) continue;
                 if (r == 0) {
                     CK(hipMemsetAsync(dC, 0xff, nc * 2, s));
                     go(v, a);

@@ -49,6 +49,14 @@ static void run_gemm(GemmArgs a) {
             return;
         }
     }
+    if constexpr (!G && !F32) {
+        if (g_gemm_variant == 12 && a.N % 256 == 0) {            // gemm4 on 192 x 256 tiles
+            a.tiles_m = (a.M + 191) / 192; a.tiles_n = a.N / 256;
+            if (a.res == nullptr) { emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(512), [=] { gemm4_bf16_kernel<ACT, SW, false, true, -1, 192>(a); }); return; }
+            emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(512), [=] { gemm4_bf16_kernel<ACT, SW, false, false, -1, 192>(a); });
+            return;
+        }
+    }
     if constexpr (!G) {
         if (g_gemm_variant == 2) {                              // stream-K: a small persistent grid so every path is exercised
             static std::vector<float> ws;

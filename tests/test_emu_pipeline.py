@@ -80,7 +80,7 @@ def test_emu_norm_carrying_gemms(emu):
     y2 = ops.gemm(x2, wl, bias=tl, norm=(ops.NORM_LN, st2, eps, sl))
     assert rel(y2, ref2) < TOL_BF16_OUT
     try:
-        for v in (1, 4, 8, 32, 256):
+        for v in (1, 4, 8, 12, 32, 256):
             ops.set_gemm_variant(v)
             stv = torch.zeros_like(st)
             assert torch.equal(ops.gemm(a, w, bias=bias, res=res, stats_out=stv), x) and torch.equal(stv, st), v

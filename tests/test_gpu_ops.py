@@ -43,17 +43,22 @@ def test_gemm_bias_act_res(ops, act):
 
 @pytest.mark.parametrize("M,N,K", [(300, 512, 448), (9232, 4096, 1024), (1621, 28672, 4096)])
 def test_gemm_pingpong_variant_is_bit_identical(ops, M, N, K):
-    """The ping-pong kernels (128x256: knob 4, 256x256: knob 8) accumulate in the same order as the 128x128 kernel:
+    """The ping-pong kernels (128x256: knob 4, 256x256: knob 8, 192x256: knob 12) accumulate in the same order as the 128x128 kernel:
     results must be bit-identical (also screens the counted-vmcnt / phase-barrier schedules for races)."""
     a, w, bias, res = bf(M, K), bf(N, K, scale=K ** -0.5), torch.randn(N), bf(M, N)
     ad, wd, bd, rd = a.to(DEV), w.to(DEV), bias.to(DEV), res.to(DEV)
     try:
         ops.set_gemm_variant(1)
         ref = ops.gemm(ad, wd, bias=bd, res=rd, act=ops.ACT_QGELU)
-        for v in (4, 8, 0):
+        for v in (4, 8, 12, 0):
             ops.set_gemm_variant(v)
             for _ in range(3):
                 assert torch.equal(ops.gemm(ad, wd, bias=bd, res=rd, act=ops.ACT_QGELU), ref)
+        ops.set_gemm_variant(1)
+        ref = ops.gemm(ad, wd, bias=bd, act=ops.ACT_QGELU)           # no residual: the register-resident C^T epilogue of 4 / 8 / 12
+        for v in (4, 8, 12, 0):
+            ops.set_gemm_variant(v)
+            assert torch.equal(ops.gemm(ad, wd, bias=bd, act=ops.ACT_QGELU), ref)
     finally:
         ops.set_gemm_variant(0)
 
@@ -600,7 +605,7 @@ def test_gemm_norm_carrying_chain_full_width(ops, M, N, K, kind, swiglu):
     y = run()
     assert rel(y, ref) < TOL_BF16_OUT
     try:
-        for v in (1, 4, 8):
+        for v in (1, 4, 8, 12):
             ops.set_gemm_variant(v)
             assert torch.equal(run(), y), f"variant {v}"
     finally:

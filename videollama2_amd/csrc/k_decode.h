@@ -270,6 +270,7 @@ __global__ __launch_bounds__(256) void gemv_mr_bf16_kernel(GemvArgs p) {
 
 // ---- the combine of the flash-decoding partials (shared by attn_decode_combine_kernel and the fused form of attn_decode_kernel)
 #define COMBINE_CHUNK 256
+#define COMBINE_EARLY 32
 // One head's combine, 128 threads (d = 0..127 = the output dimension; the threads with d < 64 are one wave and turn the (m_i, l_i)
 // pairs into weights).  ACQ = the partials were written by OTHER workgroups of the same launch (attn_decode_kernel<true>): they are
 // read with agent-scope relaxed atomic loads (global_load ... sc1: bypass this CU's vector L1, the producer stored write-through).
@@ -289,6 +290,18 @@ __device__ __forceinline__ void attn_combine_head(const float* __restrict__ src,
     // is otherwise free to contract or re-associate them differently (seen on hardware: one bf16 output element in 4096 off by an
     // ulp) -> the sums are explicit FMAs in a fixed order
 #pragma clang fp reassociate(off)
+    // short contexts (<= COMBINE_EARLY slices = 2048 positions, TPH = 128): the column's values do not depend on the weights, so they are
+    // requested BEFORE the (m, l) passes -- the whole combine is one memory round trip instead of ~four dependent ones (4.7 -> ~2.7 us
+    // per layer and token).  The FMAs below run in the same order on the same values: same bits.
+    constexpr bool EARLY = TPH == 128;
+    float ev[EARLY ? COMBINE_EARLY : 1];
+    const bool early = EARLY && nsplit <= COMBINE_EARLY;
+    if constexpr (EARLY) {
+        if (early) {
+#pragma unroll
+            for (int i = 0; i < COMBINE_EARLY; ++i) ev[i] = i < nsplit ? attn_ld<ACQ>(src + i * 130 + 2 + d) : 0.f;
+        }
+    }
     if (d < 64) {                                             // one wave: global max M, then L = sum_i l_i 2^(m_i - M)
         float M = -1e30f;
         for (int i0 = 0; i0 < nsplit; i0 += 64) M = fmaxf(M, (i0 + d < nsplit) ? attn_ld<ACQ>(src + (i0 + d) * 130) : -1e30f);
@@ -309,6 +322,14 @@ __device__ __forceinline__ void attn_combine_head(const float* __restrict__ src,
         if (c0 > 0) __syncthreads();                          // the previous chunk's weights have been consumed
         for (int i = d; i < nc; i += TPH) wgt[i] = exp2f(attn_ld<ACQ>(src + (c0 + i) * 130) - M);
         __syncthreads();
+        if constexpr (EARLY) {
+            if (early) {                                      // nc == nsplit, c0 == 0
+#pragma unroll
+                for (int i = 0; i < COMBINE_EARLY; ++i)
+                    if (i < nc) o[0] = __builtin_fmaf(ev[i], wgt[i], o[0]);
+                break;
+            }
+        }
 #pragma unroll
         for (int c = 0; c < 128 / TPH; ++c) {
             const float* s0 = src + (size_t)c0 * 130 + 2 + d + c * TPH;

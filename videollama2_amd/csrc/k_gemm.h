@@ -843,64 +843,90 @@ __device__ __forceinline__ int gemm4_lds_off(int row, int chunk) {
 // bid / nwg: this workgroup's index and the workgroup count of the tile set it belongs to (the whole grid for
 // gemm4_bf16_kernel; the big-tile part of gemm_mix_bf16_kernel)
 // TR: accumulate C^T (MFMA operands swapped) and store through gemm_store_tr (no LDS in the epilogue); bf16 output only
-template <int ACT, bool SWIGLU, bool OUT_F32, bool TR = false, int EF = -1>
+// BM = 256: group g owns rows [128g, +128), its four waves 2 x 2 (wave tile 64 x 128).
+// BM = 192: the same kernel on a 192 x 256 tile for GEMMs that leave a 256-row grid well short of one round (ViT out_proj / fc2 at
+//   16 frames: 37 x 4 = 148 tiles of 256 rows on 256 CUs, 49 x 4 = 196 tiles of 192 rows): group g owns rows [96g, +96), its four
+//   waves side by side (wave tile 96 x 64 = 3 x 2 accumulators, 5 fragment reads per 6 MFMAs), the A slab is 12 LDS-DMA pieces
+//   (waves 0, 1 of a group issue two, waves 2, 3 one: counted vmcnt per wave).  Same slabs, same k order -> same bits per element.
+template <int ACT, bool SWIGLU, bool OUT_F32, bool TR = false, int EF = -1, int BM = 256>
 __device__ __forceinline__ void gemm4_body(const GemmArgs& p, int bid, int nwg) {
     static_assert(!(TR && OUT_F32), "gemm_store_tr writes bf16");
+    static_assert(BM == 256 || BM == 192, "gemm4: 256- or 192-row tiles");
+    constexpr int GR = BM / 2;                                     // rows of a wave group
+    constexpr int MI = BM == 256 ? 2 : 3, NJ = BM == 256 ? 4 : 2;  // 32 x 32 accumulator blocks of a wave
     extern __shared__ __attribute__((aligned(16))) unsigned char vl2_smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2, w4 = wave & 3;
-    const int wm = w4 >> 1, wn = w4 & 1;
+    const int wrow = BM == 256 ? grp * 128 + (w4 >> 1) * 64 : grp * 96;     // first row / column of the wave tile inside the block tile
+    const int wcol = BM == 256 ? (w4 & 1) * 128 : w4 * 64;
 
     const int t0 = xcd_remap(bid, nwg);
     const int grp_sz = 4 * p.tiles_n;                              // 4 tile-rows (1024 rows of A) per raster group
     const int first_m = (t0 / grp_sz) * 4;
     const int gm = (p.tiles_m - first_m) < 4 ? (p.tiles_m - first_m) : 4;
     const int tm = first_m + (t0 % grp_sz) % gm, tn = (t0 % grp_sz) / gm;
-    const int m0 = tm * GEMM4_BM, n0 = tn * GEMM4_BN;
-    f32x2 rst = {0.f, 1.f}, rowst[2] = {{0.f, 1.f}, {0.f, 1.f}};
-    if constexpr (!TR) rst = gemm_row_stats(p, m0, tid, GEMM4_BM);
-    else gemm_tr_row_stats<2>(p, m0 + grp * 128 + wm * 64, lane, rowst);
+    const int m0 = tm * BM, n0 = tn * GEMM4_BN;
+    f32x2 rst = {0.f, 1.f}, rowst[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) rowst[i] = f32x2{0.f, 1.f};
+    if constexpr (!TR) rst = gemm_row_stats(p, m0, tid, BM);
+    else gemm_tr_row_stats<MI>(p, m0 + wrow, lane, rowst);
 
-    // this wave's LDS-DMA parts of a slab: 2 x A rows [128*grp, +128) and 2 x W rows [128*grp, +128), issue-lean form:
-    // `buffer_load_dwordx4 ... offen lds` with loop-invariant VGPR byte offsets, K position in the SGPR soffset
+    // this wave's LDS-DMA parts of a slab: its share of the group's A rows [GR*grp, +GR) and 2 x W rows [128*grp, +128), issue-lean
+    // form: `buffer_load_dwordx4 ... offen lds` with loop-invariant VGPR byte offsets, K position in the SGPR soffset
     const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x7fffffff, 0x00020000);
     const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0x7fffffff, 0x00020000);
+    constexpr int APG = GR / 16;                                   // A pieces (16 rows each) of a group: 8 or 6
+    const bool two_a = BM == 256 || w4 < 2;                        // this wave's second A piece exists (wave-uniform)
     unsigned a_vo[2], w_vo[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int slot = grp * 512 + ((i * 4 + w4) << 6) + lane;
-        const int R = slot >> 4, sp = slot & 15;
-        const int row = 4 * R + (sp >> 2), chk = (sp & 3) ^ (R & 3);
-        int am = m0 + row;
+        const int aslot = ((grp * APG + i * 4 + w4) << 6) + lane, wslot = grp * 512 + ((i * 4 + w4) << 6) + lane;
+        const int Ra = aslot >> 4, spa = aslot & 15, Rw = wslot >> 4, spw = wslot & 15;
+        const int rowa = 4 * Ra + (spa >> 2), chka = (spa & 3) ^ (Ra & 3);
+        const int roww = 4 * Rw + (spw >> 2), chkw = (spw & 3) ^ (Rw & 3);
+        int am = m0 + rowa;
         am = am < p.M ? am : p.M - 1;
-        a_vo[i] = ((unsigned)am * (unsigned)p.lda + chk * 8) * 2;
-        w_vo[i] = ((unsigned)(n0 + row) * (unsigned)p.ldw + chk * 8) * 2;
+#ifdef VL2_LAB_ALIAS_LOADS                  // scripts/ubench/gemm_lab.hip ablation only: every tile loads from the first 512 A rows / 1024 W rows (L2-resident operands)
+        a_vo[i] = ((unsigned)(am % 512) * (unsigned)p.lda + chka * 8) * 2;
+        w_vo[i] = ((unsigned)((n0 + roww) % 1024) * (unsigned)p.ldw + chkw * 8) * 2;
+#else
+        a_vo[i] = ((unsigned)am * (unsigned)p.lda + chka * 8) * 2;
+        w_vo[i] = ((unsigned)(n0 + roww) * (unsigned)p.ldw + chkw * 8) * 2;
+#endif
     }
     auto issue_dma = [&](int t) {
         const unsigned st = (unsigned)(t & 3) * GEMM4_STAGE, kb = (unsigned)t * (GEMM4_BK * 2);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(vl2_smem + st + ((grp * 8 + i * 4 + w4) << 10)),
-                                                     16, a_vo[i], kb, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(vl2_smem + st + ((grp * APG + w4) << 10)),
+                                                 16, a_vo[0], kb, 0, 0);
+        if (two_a)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(vl2_smem + st + ((grp * APG + 4 + w4) << 10)),
+                                                     16, a_vo[1], kb, 0, 0);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(vl2_smem + st + 16384 + ((grp * 8 + i * 4 + w4) << 10)),
                                                      16, w_vo[i], kb, 0, 0);
     };
+    // counted waits: `slabs` newer slabs of this wave's LDS-DMA stay in flight (4 or 3 pieces per slab)
+    auto wait_dma = [&](int slabs) {
+        if (slabs >= 2) { if (two_a) VL2_WAIT_VMCNT(8); else VL2_WAIT_VMCNT(6); }
+        else if (slabs == 1) { if (two_a) VL2_WAIT_VMCNT(4); else VL2_WAIT_VMCNT(3); }
+        else VL2_WAIT_VMCNT(0);
+    };
 
-    f32x16 acc[2][4];
+    f32x16 acc[MI][NJ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    bf16x8 fa[2][2], fb[2][4];                     // [ks][tile]
+    bf16x8 fa[2][MI], fb[2][NJ];                   // [ks][tile]
 
     const int nt = p.K / GEMM4_BK;
     const int frow = lane & 31, fchk = lane >> 5;
-    const int arow = grp * 128 + wm * 64 + frow, brow = wn * 128 + frow;
+    const int arow = wrow + frow, brow = wcol + frow;
     unsigned a_rd[2], b_rd[2];                     // fragment read bases per k-step; tile i / j is +2048 B (32 rows)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -910,7 +936,7 @@ __device__ __forceinline__ void gemm4_body(const GemmArgs& p, int bid, int nwg) 
     issue_dma(0);
     if (nt > 1) issue_dma(1);
     if (nt > 2) issue_dma(2);
-    if (nt > 2) VL2_WAIT_VMCNT(8); else if (nt > 1) VL2_WAIT_VMCNT(4); else VL2_WAIT_VMCNT(0);
+    wait_dma(nt > 2 ? 2 : nt > 1 ? 1 : 0);
     VL2_PHASE_BARRIER();
 
     if (grp == 1) VL2_PHASE_BARRIER();
@@ -922,22 +948,21 @@ __device__ __forceinline__ void gemm4_body(const GemmArgs& p, int bid, int nwg) 
         for (int ks = 0; ks < 2; ++ks) {
             const unsigned ab = a_rd[ks] + st, bb = b_rd[ks] + st;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) fa[ks][i] = *(const bf16x8*)(vl2_smem + ab + i * 2048);
+            for (int i = 0; i < MI; ++i) fa[ks][i] = *(const bf16x8*)(vl2_smem + ab + i * 2048);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) fb[ks][j] = *(const bf16x8*)(vl2_smem + bb + j * 2048);
+            for (int j = 0; j < NJ; ++j) fb[ks][j] = *(const bf16x8*)(vl2_smem + bb + j * 2048);
         }
         // slab t+1 must have landed before the barrier below; the (up to) two newer slabs stay in flight
-        const int newer = nt - 2 - t;              // slabs issued after t+1
-        if (newer >= 2) VL2_WAIT_VMCNT(8); else if (newer == 1) VL2_WAIT_VMCNT(4); else VL2_WAIT_VMCNT(0);
+        wait_dma(nt - 2 - t);                      // slabs issued after t+1
         VL2_WAIT_LGKMCNT0();
         VL2_PHASE_BARRIER();
         // ---------------- MFMA(t): matrix work only
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < NJ; ++j)
                     acc[i][j] = TR ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks][j], fa[ks][i], acc[i][j], 0, 0, 0)
                                    : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
         VL2_PHASE_BARRIER();
@@ -945,25 +970,25 @@ __device__ __forceinline__ void gemm4_body(const GemmArgs& p, int bid, int nwg) 
     if (grp == 0) VL2_PHASE_BARRIER();
 
     if constexpr (TR) {       // ---- register-resident epilogue: the accumulators hold C^T, rows are lane-local
-        gemm_store_tr<ACT, SWIGLU, 2, 4, EF>(p, acc, m0 + grp * 128 + wm * 64, n0 + wn * 128, lane, rowst);
+        gemm_store_tr<ACT, SWIGLU, MI, NJ, EF>(p, acc, m0 + wrow, n0 + wcol, lane, rowst);
         return;
     }
-    // ---- epilogue: four 32 x 64 patches per wave (2 row blocks x 2 column halves)
+    // ---- epilogue: 32 x 64 patches (BM = 256: 2 row blocks x 2 column halves per wave; BM = 192: 3 row blocks)
 #ifdef VL2_LAB_NO_EPILOGUE          // scripts/ubench/gemm_lab.hip ablation only: main loop without the store path (accumulators kept alive)
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(acc[mi][j]));
+        for (int j = 0; j < NJ; ++j) asm volatile("" :: "v"(acc[mi][j]));
     return;
 #endif
     float* ep = (float*)vl2_smem + wave * (32 * 68);
     float* rowtab = (float*)vl2_smem + 8 * (32 * 68);
-    gemm_park_row_stats(p, rowtab, rst, tid, GEMM4_BM);
+    gemm_park_row_stats(p, rowtab, rst, tid, BM);
     __syncthreads();                       // row table visible; the passes below are wave-private (see gemm_bf16_kernel)
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int nh = 0; nh < 2; ++nh) {
+        for (int nh = 0; nh < NJ / 2; ++nh) {
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
@@ -972,13 +997,13 @@ __device__ __forceinline__ void gemm4_body(const GemmArgs& p, int bid, int nwg) 
                     ep[row * 68 + ni * 32 + (lane & 31)] = acc[mi][nh * 2 + ni][r];
                 }
             __builtin_amdgcn_wave_barrier();
-            gemm_store_patch<ACT, SWIGLU, OUT_F32>(p, ep, m0 + grp * 128 + wm * 64 + mi * 32, n0 + wn * 128 + nh * 64, lane, rowtab, grp * 128 + wm * 64 + mi * 32);
+            gemm_store_patch<ACT, SWIGLU, OUT_F32>(p, ep, m0 + wrow + mi * 32, n0 + wcol + nh * 64, lane, rowtab, wrow + mi * 32);
             __builtin_amdgcn_wave_barrier();
         }
 }
-template <int ACT, bool SWIGLU, bool OUT_F32, bool TR = false, int EF = -1>
+template <int ACT, bool SWIGLU, bool OUT_F32, bool TR = false, int EF = -1, int BM = 256>
 __global__ __launch_bounds__(512, 2) void gemm4_bf16_kernel(GemmArgs p) {
-    gemm4_body<ACT, SWIGLU, OUT_F32, TR, EF>(p, blockIdx.x, gridDim.x);
+    gemm4_body<ACT, SWIGLU, OUT_F32, TR, EF, BM>(p, blockIdx.x, gridDim.x);
 }
 
 // ------------------------------------------------------------------------------------------------------------------

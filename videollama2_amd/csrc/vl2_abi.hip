@@ -81,7 +81,7 @@ static bool want_stream_k(const GemmArgs& a, const GemmCtl& c) { return c.ws && 
 // M edge x the kernel's measured rate on well-quantised shapes (128x128 two-barrier kernel 1.0, 128x256 ping-pong 1.07,
 // 256x256 ping-pong 1.2: profiles/r01_gemm_experiments.md).  Fitted to the measured shapes of the T=16 workload: the LLM
 // o/gate-up/down projections and the STC 4096x4096 convs take 128x256, ViT qkv/wo/fc2 and the LLM qkv take 256x256,
-// short-K GEMMs (STC b1) stay on 128x128.  Returns 1, 4 (gemm3) or 8 (gemm4).
+// short-K GEMMs (STC b1) stay on 128x128.  Returns 1, 4 (gemm3), 8 (gemm4) or 12 (gemm4 on 192-row tiles).
 static int choose_gemm_kernel(const GemmArgs& a) {
     if (a.N % 256) return 1;
     // at most one 128x128 tile per CU: a bigger tile only halves the CUs in use and doubles the latency of the single round
@@ -96,6 +96,14 @@ static int choose_gemm_kernel(const GemmArgs& a) {
     double eb = 1.03 * e1;
     if (a.K >= 2048 && e3 > eb) { best = 4; eb = e3; }
     if (a.K >= 512 && e4 > eb) { best = 8; eb = e4; }
+    // the 256x256 kernel on 192-row tiles (variant 12): the same rate per FLOP over whole rounds (sq 4096^3: 85 us per round of 192-row
+    // tiles against 117), a little less in practice (fc1 at 3.06 rounds 105.9 us vs 95.4 on 256 rows) -> 1.13.  Takes the shapes whose
+    // 256-row grid leaves a round badly filled: ViT out_proj / fc2 at 16 frames (148 -> 196 tiles: 30.7 -> 28.9 us, 84.6 -> 81.3), the
+    // LLM q/k/v at S = 1621 (168 -> 216 tiles: 84.0 -> 81.2), the STC K = 1024 conv (576 = 2.25 rounds -> 768 = 3.0: 87.6 -> 82.2).
+    // scripts/ubench/gemm_lab.hip (bit-identical, hash-checked) and scripts/kernel_bench.py, profiles/r03_gemm_lab_t192.txt
+    const double m192 = (double)a.M / (((a.M + 191) / 192) * 192.0);
+    const double e5 = fill((double)((a.M + 191) / 192) * (a.N / 256) / 256.0) * m192 * 1.13;
+    if (a.K >= 512 && e5 > eb * 1.02) { best = 12; eb = e5; }
     return best;
 }
 
@@ -135,20 +143,20 @@ static bool want_small_m(const GemmArgs& a, const GemmCtl& c) {
 // produce the same bits (hash-checked per shape), so the choice is invisible to every caller.
 static bool want_tr_epilogue(const GemmArgs& a) { return a.res == nullptr; }
 
-template <int ACT, bool SW, bool F32>
+template <int ACT, bool SW, bool F32, int BM = GEMM4_BM>
 static void launch_gemm4(const GemmArgs& a0, hipStream_t s) {
     GemmArgs a = a0;
-    a.tiles_m = (a.M + GEMM4_BM - 1) / GEMM4_BM;
+    a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = a.N / GEMM4_BN;
     if constexpr (!F32) {
         if (want_tr_epilogue(a)) {
-            lds_attr<gemm4_bf16_kernel<ACT, SW, false, true>>(GEMM4_LDS_BYTES);
-            hipLaunchKernelGGL((gemm4_bf16_kernel<ACT, SW, false, true>), dim3(a.tiles_m * a.tiles_n), dim3(512), GEMM4_LDS_BYTES, s, a);
+            lds_attr<gemm4_bf16_kernel<ACT, SW, false, true, -1, BM>>(GEMM4_LDS_BYTES);
+            hipLaunchKernelGGL((gemm4_bf16_kernel<ACT, SW, false, true, -1, BM>), dim3(a.tiles_m * a.tiles_n), dim3(512), GEMM4_LDS_BYTES, s, a);
             return;
         }
     }
-    lds_attr<gemm4_bf16_kernel<ACT, SW, F32>>(GEMM4_LDS_BYTES);
-    hipLaunchKernelGGL((gemm4_bf16_kernel<ACT, SW, F32>), dim3(a.tiles_m * a.tiles_n), dim3(512), GEMM4_LDS_BYTES, s, a);
+    lds_attr<gemm4_bf16_kernel<ACT, SW, F32, false, -1, BM>>(GEMM4_LDS_BYTES);
+    hipLaunchKernelGGL((gemm4_bf16_kernel<ACT, SW, F32, false, -1, BM>), dim3(a.tiles_m * a.tiles_n), dim3(512), GEMM4_LDS_BYTES, s, a);
 }
 
 // Row split (returns the number of leading rows that go to the 256x256 kernel, 0 = no split).  Two cases, both two launches on the
@@ -246,6 +254,12 @@ static void launch_gemm(const GemmArgs& a0, const GemmCtl& c, hipStream_t s) {
             launch_gemm4<ACT, SW, F32>(a0, s);
             return;
         }
+        if constexpr (!F32) {
+            if (kern == 12 && a0.N % GEMM4_BN == 0) {
+                launch_gemm4<ACT, SW, false, 192>(a0, s);
+                return;
+            }
+        }
     }
     if constexpr (!G) {
         if (want_stream_k(a0, c)) {
@@ -315,7 +329,7 @@ extern "C" int32_t vl2_gemm(const vl2_gemm_desc* d, void* stream) {
     if (d->stats_out && (sw || f32)) return fail(VL2_E_UNSUPP, "vl2_gemm: stats_out needs a plain bf16 output");
     if (d->ws && (d->ws_bytes < SK_WS_BYTES || !ALIGNED16(d->ws))) return fail(VL2_E_BADARG, "vl2_gemm: workspace needs >= %lld bytes, 16-byte aligned", (long long)SK_WS_BYTES);
     const int v = d->variant;
-    if (!(v == 0 || v == 1 || v == 2 || v == 4 || v == 8 || v == 32 || v == 256)) return fail(VL2_E_BADARG, "vl2_gemm: unknown variant %d", v);
+    if (!(v == 0 || v == 1 || v == 2 || v == 4 || v == 8 || v == 12 || v == 32 || v == 256)) return fail(VL2_E_BADARG, "vl2_gemm: unknown variant %d", v);
     const GemmCtl ctl{d->ws, d->ws_bytes, v, (d->flags & VL2_GEMM_SPLITK) != 0};
     GemmArgs a{};
     a.A = (const bf16_t*)d->A; a.W = (const bf16_t*)d->W; a.C = d->C; a.bias = d->bias; a.res = (const bf16_t*)d->res;
