@@ -156,6 +156,7 @@ def main():
     ap.add_argument("--new-tokens", type=int, default=32)
     ap.add_argument("--llm-layers", type=int, default=None, help="debug only: fewer decoder layers (INVALID as a result)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-vit-only", action="store_true", help="skip the extra tower-only passes behind the `vit_only` key (profiling runs)")
     ap.add_argument("--u8-frames", action="store_true", help="(default since round 3; kept for old command lines) raw uint8 [T,S,S,3] frames")
     ap.add_argument("--bf16-frames", action="store_true",
                     help="feed randn bf16 [T,3,S,S] frames (rounds 1-2) instead of SURVEY 8d's recipe: np.random.default_rng(0) uint8 "
@@ -328,7 +329,8 @@ def main():
     enc_iters = max(args.steps, 3)
     parts = model.sharder.split(T, world)
     s0, c0 = parts[rank]
-    vit_ms = timed(lambda: model.vision_tower(frames[s0:s0 + c0]) if c0 > 0 else None, enc_iters)
+    # (--no-vit-only: a rocprofv3 trace of this command then holds whole steps only; the world == 1 line does not need the figure)
+    vit_ms = None if args.no_vit_only else timed(lambda: model.vision_tower(frames[s0:s0 + c0]) if c0 > 0 else None, enc_iters)
     cuts = {}
     if world > 1:
         keep = model.sharder.cut
@@ -497,7 +499,7 @@ def main():
             "decode_hbm_frac": round(decode_bytes_per_token(cfg, S + n_new // 2) / (dec_ms / n_new / 1e3) / 1e9 / PEAK_HBM_GBS, 4),
             "roofline": roof,
             "frames_input": "bf16 randn [T,3,S,S]" if args.bf16_frames else "uint8 [T,S,S,3] (np.random.default_rng(0)), normalised on the GPU in the patch-row kernel",
-            "vit_only": {"ms": round(vit_ms, 3), "frames_per_s": round(T / (vit_ms / 1e3), 1),
+            "vit_only": None if vit_ms is None else {"ms": round(vit_ms, 3), "frames_per_s": round(T / (vit_ms / 1e3), 1),
                          "what": f"CLIP tower alone on the rank's {c0} of {T} frames (no collective, no connector), max over ranks"},
         }
         if world > 1:
