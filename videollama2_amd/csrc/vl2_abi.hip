@@ -250,7 +250,7 @@ static void launch_gemm(const GemmArgs& a0, const GemmCtl& c, hipStream_t s) {
             hipLaunchKernelGGL((gemm3_bf16_kernel<ACT, SW, F32>), dim3(a.tiles_m * a.tiles_n), dim3(512), GEMM3_LDS_BYTES, s, a);
             return;
         }
-        if (kern == 8 && a0.N % GEMM4_BN == 0) {
+        if ((kern == 8 || (F32 && kern == 12)) && a0.N % GEMM4_BN == 0) {     // (the 192-row form is built for bf16 outputs only)
             launch_gemm4<ACT, SW, F32>(a0, s);
             return;
         }
