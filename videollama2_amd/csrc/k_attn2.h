@@ -47,7 +47,10 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, unsigned ch
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_dst, 16, voff, 0, 0, 0);
 }
 
-template <int D, bool CAUSAL>
+// ONES: the softmax denominators come off the matrix pipe -- one more MFMA per P fragment with an all-ones A operand accumulates
+// sum_k P[q][k] (of the bf16-rounded P the numerator uses) in every row of a 32 x 32 block; the 32 adds per lane and tile and the
+// cross-half shuffle go away.  Lab variant 4 of vl2_attn_fwd (scripts/attn_bench2.py); see profiles/r03_experiments.md section 5b.
+template <int D, bool CAUSAL, bool ONES = false>
 __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(AttnArgs p) {
     static_assert(D == 64 || D == 128, "attn2: head_dim 64 or 128");
     constexpr int NKS = D / 16;                // k-steps of the QK^T MFMA chain
@@ -134,6 +137,10 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(AttnArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) oT[i][r] = 0.f;
     float m = -1e30f, l = 0.f;      // m: running max in the exp2 domain (first tile always rescales: mt - m is huge)
+    f32x16 oL;                      // ONES: every register of the lane = l of its query row
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oL[r] = 0.f;
+    const bf16x8 ones8 = __builtin_bit_cast(bf16x8, u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u});
 
     auto compute_tile = [&](int t, unsigned so) {
         const int kv0 = t * 64;
@@ -178,6 +185,10 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(AttnArgs p) {
             for (int i = 0; i < NDB; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) oT[i][r] *= alpha;
+            if constexpr (ONES) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oL[r] *= alpha;
+            }
         }
         float rs = 0.f;
 #pragma unroll
@@ -186,9 +197,9 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(AttnArgs p) {
             for (int r = 0; r < 16; ++r) {
                 const float pv = __builtin_amdgcn_exp2f(fmaf(sT[kh][r], c, -m));
                 sT[kh][r] = pv;
-                rs += pv;
+                if constexpr (!ONES) rs += pv;
             }
-        l += rs + __shfl_xor(rs, 32);
+        if constexpr (!ONES) l += rs + __shfl_xor(rs, 32);
 
         // O^T += V^T . P^T: P fragment = the score registers; V^T fragment = two transpose reads (keys kb..kb+3, kb+8..kb+11)
 #pragma unroll
@@ -199,6 +210,7 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(AttnArgs p) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) pw[j] = pack2bf(sT[kh][ks2 * 8 + 2 * j], sT[kh][ks2 * 8 + 2 * j + 1]);
                 const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
+                if constexpr (ONES) oL = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones8, pf, oL, 0, 0, 0);
 #pragma unroll
                 for (int db = 0; db < NDB; ++db) {
                     const unsigned a = so + vbase + (8 * kh + 4 * ks2) * QUAD + db * 256;
@@ -229,7 +241,7 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(AttnArgs p) {
     }
 
     if (qrow < p.nq) {
-        const float inv = 1.0f / l;
+        const float inv = 1.0f / (ONES ? oL[0] : l);
         bf16_t* O = p.o + b * p.o_bs + h * p.o_hs + (size_t)qrow * p.o_rs;
 #pragma unroll
         for (int db = 0; db < NDB; ++db)
