@@ -201,6 +201,12 @@ extern "C" int32_t vl2_attn_fwd(const void* q, const void* k, const void* v, voi
         else return -2;
         return 0;
     }
+    if (variant == 4 || variant == 5) {                     // lab variants of the second structure (denominators on the matrix pipe / in-wave interleave)
+        if (D == 64 && !causal) { if (variant == 4) emu::launch(g, blk, [=] { attn2_fwd_kernel<64, false, true>(a); }); else emu::launch(g, blk, [=] { attn2_fwd_kernel<64, false, false, true>(a); }); }
+        else if (D == 128 && causal) { if (variant == 4) emu::launch(g, blk, [=] { attn2_fwd_kernel<128, true, true>(a); }); else emu::launch(g, blk, [=] { attn2_fwd_kernel<128, true, false, true>(a); }); }
+        else return -2;
+        return 0;
+    }
     if (D == 64 && !causal) emu::launch(g, blk, [=] { attn_fwd_kernel<64, false>(a); });
     else if (D == 128 && causal) {
         const long per_seq = (long)((nq + 127) / 128) * H;

@@ -316,6 +316,7 @@ inline void buffer_load_lds(Rsrc r, void* lds, unsigned size, unsigned voff, uns
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 #define __builtin_readcyclecounter() 0LL
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_sched_group_barrier(m, n, id) ((void)0)
 #define __builtin_amdgcn_s_sleep(x) ((void)0)
 #define __builtin_nontemporal_load(p) (*(p))
 #define __builtin_nontemporal_store(v, p) (*(p) = (v))
@@ -334,6 +335,8 @@ template <class T> static inline void emu_permlane32_swap(T& vdst, T& src) {
     const T from_src = emu::shfl_idx(src, lane & 31), from_dst = emu::shfl_idx(vdst, (lane & 31) + 32);
     if (lane >= 32) vdst = from_src; else src = from_dst;
 }
+#define VL2_PERMLANE32_SWAP_2(a, b) emu_permlane32_swap(a, b)
+#define VL2_PIN3(a, b, c) ((void)0)
 #define VL2_PERMLANE32_SWAP_8(pk) do { emu_permlane32_swap(pk[0], pk[2]); emu_permlane32_swap(pk[1], pk[3]); \
                                        emu_permlane32_swap(pk[4], pk[6]); emu_permlane32_swap(pk[5], pk[7]); } while (0)
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }

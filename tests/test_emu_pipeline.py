@@ -216,6 +216,45 @@ def test_emu_attention_ragged_and_causal(emu):
     assert rel(o2, ref[160:]) < TOL_BF16_OUT
 
 
+def test_emu_attention_lab_variants(emu):
+    """vl2_attn_fwd variants 4 (softmax denominators summed by an all-ones MFMA row) and 5 (the tile in two halves, matrix and vector
+    work interleaved in the wave, running maximum per half): lab knobs measured not faster on MI355X (profiles/r03_experiments.md 5b),
+    kept correct: against torch and the shipped variant 3, full and causal, ragged edges, a softmax spike in the second half of a tile."""
+    from videollama2_amd import ops
+    try:
+        for B, H, N in ((1, 2, 150), (2, 1, 577)):
+            D = 64
+            qkv = bf(B * N, 3 * H * D, seed=N)
+            qkv[40, :D] = 5.0                                             # a spike: key 100 (second half of tile 1) dominates row 40
+            qkv[100, H * D:H * D + D] = 5.0
+            st = (N * 3 * H * D, D, 3 * H * D)
+            outs = {}
+            for var in (3, 4, 5):
+                ops.set_attn_kv_groups(var)
+                outs[var] = torch.zeros(B * N, H * D, dtype=torch.bfloat16)
+                ops.attn_fwd(qkv, qkv[:, H * D:], qkv[:, 2 * H * D:], outs[var], st, st, st, (N * H * D, D, H * D), B, H, N, N, 1, D ** -0.5, False, 0, D)
+            q, k, v = [t.view(B, N, H, D).transpose(1, 2).float() for t in qkv.view(B * N, 3, H * D).unbind(1)]
+            ref = (torch.softmax(q @ k.transpose(-1, -2) * D ** -0.5, -1) @ v).transpose(1, 2).reshape(B * N, H * D)
+            for var in (4, 5):
+                assert rel(outs[var], ref) < TOL_BF16_OUT and rel(outs[var], outs[3]) < 4e-3, (var, N)
+        nh, nkv, D, smax = 4, 2, 128, 384
+        for S in (70, 200, 330):
+            q, kc, vc = bf(S, nh * D, seed=S), bf(nkv, smax, D, seed=S + 1), bf(nkv, smax, D, seed=S + 2)
+            outs = {}
+            for var in (3, 4, 5):
+                ops.set_attn_kv_groups(var)
+                outs[var] = torch.zeros(S, nh * D, dtype=torch.bfloat16)
+                ops.attn_fwd(q, kc, vc, outs[var], (0, D, nh * D), (0, smax * D, D), (0, smax * D, D), (0, D, nh * D), 1, nh, S, S, nh // nkv, D ** -0.5, True, 0, D)
+            qf = q.view(S, nh, D).transpose(0, 1).float()
+            kf, vf = kc[:, :S].float().repeat_interleave(2, 0), vc[:, :S].float().repeat_interleave(2, 0)
+            sc = (qf @ kf.transpose(1, 2) * D ** -0.5).masked_fill(torch.triu(torch.ones(S, S, dtype=torch.bool), 1), float("-inf"))
+            ref = (torch.softmax(sc, -1) @ vf).transpose(0, 1).reshape(S, nh * D)
+            for var in (4, 5):
+                assert rel(outs[var], ref) < TOL_BF16_OUT and rel(outs[var], outs[3]) < 4e-3, (var, S)
+    finally:
+        ops.set_attn_kv_groups(0)
+
+
 def test_emu_attention_second_structure(emu):
     """csrc/k_attn2.h (vl2_attn_fwd variant 3): K/V tiles by LDS-DMA into a two-stage ring, V through transpose reads.  Same
     cases as the first structure -- ragged non-causal D = 64 out of a fused qkv buffer, causal GQA D = 128 from the KV cache,

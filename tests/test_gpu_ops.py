@@ -670,6 +670,32 @@ def test_attn_second_structure_causal_gqa(ops, S, nh, nkv):
     assert rel(o, ref) < TOL_BF16_OUT
 
 
+def test_attn_lab_variants_match_the_shipped_kernel(ops):
+    """vl2_attn_fwd variants 4 / 5 (k_attn2.h ONES / PIPE: measured not faster, kept as lab knobs) at the workload's shapes."""
+    B, H, N, D = 4, 16, 577, 64
+    g = bf(B * N, 3 * H * D, seed=3).to(DEV)
+    st = (N * 3 * H * D, D, 3 * H * D)
+    outs = {}
+    try:
+        for var in (3, 4, 5):
+            ops.set_attn_kv_groups(var)
+            outs[var] = torch.zeros(B * N, H * D, dtype=torch.bfloat16, device=DEV)
+            for _ in range(3):
+                ops.attn_fwd(g, g[:, H * D:], g[:, 2 * H * D:], outs[var], st, st, st, (N * H * D, D, H * D), B, H, N, N, 1, D ** -0.5, False, 0, D)
+        S, nh, nkv, Dc, smax = 1621, 32, 8, 128, 2048
+        q, kc, vc = bf(S, nh * Dc).to(DEV), bf(nkv, smax, Dc).to(DEV), bf(nkv, smax, Dc, seed=1).to(DEV)
+        couts = {}
+        for var in (3, 4, 5):
+            ops.set_attn_kv_groups(var)
+            couts[var] = torch.zeros(S, nh * Dc, dtype=torch.bfloat16, device=DEV)
+            for _ in range(3):
+                ops.attn_fwd(q, kc, vc, couts[var], (0, Dc, nh * Dc), (0, smax * Dc, Dc), (0, smax * Dc, Dc), (0, Dc, nh * Dc), 1, nh, S, S, nh // nkv, Dc ** -0.5, True, 0, Dc)
+    finally:
+        ops.set_attn_kv_groups(0)
+    for var in (4, 5):
+        assert rel(outs[var], outs[3]) < 4e-3 and rel(couts[var], couts[3]) < 4e-3, var
+
+
 def test_attn_second_structure_softmax_spike(ops):
     B, H, N, D = 1, 1, 300, 64
     qkv = bf(B * N, 3 * D)

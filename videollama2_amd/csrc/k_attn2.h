@@ -50,7 +50,15 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, unsigned ch
 // ONES: the softmax denominators come off the matrix pipe -- one more MFMA per P fragment with an all-ones A operand accumulates
 // sum_k P[q][k] (of the bf16-rounded P the numerator uses) in every row of a 32 x 32 block; the 32 adds per lane and tile and the
 // cross-half shuffle go away.  Lab variant 4 of vl2_attn_fwd (scripts/attn_bench2.py); see profiles/r03_experiments.md section 5b.
-template <int D, bool CAUSAL, bool ONES = false>
+// PIPE: the tile is worked in two 32-key halves and the two halves' matrix and vector work are interleaved IN the wave (MFMA and VALU share
+// the issue port, and four resident waves were measured not to overlap them: profiles/r03_experiments.md section 5b): the QK^T MFMAs of half 1
+// run between the exp / sum / pack instructions of half 0, the PV MFMAs of half 0 between those of half 1; the running maximum is updated per
+// half (a rescale found in half 1 is applied to O after PV of half 0 has been issued).  Lab variant 5 of vl2_attn_fwd.
+#ifndef VL2_PERMLANE32_SWAP_2
+#define VL2_PERMLANE32_SWAP_2(a, b) asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b))
+#define VL2_PIN3(a, b, c) asm volatile("" :: "v"(a), "v"(b), "v"(c))     // a use the optimiser cannot move: pins the producers before this point
+#endif
+template <int D, bool CAUSAL, bool ONES = false, bool PIPE = false>
 __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(AttnArgs p) {
     static_assert(D == 64 || D == 128, "attn2: head_dim 64 or 128");
     constexpr int NKS = D / 16;                // k-steps of the QK^T MFMA chain
@@ -221,6 +229,144 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(AttnArgs p) {
             }
     };
 
+    // ---- PIPE: the same tile in two halves, matrix and vector work interleaved by hand (sched_barrier fences pin the order)
+    auto compute_tile_pipe = [&](int t, unsigned so) {
+        const int kv0 = t * 64;
+        const int wq0 = q0 + wave * 32;
+        const bool need_mask = (kv0 + 64 > p.nk) || (CAUSAL && (kv0 + 63 > wq0 + p.causal_off));
+        const float c = p.scale_log2e;
+        constexpr float THR = 6.0f;
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        f32x16 sT[2];
+        u32x4 pw[2][2];
+        bf16x8 kf[NKS];
+        // (mask +) max of half kh over the lane's 16 keys and the partner lane's (lanes l, l + 32 hold the two key sets of row qrow)
+        auto half_max = [&](int kh) -> float {
+            if (need_mask) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kv0 + kh * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    const bool ok = key < p.nk && (!CAUSAL || key <= qrow + p.causal_off);
+                    sT[kh][r] = ok ? sT[kh][r] : -1e30f;
+                }
+            }
+            float mt = -3.0e38f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mt = fmaxf(mt, sT[kh][r]);
+            float a = mt, b = mt;
+            VL2_PERMLANE32_SWAP_2(a, b);                  // a = lower half's value, b = upper half's, in every lane
+            return fmaxf(a, b) * c;
+        };
+        // exp / sum / pack of elements [first, first + n) of half kh (n even: whole bf16 pairs)
+        auto exp_chunk = [&](int kh, int first, int n) {
+#pragma unroll
+            for (int r = first; r < first + n; ++r) {
+                const float pv = __builtin_amdgcn_exp2f(fmaf(sT[kh][r], c, -m));
+                sT[kh][r] = pv;
+                l += pv;
+            }
+#pragma unroll
+            for (int r = first; r < first + n; r += 2) pw[kh][r >> 3][(r & 7) >> 1] = pack2bf(sT[kh][r], sT[kh][r + 1]);
+        };
+        // ---- S of half 0; the K fragments of half 1 are requested behind it
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) kf[ks] = *(const bf16x8*)(lds + so + kbase[ks]);
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) sT[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], ks == 0 ? zero16 : sT[0], 0, 0, 0);
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) kf[ks] = *(const bf16x8*)(lds + so + KH_STEP + kbase[ks]);
+        float mt = half_max(0);
+        if (!__all(mt - m <= THR)) {
+            const float m_new = fmaxf(fmaxf(m, mt), -1e28f);
+            const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+            m = m_new;
+            l *= alpha;
+#pragma unroll
+            for (int i = 0; i < NDB; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oT[i][r] *= alpha;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- region 1: S of half 1 between the exp / sum / pack of half 0.  One scheduling region; the sched_group_barrier pipeline
+        //      below tells the machine scheduler the issue order: MFMA, then its share of the vector work (VALU mask 0x2 + transcendental
+        //      mask 0x400), NKS times.  (Fences in source order are not enough: the pure exp2 / fma calls are regrouped before scheduling.)
+        constexpr int VPM1 = (16 * 3 + 8) / NKS, TPM1 = 16 / NKS;      // vector / transcendental instructions per MFMA: 16 x (fma, add) + 8 cvt; 16 exp
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) sT[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], ks == 0 ? zero16 : sT[1], 0, 0, 0);
+        exp_chunk(0, 0, 16);
+        VL2_PIN3(pw[0][0], pw[0][1], l);                  // a use INSIDE the region: the optimiser otherwise sinks the pure exp / pack work to PV
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, VPM1 - TPM1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x400, TPM1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // V^T fragments of half 0 (all of them) requested before the statistics of half 1
+        s16x4 v0[2 * NDB], v1[2 * NDB];
+#pragma unroll
+        for (int ks2 = 0; ks2 < 2; ++ks2)
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) {
+                const unsigned a = so + vbase + (4 * ks2) * QUAD + db * 256;
+                v0[ks2 * NDB + db] = lds_read_tr16(lds + a);
+                v1[ks2 * NDB + db] = lds_read_tr16(lds + a + 2 * QUAD);
+            }
+        mt = half_max(1);
+        float alpha1 = 1.0f;
+        const bool resc = !__all(mt - m <= THR);
+        if (resc) {
+            const float m_new = fmaxf(fmaxf(m, mt), -1e28f);
+            alpha1 = __builtin_amdgcn_exp2f(m - m_new);
+            m = m_new;
+            l *= alpha1;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- region 2: PV of half 0 between the exp / sum / pack of half 1 (same pipeline, 2 NDB MFMAs)
+        constexpr int VPM2 = (16 * 3 + 8) / (2 * NDB), TPM2 = 16 / (2 * NDB);
+#pragma unroll
+        for (int ks2 = 0; ks2 < 2; ++ks2)
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) {
+                const int st = ks2 * NDB + db;
+                const bf16x8 vf = {v0[st][0], v0[st][1], v0[st][2], v0[st][3], v1[st][0], v1[st][1], v1[st][2], v1[st][3]};
+                oT[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, __builtin_bit_cast(bf16x8, pw[0][ks2]), oT[db], 0, 0, 0);
+            }
+        exp_chunk(1, 0, 16);
+        VL2_PIN3(pw[1][0], pw[1][1], l);
+#pragma unroll
+        for (int st = 0; st < 2 * NDB; ++st) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, VPM2 - TPM2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x400, TPM2, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // V^T fragments of half 1
+#pragma unroll
+        for (int ks2 = 0; ks2 < 2; ++ks2)
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) {
+                const unsigned a = so + vbase + (8 + 4 * ks2) * QUAD + db * 256;
+                v0[ks2 * NDB + db] = lds_read_tr16(lds + a);
+                v1[ks2 * NDB + db] = lds_read_tr16(lds + a + 2 * QUAD);
+            }
+        if (resc) {                                       // the maximum moved in half 1: O (now holding half 0's PV as well) follows
+#pragma unroll
+            for (int i = 0; i < NDB; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oT[i][r] *= alpha1;
+        }
+        // ---- PV of half 1
+#pragma unroll
+        for (int ks2 = 0; ks2 < 2; ++ks2)
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) {
+                const int st = ks2 * NDB + db;
+                const bf16x8 vf = {v0[st][0], v0[st][1], v0[st][2], v0[st][3], v1[st][0], v1[st][1], v1[st][2], v1[st][3]};
+                oT[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, __builtin_bit_cast(bf16x8, pw[1][ks2]), oT[db], 0, 0, 0);
+            }
+    };
+
     // ---- main loop: tile t lives in stage t & 1.  Top of tile t: this wave's pieces of tile t have landed (its only
     //      outstanding VMEM), the barrier makes everyone's pieces visible AND proves every wave is done reading the other stage
     //      (tile t-1), which the DMA of tile t+1 may therefore overwrite while tile t is computed.  One barrier per tile.
@@ -232,16 +378,21 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(AttnArgs p) {
         VL2_WAIT_VMCNT(0);
         VL2_ATTN2_BARRIER();
         if (t + 1 < ntiles) dma_tile(t + 1, STAGE);
-        if (live) compute_tile(t, 0);
+        if (live) { if constexpr (PIPE) compute_tile_pipe(t, 0); else compute_tile(t, 0); }
         if (t + 1 >= ntiles) break;
         VL2_WAIT_VMCNT(0);
         VL2_ATTN2_BARRIER();
         if (t + 2 < ntiles) dma_tile(t + 2, 0);
-        if (live) compute_tile(t + 1, STAGE);
+        if (live) { if constexpr (PIPE) compute_tile_pipe(t + 1, STAGE); else compute_tile(t + 1, STAGE); }
     }
 
+    if constexpr (PIPE) {                 // l holds this lane's keys only: add the partner lane's (same query row, the other key sets)
+        float a = l, b = l;
+        VL2_PERMLANE32_SWAP_2(a, b);
+        l = a + b;
+    }
     if (qrow < p.nq) {
-        const float inv = 1.0f / (ONES ? oL[0] : l);
+        const float inv = 1.0f / (ONES ? oL[0] : l);        // (PIPE: l was completed across the two half-waves just above)
         bf16_t* O = p.o + b * p.o_bs + h * p.o_hs + (size_t)qrow * p.o_rs;
 #pragma unroll
         for (int db = 0; db < NDB; ++db)

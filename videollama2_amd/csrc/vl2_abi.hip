@@ -507,7 +507,7 @@ extern "C" int32_t vl2_attn_fwd(const void* q, const void* k, const void* v, voi
         !ALIGNED16(k) || !ALIGNED16(v) || ((uintptr_t)o & 7))
         return fail(VL2_E_SHAPE, "vl2_attn_fwd: strides must keep 16-byte row alignment");
     if (causal && causal_off < 0) return fail(VL2_E_SHAPE, "vl2_attn_fwd: causal_off must be >= 0");
-    if (variant < 0 || variant > 4) return fail(VL2_E_BADARG, "vl2_attn_fwd: unknown variant %d", variant);
+    if (variant < 0 || variant > 5) return fail(VL2_E_BADARG, "vl2_attn_fwd: unknown variant %d", variant);
     // auto: the LDS-DMA / transpose-read structure wherever it is built (measured on MI355X, profiles/r02_attn_ab_*.jsonl:
     // causal D=128 S=945 / 1621 / 2973: 23.3 / 38.1 / 97.7 us vs 26.3 / 43.8 / 106.1 us; ViT D=64 T=8 / 16 / 32: 25.4 / 43.0 / 78.5 vs
     // 26.9 / 43.8 / 78.1 us); head_dim 96 (SigLIP's padded 72) stays on the register-staged kernel
@@ -526,6 +526,12 @@ extern "C" int32_t vl2_attn_fwd(const void* q, const void* k, const void* v, voi
         else if (D == 128 && !causal) hipLaunchKernelGGL((attn2_fwd_kernel<128, false>), g, b, 0, s, a);
         else if (D == 128 && causal) hipLaunchKernelGGL((attn2_fwd_kernel<128, true>), g, b, 0, s, a);
         else return fail(VL2_E_SHAPE, "vl2_attn_fwd: variant 3 is built for head_dim 64 and 128 (got %d)", D);
+        return launched("vl2_attn_fwd");
+    }
+    if (variant == 5) {                                   // lab: variant 3 with matrix and vector work of the two tile halves interleaved in the wave
+        if (D == 64 && !causal) hipLaunchKernelGGL((attn2_fwd_kernel<64, false, false, true>), g, b, 0, s, a);
+        else if (D == 128 && causal) hipLaunchKernelGGL((attn2_fwd_kernel<128, true, false, true>), g, b, 0, s, a);
+        else return fail(VL2_E_SHAPE, "vl2_attn_fwd: variant 5 is built for (head_dim 64, full) and (head_dim 128, causal)");
         return launched("vl2_attn_fwd");
     }
     if (variant == 4) {                                   // lab: variant 3 with the softmax denominators on the matrix pipe (ones-row MFMA)
