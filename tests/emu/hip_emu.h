@@ -337,6 +337,7 @@ template <class T> static inline void emu_permlane32_swap(T& vdst, T& src) {
 }
 #define VL2_PERMLANE32_SWAP_2(a, b) emu_permlane32_swap(a, b)
 #define VL2_PIN3(a, b, c) ((void)0)
+#define VL2_PIN2(a, b) ((void)0)
 #define VL2_PERMLANE32_SWAP_8(pk) do { emu_permlane32_swap(pk[0], pk[2]); emu_permlane32_swap(pk[1], pk[3]); \
                                        emu_permlane32_swap(pk[4], pk[6]); emu_permlane32_swap(pk[5], pk[7]); } while (0)
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
