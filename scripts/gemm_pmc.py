@@ -12,8 +12,16 @@ def go(M, N, K, v, swiglu=False):
     for _ in range(3):
         ops.gemm(a, w, swiglu=swiglu, out=c)
     torch.cuda.synchronize()
-go(8192, 4096, 4096, 8)            # 256x256 ping-pong, well quantised
-go(9216, 4096, 4096, 4)            # 128x256 ping-pong, STC s1
-go(1621, 28672, 4096, 4, True)     # 128x256 ping-pong, gate-up + SwiGLU
-go(1621, 4096, 14336, 4)           # down
-go(9232, 4096, 1024, 1)            # 128x128, ViT fc1 (K=1024)
+SHAPES = [                                   # (M, N, K, variant, swiglu): the kernels HEAD dispatches on the step's dominant shapes
+    (8192, 4096, 4096, 8, False),            # 256x256 ping-pong, C^T epilogue, well quantised
+    (9232, 3072, 1024, 0, False),            # ViT qkv (auto: 256x256, C^T epilogue)
+    (9232, 1024, 4096, 12, False),           # ViT fc2 shape on 192-row tiles (no residual here: C^T epilogue)
+    (1621, 6144, 4096, 0, False),            # LLM q/k/v (auto: 192-row tiles)
+    (1621, 28672, 4096, 0, True),            # gate/up + SwiGLU (auto: 256x256 on 1536 rows + one-round kernel on 85)
+    (1621, 4096, 14336, 0, False),           # down (auto: 128x256 ping-pong)
+    (9232, 4096, 1024, 0, False),            # ViT fc1 shape (auto)
+]
+if __name__ == "__main__":
+    for M, N, K, v, sw in SHAPES:
+        go(M, N, K, v, sw)
+    ops.set_gemm_variant(0)
