@@ -363,8 +363,9 @@ static int32_t attn_decode_fused(const void* qkv, void* kc, void* vc, const floa
         attn_decode_kernel<true>((const bf16_t*)qkv, (bf16_t*)kc, (bf16_t*)vc, cos_t, sin_t, partial, nh, group, nkv, smax, 0, pos_dev, scale * 1.4426950408889634f, 0L, 0L, 0L, (int*)cnt, (bf16_t*)out); });
     return 0;
 }
-static int32_t argmax_and_clear(const float* logits, int32_t V, int32_t* tok, int32_t* hist, int32_t* state, int32_t* zero, int32_t nzero, void*) {
-    emu::launch(dim3(1), dim3(1024), [=] { argmax_kernel(logits, V, tok, hist, 0, state, (int*)zero, nzero); });
+static int32_t argmax_and_clear(const float* logits, int32_t V, int32_t* tok, int32_t* hist, int32_t* state, int32_t* zero, int32_t nzero,
+                                const void* embed, void* x0, int32_t D, void*) {
+    emu::launch(dim3(1), dim3(1024), [=] { argmax_kernel(logits, V, tok, hist, 0, state, (int*)zero, nzero, (const bf16_t*)embed, (bf16_t*)x0, D); });
     return 0;
 }
 extern "C" int32_t vl2_attn_decode_fused(const void* qkv, void* kc, void* vc, const float* cos_t, const float* sin_t, float* partial, void* out,
@@ -383,7 +384,7 @@ extern "C" int32_t vl2_attn_decode_batched(const void* qkv, void* kc, void* vc, 
     return 0;
 }
 extern "C" int32_t vl2_argmax(const float* logits, int32_t V, int32_t* tok, int32_t* hist, int32_t step, int32_t* state, void*) {
-    emu::launch(dim3(1), dim3(1024), [=] { argmax_kernel(logits, V, tok, hist, step, state, (int*)nullptr, 0); });
+    emu::launch(dim3(1), dim3(1024), [=] { argmax_kernel(logits, V, tok, hist, step, state, (int*)nullptr, 0, (const bf16_t*)nullptr, (bf16_t*)nullptr, 0); });
     return 0;
 }
 extern "C" int32_t vl2_embed_rows(const int32_t* ids, const void* table, void* out, int32_t n, int32_t D, int32_t ldo, void*) {

@@ -538,17 +538,27 @@ __global__ __launch_bounds__(128) void attn_decode_combine_kernel(const float* _
 // state != null (hipGraph-replayable decode): step = state[1]; afterwards state[0] (position) and state[1] advance by one.
 // zero / nzero: int32 words this launch clears first (the ticket counters of the fused attention launches of the step that follows:
 // a kernel-side clear instead of a memset node, which replayed wrongly from a captured hipGraph for a 32-byte range on ROCm 7.2).
+// embed != null (the stage-level decode step): the block then copies row `tok` of the embedding table (D bf16) to x0 -- the
+// embed_rows launch that used to follow (every launch of the decode graph costs ~4.5 us whatever it does).
 __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ logits, int V, int* __restrict__ tok,
                                                       int* __restrict__ hist, int step, int* __restrict__ state,
-                                                      int* __restrict__ zero, int nzero) {
+                                                      int* __restrict__ zero, int nzero, const bf16_t* __restrict__ embed,
+                                                      bf16_t* __restrict__ x0, int D) {
     __shared__ float bv[16];
     __shared__ int bi[16];
+    __shared__ int s_tok;
     for (int i = threadIdx.x; i < nzero; i += 1024) zero[i] = 0;
     float best = -3.4e38f;
     int idx = 0x7fffffff;
-    for (int i = threadIdx.x; i < V; i += 1024) {
-        const float v = logits[i];
-        if (v > best) { best = v; idx = i; }
+    // eight independent loads per trip (the scalar loop was one L2 round trip per element: ~31 dependent trips for V = 32000, 12 us);
+    // the compares stay in increasing index order, so ties still resolve to the first index
+    for (int i0 = threadIdx.x; i0 < V; i0 += 8 * 1024) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (i0 + k * 1024 < V) ? logits[i0 + k * 1024] : -3.4e38f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (v[k] > best) { best = v[k]; idx = i0 + k * 1024; }
     }
 #pragma unroll
     for (int msk = 32; msk >= 1; msk >>= 1) {
@@ -562,6 +572,7 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ 
         for (int w = 1; w < 16; ++w)
             if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
         *tok = idx;
+        s_tok = idx;
         if (state) {
             if (hist) hist[state[1]] = idx;
             state[0] += 1;
@@ -569,6 +580,11 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ 
         } else if (hist) {
             hist[step] = idx;
         }
+    }
+    if (embed) {
+        __syncthreads();
+        const bf16_t* src = embed + (size_t)s_tok * D;
+        for (int c = threadIdx.x * 8; c < D; c += 8 * 1024) *(u32x4*)(x0 + c) = *(const u32x4*)(src + c);
     }
 }
 

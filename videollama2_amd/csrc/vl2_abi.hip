@@ -760,13 +760,15 @@ extern "C" int32_t vl2_attn_decode_batched(const void* qkv, void* kcache, void* 
 extern "C" int32_t vl2_argmax(const float* logits, int32_t V, int32_t* tok, int32_t* hist, int32_t step, int32_t* state,
                               void* stream) {
     if (!logits || !tok || V <= 0) return fail(VL2_E_BADARG, "vl2_argmax: bad args");
-    hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(1024), 0, ST(stream), logits, V, tok, hist, step, state, (int*)nullptr, 0);
+    hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(1024), 0, ST(stream), logits, V, tok, hist, step, state, (int*)nullptr, 0, (const bf16_t*)nullptr, (bf16_t*)nullptr, 0);
     return launched("vl2_argmax");
 }
 // the decode step's argmax, which also clears `nzero` int32 words (the fused attention launches' ticket counters)
-static int32_t argmax_and_clear(const float* logits, int32_t V, int32_t* tok, int32_t* hist, int32_t* state, int32_t* zero, int32_t nzero, void* stream) {
-    hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(1024), 0, ST(stream), logits, V, tok, hist, 0, state, (int*)zero, nzero);
-    return launched("vl2_llm_decode_step (argmax)");
+static int32_t argmax_and_clear(const float* logits, int32_t V, int32_t* tok, int32_t* hist, int32_t* state, int32_t* zero, int32_t nzero,
+                                const void* embed, void* x0, int32_t D, void* stream) {
+    hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(1024), 0, ST(stream), logits, V, tok, hist, 0, state, (int*)zero, nzero,
+                       (const bf16_t*)embed, (bf16_t*)x0, D);
+    return launched("vl2_llm_decode_step: argmax");
 }
 extern "C" int32_t vl2_embed_rows(const int32_t* ids, const void* table, void* out, int32_t n, int32_t D, int32_t ldo, void* stream) {
     if (!ids || !table || !out || n <= 0 || D % 8 || ldo % 8) return fail(VL2_E_BADARG, "vl2_embed_rows: bad args");
