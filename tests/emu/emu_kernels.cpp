@@ -50,6 +50,21 @@ static void run_gemm(GemmArgs a) {
         }
     }
     if constexpr (!G && !F32) {
+        if (g_gemm_variant == 24 && a.N % 256 == 0 && a.M > 256) {   // the row-split call as ONE mixed launch (vl2_abi.hip launch_gemm): big tiles on
+            const int M1 = (a.M / 256) * 256 == a.M ? a.M - 256 : (a.M / 256) * 256;      // the leading whole 256-row tiles, 128x128 8-wave tiles on the rest
+            GemmArgs big = a, tail = a;
+            big.M = M1; big.tiles_m = M1 / 256; big.tiles_n = a.N / 256;
+            tail.M = a.M - M1; tail.A = a.A + (size_t)M1 * a.lda; tail.C = (void*)((bf16_t*)a.C + (size_t)M1 * a.ldc);
+            if (a.res) tail.res = a.res + (size_t)M1 * a.ldres;
+            if (a.stats_out) tail.stats_out = a.stats_out + (size_t)M1 * a.stats_out_np * 2;
+            if (a.stats_in) tail.stats_in = a.stats_in + (size_t)M1 * a.stats_in_np * 2;
+            if (a.row_norm) tail.row_norm = a.row_norm + (size_t)M1 * 2;
+            tail.tiles_m = (tail.M + 127) / 128; tail.tiles_n = a.N / 128;
+            const int n_big = big.tiles_m * big.tiles_n, n_all = n_big + tail.tiles_m * tail.tiles_n;
+            if (a.res == nullptr) emu::launch(dim3(n_all), dim3(512), [=] { gemm_mix_bf16_kernel<ACT, SW, true>(big, tail, n_big); });
+            else emu::launch(dim3(n_all), dim3(512), [=] { gemm_mix_bf16_kernel<ACT, SW, false>(big, tail, n_big); });
+            return;
+        }
         if (g_gemm_variant == 12 && a.N % 256 == 0) {            // gemm4 on 192 x 256 tiles
             a.tiles_m = (a.M + 191) / 192; a.tiles_n = a.N / 256;
             if (a.res == nullptr) { emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(512), [=] { gemm4_bf16_kernel<ACT, SW, false, true, -1, 192>(a); }); return; }

@@ -42,6 +42,34 @@ def test_emu_gemm_variants(emu):
     assert rel(out.view(4, 17, 128)[:, 1:], ref) < TOL_BF16_OUT and out.view(4, 17, 128)[:, 0].abs().max() == 0
 
 
+def test_emu_gemm_mixed_launch(emu):
+    """k_gemm.h gemm_mix_bf16_kernel (the row-split GEMM as ONE launch: 256x256 ping-pong tiles on the leading rows, 8-wave 128x128 tiles
+    on the tail; emulator knob 24): same bits as the 128x128 kernel, with and without a residual (LDS / C^T epilogue of the big part),
+    SwiGLU, and a LayerNorm-carrying input whose statistics rows are shifted for the tail."""
+    from videollama2_amd import ops
+    from videollama2_amd.weights import pack_gate_up
+    M, N, K = 300, 512, 128
+    a, w, bias, res = bf(M, K), bf(N, K, scale=K ** -0.5), torch.randn(N), bf(M, N)
+    wgu = pack_gate_up(bf(256, K, seed=3), bf(256, K, seed=4))
+    st = ops.row_stats(a)
+    try:
+        ops.set_gemm_variant(1)
+        refs = (ops.gemm(a, w, bias=bias, res=res, act=ops.ACT_QGELU), ops.gemm(a, w, bias=bias, act=ops.ACT_GELU), ops.gemm(a, wgu, swiglu=True),
+                ops.gemm(a, w, norm=(ops.NORM_RMS, st, 1e-5, None)))
+        st_ref = torch.zeros(M, N // 64, 2)
+        ops.gemm(a, w, bias=bias, res=res, stats_out=st_ref)
+        ops.set_gemm_variant(24)
+        outs = (ops.gemm(a, w, bias=bias, res=res, act=ops.ACT_QGELU), ops.gemm(a, w, bias=bias, act=ops.ACT_GELU), ops.gemm(a, wgu, swiglu=True),
+                ops.gemm(a, w, norm=(ops.NORM_RMS, st, 1e-5, None)))
+        st_out = torch.zeros(M, N // 64, 2)
+        ops.gemm(a, w, bias=bias, res=res, stats_out=st_out)
+    finally:
+        ops.set_gemm_variant(0)
+    for i, (r, o) in enumerate(zip(refs, outs)):
+        assert torch.equal(r, o), i
+    assert torch.equal(st_ref, st_out)
+
+
 def test_emu_norm_carrying_gemms(emu):
     """csrc/k_gemm.h "norm-carrying GEMMs": (1) the statistics a producer GEMM emits are bit-identical to `row_stats` of its
     stored output, whichever kernel ran it; (2) RMSNorm / LayerNorm computed in the consumer's epilogue from those statistics

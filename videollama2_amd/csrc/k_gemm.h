@@ -1295,13 +1295,15 @@ __global__ __launch_bounds__(128, 2) void gemm_s_bf16_kernel(GemmArgs p) {
 #define GEMML_STAGE_BYTES 32768
 #define GEMML_LDS_BYTES (GEMML_STAGES * GEMML_STAGE_BYTES)
 
+// bid / nwg: this workgroup's index and the workgroup count of the tile set it belongs to (the whole grid for gemm_l8_bf16_kernel;
+// the small-tile part of gemm_mix_bf16_kernel)
 template <int ACT, bool SWIGLU, bool OUT_F32>
-__global__ __launch_bounds__(512, 1) void gemm_l8_bf16_kernel(GemmArgs p) {
+__device__ __forceinline__ void gemm_l8_body(const GemmArgs& p, int bid, int nwg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char vl2_smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;                    // wm 0..3 (32 rows each), wn 0..1 (64 columns each)
-    const int t = xcd_remap(blockIdx.x, gridDim.x);
+    const int t = xcd_remap(bid, nwg);
     const int tm = t % p.tiles_m, tn = t / p.tiles_m;            // consecutive workgroups share a W panel
     const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
     const int nt = p.K / GEMM_BK;
@@ -1377,4 +1379,19 @@ __global__ __launch_bounds__(512, 1) void gemm_l8_bf16_kernel(GemmArgs p) {
     gemm_park_row_stats(p, rowtab, rst, tid, GEMM_BM);
     __syncthreads();
     gemm_store_patch<ACT, SWIGLU, OUT_F32>(p, ep, m0 + wm * 32, n0 + wn * 64, lane, rowtab, wm * 32);
+}
+template <int ACT, bool SWIGLU, bool OUT_F32>
+__global__ __launch_bounds__(512, 1) void gemm_l8_bf16_kernel(GemmArgs p) {
+    gemm_l8_body<ACT, SWIGLU, OUT_F32>(p, blockIdx.x, gridDim.x);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// gemm_mix: ONE launch for a row-split GEMM (vl2_abi.hip m_split_rows): workgroups [0, n_big) run the 256 x 256 ping-pong body on the
+// leading rows (`pb`), workgroups [n_big, grid) the one-round 128 x 128 body on the tail rows (`ps`).  Workgroups are dispatched in
+// index order, so the small tiles start on the CUs that run out of big tiles during the last, partially filled round of big tiles
+// (gate/up at S = 1621: 672 big tiles = 2.625 rounds, 224 tail tiles) instead of in a second launch behind it.  Same bodies -> same bits.
+template <int ACT, bool SWIGLU, bool TR>
+__global__ __launch_bounds__(512, 2) void gemm_mix_bf16_kernel(GemmArgs pb, GemmArgs ps, int n_big) {
+    if ((int)blockIdx.x < n_big) gemm4_body<ACT, SWIGLU, false, TR>(pb, blockIdx.x, n_big);
+    else gemm_l8_body<ACT, SWIGLU, false>(ps, (int)blockIdx.x - n_big, (int)gridDim.x - n_big);
 }

@@ -171,7 +171,7 @@ static void launch_gemm4(const GemmArgs& a0, hipStream_t s) {
 //      half a round of big tiles) go through the chooser, which gives them a finer-tiled one-round kernel
 //      (2 rounds 224 us + 1024 rows on the 8-wave 128x128 kernel ~40 us against 287 us for the single launch).
 static int m_split_rows(const GemmArgs& a, const GemmCtl& c) {
-    if (c.variant != 0 || a.out_grp > 0 || a.res_row_mod > 0 || a.N % GEMM4_BN || a.K < 2048 || a.M < 1024) return 0;
+    if (c.variant != 0 || a.out_grp > 0 || a.res_row_mod > 0 || a.N % GEMM4_BN || a.K < 1024 || a.M < 1024) return 0;
     const int r = a.M % GEMM4_BM, m1_tiles = a.M / GEMM4_BM, n_tiles = a.N / GEMM4_BN;
     if (r != 0 && r <= 96 && n_tiles >= 64) {
         const long t4 = (long)m1_tiles * n_tiles;
@@ -204,9 +204,30 @@ template <int ACT, bool SW, bool F32, bool G>
 static void launch_gemm(const GemmArgs& a0, const GemmCtl& c, hipStream_t s) {
     if constexpr (!G && !F32) {
         if (const int M1 = m_split_rows(a0, c); M1 > 0) {
-            launch_gemm4<ACT, SW, F32>(gemm_rows(a0, 0, M1, F32), s);
-            launch_gemm<ACT, SW, F32, G>(gemm_rows(a0, M1, a0.M - M1, F32), c, s);
-            return;
+            GemmArgs big = gemm_rows(a0, 0, M1, F32), tail = gemm_rows(a0, M1, a0.M - M1, F32);
+            // ONE launch (k_gemm.h gemm_mix_bf16_kernel) when the tail is 129..512 tiles of the 8-wave 128x128 body: its workgroups start on
+            // the CUs that run out of big tiles instead of behind a second launch.  Measured against the two launches on one box
+            // (scripts/gpu_r3_k.sh): gate/up at S = 1621 383.0 -> 369.7 us (prefill 26.0 -> 25.6 ms), STC 4096x4096 conv 274.7 -> 265.0,
+            // STC K = 1024 conv 85.9 -> 82.2, ViT fc1 99.2 -> 96.5 (T = 8: 54.7 -> 49.9); in the pipeline the K = 1024 cases are neutral at T = 16
+            // (encode 12.90 vs 12.89 ms) and the prefill gains 0.4 ms.  VL2_GEMM_NO_MIX=1 (read once) keeps two launches / the single kernel.
+            static const bool no_mix = getenv("VL2_GEMM_NO_MIX") != nullptr;
+            const long t_big = (long)(M1 / GEMM4_BM) * (a0.N / GEMM4_BN), t_tail = (long)tail.tiles_m * tail.tiles_n;
+            if (!no_mix && t_tail > 128 && t_tail <= 512) {
+                big.tiles_m = M1 / GEMM4_BM; big.tiles_n = a0.N / GEMM4_BN;
+                if (want_tr_epilogue(big)) {
+                    lds_attr<gemm_mix_bf16_kernel<ACT, SW, true>>(GEMM4_LDS_BYTES);
+                    hipLaunchKernelGGL((gemm_mix_bf16_kernel<ACT, SW, true>), dim3((unsigned)(t_big + t_tail)), dim3(512), GEMM4_LDS_BYTES, s, big, tail, (int)t_big);
+                } else {
+                    lds_attr<gemm_mix_bf16_kernel<ACT, SW, false>>(GEMM4_LDS_BYTES);
+                    hipLaunchKernelGGL((gemm_mix_bf16_kernel<ACT, SW, false>), dim3((unsigned)(t_big + t_tail)), dim3(512), GEMM4_LDS_BYTES, s, big, tail, (int)t_big);
+                }
+                return;
+            }
+            if (a0.K >= 2048) {                       // two launches (measured wins at K >= 2048 only: profiles/r02_experiments.md section 3)
+                launch_gemm4<ACT, SW, F32>(big, s);
+                launch_gemm<ACT, SW, F32, G>(tail, c, s);
+                return;
+            }
         }
     }
     if constexpr (!SW && !F32) {
