@@ -203,7 +203,10 @@ static GemmArgs gemm_rows(const GemmArgs& a0, int m0, int rows, bool f32) {
 template <int ACT, bool SW, bool F32, bool G>
 static void launch_gemm(const GemmArgs& a0, const GemmCtl& c, hipStream_t s) {
     if constexpr (!G && !F32) {
-        if (const int M1 = m_split_rows(a0, c); M1 > 0) {
+        // (K < 2048 with an activation in the epilogue -- ViT fc1 + QuickGELU -- stays on its single launch: in the pipeline's rocprofv3 trace the
+        //  mixed form took 105 us against 98.6 for the 128x128 kernel, although it wins the isolated micro-benchmark; end to end the two are equal:
+        //  encode 12.52 vs 12.52 ms over three alternations)
+        if (const int M1 = (a0.K < 2048 && ACT != ACT_NONE) ? 0 : m_split_rows(a0, c); M1 > 0) {
             GemmArgs big = gemm_rows(a0, 0, M1, F32), tail = gemm_rows(a0, M1, a0.M - M1, F32);
             // ONE launch (k_gemm.h gemm_mix_bf16_kernel) when the tail is 129..512 tiles of the 8-wave 128x128 body: its workgroups start on
             // the CUs that run out of big tiles instead of behind a second launch.  Measured against the two launches on one box
