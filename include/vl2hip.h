@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define VL2_ABI_VERSION 2
+#define VL2_ABI_VERSION 3
 #define VL2_E_BADARG  (-1)   /* null pointer / non-positive size */
 #define VL2_E_SHAPE   (-2)   /* shape not supported by the gfx950 kernels (alignment / multiple-of constraints) */
 #define VL2_E_UNSUPP  (-3)   /* option combination not built */
@@ -50,7 +50,12 @@ int64_t vl2_workspace_bytes(void);
 /* kernel variants (vl2_gemm_desc.variant; 0 = per-shape choice): 1 = 128x128x64 two-barrier kernel, 2 = its stream-K form
  * (needs `ws`), 4 = 128x256x64 ping-pong, 8 = 256x256x32 ping-pong, 12 = the same on 192x256 tiles (4, 8, 12: N%256==0; 12: bf16
  * output), 32 = 64x64 small-M kernel,
- * 256 = 128x128 8-wave deep-ring one-round kernel.  profiles/r01_gemm_experiments.md. */
+ * 256 = 128x128 8-wave deep-ring one-round kernel; 60 / 61 = the PERSISTENT 256x256 / 192x256 ping-pong kernel with a static tile walk, 70 / 71 = with tiles handed out through
+ * `tile_ctr` (what the automatic choice uses; one workgroup per CU
+ * walks its tiles, csrc/k_gemm6.h: bf16 output without residual / statistics / gather, norm through `row_norm`, K >= 1024; a call that
+ * does not qualify gets the automatic choice), 62 = 61 with two accumulator sets (the previous tile's epilogue drained under the next
+ * tile's phases; measured slower than 61, kept for A/B), 24 = the automatic choice without the persistent form (A/B).
+ * Every variant produces the same bits.  profiles/r01_gemm_experiments.md, r03_experiments.md, r04_experiments.md. */
 #define VL2_NORM_NONE 0
 #define VL2_NORM_RMS  1     /* HF:modeling_mistral.py MistralRMSNorm in front of q/k/v and gate/up */
 #define VL2_NORM_LN   2     /* HF:modeling_clip.py layer_norm1 / layer_norm2 in front of q/k/v and fc1 */
@@ -89,12 +94,18 @@ typedef struct vl2_gemm_desc {
     const float* row_norm;         /* optional [M][2] (mean, rstd) from vl2_row_norm_finalize: replaces the per-tile reduction of stats_in */
     void* ws;  int64_t ws_bytes;   /* optional workspace (vl2_workspace_bytes()); NULL = no split-K / stream-K */
     int32_t variant;               /* 0 = auto */
+    void* tile_ctr;                /* optional: 8 zeroed bytes (two uint32) through which the persistent GEMM hands out its tiles; the kernel
+                                      re-arms them, so one block serves every GEMM of a stream (vl2_fill_zero once).  NULL: the block at the
+                                      end of `ws` if that is given, else the persistent form is used on request only (static tile walk) */
 } vl2_gemm_desc;
 int32_t vl2_gemm(const vl2_gemm_desc* d, void* stream);
 /* (sum, sum of squares) per row and 64-column block of a bf16 activation x [rows, C] -> stats fp32 [rows][C/64][2], in the
  * layout / summation order of vl2_gemm's `stats_out`: seeds a norm-carrying chain whose first tensor no GEMM wrote
  * (inputs_embeds; the CLIP embeddings after pre_layrnorm) or re-derives it after a tensor-parallel all-reduce.  C % 64 == 0. */
 int32_t vl2_row_stats(const void* x, float* stats, int32_t rows, int32_t C, int32_t ldx, void* stream);
+/* p[0, bytes) = 0 (bytes % 4 == 0) as a KERNEL on `stream`: the counter blocks this library's kernels re-arm themselves (vl2_gemm_desc.tile_ctr,
+ * the split-K tile counters) must start from zero, and a captured hipMemsetAsync node of this size did not replay on ROCm 7.2. */
+int32_t vl2_fill_zero(void* p, int64_t bytes, void* stream);
 /* stats [rows][np][2] (as vl2_gemm's stats_out / vl2_row_stats write them, np = K/64) -> row_norm [rows][2] = (mean, rstd):
  * norm = VL2_NORM_RMS (mean 0, rstd = rsqrt(sum x^2 / K + eps)) or VL2_NORM_LN.  Pass the result as vl2_gemm_desc.row_norm so
  * the consuming GEMM does not repeat the reduction in each of its column tiles. */

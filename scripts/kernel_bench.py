@@ -77,10 +77,17 @@ def main():
     out = {}
     ops.attach_workspace(dev)
     if "--frames" in sys.argv:
-        SHAPES, VARIANTS = shapes_for(int(sys.argv[sys.argv.index("--frames") + 1])), (1, 0, 4, 8, 12, 256)
+        SHAPES, VARIANTS = shapes_for(int(sys.argv[sys.argv.index("--frames") + 1])), (1, 0, 24, 8, 12, 60, 61)
+        if "--peeled" in sys.argv:                      # the ViT GEMMs on the patch rows only (CLS rows peeled off: M = 576 T)
+            T = int(sys.argv[sys.argv.index("--frames") + 1])
+            SHAPES = [(n + "_p", T * 576, N, K, kw) for n, M, N, K, kw in SHAPES if n.startswith("vit_")] + SHAPES
     if "--small" in sys.argv:
         SHAPES, VARIANTS = SMALL, (1, 0, 32, 256)   # 0 = auto, 1 = 128x128, 32 = 64x64 small-M kernel, 's' = 128x128 + split-K
     rounds = 2 if "--quick" in sys.argv else 3
+    iters = int(sys.argv[sys.argv.index("--iters") + 1]) if "--iters" in sys.argv else 20   # --iters 400: power steady state per variant
+    only = sys.argv[sys.argv.index("--only") + 1].split(",") if "--only" in sys.argv else None
+    if only:
+        SHAPES = [s for s in SHAPES if s[0] in only]
     for name, M, N, K, kw in SHAPES:
         a, w = rnd(M, K), rnd(N, K, scale=K ** -0.5)
         ncol = N // 2 if kw.get("swiglu") else N
@@ -90,11 +97,11 @@ def main():
         best = {}
         for r in range(rounds):
             for v in VARIANTS:
-                if v in (4, 8, 12) and N % 256:
+                if v in (4, 8, 12, 60, 61) and N % 256:
                     continue
                 ops.set_gemm_variant(1 if v == 's' else v)
                 ops.set_splitk(v == 's')
-                us = timeit(lambda: ops.gemm(a, w, bias=bias, res=res, act=kw.get("act", 0), swiglu=kw.get("swiglu", False), out=c))
+                us = timeit(lambda: ops.gemm(a, w, bias=bias, res=res, act=kw.get("act", 0), swiglu=kw.get("swiglu", False), out=c), iters=iters)
                 best[v] = min(best.get(v, 1e9), us)
                 if v == 1:
                     ref = c.clone()

@@ -5,6 +5,7 @@
 #include "hip_emu.h"
 alignas(64) unsigned char vl2_smem[160 * 1024];
 #include "k_gemm.h"
+#include "k_gemm6.h"
 #include "k_norm.h"
 #include "k_vit.h"
 #include "k_attn.h"
@@ -22,9 +23,11 @@ static char g_err[256] = "emu";
 extern "C" int32_t vl2_version(void) { return VL2_ABI_VERSION; }
 extern "C" const char* vl2_last_error_string(void) { return g_err; }
 extern "C" int64_t vl2_workspace_bytes(void) { return 64; }
+extern "C" int32_t vl2_fill_zero(void* p, int64_t bytes, void*) { if (!p || bytes < 0 || (bytes & 3)) return -1; memset(p, 0, (size_t)bytes); return 0; }
 
 // per-call controls (vl2_gemm_desc.variant, VL2_GEMM_SPLITK, vl2_attn_fwd variant): set by the entry points below
 static int g_gemm_variant = 0;
+static bool g_gemm6_dynamic = false;       // gemm6: tiles handed out through the counter block (variants 70 / 71 = 60 / 61 dynamic)
 template <int ACT, bool SW, bool F32, bool G>
 static void run_gemm(GemmArgs a) {
     if constexpr (!G) {
@@ -63,6 +66,22 @@ static void run_gemm(GemmArgs a) {
             const int n_big = big.tiles_m * big.tiles_n, n_all = n_big + tail.tiles_m * tail.tiles_n;
             if (a.res == nullptr) emu::launch(dim3(n_all), dim3(512), [=] { gemm_mix_bf16_kernel<ACT, SW, true>(big, tail, n_big); });
             else emu::launch(dim3(n_all), dim3(512), [=] { gemm_mix_bf16_kernel<ACT, SW, false>(big, tail, n_big); });
+            return;
+        }
+        if (g_gemm_variant == 70 || g_gemm_variant == 71) { g_gemm6_dynamic = true; g_gemm_variant -= 10; } else g_gemm6_dynamic = false;
+        if ((g_gemm_variant == 60 || g_gemm_variant == 61 || g_gemm_variant == 62) && a.N % 256 == 0 && a.res == nullptr && !a.stats_out &&
+            (!a.norm || a.row_norm) && a.M >= (g_gemm_variant == 60 ? 256 : 192) && a.K >= 512) {
+            // gemm6 (persistent ping-pong): 256-row / 192-row / 192-row with two accumulator sets.  THREE workgroups, so that every
+            // workgroup walks several tiles (the emulator runs workgroups one after the other; a real launch has one per CU)
+            const int bm = g_gemm_variant == 60 ? 256 : 192;
+            a.tiles_m = (a.M + bm - 1) / bm; a.tiles_n = a.N / 256;
+            const int nt = a.tiles_m * a.tiles_n, g = nt < 3 ? nt : 3;
+            static unsigned tile_ctr[2] = {0, 0};                 // zero once; the kernel re-arms it (checked below)
+            a.tile_ctr = g_gemm6_dynamic ? (a.tile_ctr ? a.tile_ctr : tile_ctr) : nullptr;
+            if (g_gemm_variant == 60) emu::launch(dim3(g), dim3(512), [=] { gemm6_bf16_kernel<ACT, SW, 256, false>(a); });
+            else if (g_gemm_variant == 61) emu::launch(dim3(g), dim3(512), [=] { gemm6_bf16_kernel<ACT, SW, 192, false>(a); });
+            else emu::launch(dim3(g), dim3(512), [=] { gemm6_bf16_kernel<ACT, SW, 192, true>(a); });
+            if (tile_ctr[0] || tile_ctr[1]) fprintf(stderr, "EMU: gemm6 tile counters not re-armed (%u, %u)\n", tile_ctr[0], tile_ctr[1]);
             return;
         }
         if (g_gemm_variant == 12 && a.N % 256 == 0) {            // gemm4 on 192 x 256 tiles
@@ -126,6 +145,7 @@ extern "C" int32_t vl2_gemm(const vl2_gemm_desc* d, void*) {
     a.res_row_mod = d->res_row_mod; a.res_row_off = d->res_row_off; a.tiles_m = (M + 127) / 128; a.tiles_n = N / 128;
     a.idx_ld = M; a.stats_out = d->stats_out; a.stats_out_np = N / 64; a.stats_in = d->stats_in; a.stats_in_np = K / 64;
     a.norm = d->norm; a.norm_eps = d->norm_eps; a.w_colsum = d->w_colsum; a.row_norm = d->row_norm;
+    a.tile_ctr = (unsigned*)d->tile_ctr;
     g_gemm_variant = (d->flags & VL2_GEMM_SPLITK) ? 16 : d->variant;     // 16 = the emulator's split-K form of the 128x128 kernel
     const bool sw = d->flags & 1, f32 = d->flags & 2, g = a.a_idx != nullptr;
     if (d->norm && ((!d->stats_in && !d->row_norm) || (d->norm == 2 && !d->w_colsum))) return -1;

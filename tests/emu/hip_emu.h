@@ -336,12 +336,17 @@ template <class T> static inline void emu_permlane32_swap(T& vdst, T& src) {
     if (lane >= 32) vdst = from_src; else src = from_dst;
 }
 #define VL2_PERMLANE32_SWAP_2(a, b) emu_permlane32_swap(a, b)
+#define VL2_PERMLANE32_SWAP_4(pk) do { emu_permlane32_swap(pk[0], pk[2]); emu_permlane32_swap(pk[1], pk[3]); } while (0)
+#define VL2_LANE_ID_FRESH(ln) do { ln = (int)emu::cur->lane; } while (0)
+#define VL2_LDS_I32(off) (*(int*)(vl2_smem + (off)))
+#define VL2_ATOMIC_INC_ASYNC(dst, ptr) do { dst = *(ptr); *(ptr) = dst + 1; } while (0)
 #define VL2_PIN3(a, b, c) ((void)0)
 #define VL2_PIN2(a, b) ((void)0)
 #define VL2_PERMLANE32_SWAP_8(pk) do { emu_permlane32_swap(pk[0], pk[2]); emu_permlane32_swap(pk[1], pk[3]); \
                                        emu_permlane32_swap(pk[4], pk[6]); emu_permlane32_swap(pk[5], pk[7]); } while (0)
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 static inline int emu_fetch_add(int* p, int v) { int o = *p; *p = o + v; return o; }
+static inline unsigned emu_fetch_add(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
 static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
 static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }

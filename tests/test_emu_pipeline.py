@@ -132,6 +132,37 @@ def test_emu_gemm_pingpong_variant(emu):
             ops.set_gemm_variant(0)
 
 
+def test_emu_gemm_persistent_kernels_are_bit_identical(emu):
+    """csrc/k_gemm6.h (persistent ping-pong GEMM; emulator knobs 60 = 256-row tiles, 61 = 192-row tiles, 62 = 192-row tiles with two
+    accumulator sets and the previous tile's epilogue drained under the next tile's phases): three workgroups walk 6-15 tiles each across
+    tile boundaries (ring never drained, epilogue vectors through the LDS aux block, last row tile shifted back to end at M): same bits
+    as the one-tile-per-workgroup kernel for plain / bias + QuickGELU / LayerNorm- and RMSNorm-carrying / SwiGLU epilogues."""
+    from videollama2_amd import ops
+    from videollama2_amd.weights import pack_gate_up
+    M, N, K = 700, 768, 512
+    a, w, bias = bf(M, K), bf(N, K, scale=K ** -0.5), torch.randn(N)
+    wgu = pack_gate_up(bf(384, K, seed=3, scale=K ** -0.5), bf(384, K, seed=4, scale=K ** -0.5))
+    st = ops.row_norm_finalize(ops.row_stats(a), K, ops.NORM_LN, 1e-5)
+    st_rms = ops.row_norm_finalize(ops.row_stats(a), K, ops.NORM_RMS, 1e-5)
+    colsum = w.float().sum(1)
+
+    def run():
+        return (ops.gemm(a, w), ops.gemm(a, w, bias=bias, act=ops.ACT_QGELU),
+                ops.gemm(a, w, bias=bias, norm=(ops.NORM_LN, st, 1e-5, colsum)),
+                ops.gemm(a, w, bias=bias, act=ops.ACT_QGELU, norm=(ops.NORM_LN, st, 1e-5, colsum)),
+                ops.gemm(a, w, norm=(ops.NORM_RMS, st_rms, 1e-5, None)),
+                ops.gemm(a, wgu, swiglu=True), ops.gemm(a, wgu, swiglu=True, norm=(ops.NORM_RMS, st_rms, 1e-5, None)))
+    try:
+        ops.set_gemm_variant(8)
+        refs = run()
+        for v in (60, 61, 62, 70, 71):          # 70 / 71 = 60 / 61 with the tiles handed out through the counter block
+            ops.set_gemm_variant(v)
+            for i, (r, o) in enumerate(zip(refs, run())):
+                assert torch.equal(r, o), (v, i, (r.float() - o.float()).abs().max().item())
+    finally:
+        ops.set_gemm_variant(0)
+
+
 def test_emu_gemm_splitk_plain_and_gathered(emu):
     """Split-K form of the 128x128 kernel (emulator knob 16): partial tiles through the workspace, last arriver reduces in
     split order and re-arms the tile counter (second launch reuses the counters without a host reset)."""

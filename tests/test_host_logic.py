@@ -22,7 +22,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert _lib.load().vl2_version() == 2
+    assert _lib.load().vl2_version() == 3
 
 
 def test_abi_argument_validation_without_gpu():

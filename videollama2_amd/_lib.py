@@ -17,7 +17,7 @@ class GemmDesc(ctypes.Structure):
                 ("a_idx", _vp), ("seg_k", _i32),
                 ("out_grp", _i32), ("out_grp_pad", _i32), ("out_row_off", _i32), ("res_row_mod", _i32), ("res_row_off", _i32),
                 ("stats_out", _vp), ("stats_in", _vp), ("norm", _i32), ("norm_eps", _f32), ("w_colsum", _vp), ("row_norm", _vp),
-                ("ws", _vp), ("ws_bytes", _i64), ("variant", _i32)]
+                ("ws", _vp), ("ws_bytes", _i64), ("variant", _i32), ("tile_ctr", _vp)]
 
 
 class VitLayer(ctypes.Structure):
@@ -61,6 +61,7 @@ class LlmDesc(ctypes.Structure):
 SIGNATURES = {
     "vl2_gemm": [ctypes.POINTER(GemmDesc), _vp],
     "vl2_row_stats": [_vp, _vp, _i32, _i32, _i32, _vp],
+    "vl2_fill_zero": [_vp, _i64, _vp],
     "vl2_row_norm_finalize": [_vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp],
     "vl2_vit_forward": [ctypes.POINTER(VitDesc), _vp, _i32, _vp, _i32, _vp, _vp, _i64, _vp],
     "vl2_stc_forward": [ctypes.POINTER(StcDesc), _vp, _i32, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _i64, _vp],
@@ -126,7 +127,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = _i32
         fn.argtypes = args
-    if lib.vl2_version() != 2:
+    if lib.vl2_version() != 3:
         raise Vl2HipError("libvl2hip.so ABI version mismatch")
     _lib = lib
     return lib

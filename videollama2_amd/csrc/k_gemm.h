@@ -48,6 +48,7 @@ struct GemmArgs {
     float norm_eps;
     const float* w_colsum;   // LayerNorm: s[n] = sum_k W[n][k] (fp32, of the bf16 weights as packed) [N]
     const float* row_norm;   // [rows][2] = (mean, rstd) of the A rows, already reduced (row_norm_finalize_kernel); overrides stats_in
+    unsigned* tile_ctr;      // persistent form (k_gemm6.h): two zeroed words {tiles handed out, workgroups finished}, re-armed by the kernel; null = static walk
 };
 
 // ---- norm-carrying GEMMs ------------------------------------------------------------------------------------------------

@@ -10,6 +10,7 @@
 #include "k_attn2.h"
 #include "k_decode.h"
 #include "k_gemm.h"
+#include "k_gemm6.h"
 #include "k_norm.h"
 #include "k_pack.h"
 #include "k_skinny.h"
@@ -61,8 +62,21 @@ extern "C" const char* vl2_last_error_string(void) { return g_err; }
 // [SK_GRID + 1] | split-K tile counters [SPLITK_MAX_TILES] (zero when allocated, re-armed by the kernel itself)
 #define SK_FLAGS_OFF ((int64_t)SPLITK_MAX_WG * 64 * 256 * 4)
 #define SPLITK_CNT_OFF (SK_FLAGS_OFF + (int64_t)(SK_GRID + 1) * 4 + 12)
-#define SK_WS_BYTES (SPLITK_CNT_OFF + (int64_t)SPLITK_MAX_TILES * 4)
+#define GEMM6_CTR_OFF ((SPLITK_CNT_OFF + (int64_t)SPLITK_MAX_TILES * 4 + 15) / 16 * 16)   // persistent GEMM: {tiles handed out, workgroups finished}
+#define SK_WS_BYTES (GEMM6_CTR_OFF + 16)
 extern "C" int64_t vl2_workspace_bytes(void) { return SK_WS_BYTES; }
+
+__global__ void fill_zero_kernel(uint32_t* p, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+extern "C" int32_t vl2_fill_zero(void* p, int64_t bytes, void* stream) {
+    if (!p || bytes < 0 || (bytes & 3) || ((uintptr_t)p & 3)) return fail(VL2_E_BADARG, "vl2_fill_zero: null / unaligned pointer or size");
+    if (bytes == 0) return 0;
+    const int64_t n = bytes / 4;
+    const int grid = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    hipLaunchKernelGGL(fill_zero_kernel, dim3(grid), dim3(256), 0, ST(stream), (uint32_t*)p, n);
+    return launched("vl2_fill_zero");
+}
 
 // per-call launch controls (vl2_gemm_desc: ws / ws_bytes / variant / VL2_GEMM_SPLITK) -- nothing of this is process state
 struct GemmCtl {
@@ -70,6 +84,7 @@ struct GemmCtl {
     int64_t ws_bytes;
     int variant;
     bool splitk;
+    bool no_persist = false;       // variant 24: the automatic choice without the persistent form
 };
 
 // ------------------------------------------------------------------------------------------------ GEMM
@@ -159,6 +174,66 @@ static void launch_gemm4(const GemmArgs& a0, hipStream_t s) {
     hipLaunchKernelGGL((gemm4_bf16_kernel<ACT, SW, F32, false, -1, BM>), dim3(a.tiles_m * a.tiles_n), dim3(512), GEMM4_LDS_BYTES, s, a);
 }
 
+// ---- persistent ping-pong GEMM (k_gemm6.h): ONE workgroup per CU walks its tiles, the LDS ring runs across tile boundaries, the stores
+// of a tile are never waited for, the epilogue vectors arrive by LDS-DMA.  For bf16 outputs without residual / statistics / gather / remap
+// whose 256-row grid is more than one round of workgroups (a one-round grid has nothing to overlap).  Measured in the C++ lab on one box,
+// interleaved with the one-tile-per-workgroup kernels and bit-identical to them (profiles/r04_gemm_lab_persistent.txt): ViT q/k/v
+// 9232x3072x1024 65.8 -> 59.6 us, ViT fc1 + QuickGELU 94.5 -> 87.3 (101.8 -> 89.9 with the LayerNorm carried), STC K = 1024 conv
+// 81.8 -> 75.8, STC 4096x4096 conv 258.8 -> 254.0, 8192x4096x4096 216.2 -> 212.3 (1295 TF/s).
+static int cu_count() {
+    static std::atomic<int> n{0};                                  // idempotent cache of a device constant (like lds_attr's bits)
+    int v = n.load(std::memory_order_relaxed);
+    if (v == 0) {
+        int dev = 0;
+        check(hipGetDevice(&dev));
+        check(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
+        if (v <= 0) v = 256;
+        n.store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+static bool gemm6_ok(const GemmArgs& a, int bm) {
+    return a.res == nullptr && a.stats_out == nullptr && a.a_idx == nullptr && a.out_grp == 0 && a.res_row_mod == 0 &&
+           (a.norm == 0 || a.row_norm != nullptr) && a.N % GEMM4_BN == 0 && a.K % GEMM4_BK == 0 && a.K >= 1024 && a.M >= bm;
+}
+// 0 = not this call; 60 = 256-row tiles, 61 = 192-row tiles: the smaller makespan in units of a 256-row tile (a 192-row tile costs 0.75)
+static int choose_gemm6(const GemmArgs& a) {
+#ifdef VL2_LAB_NO_PERSIST                  // scripts/gpu_r4_d.sh: the second build of a two-build A/B of the whole pipeline on one box
+    return 0;
+#endif
+#ifdef VL2_LAB_PERSIST_MASK                // 1: K < 2048 calls only (ViT q/k/v, fc1, STC K = 1024 conv), 2: K >= 2048 only
+    if ((VL2_LAB_PERSIST_MASK == 1 && a.K >= 2048) || (VL2_LAB_PERSIST_MASK == 2 && a.K < 2048)) return 0;
+#endif
+    // only with a counter block (dynamic tile hand-out): the static walk is as slow as its slowest CU (k_gemm6.h)
+    if (!gemm6_ok(a, 256) || a.tile_ctr == nullptr) return 0;
+    const int cus = cu_count();
+    const long t256 = (long)((a.M + 255) / 256) * (a.N / GEMM4_BN), t192 = (long)((a.M + 191) / 192) * (a.N / GEMM4_BN);
+    if (t256 <= cus) return 0;
+    const double ms256 = (double)((t256 + cus - 1) / cus), ms192 = 0.75 * (double)((t192 + cus - 1) / cus);
+    return ms192 < ms256 ? 71 : 70;
+}
+// kern: 60 / 61 / 62 static tile walk (256- / 192-row tiles / 192 rows + two accumulator sets), 70 / 71 = 60 / 61 through the counter block
+template <int ACT, bool SW>
+static void launch_gemm6(const GemmArgs& a0, int kern, hipStream_t s) {
+    GemmArgs a = a0;
+    if (kern >= 70) kern -= 10; else a.tile_ctr = nullptr;
+    const int bm = kern == 60 ? 256 : 192;
+    a.tiles_m = (a.M + bm - 1) / bm;
+    a.tiles_n = a.N / GEMM4_BN;
+    const long nt = (long)a.tiles_m * a.tiles_n;
+    const int g = (int)(nt < cu_count() ? nt : cu_count());
+    if (kern == 60) {
+        lds_attr<gemm6_bf16_kernel<ACT, SW, 256, false>>(GEMM6_LDS_BYTES);
+        hipLaunchKernelGGL((gemm6_bf16_kernel<ACT, SW, 256, false>), dim3(g), dim3(512), GEMM6_LDS_BYTES, s, a);
+    } else if (kern == 61) {
+        lds_attr<gemm6_bf16_kernel<ACT, SW, 192, false>>(GEMM6_LDS_BYTES);
+        hipLaunchKernelGGL((gemm6_bf16_kernel<ACT, SW, 192, false>), dim3(g), dim3(512), GEMM6_LDS_BYTES, s, a);
+    } else {
+        lds_attr<gemm6_bf16_kernel<ACT, SW, 192, true>>(GEMM6_LDS_BYTES);
+        hipLaunchKernelGGL((gemm6_bf16_kernel<ACT, SW, 192, true>), dim3(g), dim3(512), GEMM6_LDS_BYTES, s, a);
+    }
+}
+
 // Row split (returns the number of leading rows that go to the 256x256 kernel, 0 = no split).  Two cases, both two launches on the
 // same stream; every kernel accumulates K in the same order and shares one epilogue, so the output bits do not change (asserted
 // in tests/test_gpu_ops.py):
@@ -202,6 +277,22 @@ static GemmArgs gemm_rows(const GemmArgs& a0, int m0, int rows, bool f32) {
 
 template <int ACT, bool SW, bool F32, bool G>
 static void launch_gemm(const GemmArgs& a0, const GemmCtl& c, hipStream_t s) {
+    if constexpr (!G && !F32) {
+        // persistent form: on request (variants 60 / 61; 62 = 192-row tiles with two accumulator sets, measured slower, kept for the lab) or
+        // by the rule of choose_gemm6; a forced variant the call does not qualify for falls through to the automatic choice below
+        const int v6 = c.variant;
+        const int k6 = v6 == 0 ? (c.no_persist ? 0 : choose_gemm6(a0))
+                     : (v6 == 60 || v6 == 61 || v6 == 62 || ((v6 == 70 || v6 == 71) && a0.tile_ctr)) && gemm6_ok(a0, v6 == 60 || v6 == 70 ? 256 : 192) &&
+                               (v6 != 62 || a0.K >= 32 * 28) ? v6 : 0;
+        if (k6) { launch_gemm6<ACT, SW>(a0, k6, s); return; }
+        if (v6 == 24 || (v6 >= 60 && v6 <= 71)) {   // 24 = the automatic choice WITHOUT the persistent form (A/B)
+            GemmCtl c0 = c;
+            c0.variant = 0;
+            c0.no_persist = true;
+            launch_gemm<ACT, SW, F32, G>(a0, c0, s);
+            return;
+        }
+    }
     if constexpr (!G && !F32) {
         // (K < 2048 with an activation in the epilogue -- ViT fc1 + QuickGELU -- stays on its single launch: in the pipeline's rocprofv3 trace the
         //  mixed form took 105 us against 98.6 for the 128x128 kernel, although it wins the isolated micro-benchmark; end to end the two are equal:
@@ -353,7 +444,7 @@ extern "C" int32_t vl2_gemm(const vl2_gemm_desc* d, void* stream) {
     if (d->stats_out && (sw || f32)) return fail(VL2_E_UNSUPP, "vl2_gemm: stats_out needs a plain bf16 output");
     if (d->ws && (d->ws_bytes < SK_WS_BYTES || !ALIGNED16(d->ws))) return fail(VL2_E_BADARG, "vl2_gemm: workspace needs >= %lld bytes, 16-byte aligned", (long long)SK_WS_BYTES);
     const int v = d->variant;
-    if (!(v == 0 || v == 1 || v == 2 || v == 4 || v == 8 || v == 12 || v == 32 || v == 256)) return fail(VL2_E_BADARG, "vl2_gemm: unknown variant %d", v);
+    if (!(v == 0 || v == 1 || v == 2 || v == 4 || v == 8 || v == 12 || v == 32 || v == 24 || v == 60 || v == 61 || v == 62 || v == 70 || v == 71 || v == 256)) return fail(VL2_E_BADARG, "vl2_gemm: unknown variant %d", v);
     const GemmCtl ctl{d->ws, d->ws_bytes, v, (d->flags & VL2_GEMM_SPLITK) != 0};
     GemmArgs a{};
     a.A = (const bf16_t*)d->A; a.W = (const bf16_t*)d->W; a.C = d->C; a.bias = d->bias; a.res = (const bf16_t*)d->res;
@@ -366,6 +457,8 @@ extern "C" int32_t vl2_gemm(const vl2_gemm_desc* d, void* stream) {
     a.stats_out = d->stats_out; a.stats_out_np = N / 64;
     a.stats_in = d->stats_in; a.stats_in_np = K / 64;
     a.norm = d->norm; a.norm_eps = d->norm_eps; a.w_colsum = d->w_colsum; a.row_norm = d->row_norm;
+    a.tile_ctr = d->tile_ctr ? (unsigned*)d->tile_ctr : d->ws ? (unsigned*)((char*)d->ws + GEMM6_CTR_OFF) : nullptr;
+    if (d->tile_ctr && ((uintptr_t)d->tile_ctr & 7)) return fail(VL2_E_BADARG, "vl2_gemm: tile_ctr must be 8-byte aligned");
     hipStream_t s = ST(stream);
     // The kernels address A and W through raw buffer resources: 32-bit byte offsets, NUM_RECORDS 2^31 - 1.  Operands beyond
     // that are covered in chunks of rows (A, C, residual, statistics) / columns (W, bias, w_colsum, C columns): e.g. the
