@@ -177,6 +177,8 @@ def main():
     ap.add_argument("--no-encoder-graph", action="store_true",
                     help="with --gpus N > 1: launch the rank-local encoder pieces kernel by kernel instead of replaying their two hipGraphs")
     ap.add_argument("--vit-streams", type=int, default=None, help="ViT frames as N chunks on N HIP streams (default: the tower's own, 3)")
+    ap.add_argument("--stage-flags", type=int, default=0, help="experiment controls of the stage-level calls (include/vl2hip.h VL2_STAGE_*: 1 persistent GEMM, "
+                    "2 no mixed launch, 4 in-GEMM statistics reduction (ViT), 8 fused decode attention); travel in the call descriptors")
     ap.add_argument("--tune", type=str, default="", help="debug: comma list of gemm=<variant>, splitk=<0|1>, attn=<variant> (videollama2_amd/ops.py launch controls)")
     args = ap.parse_args()
 
@@ -203,6 +205,8 @@ def main():
     from videollama2_amd.model import VideoLLaMA2Hip
     from videollama2_amd.weights import LazyRandomStateDict, random_state_dict
 
+    if args.stage_flags:
+        ops.set_stage_flags(args.stage_flags)
     for kv in filter(None, args.tune.split(",")):
         k, v = kv.split("=")
         {"gemm": ops.set_gemm_variant, "splitk": lambda x: ops.set_splitk(bool(x)), "attn": ops.set_attn_kv_groups}[k](int(v))
@@ -453,16 +457,22 @@ def main():
                 e = by_shape.setdefault(pr[4], [0, 0.0, 0.0])
                 e[0] += 1; e[1] += pr[1] / 1e9; e[2] += pr[2].elapsed_time(pr[3])
         dom = max(by_shape.items(), key=lambda kv: kv[1][2]) if by_shape else None
-        kernels = ("gemm_bf16_kernel + gemm3_bf16_kernel + gemm4_bf16_kernel + gemm_l8_bf16_kernel (every vl2_gemm call of the "
-                   "step; a row-split call is two kernels back to back)")
+        kernels = ("every vl2_gemm call of the step, whichever kernel the library picks per shape: gemm_mix_bf16_kernel (a row-split call = 256x256 ping-pong "
+                   "tiles + 128x128 tail tiles in ONE launch: gate/up, STC 4096-wide convs), gemm4_bf16_kernel (256x256 / 192x256 ping-pong), "
+                   "gemm3_bf16_kernel (128x256 ping-pong), gemm_bf16_kernel (128x128), gemm_l8_bf16_kernel (one-round 128x128), gemm_s_bf16_kernel (64x64); "
+                   "gemm6_bf16_kernel (persistent) only with --stage-flags 1")
         roof = dict(bound="mfma", kernel=kernels, achieved=round(ach, 2), peak=PEAK_MFMA_BF16_TFLOPS,
                     unit="TFLOP/s", frac=round(ach / PEAK_MFMA_BF16_TFLOPS, 4), traffic=traffic,
                     launches=ngemm, avg_launch_us=round(1e3 * gms / max(ngemm, 1), 2),
                     flop_per_launch_avg=round(1e9 * gflop / max(ngemm, 1), 0), traffic_source=tsrc)
+        # every GEMM shape of the step as timed IN the pipeline (HIP events around each launch on the launch stream)
+        roof["shapes"] = [dict(M=k[0], N=k[1], K=k[2], launches=v[0], avg_launch_us=round(1e3 * v[2] / v[0], 2), tflops=round(v[1] / v[2], 1))
+                          for k, v in sorted(by_shape.items(), key=lambda kv: -kv[1][2])]
         if dom is not None:
             (dM, dN, dK), (dn, dgf, dms) = dom
-            roof["dominant"] = dict(gemm=f"M={dM} N={dN} K={dK}" + (" (gate/up + SwiGLU: 256x256 ping-pong kernel on the first 1536 rows + one-round 128x128 kernel on the last 85)"
-                                                                     if (dN, dK) == (2 * cfg["llm"]["intermediate_size"], cfg["llm"]["hidden_size"]) else ""),
+            roof["dominant"] = dict(gemm=f"M={dM} N={dN} K={dK}" + (f" (gate/up + SwiGLU: gemm_mix_bf16_kernel = 256x256 ping-pong tiles on the first {dM // 256 * 256} rows + "
+                                                                     f"128x128 tiles on the last {dM - dM // 256 * 256}, one launch)"
+                                                                     if (dN, dK) == (2 * cfg["llm"]["intermediate_size"], cfg["llm"]["hidden_size"]) and dM % 256 else ""),
                                     launches=dn, avg_launch_us=round(1e3 * dms / dn, 2), gflop_per_launch=round(dgf / dn, 1),
                                     achieved=round(dgf / dms, 2), frac=round(dgf / dms / PEAK_MFMA_BF16_TFLOPS, 4), share_of_gemm_time=round(dms / gms, 3))
 

@@ -56,6 +56,15 @@ int64_t vl2_workspace_bytes(void);
  * does not qualify gets the automatic choice), 62 = 61 with two accumulator sets (the previous tile's epilogue drained under the next
  * tile's phases; measured slower than 61, kept for A/B), 24 = the automatic choice without the persistent form (A/B).
  * Every variant produces the same bits.  profiles/r01_gemm_experiments.md, r03_experiments.md, r04_experiments.md. */
+#define VL2_GEMM_PERSISTENT 8  /* the automatic kernel choice may take the persistent form (variants 70 / 71; needs `tile_ctr` or `ws`).  Off by default:
+                                 7-10 % faster per kernel on multi-round K = 1024 shapes, but in the power-limited pipeline it slows its successors
+                                 and lost 1 ms per ViT pass on 3 of 11 boxes (profiles/r04_experiments.md) */
+#define VL2_GEMM_NO_MIX  16   /* a row-split call stays two launches instead of ONE mixed launch (A/B of gemm_mix_bf16_kernel) */
+/* stage-level descriptors (vl2_vit_desc / vl2_stc_desc / vl2_llm_desc) `flags`: experiment controls, all off by default */
+#define VL2_STAGE_PERSISTENT_GEMM  1   /* every GEMM of the stage with VL2_GEMM_PERSISTENT */
+#define VL2_STAGE_NO_MIX           2   /* ... with VL2_GEMM_NO_MIX */
+#define VL2_STAGE_SELF_REDUCE      4   /* ViT: the norm-carrying GEMMs reduce the row statistics themselves (no row_norm_finalize launches) */
+#define VL2_STAGE_FUSED_DECODE_ATTN 8  /* decode step: attention + combine as one launch (vl2_attn_decode_fused; measured slower) */
 #define VL2_NORM_NONE 0
 #define VL2_NORM_RMS  1     /* HF:modeling_mistral.py MistralRMSNorm in front of q/k/v and gate/up */
 #define VL2_NORM_LN   2     /* HF:modeling_clip.py layer_norm1 / layer_norm2 in front of q/k/v and fc1 */
@@ -229,6 +238,7 @@ typedef struct vl2_vit_desc {
     float eps, attn_scale;
     const void* patch_w; const float* patch_b; const void* pos; const void* cls_pos; const float* pre_w; const float* pre_b;
     const vl2_vit_layer* layers;   /* host array [n_layers] */
+    uint32_t flags;                /* VL2_STAGE_* */
 } vl2_vit_desc;
 int64_t vl2_vit_workspace_bytes(const vl2_vit_desc* w, int32_t T);
 /* frames: frame_dtype 0 fp32 / 1 fp16 / 2 bf16 [T,3,image,image], or 3 = uint8 [T,image,image,3] normalised in the patch-row
@@ -270,6 +280,7 @@ typedef struct vl2_stc_desc {
     vl2_stc_block s1[4], s2[4];
     const void* samp_w; const float* samp_b;                         /* Conv3d as [C, 8*C], K order (kt, kh, kw, cin) */
     const void* ro0_w; const float* ro0_b; const void* ro2_w; const float* ro2_b;
+    uint32_t flags;                /* VL2_STAGE_* */
 } vl2_stc_desc;
 int64_t vl2_stc_workspace_bytes(const vl2_stc_desc* w, int32_t T, int32_t hw, int32_t n_out);
 /* conv3d_idx: device int32 [8][n_out] gather table of the Conv3d(k2, s2, padding 1 | 0) taps (row of the s1 output per tap and
@@ -292,6 +303,7 @@ typedef struct vl2_llm_desc {
     const vl2_llm_layer* layers;   /* host array [n_layers] */
     const void* embed; const float* norm_w; const float* ones /* [D] of 1.0f */; const void* lm_head;
     const float* cos_t; const float* sin_t;                      /* fp32 [smax][64] */
+    uint32_t flags;                /* VL2_STAGE_* */
 } vl2_llm_desc;
 int64_t vl2_llm_workspace_bytes(const vl2_llm_desc* w, int32_t S);
 /* Prefill: inputs_embeds x [S, D] bf16 -> K/V cache rows 0..S-1 of every layer, fp32 logits of the LAST position [vocab]. */

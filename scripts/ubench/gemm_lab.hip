@@ -1,6 +1,6 @@
 // GEMM kernel lab (diagnostic, not part of the library): A/B of the library's GEMM kernels straight from C++ -- no Python, no
 // torch -- so a kernel edit is one hipcc of this file and a few seconds on the GPU box.
-//   build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffast-math -fno-finite-math-only -I videollama2_amd/csrc scripts/ubench/gemm_lab.hip -o scripts/ubench/gemm_lab
+//   build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffast-math -fno-finite-math-only -I videollama2_amd/csrc -I scripts/ubench scripts/ubench/gemm_lab.hip -o scripts/ubench/gemm_lab
 //   run:   scripts/ubench/gemm_lab [rounds]          (prints one line per shape and variant: us, TFLOP/s, bitwise == gemm4)
 // Operands: N(0,1) bf16 activations, N(0,1)/sqrt(K) weights (random data: the chip is power-limited, zero-filled operands
 // flatter every kernel by 15-20 %).  Variants are run in interleaved rounds inside ONE process; min over rounds is reported.
@@ -11,8 +11,8 @@
 #include <cmath>
 #include <vector>
 #include <string>
-#include "k_gemm5.h"
 #include "k_gemm6.h"
+#include "k_gemm5.h"            // scripts/ubench/: the one-wave-per-SIMD lab kernel (measured slower, never dispatched by the library)
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1); } } while (0)
 
@@ -70,11 +70,12 @@ static void launch(int variant, GemmArgs a, hipStream_t s) {
         lds_attr(gemm_bf16_kernel<ACT, SW, false, false>, GEMM_LDS_BYTES);
         a.tiles_m = (a.M + 127) / 128; a.tiles_n = a.N / 128;
         hipLaunchKernelGGL((gemm_bf16_kernel<ACT, SW, false, false>), dim3(a.tiles_m * a.tiles_n), dim3(256), GEMM_LDS_BYTES, s, a);
-    } else if (variant == 60 || variant == 61 || variant == 62 || variant == 70 || variant == 71) {   // gemm6: persistent 256-row / 192-row / 192-row with two accumulator sets; 70 / 71 = 60 / 61 with dynamic tile hand-out
+    } else if (variant == 60 || variant == 61 || variant == 62 || variant == 70 || variant == 71 || variant == 80 || variant == 81) {   // gemm6: persistent 256-row / 192-row / 192-row with two accumulator sets; 70 / 71 = 60 / 61 with dynamic tile hand-out
         static unsigned* dctr = nullptr;
         if (!dctr) { CK(hipMalloc(&dctr, 16)); CK(hipMemset(dctr, 0, 16)); }
         a.tile_ctr = variant >= 70 ? dctr : nullptr;
-        if (variant >= 70) variant -= 10;
+        a.tile_first_dyn = variant >= 80;
+        if (variant >= 80) variant -= 20; else if (variant >= 70) variant -= 10;
         static int ncu = 0;
         if (!ncu) { hipDeviceProp_t pr; CK(hipGetDeviceProperties(&pr, 0)); ncu = pr.multiProcessorCount; if (getenv("LAB_NCU")) ncu = atoi(getenv("LAB_NCU")); }
         const int bm = variant == 60 ? 256 : 192;

@@ -47,23 +47,20 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, unsigned ch
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_dst, 16, voff, 0, 0, 0);
 }
 
-// (Two lab variants of this kernel -- the softmax denominators on the matrix pipe, and the tile in two halves with matrix and vector work
-// interleaved in the wave -- were measured not faster (profiles/r03_experiments.md section 5b); their source is frozen in
-// scripts/ubench/k_attn2_lab.h, outside the product.)
+// ONES: the softmax denominators come off the matrix pipe -- one more MFMA per P fragment with an all-ones A operand accumulates
+// sum_k P[q][k] (of the bf16-rounded P the numerator uses) in every row of a 32 x 32 block; the 32 adds per lane and tile and the
+// cross-half shuffle go away.  Lab variant 4 of vl2_attn_fwd (scripts/attn_bench2.py); see profiles/r03_experiments.md section 5b.
+// PIPE: the tile is worked in two 32-key halves and the two halves' matrix and vector work are interleaved IN the wave (MFMA and VALU share
+// the issue port, and four resident waves were measured not to overlap them: profiles/r03_experiments.md section 5b): the QK^T MFMAs of half 1
+// run between the exp / sum / pack instructions of half 0, the PV MFMAs of half 0 between those of half 1; the running maximum is updated per
+// half (a rescale found in half 1 is applied to O after PV of half 0 has been issued).  Lab variant 5 of vl2_attn_fwd.
 #ifndef VL2_PERMLANE32_SWAP_2
 #define VL2_PERMLANE32_SWAP_2(a, b) asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b))
 #define VL2_PIN3(a, b, c) asm volatile("" :: "v"(a), "v"(b), "v"(c))     // a use the optimiser cannot move: pins the producers before this point
 #endif
-// CLS = true (full attention of a sequence whose row 0 is a class token, nq == nk == 1 + 64 n: the CLIP tower's 577 = 1 + 576 tokens; same
-// result as CLS = false): the class token is PEELED off the tiling.  Its KEY becomes the initial online-softmax state of every query --
-// m = s_cls, l = 1, O = V[0] from one 64-wide dot product on the vector ALU -- so the key tiles cover rows 1 .. nk - 1 exactly (nine
-// 64-key tiles instead of ten, the tenth holding ONE key) and never need a mask; its QUERY is the only live row of one extra workgroup per
-// (head, frame), so the patch queries fill whole 32-row waves (576 = 18 x 32; unpeeled, one wave of the fifth query block ran all ten
-// tiles for a single row).  19 % of the unpeeled ViT kernel's tile work was padding (HF:modeling_clip.py:272 computes the same softmax).
-template <int D, bool CAUSAL, bool CLS = false>
+template <int D, bool CAUSAL, bool ONES = false, bool PIPE = false>
 __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(AttnArgs p) {
     static_assert(D == 64 || D == 128, "attn2: head_dim 64 or 128");
-    static_assert(!(CLS && CAUSAL), "the class-token peel is for full attention");
     constexpr int NKS = D / 16;                // k-steps of the QK^T MFMA chain
     constexpr int NDB = D / 32;                // 32-row d blocks of O^T
     constexpr int K_BYTES = 64 * D * 2, STAGE = 2 * K_BYTES;
@@ -89,25 +86,21 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(AttnArgs p) {
         b = g / p.heads;
     }
     const int hk = h / p.group;
-    const int nqb_p = (p.nq - 1 + 127) >> 7;               // CLS: query blocks over the patch rows; block nqb_p holds the class query alone
-    const bool cls_blk = CLS && qb == nqb_p;
-    const int q0 = CLS ? (cls_blk ? 0 : 1 + qb * 128) : qb * 128;
+    const int q0 = qb * 128;
     const bf16_t* Q = p.q + b * p.q_bs + h * p.q_hs;
     const bf16_t* K = p.k + b * p.k_bs + hk * p.k_hs;
     const bf16_t* V = p.v + b * p.v_bs + hk * p.v_hs;
 
     // Q^T fragments: lane (q, hi) holds Q[q][16*ks + 8*hi .. +7]
-    // CLS, class-query block: only (wave 0, row 0) is a query; every other row of the block is dead (stored nowhere)
-    const int qrow = cls_blk ? (wave == 0 && l31 == 0 ? 0 : p.nq) : q0 + wave * 32 + l31;
+    const int qrow = q0 + wave * 32 + l31;
     const int qrow_c = qrow < p.nq ? qrow : p.nq - 1;
     bf16x8 qf[NKS];
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) qf[ks] = *(const bf16x8*)(Q + (size_t)qrow_c * p.q_rs + ks * 16 + hi * 8);
 
-    int kmax = CLS ? p.nk - 1 : p.nk;                       // CLS: keys of the tiles = rows 1 .. nk - 1
+    int kmax = p.nk;
     if (CAUSAL) { const int lim = q0 + 128 + p.causal_off; kmax = lim < kmax ? lim : kmax; }
     const int ntiles = (kmax + 63) >> 6;
-    constexpr int KROW0 = CLS ? 1 : 0;                      // first K / V row of tile 0
 
     // ---- LDS-DMA source offsets of this lane (bytes inside a tile; loop-invariant).  Piece pc = i * 4 + wave fills LDS bytes
     //      [pc * 1024, +1024): lane L lands at slot pc * 64 + L (16-B slots).
@@ -127,7 +120,7 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(AttnArgs p) {
     // rows past nk lie outside NUM_RECORDS and arrive as zeros (their scores are masked, their P is 0).
     // (descriptors declared with their type, not `auto`: see lds_dma16)
     auto dma_tile = [&](int t, unsigned so) {
-        const int kskip = (KROW0 + t * 64) * p.k_rs * 2, vskip = (KROW0 + t * 64) * p.v_rs * 2;
+        const int kskip = t * 64 * p.k_rs * 2, vskip = t * 64 * p.v_rs * 2;
         const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)K + kskip), 0, k_bytes > kskip ? k_bytes - kskip : 0, 0x00020000);
         const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)V + vskip), 0, v_bytes > vskip ? v_bytes - vskip : 0, 0x00020000);
 #pragma unroll
@@ -152,33 +145,10 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(AttnArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) oT[i][r] = 0.f;
     float m = -1e30f, l = 0.f;      // m: running max in the exp2 domain (first tile always rescales: mt - m is huge)
-    if constexpr (CLS) {
-        // the class token's key (row 0) as the initial state: s = q . K[0] (this lane holds half of its query's dims, the partner lane the
-        // other half), p = exp2(s c - m) = 1 with m = s c, O^T = 1 * V[0]
-        float part = 0.f;
+    f32x16 oL;                      // ONES: every register of the lane = l of its query row
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-            const u32x4 kc = *(const u32x4*)(K + ks * 16 + hi * 8);
-            const u32x4 qc = __builtin_bit_cast(u32x4, qf[ks]);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                part = __builtin_fmaf(__builtin_bit_cast(float, qc[j] << 16), __builtin_bit_cast(float, kc[j] << 16), part);
-                part = __builtin_fmaf(__builtin_bit_cast(float, qc[j] & 0xffff0000u), __builtin_bit_cast(float, kc[j] & 0xffff0000u), part);
-            }
-        }
-        m = (part + __shfl_xor(part, 32)) * p.scale_log2e;
-        l = 1.f;
-#pragma unroll
-        for (int db = 0; db < NDB; ++db)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const u32x2 vc = *(const u32x2*)(V + db * 32 + 8 * g + 4 * hi);
-                oT[db][4 * g] = __builtin_bit_cast(float, vc[0] << 16);
-                oT[db][4 * g + 1] = __builtin_bit_cast(float, vc[0] & 0xffff0000u);
-                oT[db][4 * g + 2] = __builtin_bit_cast(float, vc[1] << 16);
-                oT[db][4 * g + 3] = __builtin_bit_cast(float, vc[1] & 0xffff0000u);
-            }
-    }
+    for (int r = 0; r < 16; ++r) oL[r] = 0.f;
+    const bf16x8 ones8 = __builtin_bit_cast(bf16x8, u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u});
 
     auto compute_tile = [&](int t, unsigned so) {
         const int kv0 = t * 64;
@@ -195,8 +165,7 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(AttnArgs p) {
         }
         // online softmax, exp2 domain (k_attn.h): lane owns keys kv0 + 32kh + (r&3) + 8(r>>2) + 4hi of row qrow
         const int wq0 = q0 + wave * 32;
-        const int nk_t = CLS ? p.nk - 1 : p.nk;                 // keys covered by the tiles
-        const bool need_mask = (kv0 + 64 > nk_t) || (CAUSAL && (kv0 + 63 > wq0 + p.causal_off));
+        const bool need_mask = (kv0 + 64 > p.nk) || (CAUSAL && (kv0 + 63 > wq0 + p.causal_off));
         const float c = p.scale_log2e;
         float mt = -3.0e38f;
         if (need_mask) {
@@ -205,7 +174,7 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(AttnArgs p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = kv0 + kh * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    const bool ok = key < nk_t && (!CAUSAL || key <= qrow + p.causal_off);
+                    const bool ok = key < p.nk && (!CAUSAL || key <= qrow + p.causal_off);
                     sT[kh][r] = ok ? sT[kh][r] : -1e30f;           // raw domain; c > 0
                 }
         }
@@ -224,6 +193,10 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(AttnArgs p) {
             for (int i = 0; i < NDB; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) oT[i][r] *= alpha;
+            if constexpr (ONES) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oL[r] *= alpha;
+            }
         }
         float rs = 0.f;
 #pragma unroll
@@ -232,9 +205,9 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(AttnArgs p) {
             for (int r = 0; r < 16; ++r) {
                 const float pv = __builtin_amdgcn_exp2f(fmaf(sT[kh][r], c, -m));
                 sT[kh][r] = pv;
-                rs += pv;
+                if constexpr (!ONES) rs += pv;
             }
-        l += rs + __shfl_xor(rs, 32);
+        if constexpr (!ONES) l += rs + __shfl_xor(rs, 32);
 
         // O^T += V^T . P^T: P fragment = the score registers; V^T fragment = two transpose reads (keys kb..kb+3, kb+8..kb+11)
 #pragma unroll
@@ -245,6 +218,7 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(AttnArgs p) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) pw[j] = pack2bf(sT[kh][ks2 * 8 + 2 * j], sT[kh][ks2 * 8 + 2 * j + 1]);
                 const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
+                if constexpr (ONES) oL = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones8, pf, oL, 0, 0, 0);
 #pragma unroll
                 for (int db = 0; db < NDB; ++db) {
                     const unsigned a = so + vbase + (8 * kh + 4 * ks2) * QUAD + db * 256;
@@ -255,28 +229,170 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(AttnArgs p) {
             }
     };
 
+    // ---- PIPE: the same tile in two halves, matrix and vector work interleaved by hand (sched_barrier fences pin the order)
+    auto compute_tile_pipe = [&](int t, unsigned so) {
+        const int kv0 = t * 64;
+        const int wq0 = q0 + wave * 32;
+        const bool need_mask = (kv0 + 64 > p.nk) || (CAUSAL && (kv0 + 63 > wq0 + p.causal_off));
+        const float c = p.scale_log2e;
+        constexpr float THR = 6.0f;
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        f32x16 sT[2];
+        u32x4 pw[2][2];
+        bf16x8 kf[NKS];
+        // (mask +) max of half kh over the lane's 16 keys and the partner lane's (lanes l, l + 32 hold the two key sets of row qrow)
+        auto half_max = [&](int kh) -> float {
+            if (need_mask) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kv0 + kh * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    const bool ok = key < p.nk && (!CAUSAL || key <= qrow + p.causal_off);
+                    sT[kh][r] = ok ? sT[kh][r] : -1e30f;
+                }
+            }
+            float mt = -3.0e38f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mt = fmaxf(mt, sT[kh][r]);
+            float a = mt, b = mt;
+            VL2_PERMLANE32_SWAP_2(a, b);                  // a = lower half's value, b = upper half's, in every lane
+            return fmaxf(a, b) * c;
+        };
+        // exp / sum / pack of elements [first, first + n) of half kh (n even: whole bf16 pairs)
+        auto exp_chunk = [&](int kh, int first, int n) {
+#pragma unroll
+            for (int r = first; r < first + n; ++r) {
+                const float pv = __builtin_amdgcn_exp2f(fmaf(sT[kh][r], c, -m));
+                sT[kh][r] = pv;
+                l += pv;
+            }
+#pragma unroll
+            for (int r = first; r < first + n; r += 2) pw[kh][r >> 3][(r & 7) >> 1] = pack2bf(sT[kh][r], sT[kh][r + 1]);
+        };
+        // ---- S of half 0; the K fragments of half 1 are requested behind it
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) kf[ks] = *(const bf16x8*)(lds + so + kbase[ks]);
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) sT[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], ks == 0 ? zero16 : sT[0], 0, 0, 0);
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) kf[ks] = *(const bf16x8*)(lds + so + KH_STEP + kbase[ks]);
+        float mt = half_max(0);
+        if (!__all(mt - m <= THR)) {
+            const float m_new = fmaxf(fmaxf(m, mt), -1e28f);
+            const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+            m = m_new;
+            l *= alpha;
+#pragma unroll
+            for (int i = 0; i < NDB; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oT[i][r] *= alpha;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- region 1: S of half 1 between the exp / sum / pack of half 0.  One scheduling region; the sched_group_barrier pipeline
+        //      below tells the machine scheduler the issue order: MFMA, then its share of the vector work (VALU mask 0x2 + transcendental
+        //      mask 0x400), NKS times.  (Fences in source order are not enough: the pure exp2 / fma calls are regrouped before scheduling.)
+        constexpr int VPM1 = (16 * 3 + 8) / NKS, TPM1 = 16 / NKS;      // vector / transcendental instructions per MFMA: 16 x (fma, add) + 8 cvt; 16 exp
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) sT[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], ks == 0 ? zero16 : sT[1], 0, 0, 0);
+        exp_chunk(0, 0, 16);
+        VL2_PIN3(pw[0][0], pw[0][1], l);                  // a use INSIDE the region: the optimiser otherwise sinks the pure exp / pack work to PV
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, VPM1 - TPM1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x400, TPM1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // V^T fragments of half 0 (all of them) requested before the statistics of half 1
+        s16x4 v0[2 * NDB], v1[2 * NDB];
+#pragma unroll
+        for (int ks2 = 0; ks2 < 2; ++ks2)
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) {
+                const unsigned a = so + vbase + (4 * ks2) * QUAD + db * 256;
+                v0[ks2 * NDB + db] = lds_read_tr16(lds + a);
+                v1[ks2 * NDB + db] = lds_read_tr16(lds + a + 2 * QUAD);
+            }
+        mt = half_max(1);
+        float alpha1 = 1.0f;
+        const bool resc = !__all(mt - m <= THR);
+        if (resc) {
+            const float m_new = fmaxf(fmaxf(m, mt), -1e28f);
+            alpha1 = __builtin_amdgcn_exp2f(m - m_new);
+            m = m_new;
+            l *= alpha1;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- region 2: PV of half 0 between the exp / sum / pack of half 1 (same pipeline, 2 NDB MFMAs)
+        constexpr int VPM2 = (16 * 3 + 8) / (2 * NDB), TPM2 = 16 / (2 * NDB);
+#pragma unroll
+        for (int ks2 = 0; ks2 < 2; ++ks2)
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) {
+                const int st = ks2 * NDB + db;
+                const bf16x8 vf = {v0[st][0], v0[st][1], v0[st][2], v0[st][3], v1[st][0], v1[st][1], v1[st][2], v1[st][3]};
+                oT[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, __builtin_bit_cast(bf16x8, pw[0][ks2]), oT[db], 0, 0, 0);
+            }
+        exp_chunk(1, 0, 16);
+        VL2_PIN3(pw[1][0], pw[1][1], l);
+#pragma unroll
+        for (int st = 0; st < 2 * NDB; ++st) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, VPM2 - TPM2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x400, TPM2, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // V^T fragments of half 1
+#pragma unroll
+        for (int ks2 = 0; ks2 < 2; ++ks2)
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) {
+                const unsigned a = so + vbase + (8 + 4 * ks2) * QUAD + db * 256;
+                v0[ks2 * NDB + db] = lds_read_tr16(lds + a);
+                v1[ks2 * NDB + db] = lds_read_tr16(lds + a + 2 * QUAD);
+            }
+        if (resc) {                                       // the maximum moved in half 1: O (now holding half 0's PV as well) follows
+#pragma unroll
+            for (int i = 0; i < NDB; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oT[i][r] *= alpha1;
+        }
+        // ---- PV of half 1
+#pragma unroll
+        for (int ks2 = 0; ks2 < 2; ++ks2)
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) {
+                const int st = ks2 * NDB + db;
+                const bf16x8 vf = {v0[st][0], v0[st][1], v0[st][2], v0[st][3], v1[st][0], v1[st][1], v1[st][2], v1[st][3]};
+                oT[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, __builtin_bit_cast(bf16x8, pw[1][ks2]), oT[db], 0, 0, 0);
+            }
+    };
 
     // ---- main loop: tile t lives in stage t & 1.  Top of tile t: this wave's pieces of tile t have landed (its only
     //      outstanding VMEM), the barrier makes everyone's pieces visible AND proves every wave is done reading the other stage
     //      (tile t-1), which the DMA of tile t+1 may therefore overwrite while tile t is computed.  One barrier per tile.
     // a wave whose 32 query rows all lie past nq (the last query block of a 577-row ViT frame: rows 65..127 of it) still moves its
     // share of every K/V tile and meets every barrier, but skips the arithmetic: its issue slots go to the waves it shares a SIMD with
-    const bool live = cls_blk ? wave == 0 : q0 + wave * 32 < p.nq;
+    const bool live = q0 + wave * 32 < p.nq;
     dma_tile(0, 0);
     for (int t = 0; t < ntiles; t += 2) {
         VL2_WAIT_VMCNT(0);
         VL2_ATTN2_BARRIER();
         if (t + 1 < ntiles) dma_tile(t + 1, STAGE);
-        if (live) compute_tile(t, 0);
+        if (live) { if constexpr (PIPE) compute_tile_pipe(t, 0); else compute_tile(t, 0); }
         if (t + 1 >= ntiles) break;
         VL2_WAIT_VMCNT(0);
         VL2_ATTN2_BARRIER();
         if (t + 2 < ntiles) dma_tile(t + 2, 0);
-        if (live) compute_tile(t + 1, STAGE);
+        if (live) { if constexpr (PIPE) compute_tile_pipe(t + 1, STAGE); else compute_tile(t + 1, STAGE); }
     }
 
+    if constexpr (PIPE) {                 // l holds this lane's keys only: add the partner lane's (same query row, the other key sets)
+        float a = l, b = l;
+        VL2_PERMLANE32_SWAP_2(a, b);
+        l = a + b;
+    }
     if (qrow < p.nq) {
-        const float inv = 1.0f / l;
+        const float inv = 1.0f / (ONES ? oL[0] : l);        // (PIPE: l was completed across the two half-waves just above)
         bf16_t* O = p.o + b * p.o_bs + h * p.o_hs + (size_t)qrow * p.o_rs;
 #pragma unroll
         for (int db = 0; db < NDB; ++db)

@@ -68,7 +68,9 @@ static void run_gemm(GemmArgs a) {
             else emu::launch(dim3(n_all), dim3(512), [=] { gemm_mix_bf16_kernel<ACT, SW, false>(big, tail, n_big); });
             return;
         }
-        if (g_gemm_variant == 70 || g_gemm_variant == 71) { g_gemm6_dynamic = true; g_gemm_variant -= 10; } else g_gemm6_dynamic = false;
+        a.tile_first_dyn = 0;
+        if (g_gemm_variant == 80 || g_gemm_variant == 81) { g_gemm6_dynamic = true; a.tile_first_dyn = 1; g_gemm_variant -= 20; }
+        else if (g_gemm_variant == 70 || g_gemm_variant == 71) { g_gemm6_dynamic = true; g_gemm_variant -= 10; } else g_gemm6_dynamic = false;
         if ((g_gemm_variant == 60 || g_gemm_variant == 61 || g_gemm_variant == 62) && a.N % 256 == 0 && a.res == nullptr && !a.stats_out &&
             (!a.norm || a.row_norm) && a.M >= (g_gemm_variant == 60 ? 256 : 192) && a.K >= 512) {
             // gemm6 (persistent ping-pong): 256-row / 192-row / 192-row with two accumulator sets.  THREE workgroups, so that every
@@ -227,18 +229,14 @@ extern "C" int32_t vl2_attn_fwd(const void* q, const void* k, const void* v, voi
                v_bs, v_hs, v_rs, o_bs, o_hs, o_rs, nq, nk, group, H, B, scale * 1.4426950408889634f, causal_off};
     dim3 g((nq + 127) / 128, H, B), blk(256);
     if (causal) g = dim3(((nq + 127) / 128) * H * B, 1, 1);
+    const bool cls_peel = variant == 0 && D == 64 && !causal && nq == nk && nk > 64 && (nk - 1) % 64 == 0 && group == 1;   // as the product launcher
     if (variant == 0 && (D == 64 || D == 128)) variant = 3;   // auto, as the product launcher
     if (variant == 3) {                                     // second structure (k_attn2.h): LDS-DMA ring + transpose reads
-        if (D == 64 && !causal) emu::launch(g, blk, [=] { attn2_fwd_kernel<64, false>(a); });
+        if (cls_peel) emu::launch(dim3((nq - 1 + 127) / 128 + 1, H, B), blk, [=] { attn2_fwd_kernel<64, false, true>(a); });
+        else if (D == 64 && !causal) emu::launch(g, blk, [=] { attn2_fwd_kernel<64, false>(a); });
         else if (D == 64 && causal) emu::launch(g, blk, [=] { attn2_fwd_kernel<64, true>(a); });
         else if (D == 128 && !causal) emu::launch(g, blk, [=] { attn2_fwd_kernel<128, false>(a); });
         else if (D == 128 && causal) emu::launch(g, blk, [=] { attn2_fwd_kernel<128, true>(a); });
-        else return -2;
-        return 0;
-    }
-    if (variant == 4 || variant == 5) {                     // lab variants of the second structure (denominators on the matrix pipe / in-wave interleave)
-        if (D == 64 && !causal) { if (variant == 4) emu::launch(g, blk, [=] { attn2_fwd_kernel<64, false, true>(a); }); else emu::launch(g, blk, [=] { attn2_fwd_kernel<64, false, false, true>(a); }); }
-        else if (D == 128 && causal) { if (variant == 4) emu::launch(g, blk, [=] { attn2_fwd_kernel<128, true, true>(a); }); else emu::launch(g, blk, [=] { attn2_fwd_kernel<128, true, false, true>(a); }); }
         else return -2;
         return 0;
     }

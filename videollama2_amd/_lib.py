@@ -30,7 +30,7 @@ class VitDesc(ctypes.Structure):
     _fields_ = [("size", ctypes.c_uint32), ("family", _i32), ("image", _i32), ("patch", _i32), ("D", _i32), ("I", _i32), ("heads", _i32),
                 ("head_dim", _i32), ("n_layers", _i32), ("kp", _i32), ("act", _i32), ("eps", _f32), ("attn_scale", _f32),
                 ("patch_w", _vp), ("patch_b", _vp), ("pos", _vp), ("cls_pos", _vp), ("pre_w", _vp), ("pre_b", _vp),
-                ("layers", ctypes.POINTER(VitLayer))]
+                ("layers", ctypes.POINTER(VitLayer)), ("flags", ctypes.c_uint32)]
 
 
 class StcBlock(ctypes.Structure):
@@ -42,7 +42,7 @@ class StcBlock(ctypes.Structure):
 class StcDesc(ctypes.Structure):
     """include/vl2hip.h `vl2_stc_desc`."""
     _fields_ = [("size", ctypes.c_uint32), ("cin", _i32), ("C", _i32), ("s1", StcBlock * 4), ("s2", StcBlock * 4),
-                ("samp_w", _vp), ("samp_b", _vp), ("ro0_w", _vp), ("ro0_b", _vp), ("ro2_w", _vp), ("ro2_b", _vp)]
+                ("samp_w", _vp), ("samp_b", _vp), ("ro0_w", _vp), ("ro0_b", _vp), ("ro2_w", _vp), ("ro2_b", _vp), ("flags", ctypes.c_uint32)]
 
 
 class LlmLayer(ctypes.Structure):
@@ -54,7 +54,7 @@ class LlmDesc(ctypes.Structure):
     """include/vl2hip.h `vl2_llm_desc`."""
     _fields_ = [("size", ctypes.c_uint32), ("D", _i32), ("I", _i32), ("heads", _i32), ("kv_heads", _i32), ("n_layers", _i32), ("vocab", _i32),
                 ("smax", _i32), ("eps", _f32), ("layers", ctypes.POINTER(LlmLayer)), ("embed", _vp), ("norm_w", _vp), ("ones", _vp),
-                ("lm_head", _vp), ("cos_t", _vp), ("sin_t", _vp)]
+                ("lm_head", _vp), ("cos_t", _vp), ("sin_t", _vp), ("flags", ctypes.c_uint32)]
 
 
 # name -> argtypes (all return int32 except the two below)

@@ -49,6 +49,7 @@ struct GemmArgs {
     const float* w_colsum;   // LayerNorm: s[n] = sum_k W[n][k] (fp32, of the bf16 weights as packed) [N]
     const float* row_norm;   // [rows][2] = (mean, rstd) of the A rows, already reduced (row_norm_finalize_kernel); overrides stats_in
     unsigned* tile_ctr;      // persistent form (k_gemm6.h): two zeroed words {tiles handed out, workgroups finished}, re-armed by the kernel; null = static walk
+    int tile_first_dyn;      // persistent form: 1 = the FIRST tile of a workgroup is drawn from the counter too (a workgroup that starts late finds no work)
 };
 
 // ---- norm-carrying GEMMs ------------------------------------------------------------------------------------------------
@@ -140,12 +141,7 @@ __device__ __forceinline__ void gemm_store_patch(const GemmArgs& p0, const float
         // (sharded == unsharded, batched == one by one): (acc + bias) + residual stays in that order in every instantiation.
         // rowtab: LDS table of (mean, rstd) of the tile's rows (p.norm != 0), indexed by the row's offset in the tile.
 #pragma clang fp reassociate(off)
-#ifdef VL2_LAB_PLAIN                       // scripts/ubench/gemm_lab.hip ablation only: norm / residual / statistics compiled out
-        GemmArgs p = p0;
-        p.norm = 0; p.res = nullptr; p.stats_out = nullptr;
-#else
         const GemmArgs& p = p0;
-#endif
         constexpr int LPR = SWIGLU ? 4 : 8;            // lanes per row
         constexpr int RPP = 64 / LPR;                  // rows per pass
         constexpr int NP = 32 / RPP;                   // row passes per patch (4, SwiGLU 2)
@@ -168,9 +164,6 @@ __device__ __forceinline__ void gemm_store_patch(const GemmArgs& p0, const float
             const int m = m_base + pass * RPP + lane / LPR;
             const int mc = m < p.M ? m : p.M - 1;
             orow_[pass] = (REMAP && p.out_grp > 0) ? mc + (mc / p.out_grp) * p.out_grp_pad + p.out_row_off : mc;
-#ifdef VL2_LAB_STORE_WRAP                  // scripts/ubench/gemm_lab.hip ablation only: every tile stores into the same 256 rows (no HBM writes)
-            orow_[pass] &= 255;
-#endif
             if (p.res) {
                 const int rrow = (REMAP && p.res_row_mod > 0) ? (mc % p.res_row_mod) + p.res_row_off : orow_[pass];
                 rv_[pass] = *(const u32x4*)(p.res + (size_t)rrow * p.ldres + n);
@@ -232,12 +225,7 @@ __device__ __forceinline__ void gemm_store_patch(const GemmArgs& p0, const float
                     *(f32x4*)(c + 4) = o1;
                 } else {
                     const u32x4 packed = pack8(v);
-#ifdef VL2_LAB_NO_GSTORE                   // scripts/ubench/gemm_lab.hip ablation only: the whole epilogue except the global store itself
-                    if (p.ldc == -12345) *(u32x4*)((bf16_t*)p.C + (size_t)orow * p.ldc + n) = packed;
-                    asm volatile("" :: "v"(packed));
-#else
                     *(u32x4*)((bf16_t*)p.C + (size_t)orow * p.ldc + n) = packed;
-#endif
                     if (!SWIGLU && !REMAP && p.stats_out) {       // statistics of the row AS STORED (bf16-rounded)
                         float rf[8];
                         unpack8(packed, rf);
@@ -275,11 +263,12 @@ __device__ __forceinline__ void gemm_store_patch(const GemmArgs& p0, const float
 // a row's bits do not depend on which epilogue stored it (hash-checked on hardware, scripts/ubench/gemm_lab.hip).
 // acc[mi][nj]: 32-row blocks mi (rows m_w0 + 32 mi + (lane & 31)), 32-column blocks nj (columns n_w0 + 32 nj + ...), NJ even.
 // four v_permlane32_swap on pk[0..7]: (pk[0], pk[2]), (pk[1], pk[3]), (pk[4], pk[6]), (pk[5], pk[7]) as (vdst, src) -- lanes 32-63 of vdst
-// trade places with lanes 0-31 of src.  (The CPU test build defines the macro itself.)
+// trade places with lanes 0-31 of src; s_nop 1 in front = the wait states a VALU write needs before the swap reads it, s_nop 1 behind
+// = the same for the swap's results (the hazard recogniser does not see inside the asm).  (The CPU test build defines the macro itself.)
 #ifndef VL2_PERMLANE32_SWAP_8
 #define VL2_PERMLANE32_SWAP_8(pk)                                                                                              \
     asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\t"                                 \
-                 "v_permlane32_swap_b32 %4, %6\n\tv_permlane32_swap_b32 %5, %7"                                                 \
+                 "v_permlane32_swap_b32 %4, %6\n\tv_permlane32_swap_b32 %5, %7\n\ts_nop 1"                                        \
                  : "+v"(pk[0]), "+v"(pk[1]), "+v"(pk[2]), "+v"(pk[3]), "+v"(pk[4]), "+v"(pk[5]), "+v"(pk[6]), "+v"(pk[7]))
 #endif
 enum { EF_BIAS = 1, EF_RMS = 2, EF_LN = 4, EF_RES = 8, EF_STATS = 16 };
@@ -896,13 +885,8 @@ __device__ __forceinline__ void gemm4_body(const GemmArgs& p, int bid, int nwg) 
         const int roww = 4 * Rw + (spw >> 2), chkw = (spw & 3) ^ (Rw & 3);
         int am = m0 + rowa;
         am = am < p.M ? am : p.M - 1;
-#ifdef VL2_LAB_ALIAS_LOADS                  // scripts/ubench/gemm_lab.hip ablation only: every tile loads from the first 512 A rows / 1024 W rows (L2-resident operands)
-        a_vo[i] = ((unsigned)(am % 512) * (unsigned)p.lda + chka * 8) * 2;
-        w_vo[i] = ((unsigned)((n0 + roww) % 1024) * (unsigned)p.ldw + chkw * 8) * 2;
-#else
         a_vo[i] = ((unsigned)am * (unsigned)p.lda + chka * 8) * 2;
         w_vo[i] = ((unsigned)(n0 + roww) * (unsigned)p.ldw + chkw * 8) * 2;
-#endif
     }
     auto issue_dma = [&](int t) {
         const unsigned st = (unsigned)(t & 3) * GEMM4_STAGE, kb = (unsigned)t * (GEMM4_BK * 2);
@@ -991,13 +975,6 @@ __device__ __forceinline__ void gemm4_body(const GemmArgs& p, int bid, int nwg) 
         return;
     }
     // ---- epilogue: 32 x 64 patches (BM = 256: 2 row blocks x 2 column halves per wave; BM = 192: 3 row blocks)
-#ifdef VL2_LAB_NO_EPILOGUE          // scripts/ubench/gemm_lab.hip ablation only: main loop without the store path (accumulators kept alive)
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) asm volatile("" :: "v"(acc[mi][j]));
-    return;
-#endif
     float* ep = (float*)vl2_smem + wave * (32 * 68);
     float* rowtab = (float*)vl2_smem + 8 * (32 * 68);
     gemm_park_row_stats(p, rowtab, rst, tid, BM);

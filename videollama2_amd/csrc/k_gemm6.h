@@ -307,7 +307,30 @@ __device__ __forceinline__ void gemm6_body(const GemmArgs& p) {
 
     int c_m0, c_n0, p_m0 = 0, p_n0 = 0, n_m0 = 0, n_n0 = 0;                 // origins of the current / previous / next tile
     unsigned nxt_v = 0;                                                     // dynamic form, wave 0 lane 0: the counter value drawn for the next tile
-    tile_origin(static_t0(0), c_m0, c_n0);
+    const bool dyn0 = dyn && p.tile_first_dyn;                              // the first tile from the counter too: tickets 0, 1, 2, ... are the tiles
+    const int t_base = dyn0 ? 0 : G;                                        // tile of ticket v = t_base + v
+    int first_t0 = static_t0(0);
+    if (dyn0) {
+        // every workgroup draws its first tile: ~1.5-3 us at the head of the launch (256 tickets on one word), in exchange a workgroup that
+        // is not resident when the grid starts (a CU short on some XCD) does not hold a statically assigned tile back by a whole tile time
+        if (wave == 0 && lane == 0) VL2_LDS_I32(GEMM6_SLOT_OFF) = (int)__hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        first_t0 = __builtin_amdgcn_readfirstlane(VL2_LDS_I32(GEMM6_SLOT_OFF));
+        __syncthreads();
+        // the first G tickets are drawn in (roughly) workgroup order, i.e. round-robin over the XCDs: keep gemm4's XCD-contiguous tile order
+        if (first_t0 < G) first_t0 = xcd_remap(first_t0, G < ntiles ? G : ntiles);
+    }
+    if (dyn0 && first_t0 >= ntiles) {                                       // nothing left: count this workgroup as finished and leave
+        if constexpr (!DB) if (wave == 0 && lane == 0) {
+            const unsigned fin = __hip_atomic_fetch_add(ctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (fin == (unsigned)G - 1u) {
+                __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(ctr + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        return;
+    }
+    tile_origin(first_t0, c_m0, c_n0);
     set_offsets(c_m0, c_n0);
     issue_aux(0, c_m0, c_n0);
     issue_slab(0, 0);
@@ -363,7 +386,7 @@ __device__ __forceinline__ void gemm6_body(const GemmArgs& p) {
             VL2_WAIT_LGKMCNT0();
             VL2_PHASE_BARRIER();
             if constexpr (t == 1 && !DB) {
-                if (dyn && wave == 0 && lane == 0) VL2_LDS_I32(GEMM6_SLOT_OFF) = G + (int)nxt_v;
+                if (dyn && wave == 0 && lane == 0) VL2_LDS_I32(GEMM6_SLOT_OFF) = t_base + (int)nxt_v;
             }
             if constexpr (t == 0) {
 #pragma unroll

@@ -85,6 +85,8 @@ struct GemmCtl {
     int variant;
     bool splitk;
     bool no_persist = false;       // variant 24: the automatic choice without the persistent form
+    bool persist = false;          // VL2_GEMM_PERSISTENT: the automatic choice may take the persistent form
+    bool no_mix = false;           // VL2_GEMM_NO_MIX
 };
 
 // ------------------------------------------------------------------------------------------------ GEMM
@@ -198,12 +200,6 @@ static bool gemm6_ok(const GemmArgs& a, int bm) {
 }
 // 0 = not this call; 60 = 256-row tiles, 61 = 192-row tiles: the smaller makespan in units of a 256-row tile (a 192-row tile costs 0.75)
 static int choose_gemm6(const GemmArgs& a) {
-#ifdef VL2_LAB_NO_PERSIST                  // scripts/gpu_r4_d.sh: the second build of a two-build A/B of the whole pipeline on one box
-    return 0;
-#endif
-#ifdef VL2_LAB_PERSIST_MASK                // 1: K < 2048 calls only (ViT q/k/v, fc1, STC K = 1024 conv), 2: K >= 2048 only
-    if ((VL2_LAB_PERSIST_MASK == 1 && a.K >= 2048) || (VL2_LAB_PERSIST_MASK == 2 && a.K < 2048)) return 0;
-#endif
     // only with a counter block (dynamic tile hand-out): the static walk is as slow as its slowest CU (k_gemm6.h)
     if (!gemm6_ok(a, 256) || a.tile_ctr == nullptr) return 0;
     const int cus = cu_count();
@@ -216,7 +212,8 @@ static int choose_gemm6(const GemmArgs& a) {
 template <int ACT, bool SW>
 static void launch_gemm6(const GemmArgs& a0, int kern, hipStream_t s) {
     GemmArgs a = a0;
-    if (kern >= 70) kern -= 10; else a.tile_ctr = nullptr;
+    a.tile_first_dyn = kern >= 80;                                     // 80 / 81: the first tile of a workgroup from the counter too
+    if (kern >= 80) kern -= 20; else if (kern >= 70) kern -= 10; else a.tile_ctr = nullptr;
     const int bm = kern == 60 ? 256 : 192;
     a.tiles_m = (a.M + bm - 1) / bm;
     a.tiles_n = a.N / GEMM4_BN;
@@ -281,11 +278,12 @@ static void launch_gemm(const GemmArgs& a0, const GemmCtl& c, hipStream_t s) {
         // persistent form: on request (variants 60 / 61; 62 = 192-row tiles with two accumulator sets, measured slower, kept for the lab) or
         // by the rule of choose_gemm6; a forced variant the call does not qualify for falls through to the automatic choice below
         const int v6 = c.variant;
-        const int k6 = v6 == 0 ? (c.no_persist ? 0 : choose_gemm6(a0))
-                     : (v6 == 60 || v6 == 61 || v6 == 62 || ((v6 == 70 || v6 == 71) && a0.tile_ctr)) && gemm6_ok(a0, v6 == 60 || v6 == 70 ? 256 : 192) &&
+        const int k6 = v6 == 0 ? (c.persist && !c.no_persist ? choose_gemm6(a0) : 0)
+                     : (v6 == 60 || v6 == 61 || v6 == 62 || ((v6 == 70 || v6 == 71 || v6 == 80 || v6 == 81) && a0.tile_ctr)) &&
+                               gemm6_ok(a0, v6 == 60 || v6 == 70 || v6 == 80 ? 256 : 192) &&
                                (v6 != 62 || a0.K >= 32 * 28) ? v6 : 0;
         if (k6) { launch_gemm6<ACT, SW>(a0, k6, s); return; }
-        if (v6 == 24 || (v6 >= 60 && v6 <= 71)) {   // 24 = the automatic choice WITHOUT the persistent form (A/B)
+        if (v6 == 24 || (v6 >= 60 && v6 <= 81)) {   // 24 = the automatic choice WITHOUT the persistent form (A/B)
             GemmCtl c0 = c;
             c0.variant = 0;
             c0.no_persist = true;
@@ -303,8 +301,8 @@ static void launch_gemm(const GemmArgs& a0, const GemmCtl& c, hipStream_t s) {
             // the CUs that run out of big tiles instead of behind a second launch.  Measured against the two launches on one box
             // (scripts/gpu_r3_k.sh): gate/up at S = 1621 383.0 -> 369.7 us (prefill 26.0 -> 25.6 ms), STC 4096x4096 conv 274.7 -> 265.0,
             // STC K = 1024 conv 85.9 -> 82.2, ViT fc1 99.2 -> 96.5 (T = 8: 54.7 -> 49.9); in the pipeline the K = 1024 cases are neutral at T = 16
-            // (encode 12.90 vs 12.89 ms) and the prefill gains 0.4 ms.  VL2_GEMM_NO_MIX=1 (read once) keeps two launches / the single kernel.
-            static const bool no_mix = getenv("VL2_GEMM_NO_MIX") != nullptr;
+            // (encode 12.90 vs 12.89 ms) and the prefill gains 0.4 ms.  VL2_GEMM_NO_MIX in the descriptor keeps two launches / the single kernel.
+            const bool no_mix = c.no_mix;
             const long t_big = (long)(M1 / GEMM4_BM) * (a0.N / GEMM4_BN), t_tail = (long)tail.tiles_m * tail.tiles_n;
             if (!no_mix && t_tail > 128 && t_tail <= 512) {
                 big.tiles_m = M1 / GEMM4_BM; big.tiles_n = a0.N / GEMM4_BN;
@@ -444,8 +442,10 @@ extern "C" int32_t vl2_gemm(const vl2_gemm_desc* d, void* stream) {
     if (d->stats_out && (sw || f32)) return fail(VL2_E_UNSUPP, "vl2_gemm: stats_out needs a plain bf16 output");
     if (d->ws && (d->ws_bytes < SK_WS_BYTES || !ALIGNED16(d->ws))) return fail(VL2_E_BADARG, "vl2_gemm: workspace needs >= %lld bytes, 16-byte aligned", (long long)SK_WS_BYTES);
     const int v = d->variant;
-    if (!(v == 0 || v == 1 || v == 2 || v == 4 || v == 8 || v == 12 || v == 32 || v == 24 || v == 60 || v == 61 || v == 62 || v == 70 || v == 71 || v == 256)) return fail(VL2_E_BADARG, "vl2_gemm: unknown variant %d", v);
-    const GemmCtl ctl{d->ws, d->ws_bytes, v, (d->flags & VL2_GEMM_SPLITK) != 0};
+    if (!(v == 0 || v == 1 || v == 2 || v == 4 || v == 8 || v == 12 || v == 32 || v == 24 || v == 60 || v == 61 || v == 62 || v == 70 || v == 71 || v == 80 || v == 81 || v == 256)) return fail(VL2_E_BADARG, "vl2_gemm: unknown variant %d", v);
+    GemmCtl ctl{d->ws, d->ws_bytes, v, (d->flags & VL2_GEMM_SPLITK) != 0};
+    ctl.persist = (d->flags & VL2_GEMM_PERSISTENT) != 0;
+    ctl.no_mix = (d->flags & VL2_GEMM_NO_MIX) != 0;
     GemmArgs a{};
     a.A = (const bf16_t*)d->A; a.W = (const bf16_t*)d->W; a.C = d->C; a.bias = d->bias; a.res = (const bf16_t*)d->res;
     a.a_idx = d->a_idx; a.zero_row = nullptr;
@@ -624,10 +624,13 @@ extern "C" int32_t vl2_attn_fwd(const void* q, const void* k, const void* v, voi
         !ALIGNED16(k) || !ALIGNED16(v) || ((uintptr_t)o & 7))
         return fail(VL2_E_SHAPE, "vl2_attn_fwd: strides must keep 16-byte row alignment");
     if (causal && causal_off < 0) return fail(VL2_E_SHAPE, "vl2_attn_fwd: causal_off must be >= 0");
-    if (variant < 0 || variant > 5) return fail(VL2_E_BADARG, "vl2_attn_fwd: unknown variant %d", variant);
+    if (variant < 0 || variant > 3) return fail(VL2_E_BADARG, "vl2_attn_fwd: unknown variant %d", variant);
     // auto: the LDS-DMA / transpose-read structure wherever it is built (measured on MI355X, profiles/r02_attn_ab_*.jsonl:
     // causal D=128 S=945 / 1621 / 2973: 23.3 / 38.1 / 97.7 us vs 26.3 / 43.8 / 106.1 us; ViT D=64 T=8 / 16 / 32: 25.4 / 43.0 / 78.5 vs
     // 26.9 / 43.8 / 78.1 us); head_dim 96 (SigLIP's padded 72) stays on the register-staged kernel
+    // full attention over [class token | 64 n patch tokens] (the CLIP tower: 577 = 1 + 576): the class token is peeled off the tiling
+    // (k_attn2.h CLS = true: nine key tiles instead of ten, no dead query rows) -- automatic choice only, variant 3 keeps the plain tiling
+    const bool cls_peel = variant == 0 && D == 64 && !causal && nq == nk && nk > 64 && (nk - 1) % 64 == 0 && group == 1;
     if (variant == 0 && (D == 64 || D == 128)) variant = 3;
     // K / V tiles are fetched through raw buffer resources whose byte offsets and NUM_RECORDS are 32-bit
     if (((int64_t)(nk - 1) * k_rs + D) * 2 >= (int64_t)1 << 31 || ((int64_t)(nk - 1) * v_rs + D) * 2 >= (int64_t)1 << 31)
@@ -638,23 +641,12 @@ extern "C" int32_t vl2_attn_fwd(const void* q, const void* k, const void* v, voi
     if (causal) g = dim3(((nq + 127) / 128) * H * B, 1, 1);
     hipStream_t s = ST(stream);
     if (variant == 3) {                                   // second structure (k_attn2.h): LDS-DMA ring + transpose reads
-        if (D == 64 && !causal) hipLaunchKernelGGL((attn2_fwd_kernel<64, false>), g, b, 0, s, a);
+        if (cls_peel) hipLaunchKernelGGL((attn2_fwd_kernel<64, false, true>), dim3((nq - 1 + 127) / 128 + 1, H, B), b, 0, s, a);
+        else if (D == 64 && !causal) hipLaunchKernelGGL((attn2_fwd_kernel<64, false>), g, b, 0, s, a);
         else if (D == 64 && causal) hipLaunchKernelGGL((attn2_fwd_kernel<64, true>), g, b, 0, s, a);
         else if (D == 128 && !causal) hipLaunchKernelGGL((attn2_fwd_kernel<128, false>), g, b, 0, s, a);
         else if (D == 128 && causal) hipLaunchKernelGGL((attn2_fwd_kernel<128, true>), g, b, 0, s, a);
         else return fail(VL2_E_SHAPE, "vl2_attn_fwd: variant 3 is built for head_dim 64 and 128 (got %d)", D);
-        return launched("vl2_attn_fwd");
-    }
-    if (variant == 5) {                                   // lab: variant 3 with matrix and vector work of the two tile halves interleaved in the wave
-        if (D == 64 && !causal) hipLaunchKernelGGL((attn2_fwd_kernel<64, false, false, true>), g, b, 0, s, a);
-        else if (D == 128 && causal) hipLaunchKernelGGL((attn2_fwd_kernel<128, true, false, true>), g, b, 0, s, a);
-        else return fail(VL2_E_SHAPE, "vl2_attn_fwd: variant 5 is built for (head_dim 64, full) and (head_dim 128, causal)");
-        return launched("vl2_attn_fwd");
-    }
-    if (variant == 4) {                                   // lab: variant 3 with the softmax denominators on the matrix pipe (ones-row MFMA)
-        if (D == 64 && !causal) hipLaunchKernelGGL((attn2_fwd_kernel<64, false, true>), g, b, 0, s, a);
-        else if (D == 128 && causal) hipLaunchKernelGGL((attn2_fwd_kernel<128, true, true>), g, b, 0, s, a);
-        else return fail(VL2_E_SHAPE, "vl2_attn_fwd: variant 4 is built for (head_dim 64, full) and (head_dim 128, causal)");
         return launched("vl2_attn_fwd");
     }
     if (D == 64 && !causal) hipLaunchKernelGGL((attn_fwd_kernel<64, false>), g, b, 0, s, a);

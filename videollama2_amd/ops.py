@@ -38,7 +38,9 @@ NORM_NONE, NORM_RMS, NORM_LN = 0, 1, 2
 # Launch controls of the GEMM family.  They are HOST-side settings of this binding layer, handed to libvl2hip.so with every
 # call (vl2_gemm_desc.variant / flags / ws): the library itself holds no mutable state.
 _WORKSPACE = {}
-_CTL = dict(variant=0, splitk=False, attn_variant=0)
+_CTL = dict(variant=0, splitk=False, attn_variant=0, stage_flags=0, gemm_flags=0)
+GEMM_PERSISTENT, GEMM_NO_MIX = 8, 16                                    # vl2_gemm_desc.flags (include/vl2hip.h)
+STAGE_PERSISTENT_GEMM, STAGE_NO_MIX, STAGE_SELF_REDUCE, STAGE_FUSED_DECODE_ATTN = 1, 2, 4, 8   # vl2_*_desc.flags of the stage calls
 
 
 def attach_workspace(device):
@@ -68,6 +70,14 @@ def set_attn_kv_groups(n):
     """Causal D=128 attention (vl2_attn_fwd `variant`): 0 = auto, 1 = one group of 4 waves per workgroup, 2 = two groups that
     split the KV tiles and merge through LDS."""
     _CTL["attn_variant"] = int(n)
+
+
+def set_stage_flags(flags):
+    """Experiment controls of the stage-level entry points and of `gemm` (VL2_STAGE_* in include/vl2hip.h; all off by default):
+    STAGE_PERSISTENT_GEMM, STAGE_NO_MIX, STAGE_SELF_REDUCE, STAGE_FUSED_DECODE_ATTN.  They travel in the descriptors of the calls
+    (the library reads no environment variables and keeps no state)."""
+    _CTL["stage_flags"] = int(flags)
+    _CTL["gemm_flags"] = (GEMM_PERSISTENT if flags & STAGE_PERSISTENT_GEMM else 0) | (GEMM_NO_MIX if flags & STAGE_NO_MIX else 0)
 
 
 def set_gemm_variant(v):
@@ -103,7 +113,7 @@ def gemm(a, w, bias=None, res=None, act=ACT_NONE, swiglu=False, out_f32=False, o
     grp, grp_pad, row_off = out_map or (0, 0, 0)
     rmod, roff = res_map or (0, 0)
     ws = _ws(a.device)
-    flags = (GEMM_SWIGLU if swiglu else 0) | (GEMM_OUT_F32 if out_f32 else 0) | (GEMM_SPLITK if (_CTL["splitk"] and ws is not None) else 0)
+    flags = (GEMM_SWIGLU if swiglu else 0) | (GEMM_OUT_F32 if out_f32 else 0) | (GEMM_SPLITK if (_CTL["splitk"] and ws is not None) else 0) | _CTL["gemm_flags"]
     kind, stats_in, eps, colsum = norm if norm is not None else (NORM_NONE, None, 0.0, None)
     row_norm = None
     if stats_in is not None and stats_in.dim() == 2:      # [rows, 2] = already reduced (row_norm_finalize)
@@ -402,6 +412,7 @@ def vit_forward(desc, frames, T, out, u8_norm=None):
         raise _lib.Vl2HipError("vl2_vit_workspace_bytes: bad descriptor")
     ws = torch.empty((n,), dtype=torch.uint8, device=out.device)
     nrm = (ctypes.c_float * 7)(*[float(x) for x in u8_norm]) if u8_norm is not None else None
+    desc.flags = _CTL["stage_flags"]
     _lib.call("vl2_vit_forward", ctypes.byref(desc), _p(frames), code, ctypes.addressof(nrm) if nrm is not None else None, T, _p(out),
               _p(ws), n, _stream())
     return out
@@ -430,6 +441,7 @@ def stc_forward(desc, x, T, hw, idx, dims, out):
     if n < 0:
         raise _lib.Vl2HipError("vl2_stc_workspace_bytes: bad descriptor")
     ws = torch.empty((n,), dtype=torch.uint8, device=out.device)
+    desc.flags = _CTL["stage_flags"]
     _lib.call("vl2_stc_forward", ctypes.byref(desc), _p(x), T, hw, _p(idx), To, Ho, Wo, _p(out), _p(ws), n, _stream())
     return out
 
@@ -456,9 +468,11 @@ def _llm_ws(desc, S, device):
 
 def llm_prefill(desc, x, logits_out):
     ws, n = _llm_ws(desc, x.shape[0], x.device)
+    desc.flags = _CTL["stage_flags"]
     _lib.call("vl2_llm_prefill", ctypes.byref(desc), _p(x), x.shape[0], _p(logits_out), _p(ws), n, _stream())
     return logits_out
 
 
 def llm_decode_step(desc, logits, tok, state, hist, partial, ws):
+    desc.flags = _CTL["stage_flags"]
     _lib.call("vl2_llm_decode_step", ctypes.byref(desc), _p(logits), _p(tok), _p(state), _p(hist), _p(partial), _p(ws), ws.numel(), _stream())
