@@ -65,6 +65,7 @@ int64_t vl2_workspace_bytes(void);
 #define VL2_STAGE_NO_MIX           2   /* ... with VL2_GEMM_NO_MIX */
 #define VL2_STAGE_SELF_REDUCE      4   /* ViT: the norm-carrying GEMMs reduce the row statistics themselves (no row_norm_finalize launches) */
 #define VL2_STAGE_FUSED_DECODE_ATTN 8  /* decode step: attention + combine as one launch (vl2_attn_decode_fused; measured slower) */
+#define VL2_STAGE_NO_DECODE_TAIL  16   /* decode step: o_proj / gate-up / down as three vl2_gemv_bf16 launches instead of vl2_decode_tail (A/B) */
 #define VL2_NORM_NONE 0
 #define VL2_NORM_RMS  1     /* HF:modeling_mistral.py MistralRMSNorm in front of q/k/v and gate/up */
 #define VL2_NORM_LN   2     /* HF:modeling_clip.py layer_norm1 / layer_norm2 in front of q/k/v and fc1 */
@@ -197,6 +198,14 @@ int32_t vl2_gemv_batched_bf16(const void* W, const void* x, const float* norm_w,
 int32_t vl2_attn_decode_fused(const void* qkv, void* kcache, void* vcache, const float* cos_t, const float* sin_t, float* partial,
                               void* out, int32_t nh, int32_t nkv, int32_t smax, const int32_t* pos_dev, float scale, int32_t* cnt,
                               void* stream);
+/* Decode "tail engine" (csrc/k_decode_tail.h): x1 = x0 + Wo o; act = silu(gate) * up of RMSNorm(x1) (norm weight folded into Wgu, packed as
+ * for VL2_GEMM_SWIGLU); xout = x1 + Wd act -- HF:modeling_mistral.py:229-241 for one token -- as ONE persistent launch (one 1024-thread
+ * workgroup per CU, two grid barriers, the next phase's first weight rows in flight across each barrier) instead of three vl2_gemv_bf16
+ * launches; the same bits as those.  o [QD], x0 / x1 / xout [D], act [I] bf16 (xout may be x0); Wo [D, QD], Wgu [2 I, D], Wd [D, I].
+ * bar: 32 int32 words that must be ZERO when the launch starts (it re-arms them; vl2_llm_decode_step clears them in its argmax launch).
+ * Every spin is bounded: on a timeout bar[24] is set and the outputs are garbage.  D, QD, I <= 32704, multiples of 8 (I of 32). */
+int32_t vl2_decode_tail(const void* Wo, const void* Wgu, const void* Wd, int32_t ldwo, int32_t ldwgu, int32_t ldwd, const void* o, const void* x0,
+                        void* x1, void* act, void* xout, int32_t D, int32_t QD, int32_t I, float eps, int32_t* bar, void* stream);
 int32_t vl2_attn_decode(const void* qkv, void* kcache, void* vcache, const float* cos_t, const float* sin_t, float* partial,
                         void* out, int32_t nh, int32_t nkv, int32_t smax, int32_t pos, const int32_t* pos_dev,
                         int32_t ctx_cap, float scale, void* stream);

@@ -12,6 +12,7 @@ alignas(64) unsigned char vl2_smem[160 * 1024];
 #include "k_attn2.h"
 #include "k_stc.h"
 #include "k_decode.h"
+#include "k_decode_tail.h"
 #include "k_skinny.h"
 #include "k_pack.h"
 #include <cstdint>
@@ -232,7 +233,7 @@ extern "C" int32_t vl2_attn_fwd(const void* q, const void* k, const void* v, voi
     const bool cls_peel = variant == 0 && D == 64 && !causal && nq == nk && nk > 64 && (nk - 1) % 64 == 0 && group == 1;   // as the product launcher
     if (variant == 0 && (D == 64 || D == 128)) variant = 3;   // auto, as the product launcher
     if (variant == 3) {                                     // second structure (k_attn2.h): LDS-DMA ring + transpose reads
-        if (cls_peel) emu::launch(dim3((nq - 1 + 127) / 128 + 1, H, B), blk, [=] { attn2_fwd_kernel<64, false, true>(a); });
+        if (cls_peel) emu::launch(dim3((nq - 1 + 127) / 128 + ((((nq - 1) & 127) == 0 || ((nq - 1) & 127) > 96) ? 1 : 0), H, B), blk, [=] { attn2_fwd_kernel<64, false, true>(a); });
         else if (D == 64 && !causal) emu::launch(g, blk, [=] { attn2_fwd_kernel<64, false>(a); });
         else if (D == 64 && causal) emu::launch(g, blk, [=] { attn2_fwd_kernel<64, true>(a); });
         else if (D == 128 && !causal) emu::launch(g, blk, [=] { attn2_fwd_kernel<128, false>(a); });
@@ -399,6 +400,18 @@ static int32_t attn_decode_fused(const void* qkv, void* kc, void* vc, const floa
 static int32_t argmax_and_clear(const float* logits, int32_t V, int32_t* tok, int32_t* hist, int32_t* state, int32_t* zero, int32_t nzero,
                                 const void* embed, void* x0, int32_t D, void*) {
     emu::launch(dim3(1), dim3(1024), [=] { argmax_kernel(logits, V, tok, hist, 0, state, (int*)zero, nzero, (const bf16_t*)embed, (bf16_t*)x0, D); });
+    return 0;
+}
+// vl2_abi.hip vl2_decode_tail: the emulator runs workgroups one after the other, so the engine's three phases are three launches of the
+// SAME kernel source (single-phase instantiations: no grid barrier), a handful of workgroups each
+extern "C" int32_t vl2_decode_tail(const void* Wo, const void* Wgu, const void* Wd, int32_t ldwo, int32_t ldwgu, int32_t ldwd, const void* o,
+                                   const void* x0, void* x1, void* act, void* xout, int32_t D, int32_t QD, int32_t I, float eps, int32_t* bar, void*) {
+    if (!Wo || !Wgu || !Wd || !o || !x0 || !x1 || !act || !xout || !bar || D % 8 || QD % 8 || I % 32) return -1;
+    TailArgs a{(const bf16_t*)Wo, (const bf16_t*)Wgu, (const bf16_t*)Wd, ldwo, ldwgu, ldwd, (const bf16_t*)o, (const bf16_t*)x0, (bf16_t*)x1,
+               (bf16_t*)act, (bf16_t*)xout, D, QD, I, eps, (unsigned*)bar};
+    emu::launch(dim3(8), dim3(1024), [=] { decode_tail_kernel<1>(a); });
+    emu::launch(dim3(8), dim3(1024), [=] { decode_tail_kernel<2>(a); });
+    emu::launch(dim3(8), dim3(1024), [=] { decode_tail_kernel<4>(a); });
     return 0;
 }
 extern "C" int32_t vl2_attn_decode_fused(const void* qkv, void* kc, void* vc, const float* cos_t, const float* sin_t, float* partial, void* out,

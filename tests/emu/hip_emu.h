@@ -339,6 +339,7 @@ template <class T> static inline void emu_permlane32_swap(T& vdst, T& src) {
 #define VL2_PERMLANE32_SWAP_4(pk) do { emu_permlane32_swap(pk[0], pk[2]); emu_permlane32_swap(pk[1], pk[3]); } while (0)
 #define VL2_LANE_ID_FRESH(ln) do { ln = (int)emu::cur->lane; } while (0)
 #define VL2_LDS_I32(off) (*(int*)(vl2_smem + (off)))
+#define VL2_TAIL_STORE_BF16(ptr, val) (*(ptr) = (val))
 #define VL2_ATOMIC_INC_ASYNC(dst, ptr) do { dst = *(ptr); *(ptr) = dst + 1; } while (0)
 #define VL2_PIN3(a, b, c) ((void)0)
 #define VL2_PIN2(a, b) ((void)0)

@@ -283,10 +283,12 @@ def test_emu_attention_class_token_peel(emu):
     from videollama2_amd import ops
     D = 64
     try:
-        for B, H, N in ((2, 2, 65), (1, 3, 193), (2, 2, 577)):
+        for B, H, N in ((2, 2, 65), (1, 3, 193), (1, 2, 129), (2, 2, 577)):     # 129: the last query block is full -> an extra block for the class query
             qkv = bf(B * N, 3 * H * D, seed=N)
-            qkv[5, :D] = 4.0; qkv[0, H * D:H * D + D] = 4.0              # row 5's query loves the class key of frame 0 (head 0)
-            qkv[9, :D] = -4.0; qkv[N - 3, H * D:H * D + D] = -4.0         # row 9's query loves a late patch key
+            qkv[5, :D] = 4.0
+            qkv[0, H * D:H * D + D] = 4.0              # row 5's query loves the class key of frame 0 (head 0)
+            qkv[9, :D] = -4.0
+            qkv[N - 3, H * D:H * D + D] = -4.0         # row 9's query loves a late patch key
             st = (N * 3 * H * D, D, 3 * H * D)
             outs = {}
             for var in (3, 0):

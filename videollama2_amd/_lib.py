@@ -62,6 +62,7 @@ SIGNATURES = {
     "vl2_gemm": [ctypes.POINTER(GemmDesc), _vp],
     "vl2_row_stats": [_vp, _vp, _i32, _i32, _i32, _vp],
     "vl2_fill_zero": [_vp, _i64, _vp],
+    "vl2_decode_tail": [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp],
     "vl2_row_norm_finalize": [_vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp],
     "vl2_vit_forward": [ctypes.POINTER(VitDesc), _vp, _i32, _vp, _i32, _vp, _vp, _i64, _vp],
     "vl2_stc_forward": [ctypes.POINTER(StcDesc), _vp, _i32, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _i64, _vp],

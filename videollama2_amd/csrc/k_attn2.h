@@ -57,9 +57,9 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, unsigned ch
 // CLS = true (full attention of a sequence whose row 0 is a class token, nq == nk == 1 + 64 n: the CLIP tower's 577 = 1 + 576 tokens; same
 // result as CLS = false): the class token is PEELED off the tiling.  Its KEY becomes the initial online-softmax state of every query --
 // m = s_cls, l = 1, O = V[0] from one 64-wide dot product on the vector ALU -- so the key tiles cover rows 1 .. nk - 1 exactly (nine
-// 64-key tiles instead of ten, the tenth holding ONE key) and never need a mask; its QUERY is the only live row of one extra workgroup per
-// (head, frame), so the patch queries fill whole 32-row waves (576 = 18 x 32; unpeeled, one wave of the fifth query block ran all ten
-// tiles for a single row).  19 % of the unpeeled ViT kernel's tile work was padding (HF:modeling_clip.py:272 computes the same softmax).
+// 64-key tiles instead of ten, the tenth holding ONE key) and never need a mask; its QUERY is the only live row of a wave that holds no
+// patch row (the patch queries fill whole 32-row waves: 576 = 18 x 32; unpeeled, that wave ran all ten tiles for row 576 alone).
+// HF:modeling_clip.py:272 computes the same softmax.
 template <int D, bool CAUSAL, bool CLS = false>
 __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(AttnArgs p) {
     static_assert(D == 64 || D == 128, "attn2: head_dim 64 or 128");
@@ -89,16 +89,23 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(AttnArgs p) {
         b = g / p.heads;
     }
     const int hk = h / p.group;
-    const int nqb_p = (p.nq - 1 + 127) >> 7;               // CLS: query blocks over the patch rows; block nqb_p holds the class query alone
-    const bool cls_blk = CLS && qb == nqb_p;
-    const int q0 = CLS ? (cls_blk ? 0 : 1 + qb * 128) : qb * 128;
+    // CLS: query blocks over the patch rows.  The class query rides in the first DEAD wave of the last block (576 = 4.5 blocks: waves 2, 3
+    // of block 4 hold no patch row) -- a workgroup of its own per (head, frame) costs more than the tenth key tile it saves (measured:
+    // +256 workgroups = +6 us against -3 us); when the last block has no dead wave the launcher adds a block (qb == nqb_p) for it.
+    const int nqb_p = (p.nq - 1 + 127) >> 7;
+    const int cls_rem = (p.nq - 1) & 127;                              // patch rows in the last block (0 = it is full)
+    const bool cls_in_last = cls_rem != 0 && cls_rem <= 96;
+    const int cls_wave = CLS ? (cls_in_last ? (cls_rem + 31) >> 5 : 0) : -1;     // first dead wave of the last block / wave 0 of the extra block
+    const int cls_qb = CLS ? (cls_in_last ? nqb_p - 1 : nqb_p) : -1;
+    const bool cls_w = CLS && qb == cls_qb && wave == cls_wave;        // this wave holds the class query (row 0 of it) and nothing else
+    const int q0 = CLS ? 1 + qb * 128 : qb * 128;
     const bf16_t* Q = p.q + b * p.q_bs + h * p.q_hs;
     const bf16_t* K = p.k + b * p.k_bs + hk * p.k_hs;
     const bf16_t* V = p.v + b * p.v_bs + hk * p.v_hs;
 
     // Q^T fragments: lane (q, hi) holds Q[q][16*ks + 8*hi .. +7]
-    // CLS, class-query block: only (wave 0, row 0) is a query; every other row of the block is dead (stored nowhere)
-    const int qrow = cls_blk ? (wave == 0 && l31 == 0 ? 0 : p.nq) : q0 + wave * 32 + l31;
+    // CLS, the class-query wave: only its row 0 is a query; its other rows are dead (stored nowhere)
+    const int qrow = cls_w ? (l31 == 0 ? 0 : p.nq) : q0 + wave * 32 + l31;
     const int qrow_c = qrow < p.nq ? qrow : p.nq - 1;
     bf16x8 qf[NKS];
 #pragma unroll
@@ -261,7 +268,7 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(AttnArgs p) {
     //      (tile t-1), which the DMA of tile t+1 may therefore overwrite while tile t is computed.  One barrier per tile.
     // a wave whose 32 query rows all lie past nq (the last query block of a 577-row ViT frame: rows 65..127 of it) still moves its
     // share of every K/V tile and meets every barrier, but skips the arithmetic: its issue slots go to the waves it shares a SIMD with
-    const bool live = cls_blk ? wave == 0 : q0 + wave * 32 < p.nq;
+    const bool live = cls_w || q0 + wave * 32 < p.nq;
     dma_tile(0, 0);
     for (int t = 0; t < ntiles; t += 2) {
         VL2_WAIT_VMCNT(0);

@@ -9,6 +9,7 @@
 #include "k_attn.h"
 #include "k_attn2.h"
 #include "k_decode.h"
+#include "k_decode_tail.h"
 #include "k_gemm.h"
 #include "k_gemm6.h"
 #include "k_norm.h"
@@ -641,7 +642,7 @@ extern "C" int32_t vl2_attn_fwd(const void* q, const void* k, const void* v, voi
     if (causal) g = dim3(((nq + 127) / 128) * H * B, 1, 1);
     hipStream_t s = ST(stream);
     if (variant == 3) {                                   // second structure (k_attn2.h): LDS-DMA ring + transpose reads
-        if (cls_peel) hipLaunchKernelGGL((attn2_fwd_kernel<64, false, true>), dim3((nq - 1 + 127) / 128 + 1, H, B), b, 0, s, a);
+        if (cls_peel) hipLaunchKernelGGL((attn2_fwd_kernel<64, false, true>), dim3((nq - 1 + 127) / 128 + ((((nq - 1) & 127) == 0 || ((nq - 1) & 127) > 96) ? 1 : 0), H, B), b, 0, s, a);
         else if (D == 64 && !causal) hipLaunchKernelGGL((attn2_fwd_kernel<64, false>), g, b, 0, s, a);
         else if (D == 64 && causal) hipLaunchKernelGGL((attn2_fwd_kernel<64, true>), g, b, 0, s, a);
         else if (D == 128 && !causal) hipLaunchKernelGGL((attn2_fwd_kernel<128, false>), g, b, 0, s, a);
@@ -878,6 +879,20 @@ static int32_t argmax_and_clear(const float* logits, int32_t V, int32_t* tok, in
     hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(1024), 0, ST(stream), logits, V, tok, hist, 0, state, (int*)zero, nzero,
                        (const bf16_t*)embed, (bf16_t*)x0, D);
     return launched("vl2_llm_decode_step: argmax");
+}
+extern "C" int32_t vl2_decode_tail(const void* Wo, const void* Wgu, const void* Wd, int32_t ldwo, int32_t ldwgu, int32_t ldwd, const void* o,
+                                   const void* x0, void* x1, void* act, void* xout, int32_t D, int32_t QD, int32_t I, float eps, int32_t* bar,
+                                   void* stream) {
+    if (!Wo || !Wgu || !Wd || !o || !x0 || !x1 || !act || !xout || !bar) return fail(VL2_E_BADARG, "vl2_decode_tail: null pointer");
+    if (D <= 0 || QD <= 0 || I <= 0 || D % 8 || QD % 8 || I % 32 || ldwo % 8 || ldwgu % 8 || ldwd % 8 || D > 32704 || QD > 32704 || I > 32704)
+        return fail(VL2_E_SHAPE, "vl2_decode_tail: need D, QD %% 8 == 0, I %% 32 == 0, all <= 32704 (D %d QD %d I %d)", D, QD, I);
+    if ((uintptr_t)bar & 3) return fail(VL2_E_BADARG, "vl2_decode_tail: bar must be 4-byte aligned");
+    TailArgs a{(const bf16_t*)Wo, (const bf16_t*)Wgu, (const bf16_t*)Wd, ldwo, ldwgu, ldwd, (const bf16_t*)o, (const bf16_t*)x0, (bf16_t*)x1,
+               (bf16_t*)act, (bf16_t*)xout, D, QD, I, eps, (unsigned*)bar};
+    const int kmax = QD > D ? (QD > I ? QD : I) : (D > I ? D : I);
+    const int g = cu_count() & ~7;                                 // one workgroup per CU (the grid barrier needs all of them resident), 8 groups
+    hipLaunchKernelGGL((decode_tail_kernel<7>), dim3(g), dim3(1024), (size_t)kmax * 2, ST(stream), a);
+    return launched("vl2_decode_tail");
 }
 extern "C" int32_t vl2_embed_rows(const int32_t* ids, const void* table, void* out, int32_t n, int32_t D, int32_t ldo, void* stream) {
     if (!ids || !table || !out || n <= 0 || D % 8 || ldo % 8) return fail(VL2_E_BADARG, "vl2_embed_rows: bad args");
