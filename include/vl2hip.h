@@ -65,7 +65,10 @@ int64_t vl2_workspace_bytes(void);
 #define VL2_STAGE_NO_MIX           2   /* ... with VL2_GEMM_NO_MIX */
 #define VL2_STAGE_SELF_REDUCE      4   /* ViT: the norm-carrying GEMMs reduce the row statistics themselves (no row_norm_finalize launches) */
 #define VL2_STAGE_FUSED_DECODE_ATTN 8  /* decode step: attention + combine as one launch (vl2_attn_decode_fused; measured slower) */
-#define VL2_STAGE_NO_DECODE_TAIL  16   /* decode step: o_proj / gate-up / down as three vl2_gemv_bf16 launches instead of vl2_decode_tail (A/B) */
+#define VL2_STAGE_DECODE_TAIL      16   /* decode step: o_proj / gate-up / down as ONE vl2_decode_tail launch instead of three vl2_gemv_bf16 launches
+                                          (same bits; measured slower: 98.5 vs 66.7 us per layer, profiles/r04_experiments.md) */
+#define VL2_GEMV_RMS_PLAIN 32  /* vl2_gemv_bf16 `flags`: RMS-normalise x with NO weight vector (the norm weight is folded into W; `norm_w` is ignored):
+                                 the same bits as a vector of ones, without every workgroup reading 4 K bytes of ones */
 #define VL2_NORM_NONE 0
 #define VL2_NORM_RMS  1     /* HF:modeling_mistral.py MistralRMSNorm in front of q/k/v and gate/up */
 #define VL2_NORM_LN   2     /* HF:modeling_clip.py layer_norm1 / layer_norm2 in front of q/k/v and fc1 */
@@ -203,7 +206,10 @@ int32_t vl2_attn_decode_fused(const void* qkv, void* kcache, void* vcache, const
  * workgroup per CU, two grid barriers, the next phase's first weight rows in flight across each barrier) instead of three vl2_gemv_bf16
  * launches; the same bits as those.  o [QD], x0 / x1 / xout [D], act [I] bf16 (xout may be x0); Wo [D, QD], Wgu [2 I, D], Wd [D, I].
  * bar: 32 int32 words that must be ZERO when the launch starts (it re-arms them; vl2_llm_decode_step clears them in its argmax launch).
- * Every spin is bounded: on a timeout bar[24] is set and the outputs are garbage.  D, QD, I <= 32704, multiples of 8 (I of 32). */
+ * Every spin is bounded: on a timeout bar[24] is set and the outputs are garbage.  D, QD, I <= 32704, multiples of 8 (I of 32).
+ * MEASURED SLOWER than the three launches on MI355X (scripts/ubench/tail_lab.hip: 98.5 vs 66.7 us per Mistral-7B layer -- a grid barrier
+ * with its write-through hand-off costs ~11 us against ~3.6 us of fixed cost per GEMV launch, and one 16-wave workgroup per CU streams the
+ * gate/up rows at 5 TB/s instead of 6.4): nothing takes it by default (VL2_STAGE_DECODE_TAIL). */
 int32_t vl2_decode_tail(const void* Wo, const void* Wgu, const void* Wd, int32_t ldwo, int32_t ldwgu, int32_t ldwd, const void* o, const void* x0,
                         void* x1, void* act, void* xout, int32_t D, int32_t QD, int32_t I, float eps, int32_t* bar, void* stream);
 int32_t vl2_attn_decode(const void* qkv, void* kcache, void* vcache, const float* cos_t, const float* sin_t, float* partial,

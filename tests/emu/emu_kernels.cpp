@@ -317,7 +317,8 @@ extern "C" int32_t vl2_rope_kv(const void* qkv, void* q_out, void* kc, void* vc,
 }
 extern "C" int32_t vl2_gemv_bf16(const void* W, const void* x, const float* norm_w, const void* res, const float* bias, void* y,
                                  int32_t N, int32_t K, int32_t ldw, float eps, int32_t flags, void*) {
-    GemvArgs a{(const bf16_t*)W, (const bf16_t*)x, norm_w, (const bf16_t*)res, y, N, K, ldw, eps, bias, 0, 0, 0};
+    GemvArgs a{(const bf16_t*)W, (const bf16_t*)x, norm_w, (const bf16_t*)res, y, N, K, ldw, eps, bias, 0, 0, 0, 0};
+    if (flags & VL2_GEMV_RMS_PLAIN) { a.norm_w = nullptr; a.rms_plain = 1; }
     const bool sw = flags & 1, f32 = flags & 2;
     const int n_out = sw ? N / 2 : N;
     dim3 g((n_out + 7) / 8), blk(256);

@@ -63,6 +63,7 @@ struct GemvArgs {
     float eps;
     const float* bias;      // [N_out] added before the residual (Qwen2 q/k/v bias) or null; not with SWIGLU
     int ldx, ldy, ldres;    // gemv_mr only: element strides between the MB rows of x / y / res
+    int rms_plain;          // gemv_bf16_kernel: RMS-normalise x without a weight vector (norm_w folded into W): (v * rstd) * 1 == v * rstd, same bits
 };
 
 // grid = ceil(N_out / (4*RPW)), block 256; dynamic LDS = K * 2 bytes (x as bf16)
@@ -100,7 +101,8 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvArgs p) {
     if (one_pass && jfirst < n_out) issue_row(jfirst, 0);
     // stage x (optionally RMS-normalised: HF MistralRMSNorm, fp32 statistics, result rounded to bf16)
     float rstd = 1.f;
-    if (p.norm_w) {
+    const bool norm = p.norm_w != nullptr || p.rms_plain;
+    if (norm) {
         float ss = 0.f;
         for (int k = tid * 8; k < p.K; k += 2048) {
             float v[8];
@@ -115,10 +117,11 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvArgs p) {
     }
     for (int k = tid * 8; k < p.K; k += 2048) {
         u32x4 raw = *(const u32x4*)(p.x + k);
-        if (p.norm_w) {
+        if (norm) {
             float v[8];
             unpack8(raw, v);
-            const f32x4 w0 = *(const f32x4*)(p.norm_w + k), w1 = *(const f32x4*)(p.norm_w + k + 4);
+            f32x4 w0 = {1.f, 1.f, 1.f, 1.f}, w1 = w0;
+            if (p.norm_w) { w0 = *(const f32x4*)(p.norm_w + k); w1 = *(const f32x4*)(p.norm_w + k + 4); }
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = (v[j] * rstd) * (j < 4 ? w0[j] : w1[j - 4]);
             raw = pack8(v);

@@ -40,6 +40,7 @@ struct TailArgs {
 #define TAIL_WAVES 16
 #define TAIL_BARW 15                      // the wave that runs the grid-barrier protocol (it prefetches nothing across a barrier)
 #define TAIL_SPIN_LIMIT (1 << 20)
+#define TAIL_MAX_ROWS 8                   // rows of one phase per wave (the launcher checks I <= 8 * 16 * workgroups)
 
 #ifndef VL2_TAIL_STORE_BF16               // write-through store of one bf16 (the CPU test build defines its own)
 #define VL2_TAIL_STORE_BF16(ptr, val) __hip_atomic_store((unsigned short*)(ptr), (unsigned short)(val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
@@ -73,6 +74,7 @@ __global__ __launch_bounds__(1024) void decode_tail_kernel(TailArgs p) {
 #pragma clang fp reassociate(off)                                     // the RMSNorm arithmetic in gemv_bf16_kernel's order (k_decode.h)
     extern __shared__ __attribute__((aligned(16))) unsigned char vl2_smem[];
     __shared__ float red[4];
+    __shared__ float outs[TAIL_WAVES][TAIL_MAX_ROWS];                // a wave's results of the current phase (stored behind the row loop)
     bf16_t* xs = (bf16_t*)vl2_smem;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -148,20 +150,44 @@ __global__ __launch_bounds__(1024) void decode_tail_kernel(TailArgs p) {
     unsigned gen = 0;
     bool pre = false;                                                 // the first pass of the next phase's first row is already in flight
 
-    // ---------------- phase 0: x1 = x0 + Wo o
-    if constexpr (PHASES & 1) {
-        const int nvec = p.QD >> 3;
-        if (gw < p.D) issue_row(p.Wo, p.ldwo, nvec, false, gw, 0);
-        stage_x(p.o, p.QD, false);
-        for (int j = gw; j < p.D; j += nwaves) {
+    // One phase: rows gw, gw + nwaves, ... < N of W [N, K] against x (already being staged by the caller's stage_x).  The FIRST pass of the
+    // first row is in flight when this is called (issued at the phase start, or before the grid barrier) and is consumed first, on its own
+    // path: hipcc's waitcnt pass then sees no load pending when the loop below re-issues into the same registers (with the first row inside
+    // the loop it drains vmcnt before EVERY load it issues -- eight serialized memory round trips per row, measured 3.77 ms per token).
+    // fin(row ordinal r, row j, a0, a1) -> the row's value, parked in LDS; the stores leave behind the loop (a pending store next to the row
+    // loads has the same effect on the pass).
+    auto run_rows = [&](const bf16_t* W, int ldw, int K, bool swiglu, int N, auto fin) {
+        const int nvec = K >> 3;
+        if (gw < N) {
             float a0 = 0.f, a1 = 0.f;
-            for (int v0 = 0; v0 < nvec; v0 += 512) {
-                if (!(j == gw && v0 == 0)) issue_row(p.Wo, p.ldwo, nvec, false, j, v0);
-                dots(nvec, false, v0, a0, a1);
+            dots(nvec, swiglu, 0, a0, a1);
+            for (int v0 = 512; v0 < nvec; v0 += 512) {
+                issue_row(W, ldw, nvec, swiglu, gw, v0);
+                dots(nvec, swiglu, v0, a0, a1);
             }
             a0 = wave_sum(a0);
-            if (lane == 0) store_out(p.x1 + j, a0 + bf2f(p.x0[j]));
+            if (swiglu) a1 = wave_sum(a1);
+            if (lane == 0) outs[wave][0] = fin(gw, a0, a1);
         }
+        int r = 1;
+        for (int j = gw + nwaves; j < N; j += nwaves, ++r) {
+            float a0 = 0.f, a1 = 0.f;
+            for (int v0 = 0; v0 < nvec; v0 += 512) {
+                issue_row(W, ldw, nvec, swiglu, j, v0);
+                dots(nvec, swiglu, v0, a0, a1);
+            }
+            a0 = wave_sum(a0);
+            if (swiglu) a1 = wave_sum(a1);
+            if (lane == 0) outs[wave][r] = fin(j, a0, a1);
+        }
+    };
+    // ---------------- phase 0: x1 = x0 + Wo o
+    if constexpr (PHASES & 1) {
+        if (gw < p.D) issue_row(p.Wo, p.ldwo, p.QD >> 3, false, gw, 0);
+        stage_x(p.o, p.QD, false);
+        run_rows(p.Wo, p.ldwo, p.QD, false, p.D, [&](int j, float a0, float) { return a0 + bf2f(p.x0[j]); });
+        if (lane == 0)
+            for (int j = gw, r = 0; j < p.D; j += nwaves, ++r) store_out(p.x1 + j, outs[wave][r]);
     }
     if constexpr (ENGINE) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's write-through stores have left
@@ -170,19 +196,11 @@ __global__ __launch_bounds__(1024) void decode_tail_kernel(TailArgs p) {
     }
     // ---------------- phase 1: act = silu(gate) * up of RMSNorm(x1)
     if constexpr (PHASES & 2) {
-        const int nvec = p.D >> 3;
-        if (!pre && gw < p.I) issue_row(p.Wgu, p.ldwgu, nvec, true, gw, 0);
+        if (!pre && gw < p.I) issue_row(p.Wgu, p.ldwgu, p.D >> 3, true, gw, 0);
         stage_x(p.x1, p.D, true);
-        for (int j = gw; j < p.I; j += nwaves) {
-            float a0 = 0.f, a1 = 0.f;
-            for (int v0 = 0; v0 < nvec; v0 += 512) {
-                if (!(j == gw && v0 == 0)) issue_row(p.Wgu, p.ldwgu, nvec, true, j, v0);
-                dots(nvec, true, v0, a0, a1);
-            }
-            a0 = wave_sum(a0);
-            a1 = wave_sum(a1);
-            if (lane == 0) store_out(p.act + j, silu_f(a0) * a1);
-        }
+        run_rows(p.Wgu, p.ldwgu, p.D, true, p.I, [&](int, float a0, float a1) { return silu_f(a0) * a1; });
+        if (lane == 0)
+            for (int j = gw, r = 0; j < p.I; j += nwaves, ++r) store_out(p.act + j, outs[wave][r]);
         pre = false;
     }
     if constexpr (ENGINE) {
@@ -192,18 +210,11 @@ __global__ __launch_bounds__(1024) void decode_tail_kernel(TailArgs p) {
     }
     // ---------------- phase 2: xout = x1 + Wd act
     if constexpr (PHASES & 4) {
-        const int nvec = p.I >> 3;
-        if (!pre && gw < p.D) issue_row(p.Wd, p.ldwd, nvec, false, gw, 0);
+        if (!pre && gw < p.D) issue_row(p.Wd, p.ldwd, p.I >> 3, false, gw, 0);
         stage_x(p.act, p.I, false);
-        for (int j = gw; j < p.D; j += nwaves) {
-            float a0 = 0.f, a1 = 0.f;
-            for (int v0 = 0; v0 < nvec; v0 += 512) {
-                if (!(j == gw && v0 == 0)) issue_row(p.Wd, p.ldwd, nvec, false, j, v0);
-                dots(nvec, false, v0, a0, a1);
-            }
-            a0 = wave_sum(a0);
-            if (lane == 0) p.xout[j] = f2bf(a0 + bf2f(p.x1[j]));
-        }
+        run_rows(p.Wd, p.ldwd, p.I, false, p.D, [&](int j, float a0, float) { return a0 + bf2f(p.x1[j]); });
+        if (lane == 0)
+            for (int j = gw, r = 0; j < p.D; j += nwaves, ++r) p.xout[j] = f2bf(outs[wave][r]);
     }
     if constexpr (ENGINE) {
         // the last workgroup to finish re-arms the barrier words (everyone else has left every poll by then)

@@ -771,7 +771,8 @@ extern "C" int32_t vl2_gemv_bf16(const void* W, const void* x, const float* norm
     if (K % 8 || ldw % 8 || K > 32704) return fail(VL2_E_SHAPE, "vl2_gemv_bf16: need K%%8==0, K<=32704 (x lives in LDS; K=%d)", K);
     const bool sw = flags & VL2_GEMM_SWIGLU, f32 = flags & VL2_GEMM_OUT_F32;
     if (sw && (N % 64 || f32 || bias)) return fail(VL2_E_SHAPE, "vl2_gemv_bf16: SWIGLU needs N%%64==0, bf16 output, no bias");
-    GemvArgs a{(const bf16_t*)W, (const bf16_t*)x, norm_w, (const bf16_t*)res, y, N, K, ldw, eps, bias, 0, 0, 0};
+    GemvArgs a{(const bf16_t*)W, (const bf16_t*)x, norm_w, (const bf16_t*)res, y, N, K, ldw, eps, bias, 0, 0, 0, 0};
+    if (flags & VL2_GEMV_RMS_PLAIN) { a.norm_w = nullptr; a.rms_plain = 1; }
     if (sw) launch_gemv<true, false>(a, N / 2, ST(stream));
     else if (f32) launch_gemv<false, true>(a, N, ST(stream));
     else launch_gemv<false, false>(a, N, ST(stream));
@@ -891,6 +892,8 @@ extern "C" int32_t vl2_decode_tail(const void* Wo, const void* Wgu, const void* 
                (bf16_t*)act, (bf16_t*)xout, D, QD, I, eps, (unsigned*)bar};
     const int kmax = QD > D ? (QD > I ? QD : I) : (D > I ? D : I);
     const int g = cu_count() & ~7;                                 // one workgroup per CU (the grid barrier needs all of them resident), 8 groups
+    if (g <= 0 || (long)I > (long)TAIL_MAX_ROWS * TAIL_WAVES * g || (long)D > (long)TAIL_MAX_ROWS * TAIL_WAVES * g)
+        return fail(VL2_E_SHAPE, "vl2_decode_tail: %d rows per phase exceed %d per wave on %d workgroups", I > D ? I : D, TAIL_MAX_ROWS, g);
     hipLaunchKernelGGL((decode_tail_kernel<7>), dim3(g), dim3(1024), (size_t)kmax * 2, ST(stream), a);
     return launched("vl2_decode_tail");
 }

@@ -40,7 +40,7 @@ NORM_NONE, NORM_RMS, NORM_LN = 0, 1, 2
 _WORKSPACE = {}
 _CTL = dict(variant=0, splitk=False, attn_variant=0, stage_flags=0, gemm_flags=0)
 GEMM_PERSISTENT, GEMM_NO_MIX = 8, 16                                    # vl2_gemm_desc.flags (include/vl2hip.h)
-STAGE_PERSISTENT_GEMM, STAGE_NO_MIX, STAGE_SELF_REDUCE, STAGE_FUSED_DECODE_ATTN, STAGE_NO_DECODE_TAIL = 1, 2, 4, 8, 16   # vl2_*_desc.flags of the stage calls
+STAGE_PERSISTENT_GEMM, STAGE_NO_MIX, STAGE_SELF_REDUCE, STAGE_FUSED_DECODE_ATTN, STAGE_DECODE_TAIL = 1, 2, 4, 8, 16   # vl2_*_desc.flags of the stage calls
 
 
 def attach_workspace(device):
