@@ -911,6 +911,10 @@ def test_emu_parity_full_end_to_end_dry_run(emu):
     try:
         PF.run_end_to_end(O.config_small(4), 4, 3, 256)
         assert any(r.get("stage", "").startswith("e2e greedy tokens") for r in PF.RECORD)
+        # massive-activation channels + shifted stream (ONE planted channel: the small config's streams are 64-256 wide, six channels
+        # would be a tenth of it; the GPU test plants six in 1024 / 4096)
+        PF.run_end_to_end(O.config_small(4), 4, 2, 256, mutate=lambda sd, cfg: PF.plant_outliers(sd, cfg, n_ch=1), tag="outliers ")
+        assert any(r.get("stage", "").startswith("outliers e2e greedy tokens") for r in PF.RECORD)
     finally:
         PF.DEV = saved
         del PF.RECORD[:]

@@ -14,10 +14,26 @@ from tests.util import rel, token_tie_ok
 DEV = "cuda"
 
 
+def bf16_floor(cfg, sd, x, toks, lg, dev):
+    """rel-L2 of the REFERENCE's own bf16 arithmetic (the oracle restatement run in bf16 on torch-ROCm) against the fp32 oracle, per step
+    (prefill + teacher-forced decode): the floor the sharded decoder is judged against, measured on the same weights and inputs."""
+    sd16 = {k: v.to(device=dev, dtype=torch.bfloat16) for k, v in sd.items()}
+    out = []
+    with torch.no_grad():
+        l16, caches = O.mistral_forward(sd16, cfg, x.to(dev).bfloat16(), 0, None)
+        out.append(rel(l16[0].float(), lg[0]))
+        for s in range(len(toks) - 1):
+            xt = torch.nn.functional.embedding(torch.tensor([toks[s]], device=dev), sd16["model.embed_tokens.weight"])
+            l16, caches = O.mistral_forward(sd16, cfg, xt, x.shape[0] + s, caches)
+            out.append(rel(l16[0].float(), lg[s + 1]))
+    return out
+
+
 def run_local_tp(cfg, sd, x, toks, lg, R, max_seq_len, dev):
     from videollama2_amd.decoder import HipMistralDecoder
     from videollama2_amd.dist import LocalTensorParallel
     n_dec = len(toks) - 1
+    floor = bf16_floor(cfg, sd, x, toks, lg, dev)
     one = HipMistralDecoder(cfg, sd, dev, max_seq_len=max_seq_len)
     ref = [one.prefill(x.to(dev)).clone()]
     for s in range(n_dec):
@@ -48,8 +64,11 @@ def run_local_tp(cfg, sd, x, toks, lg, R, max_seq_len, dev):
         for r in range(1, R):
             assert torch.equal(outs[r][s], outs[0][s]), (s, r)                 # replicated lm_head on identical sums: same bits on every rank
         e_tp, e_one, e_rel = rel(outs[0][s], lg[s]), rel(ref[s], lg[s]), rel(outs[0][s], ref[s].float())
-        rows.append((e_tp, e_one, e_rel))
-        assert e_tp < 2.5e-2 and e_rel < 2.5e-2, (R, s, e_tp, e_one, e_rel)
+        rows.append((e_tp, e_one, e_rel, floor[s]))
+        # against the fp32 oracle: the floor rule of the parity suite (twice the reference's own bf16 error on the same inputs, 4e-3 at least);
+        # sharded against unsharded: two bf16 paths apart, i.e. within the sum of their distances to fp32
+        tol = max(2.0 * floor[s], 4e-3)
+        assert e_tp <= tol and e_one <= tol and e_rel <= e_tp + e_one, (R, s, e_tp, e_one, e_rel, floor[s])
         if int(outs[0][s].argmax()) != toks[s]:
             ok, margin, dmax = token_tie_ok(outs[0][s], lg[s])
             assert ok, (R, s, margin, dmax)
@@ -67,5 +86,5 @@ def test_tp_real_shards_two_full_width_layers(R):
     with torch.no_grad():
         toks, lg = O.greedy_generate(sd, cfg, x, 4)
     rows = run_local_tp(cfg, sd, x, toks, lg, R, 512, DEV)
-    print(f"[tp-local] TP={R}: rel-L2 vs fp32 oracle (sharded / unsharded) and sharded vs unsharded per step:",
+    print(f"[tp-local] TP={R}: rel-L2 vs fp32 oracle (sharded / unsharded), sharded vs unsharded, reference-bf16 floor per step:",
           [tuple(round(v, 5) for v in r) for r in rows])
