@@ -3,9 +3,10 @@
 #pragma once
 #include <stdint.h>
 
-typedef uint16_t bf16_t;                                           // raw bfloat16 bits
+typedef uint16_t bf16_t;                                           // raw bits of one 16-bit element (bfloat16; IEEE half with -DVL2_ELEM_F16)
 typedef short bf16x8 __attribute__((ext_vector_type(8)));          // 8 bf16 = one MFMA A/B fragment = 16 B
 typedef short bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -13,22 +14,47 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 #define VL2_WAVE 64
 
+// ---- the 16-bit element type of activations and weights.  Default build: bfloat16 (BASELINE.json configs[1]).  -DVL2_ELEM_F16 builds the
+// same library on IEEE half -- the reference's own dtype (videollama2/__init__.py:60 `.half().cuda()`, model/__init__.py:71
+// torch_dtype=float16): mfma_f32_32x32x16_f16 runs at the bf16 rate on gfx950 and carries three more mantissa bits.  Everything below this
+// block is written against these helpers (`bf16_t` = "raw 16-bit element" in both builds; names kept from the bf16-only rounds).
+#ifdef VL2_ELEM_F16
+typedef _Float16 vl2_f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 vl2_f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ float bf2f(bf16_t b) { return (float)__builtin_bit_cast(_Float16, b); }
+__device__ __forceinline__ float bf2f_s(short b) { return (float)__builtin_bit_cast(_Float16, b); }
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (_Float16)f); }           // round-to-nearest-even
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, vl2_f16x2));
+}
+__device__ __forceinline__ float e_lo(uint32_t u) { return (float)__builtin_bit_cast(vl2_f16x2, u)[0]; }    // element 0 / 1 of a packed pair
+__device__ __forceinline__ float e_hi(uint32_t u) { return (float)__builtin_bit_cast(vl2_f16x2, u)[1]; }
+#define VL2_MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(vl2_f16x8, a), __builtin_bit_cast(vl2_f16x8, b), c, 0, 0, 0)
+#define VL2_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(vl2_f16x8, a), __builtin_bit_cast(vl2_f16x8, b), c, 0, 0, 0)
+#define VL2_ELEM_NAME "fp16"
+#else
 __device__ __forceinline__ float bf2f(bf16_t b) { return __builtin_bit_cast(float, ((uint32_t)b) << 16); }
 __device__ __forceinline__ float bf2f_s(short b) { return __builtin_bit_cast(float, ((uint32_t)(uint16_t)b) << 16); }
 // float -> bf16, round-to-nearest-even (torch semantics); on gfx950 this is v_cvt_pk_bf16_f32
 typedef __bf16 bf16v2_hw __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
     const f32x2 v = {lo, hi};
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16v2_hw));
 }
+__device__ __forceinline__ float e_lo(uint32_t u) { return __builtin_bit_cast(float, u << 16); }              // element 0 / 1 of a packed pair
+__device__ __forceinline__ float e_hi(uint32_t u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+#define VL2_MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#define VL2_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#define VL2_ELEM_NAME "bf16"
+#endif
 
 __device__ __forceinline__ void unpack8(const u32x4& v, float* f) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        f[2 * i] = __builtin_bit_cast(float, v[i] << 16);
-        f[2 * i + 1] = __builtin_bit_cast(float, v[i] & 0xffff0000u);
+        f[2 * i] = e_lo(v[i]);
+        f[2 * i + 1] = e_hi(v[i]);
     }
 }
 __device__ __forceinline__ u32x4 pack8(const float* f) {

@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256 * NG, 2) void attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
                 const bf16x8 kf = *(const bf16x8*)(Ks + attn_k_off<D>(kh * 32 + l31, ks * 2 + hi));
-                sT[kh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? zero16 : sT[kh], 0, 0, 0);
+                sT[kh] = VL2_MFMA32(kf, qf[ks], ks == 0 ? zero16 : sT[kh]);
             }
         }
         // online softmax (exp2 domain: p = 2^(s*c - m), c = scale*log2 e folded into one FMA per score).
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256 * NG, 2) void attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
                 for (int db = 0; db < NDB; ++db) {
                     const bf16x8 vf = *(const bf16x8*)(Vt + attn_vt_off<D>(db * 32 + l31, c16));
-                    oT[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oT[db], 0, 0, 0);
+                    oT[db] = VL2_MFMA32(vf, pf, oT[db]);
                 }
             }
     }

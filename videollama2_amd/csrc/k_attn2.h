@@ -169,8 +169,8 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(AttnArgs p) {
             const u32x4 qc = __builtin_bit_cast(u32x4, qf[ks]);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                part = __builtin_fmaf(__builtin_bit_cast(float, qc[j] << 16), __builtin_bit_cast(float, kc[j] << 16), part);
-                part = __builtin_fmaf(__builtin_bit_cast(float, qc[j] & 0xffff0000u), __builtin_bit_cast(float, kc[j] & 0xffff0000u), part);
+                part = __builtin_fmaf(e_lo(qc[j]), e_lo(kc[j]), part);
+                part = __builtin_fmaf(e_hi(qc[j]), e_hi(kc[j]), part);
             }
         }
         m = (part + __shfl_xor(part, 32)) * p.scale_log2e;
@@ -180,10 +180,10 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(AttnArgs p) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const u32x2 vc = *(const u32x2*)(V + db * 32 + 8 * g + 4 * hi);
-                oT[db][4 * g] = __builtin_bit_cast(float, vc[0] << 16);
-                oT[db][4 * g + 1] = __builtin_bit_cast(float, vc[0] & 0xffff0000u);
-                oT[db][4 * g + 2] = __builtin_bit_cast(float, vc[1] << 16);
-                oT[db][4 * g + 3] = __builtin_bit_cast(float, vc[1] & 0xffff0000u);
+                oT[db][4 * g] = e_lo(vc[0]);
+                oT[db][4 * g + 1] = e_hi(vc[0]);
+                oT[db][4 * g + 2] = e_lo(vc[1]);
+                oT[db][4 * g + 3] = e_hi(vc[1]);
             }
     }
 
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(AttnArgs p) {
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
                 const bf16x8 kf = *(const bf16x8*)(lds + so + kh * KH_STEP + kbase[ks]);
-                sT[kh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? zero16 : sT[kh], 0, 0, 0);
+                sT[kh] = VL2_MFMA32(kf, qf[ks], ks == 0 ? zero16 : sT[kh]);
             }
         }
         // online softmax, exp2 domain (k_attn.h): lane owns keys kv0 + 32kh + (r&3) + 8(r>>2) + 4hi of row qrow
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(AttnArgs p) {
                     const unsigned a = so + vbase + (8 * kh + 4 * ks2) * QUAD + db * 256;
                     const s16x4 v0 = lds_read_tr16(lds + a), v1 = lds_read_tr16(lds + a + 2 * QUAD);
                     const bf16x8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                    oT[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oT[db], 0, 0, 0);
+                    oT[db] = VL2_MFMA32(vf, pf, oT[db]);
                 }
             }
     };

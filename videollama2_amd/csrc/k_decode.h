@@ -9,10 +9,17 @@
 #pragma once
 #include "dev_common.h"
 
+// c + a.lo * b.lo + a.hi * b.hi of two packed element pairs (v_dot2c_f32_bf16 / v_dot2_f32_f16)
+#ifdef VL2_ELEM_F16
+__device__ __forceinline__ float dot2_bf16(uint32_t a, uint32_t b, float c) {
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(vl2_f16x2, a), __builtin_bit_cast(vl2_f16x2, b), c, false);
+}
+#else
 typedef __bf16 bf16v2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float dot2_bf16(uint32_t a, uint32_t b, float c) {
     return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16v2_t, a), __builtin_bit_cast(bf16v2_t, b), c, false);
 }
+#endif
 
 // qkv [S, (nh+2*nkv)*HD] -> q_out [S, nh*HD] (roped), kcache/vcache [nkv][smax][HD] rows pos0+s.
 // cos/sin: fp32 [maxpos][HD/2].  One thread per (token, head, 8-dim chunk of the first half).  HD = 128.
@@ -471,7 +478,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const f32x4 p4 = *(const f32x4*)pk[wave * 16 + i];
-        const float v0 = __builtin_bit_cast(float, vv[i] << 16), v1 = __builtin_bit_cast(float, vv[i] & 0xffff0000u);
+        const float v0 = e_lo(vv[i]), v1 = e_hi(vv[i]);
 #pragma unroll
         for (int h = 0; h < 4; ++h) { o[h][0] += p4[h] * v0; o[h][1] += p4[h] * v1; }
     }

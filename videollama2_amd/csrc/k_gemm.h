@@ -350,10 +350,10 @@ __device__ __forceinline__ void gemm_store_tr(const GemmArgs& p, f32x16 (&acc)[M
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const u32x2 rv = *(const u32x2*)(rrow + ocol + 8 * g);
-                        x[4 * g + 0] += __builtin_bit_cast(float, rv[0] << 16);
-                        x[4 * g + 1] += __builtin_bit_cast(float, rv[0] & 0xffff0000u);
-                        x[4 * g + 2] += __builtin_bit_cast(float, rv[1] << 16);
-                        x[4 * g + 3] += __builtin_bit_cast(float, rv[1] & 0xffff0000u);
+                        x[4 * g + 0] += e_lo(rv[0]);
+                        x[4 * g + 1] += e_hi(rv[0]);
+                        x[4 * g + 2] += e_lo(rv[1]);
+                        x[4 * g + 3] += e_hi(rv[1]);
                     }
                 }
                 uint32_t pk[8];                                              // pk[2 g + h] = columns 8 g + 4 hi + 2 h, + 1 (bf16 pair)
@@ -495,7 +495,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = VL2_MFMA32(af[i], bfr[j], acc[i][j]);
             }
         };
         stage(0, 0);
@@ -576,7 +576,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = VL2_MFMA32(af[i], bfr[j], acc[i][j]);
             }
         };
         stage(0, 0);
@@ -743,7 +743,7 @@ __global__ __launch_bounds__(256, 2) void gemm_sk_bf16_kernel(GemmArgs p) {
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = VL2_MFMA32(af[i], bfr[j], acc[i][j]);
             }
             __syncthreads();
         }
@@ -964,8 +964,8 @@ __device__ __forceinline__ void gemm4_body(const GemmArgs& p, int bid, int nwg) 
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
-                    acc[i][j] = TR ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks][j], fa[ks][i], acc[i][j], 0, 0, 0)
-                                   : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = TR ? VL2_MFMA32(fb[ks][j], fa[ks][i], acc[i][j])
+                                   : VL2_MFMA32(fa[ks][i], fb[ks][j], acc[i][j]);
         VL2_PHASE_BARRIER();
     }
     if (grp == 0) VL2_PHASE_BARRIER();
@@ -1106,8 +1106,8 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs& p, int bid, int nwg) 
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][j] = TR ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks][j], fa[ks][i], acc[i][j], 0, 0, 0)
-                                   : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = TR ? VL2_MFMA32(fb[ks][j], fa[ks][i], acc[i][j])
+                                   : VL2_MFMA32(fa[ks][i], fb[ks][j], acc[i][j]);
         VL2_PHASE_BARRIER();
     }
     if (grp == 0) VL2_PHASE_BARRIER();
@@ -1238,8 +1238,8 @@ __global__ __launch_bounds__(128, 2) void gemm_s_bf16_kernel(GemmArgs p) {
             const bf16x8 af = *(const bf16x8*)(vl2_smem + lds_buf + a_rd[ks]);
             const bf16x8 b0 = *(const bf16x8*)(vl2_smem + lds_buf + b_rd[ks]);
             const bf16x8 b1 = *(const bf16x8*)(vl2_smem + lds_buf + b_rd[ks] + 4096);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b0, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b1, acc[1], 0, 0, 0);
+            acc[0] = VL2_MFMA32(af, b0, acc[0]);
+            acc[1] = VL2_MFMA32(af, b1, acc[1]);
         }
     }
     VL2_WAIT_LGKMCNT0();
@@ -1338,8 +1338,8 @@ __device__ __forceinline__ void gemm_l8_body(const GemmArgs& p, int bid, int nwg
             const bf16x8 af = *(const bf16x8*)(vl2_smem + lds_buf + a_rd[ks]);
             const bf16x8 b0 = *(const bf16x8*)(vl2_smem + lds_buf + b_rd[ks]);
             const bf16x8 b1 = *(const bf16x8*)(vl2_smem + lds_buf + b_rd[ks] + 4096);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b0, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b1, acc[1], 0, 0, 0);
+            acc[0] = VL2_MFMA32(af, b0, acc[0]);
+            acc[1] = VL2_MFMA32(af, b1, acc[1]);
         }
     }
     VL2_WAIT_LGKMCNT0();

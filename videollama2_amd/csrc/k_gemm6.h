@@ -360,7 +360,7 @@ __device__ __forceinline__ void gemm6_body(const GemmArgs& p) {
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
-                    acc[S][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks][j], fa[ks][i], acc[S][i][j], 0, 0, 0);
+                    acc[S][i][j] = VL2_MFMA32(fb[ks][j], fa[ks][i], acc[S][i][j]);
     };
 
     auto run_tile = [&](auto S_, int ord) -> bool {

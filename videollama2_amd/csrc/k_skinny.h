@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(SkinnyArgs p) {
 #pragma unroll
                     for (int m = 0; m < MT; ++m) {
                         const bf16x8 afrag = *(const bf16x8*)(xs + (size_t)(m * 16 + l15) * pitch + (s0 + i) * 32 + lg * 8);
-                        acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag, bfrag, acc[m], 0, 0, 0);
+                        acc[m] = VL2_MFMA16(afrag, bfrag, acc[m]);
                     }
                 }
             }

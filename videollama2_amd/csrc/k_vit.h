@@ -11,7 +11,7 @@
 template <typename T> __device__ __forceinline__ float load_as_f32(const T* p);
 template <> __device__ __forceinline__ float load_as_f32<float>(const float* p) { return *p; }
 template <> __device__ __forceinline__ float load_as_f32<_Float16>(const _Float16* p) { return (float)*p; }
-template <> __device__ __forceinline__ float load_as_f32<bf16_t>(const bf16_t* p) { return bf2f(*p); }
+template <> __device__ __forceinline__ float load_as_f32<bf16_t>(const bf16_t* p) { return __builtin_bit_cast(float, ((uint32_t)*p) << 16); }   // bfloat16 FRAMES (whatever the element type of the build)
 
 // grid = (G, T); block 256
 template <typename T>
