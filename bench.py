@@ -177,6 +177,8 @@ def main():
     ap.add_argument("--no-encoder-graph", action="store_true",
                     help="with --gpus N > 1: launch the rank-local encoder pieces kernel by kernel instead of replaying their two hipGraphs")
     ap.add_argument("--vit-streams", type=int, default=None, help="ViT frames as N chunks on N HIP streams (default: the tower's own, 3)")
+    ap.add_argument("--dtype", choices=["bf16", "fp16"], default="bf16", help="16-bit element type = which build of the library runs "
+                    "(bf16: libvl2hip.so, BASELINE.json configs[1]; fp16: libvl2hip_f16.so, the reference's own mm_infer dtype)")
     ap.add_argument("--stage-flags", type=int, default=0, help="experiment controls of the stage-level calls (include/vl2hip.h VL2_STAGE_*: 1 persistent GEMM, "
                     "2 no mixed launch, 4 in-GEMM statistics reduction (ViT), 8 fused decode attention); travel in the call descriptors")
     ap.add_argument("--tune", type=str, default="", help="debug: comma list of gemm=<variant>, splitk=<0|1>, attn=<variant> (videollama2_amd/ops.py launch controls)")
@@ -200,7 +202,8 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from videollama2_amd import ops
+    from videollama2_amd import _lib, ops
+    _lib.set_elem(args.dtype)                        # before any weight is packed: buffers and packed weights are allocated in it
     from videollama2_amd.config import videollama2_1_7b_16f, videollama2_72b, videollama2_7b
     from videollama2_amd.model import VideoLLaMA2Hip
     from videollama2_amd.weights import LazyRandomStateDict, random_state_dict
@@ -230,7 +233,7 @@ def main():
     model.sharder.cut = args.cut
     if args.bf16_frames:
         g = torch.Generator(device=dev).manual_seed(0)
-        frames = torch.randn((T, 3, side, side), generator=g, device=dev, dtype=torch.float32).to(torch.bfloat16)
+        frames = torch.randn((T, 3, side, side), generator=g, device=dev, dtype=torch.float32).to(_lib.elem_dtype())
     else:        # SURVEY.md 8(d) synthetic input: seeded uint8 video frames (what process_video decodes / resizes to), uploaded ONCE
         import numpy as np
         frames = torch.from_numpy(np.random.default_rng(0).integers(0, 256, (T, side, side, 3), dtype=np.uint8)).to(dev)
@@ -495,12 +498,12 @@ def main():
                        "72b": "video-frames/sec encoded (CLIP-ViT + STC-8192), VideoLLaMA2-72B 16f@336^2 on ONE GPU; prefill/decode tokens/sec as extra keys"}[args.model],
             "value": round(T / (enc_ms / 1e3), 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": (f"VideoLLaMA2-7B, {T}-frame 336^2 video, bf16, S={S} prefill, {n_new} greedy decode tokens "
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": (f"VideoLLaMA2-7B, {T}-frame 336^2 video, {args.dtype}, S={S} prefill, {n_new} greedy decode tokens "
                                     f"(BASELINE.json configs[1])" if args.model == "v2" else
                                     f"VideoLLaMA2-72B (CLIP-ViT-L + stc_connector + Qwen2-72B, 74.9 B parameters resident on one MI355X), {T}-frame 336^2 video, "
-                                    f"bf16, S={S} prefill, {n_new} greedy decode tokens (BASELINE.json configs[3] without the TP=8 split)" if args.model == "72b" else
-                                    f"VideoLLaMA2.1-7B-16F (SigLIP-so400m-384 + stc_connector_v35 + Qwen2-7B), {T}-frame 384^2 video, bf16, "
+                                    f"{args.dtype}, S={S} prefill, {n_new} greedy decode tokens (BASELINE.json configs[3] without the TP=8 split)" if args.model == "72b" else
+                                    f"VideoLLaMA2.1-7B-16F (SigLIP-so400m-384 + stc_connector_v35 + Qwen2-7B), {T}-frame 384^2 video, {args.dtype}, "
                                     f"S={S} prefill, {n_new} greedy decode tokens (SURVEY 8f row 1; not BASELINE.json's metric config)"), "frames": T, "prefill_tokens": S, "new_tokens": n_new,
                        "parallelism": par,
                        "llm_layers": len(model.decoder.w["layers"]),

@@ -28,6 +28,10 @@ extern "C" {
 #define VL2_E_UNSUPP  (-3)   /* option combination not built */
 
 int32_t vl2_version(void);
+/* The 16-bit element type this build of the library computes in: "bf16" (libvl2hip.so) or "fp16" (libvl2hip_f16.so, the same sources with
+ * -DVL2_ELEM_F16).  Every `*_bf16` entry point, every 16-bit buffer and weight of a descriptor is in THIS type; fp32 / int arguments do not
+ * change.  (The reference picks the type per checkpoint load: /root/reference/videollama2/model/__init__.py:71 torch_dtype=float16.) */
+const char* vl2_elem_name(void);
 const char* vl2_last_error_string(void);      /* host pointer, thread-local, valid until the next failing call */
 /* Size of the caller-owned device workspace that `vl2_gemm` (split-K / stream-K forms) and `vl2_gemm_skinny_bf16` take per
  * call.  It must be zero-filled once when allocated (split-K tile counters live in it and are re-armed by the kernels) and

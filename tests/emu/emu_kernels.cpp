@@ -22,6 +22,7 @@ alignas(64) unsigned char vl2_smem[160 * 1024];
 
 static char g_err[256] = "emu";
 extern "C" int32_t vl2_version(void) { return VL2_ABI_VERSION; }
+extern "C" const char* vl2_elem_name(void) { return VL2_ELEM_NAME; }
 extern "C" const char* vl2_last_error_string(void) { return g_err; }
 extern "C" int64_t vl2_workspace_bytes(void) { return 64; }
 extern "C" int32_t vl2_fill_zero(void* p, int64_t bytes, void*) { if (!p || bytes < 0 || (bytes & 3)) return -1; memset(p, 0, (size_t)bytes); return 0; }

@@ -23,6 +23,12 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert _lib.load().vl2_version() == 3
+    assert _lib.load().vl2_elem_name() == b"bf16"
+    f16 = ctypes.CDLL(_lib.LIB_PATHS["fp16"])               # the fp16 build: same export table, other element type
+    for name in declared:
+        assert hasattr(f16, name), name
+    f16.vl2_elem_name.restype = ctypes.c_char_p
+    assert f16.vl2_elem_name() == b"fp16"
 
 
 def test_abi_argument_validation_without_gpu():

@@ -94,9 +94,37 @@ SIGNATURES = {
     "vl2_argmax": [_vp, _i32, _vp, _vp, _i32, _vp, _vp],
     "vl2_embed_rows": [_vp, _vp, _vp, _i32, _i32, _i32, _vp],
 }
-EXPORTS = ["vl2_version", "vl2_last_error_string", "vl2_workspace_bytes", "vl2_vit_workspace_bytes", "vl2_stc_workspace_bytes", "vl2_llm_workspace_bytes"] + list(SIGNATURES)
+EXPORTS = ["vl2_version", "vl2_elem_name", "vl2_last_error_string", "vl2_workspace_bytes", "vl2_vit_workspace_bytes", "vl2_stc_workspace_bytes", "vl2_llm_workspace_bytes"] + list(SIGNATURES)
 
 _lib = None
+# ---- element type of the build in use: "bf16" (libvl2hip.so, the default: BASELINE.json configs[1]) or "fp16" (libvl2hip_f16.so = the same
+# sources with -DVL2_ELEM_F16; the reference's own dtype, videollama2/__init__.py:60 `.half().cuda()`).  Process-wide host-side setting:
+# choose it BEFORE building models (their packed weights and buffers are allocated in it).
+_ELEM = "bf16"
+_LIBS = {}
+LIB_PATHS = {"bf16": LIB_PATH, "fp16": os.path.join(_HERE, "libvl2hip_f16.so")}
+
+
+def elem():
+    return _ELEM
+
+
+def elem_dtype():
+    import torch
+    return torch.float16 if _ELEM == "fp16" else torch.bfloat16
+
+
+def set_elem(name):
+    """Select the 16-bit element type ("bf16" | "fp16") of every kernel call that follows."""
+    global _ELEM, _lib
+    if name not in LIB_PATHS:
+        raise ValueError(f"unknown element type {name!r} (bf16 | fp16)")
+    if name == _ELEM:
+        return
+    if _lib is not None:
+        _LIBS[_ELEM] = _lib
+    _ELEM = name
+    _lib = _LIBS.get(name)
 
 
 class Vl2HipError(RuntimeError):
@@ -108,10 +136,11 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise Vl2HipError(f"{LIB_PATH} not found: build it with `python -m videollama2_amd.csrc.build` "
+    path = LIB_PATHS[_ELEM] if _ELEM != "bf16" else LIB_PATH
+    if not os.path.exists(path):
+        raise Vl2HipError(f"{path} not found: build it with `python -m videollama2_amd.csrc.build` "
                           "(hipcc --offload-arch=gfx950); the HIP path has no fallback")
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(path)
     lib.vl2_version.restype = _i32
     lib.vl2_version.argtypes = []
     lib.vl2_last_error_string.restype = ctypes.c_char_p
@@ -130,7 +159,12 @@ def load():
         fn.argtypes = args
     if lib.vl2_version() != 3:
         raise Vl2HipError("libvl2hip.so ABI version mismatch")
+    lib.vl2_elem_name.restype = ctypes.c_char_p
+    lib.vl2_elem_name.argtypes = []
+    if lib.vl2_elem_name().decode() != _ELEM:
+        raise Vl2HipError(f"{path} computes in {lib.vl2_elem_name().decode()}, not {_ELEM}: rebuild it (python -m videollama2_amd.csrc.build)")
     _lib = lib
+    _LIBS[_ELEM] = lib
     return lib
 
 

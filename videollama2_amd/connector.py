@@ -5,7 +5,7 @@ LayerNorm, depthwise 3x3 + SE are direct kernels (see csrc/k_stc.h)."""
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import _lib, ops
 from .weights import pack_connector
 
 
@@ -60,7 +60,7 @@ class HipSTCConnector(nn.Module):
         if key not in self._idx_cache:
             self._idx_cache[key] = conv3d_k2s2p1_index(t, hw, hw, self._dev, padding=self.padding)
         idx, dims = self._idx_cache[key]
-        out = torch.empty((dims[0] * dims[1] * dims[2], self.w["ro2_w"].shape[0]), dtype=torch.bfloat16, device=self._dev)
+        out = torch.empty((dims[0] * dims[1] * dims[2], self.w["ro2_w"].shape[0]), dtype=_lib.elem_dtype(), device=self._dev)
         return ops.stc_forward(self._stage[0], rows, t, hw, idx, dims, out)
 
     def _bottleneck(self, x, b, F, H, W):
@@ -110,7 +110,7 @@ class HipSTCConnector(nn.Module):
         b, t, l, d = x.shape
         hw = int(l ** 0.5)
         in_dtype = x.dtype
-        x = x.to(device=self._dev, dtype=torch.bfloat16).contiguous()
+        x = x.to(device=self._dev, dtype=_lib.elem_dtype()).contiguous()
         outs, stages = [], {}
         for bi in range(b):
             if ops.stage_enabled() and not return_stages:

@@ -15,20 +15,29 @@ def _deps():
            [os.path.join(os.path.dirname(PKG), "include", "vl2hip.h")]
 
 
+OUT_F16 = os.path.join(PKG, "libvl2hip_f16.so")      # the same sources on IEEE half (-DVL2_ELEM_F16): the reference's own dtype
+
+
 def build(force=False, verbose=False):
-    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in _deps()):
-        return OUT
+    """Builds libvl2hip.so (bf16 elements) and libvl2hip_f16.so (fp16 elements) side by side (two hipcc processes)."""
+    deps = _deps()
+    todo = [(out, extra) for out, extra in ((OUT, []), (OUT_F16, ["-DVL2_ELEM_F16"]))
+            if force or not os.path.exists(out) or any(os.path.getmtime(out) < os.path.getmtime(d) for d in deps)]
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-ffast-math",
-           "-fno-finite-math-only", SRC, "-o", OUT]
-    if verbose:
-        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        sys.stderr.write(r.stdout + r.stderr)
-        raise RuntimeError("hipcc failed building libvl2hip.so")
-    if verbose:
-        print(r.stderr)
+    procs = []
+    for out, extra in todo:
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-ffast-math",
+               "-fno-finite-math-only", *extra, SRC, "-o", out]
+        if verbose:
+            cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+        procs.append((out, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
+    for out, pr in procs:
+        so, se = pr.communicate()
+        if pr.returncode != 0:
+            sys.stderr.write(so + se)
+            raise RuntimeError(f"hipcc failed building {os.path.basename(out)}")
+        if verbose:
+            print(se)
     return OUT
 
 

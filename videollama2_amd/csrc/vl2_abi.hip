@@ -54,6 +54,7 @@ static void lds_attr(int bytes) {
 }
 
 extern "C" int32_t vl2_version(void) { return VL2_ABI_VERSION; }
+extern "C" const char* vl2_elem_name(void) { return VL2_ELEM_NAME; }
 extern "C" const char* vl2_last_error_string(void) { return g_err; }
 
 #define SK_GRID 512                  // persistent stream-K workgroups: 2 per CU

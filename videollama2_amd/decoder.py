@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.nn as nn
 
-from . import ops
+from . import _lib, ops
 from .weights import pack_decoder
 
 
@@ -42,7 +42,7 @@ class HipMistralDecoder(nn.Module):
         fr = torch.arange(max_seq_len, dtype=torch.float32)[:, None] * inv[None, :]
         self.cos_t = fr.cos().contiguous().to(self._dev)
         self.sin_t = fr.sin().contiguous().to(self._dev)
-        bf = dict(dtype=torch.bfloat16, device=self._dev)
+        bf = dict(dtype=_lib.elem_dtype(), device=self._dev)
         self.kcache = [torch.zeros((self.nkv, max_seq_len, self.hd), **bf) for _ in range(self.n_layers)]
         self.vcache = [torch.zeros((self.nkv, max_seq_len, self.hd), **bf) for _ in range(self.n_layers)]
         nsplit_max = (max_seq_len + 63) // 64
@@ -111,7 +111,7 @@ class HipMistralDecoder(nn.Module):
         S = x.shape[0]
         if S > self.max_seq_len:
             raise ValueError(f"sequence length {S} exceeds the KV cache ({self.max_seq_len})")
-        x = x.to(device=self._dev, dtype=torch.bfloat16).contiguous()
+        x = x.to(device=self._dev, dtype=_lib.elem_dtype()).contiguous()
         if self._use_stage(cache) and not return_all_logits:      # the whole prefill as one call into libvl2hip.so (vl2_llm_prefill)
             out = self.logits if logits_out is None else logits_out
             ops.llm_prefill(self._stage_desc()[0], x, out)
@@ -119,8 +119,8 @@ class HipMistralDecoder(nn.Module):
             self.last_hidden = None
             return out
         nh, nkv, hd, D = self.nh, self.nkv, self.hd, self.D
-        q = torch.empty((S, nh * hd), dtype=torch.bfloat16, device=self._dev)
-        o = torch.empty((S, nh * hd), dtype=torch.bfloat16, device=self._dev)
+        q = torch.empty((S, nh * hd), dtype=_lib.elem_dtype(), device=self._dev)
+        o = torch.empty((S, nh * hd), dtype=_lib.elem_dtype(), device=self._dev)
         smax = self.max_seq_len
         rs = ops.row_stats(x)          # RMSNorm rides in the q/k/v and gate/up GEMMs (weights.fold_norm): this seeds the statistics
         rn = ops.row_norm_finalize(rs, D, ops.NORM_RMS, self.eps)       # [S, 2] (0, rstd): reduced once, not in every column tile
@@ -267,13 +267,13 @@ class HipMistralDecoder(nn.Module):
         lens = [x.shape[0] for x in xs]
         if max(lens) > self.max_seq_len:
             raise ValueError(f"sequence length {max(lens)} exceeds the KV cache ({self.max_seq_len})")
-        X = torch.cat([x.to(device=self._dev, dtype=torch.bfloat16) for x in xs], 0).contiguous()
+        X = torch.cat([x.to(device=self._dev, dtype=_lib.elem_dtype()) for x in xs], 0).contiguous()
         offs = [0]
         for n in lens:
             offs.append(offs[-1] + n)
         nh, nkv, hd, smax = self.nh, self.nkv, self.hd, self.max_seq_len
-        q = torch.empty((offs[-1], nh * hd), dtype=torch.bfloat16, device=self._dev)
-        o = torch.empty((offs[-1], nh * hd), dtype=torch.bfloat16, device=self._dev)
+        q = torch.empty((offs[-1], nh * hd), dtype=_lib.elem_dtype(), device=self._dev)
+        o = torch.empty((offs[-1], nh * hd), dtype=_lib.elem_dtype(), device=self._dev)
         rs = ops.row_stats(X)
         rn = ops.row_norm_finalize(rs, self.D, ops.NORM_RMS, self.eps)
         for li, lw in enumerate(self.w["layers"]):
@@ -305,7 +305,7 @@ class HipMistralDecoder(nn.Module):
         self._batch_graphs = {}                      # captured graphs point into the buffers replaced below
         if self._dev.type == "cuda":
             ops.attach_workspace(self._dev)          # fp32 partial sums of the skinny-M GEMMs of a large-batch decode step
-        bf = dict(dtype=torch.bfloat16, device=self._dev)
+        bf = dict(dtype=_lib.elem_dtype(), device=self._dev)
         smax, I = self.max_seq_len, self.cfg["llm"]["intermediate_size"] // self.tp
         self._bb = dict(
             B=B, k=[torch.zeros((B, self.nkv, smax, self.hd), **bf) for _ in range(self.n_layers)],

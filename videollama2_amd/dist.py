@@ -6,6 +6,8 @@ world_size 1 takes the same code path (the collective is skipped, nothing else c
 import torch
 import torch.distributed as dist
 
+from . import _lib
+
 
 class RankEncoderGraph:
     """The rank-local pieces of the sharded-connector cut as two captured hipGraphs (one per side of the halo exchange):
@@ -201,7 +203,7 @@ class FrameSharder:
         local = tower(frames[s:s + c]) if c > 0 else None
         n, h = (local.shape[1], local.shape[2]) if local is not None else (tower.num_patches, tower.hidden_size)
         # a rank without frames must send the dtype the other ranks' towers produce (uint8 ingest -> bf16 features)
-        dtype = local.dtype if local is not None else (torch.bfloat16 if frames.dtype == torch.uint8 else frames.dtype)
+        dtype = local.dtype if local is not None else (_lib.elem_dtype() if frames.dtype == torch.uint8 else frames.dtype)
         dev = local.device if local is not None else tower.device
         send = torch.zeros((maxc, n, h), dtype=dtype, device=dev)          # equal-sized shards (ragged T padded)
         if c > 0:
@@ -269,7 +271,7 @@ class FrameSharder:
         fpr = local_frames.shape[0]
         local = tower(local_frames)                                          # [fpr, n, 1024]
         n = local.shape[1]
-        rows = local.to(torch.bfloat16).reshape(fpr * n, -1).contiguous()
+        rows = local.to(_lib.elem_dtype()).reshape(fpr * n, -1).contiguous()
         return connector.run_s1(rows, fpr, int(n ** 0.5)), n, local.dtype
 
     @staticmethod

@@ -10,6 +10,8 @@ import types
 import torch
 import torch.nn as nn
 
+from . import _lib
+
 from .connector import HipSTCConnector
 from .tower import (HipCLIPVisionTower, HipSiglipVisionTower, default_image_processor, default_siglip_image_processor)
 
@@ -25,8 +27,9 @@ PUBLIC_TOWERS = {
 class ParamHost(nn.Module):
     """Parameters registered under dotted names as a tree of empty Modules: `host.state_dict()` has exactly those keys."""
 
-    def __init__(self, names_shapes, dtype=torch.bfloat16, device="cpu"):
+    def __init__(self, names_shapes, dtype=None, device="cpu"):
         super().__init__()
+        dtype = _lib.elem_dtype() if dtype is None else dtype
         for name, shape in names_shapes:
             mod, parts = self, name.split(".")
             for part in parts[:-1]:
@@ -180,7 +183,7 @@ class LazyHipVisionTower(nn.Module):
         return self.pack(images[0].device if type(images) is list else images.device)(images)
 
     # ---- attributes the reference reads (encoder.py:55-81)
-    dtype = property(lambda self: torch.bfloat16)
+    dtype = property(lambda self: _lib.elem_dtype())
     device = property(lambda self: self._hip[0].device if self._hip else next(self.vision_tower.parameters()).device)
     hidden_size = property(lambda self: self._v["hidden_size"])
     num_patches_per_side = property(lambda self: self._v["image_size"] // self._v["patch_size"])

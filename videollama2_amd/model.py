@@ -9,7 +9,7 @@ all-gathered (RCCL) in front of the connector."""
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import _lib, ops
 from .config import check_supported
 from .connector import HipSTCConnector
 from .constants import MODAL_INDEX_MAP, NUM_FRAMES
@@ -111,7 +111,7 @@ class VideoLLaMA2Hip(nn.Module):
             mm_pos = plans[bi]
             ids32 = input_ids[bi].to(self._dev).clamp(min=0).to(torch.int32)
             if not mm_pos:                                                               # pure text: consumes one (unused) block
-                emb = torch.empty((L, D), dtype=torch.bfloat16, device=self._dev)
+                emb = torch.empty((L, D), dtype=_lib.elem_dtype(), device=self._dev)
                 if L:
                     ops.embed_rows(ids32.contiguous(), self.decoder.w["embed"], emb)
                 embeds.append(emb)
@@ -119,14 +119,14 @@ class VideoLLaMA2Hip(nn.Module):
                 continue
             n_vis = sum(mm_features[cur_mm + k].shape[0] for k in range(len(mm_pos)))
             S = L - len(mm_pos) + n_vis
-            emb = torch.empty((S, D), dtype=torch.bfloat16, device=self._dev)
+            emb = torch.empty((S, D), dtype=_lib.elem_dtype(), device=self._dev)
             cur, prev = 0, 0
             for k, p in enumerate(mm_pos + [L]):
                 if p > prev:                                                             # text piece -> embed_tokens
                     ops.embed_rows(ids32[prev:p].contiguous(), self.decoder.w["embed"], emb[cur:cur + (p - prev)])
                     cur += p - prev
                 if k < len(mm_pos):                                                      # visual block in place of the sentinel
-                    f = mm_features[cur_mm].to(torch.bfloat16)
+                    f = mm_features[cur_mm].to(_lib.elem_dtype())
                     emb[cur:cur + f.shape[0]].copy_(f)
                     cur += f.shape[0]
                     cur_mm += 1
@@ -136,7 +136,7 @@ class VideoLLaMA2Hip(nn.Module):
         self._splice_lens = lens                     # unpadded spliced length of every row (host-side; see _inputs_embeds)
         max_len = max(lens)
         if any(n != max_len for n in lens):                                              # arch.py:227-253
-            out = torch.zeros((B, max_len, D), dtype=torch.bfloat16, device=self._dev)
+            out = torch.zeros((B, max_len, D), dtype=_lib.elem_dtype(), device=self._dev)
             for bi, e in enumerate(embeds):
                 out[bi, :e.shape[0]].copy_(e)
             if attention_mask is not None:
@@ -191,7 +191,7 @@ class VideoLLaMA2Hip(nn.Module):
         if images is not None:
             _, _, _, emb, _ = self.prepare_inputs_labels_for_multimodal(inputs, attention_mask, None, None, images)
         if emb is None:                            # no media, or input_ids.shape[1] == 1 (arch.py:166-169 hands the ids back)
-            emb = torch.empty((B, L, self.decoder.D), dtype=torch.bfloat16, device=self._dev)
+            emb = torch.empty((B, L, self.decoder.D), dtype=_lib.elem_dtype(), device=self._dev)
             for bi in range(B):
                 self._embed_ids(inputs[bi].to(self._dev), emb[bi])
             rows = [L] * B
@@ -293,7 +293,7 @@ class VideoLLaMA2Hip(nn.Module):
             else:
                 self._check_ids(ids[0])
                 ids32 = ids[0].to(self._dev).to(torch.int32).contiguous()
-                emb = torch.empty((ids32.numel(), self.decoder.D), dtype=torch.bfloat16, device=self._dev)
+                emb = torch.empty((ids32.numel(), self.decoder.D), dtype=_lib.elem_dtype(), device=self._dev)
                 ops.embed_rows(ids32, self.decoder.w["embed"], emb)
                 embeds.append(emb)
         return self.decoder.generate_batch(embeds, max_new_tokens=kwargs.get("max_new_tokens", 2048),

@@ -9,7 +9,6 @@ from . import _lib
 
 ACT_NONE, ACT_QGELU, ACT_GELU, ACT_SILU, ACT_SIGMOID, ACT_GELU_TANH = 0, 1, 2, 3, 4, 5
 GEMM_SWIGLU, GEMM_OUT_F32 = 1, 2
-BF16 = torch.bfloat16
 PROFILE = None      # bench.py sets this to a list: every gemm launch is then bracketed by HIP events on the launch stream
 
 
@@ -94,7 +93,7 @@ def gemm(a, w, bias=None, res=None, act=ACT_NONE, swiglu=False, out_f32=False, o
     stats_out: fp32 [M, N/64, 2] buffer the epilogue fills with (sum, sum of squares) per row and 64-column block of the
     stored output.  norm = (kind, stats_in, eps, w_colsum): Norm(a) @ w.T computed on the raw rows of `a` from the statistics
     the GEMM that wrote `a` emitted (NORM_RMS / NORM_LN; w must carry the norm weight folded in, bias the folded shift)."""
-    _chk(a, BF16, "a"); _chk(w, BF16, "w"); _chk(bias, torch.float32, "bias"); _chk(res, BF16, "res")
+    _chk(a, _lib.elem_dtype(), "a"); _chk(w, _lib.elem_dtype(), "w"); _chk(bias, torch.float32, "bias"); _chk(res, _lib.elem_dtype(), "res")
     N = w.shape[0]
     if gather is not None:
         a_idx, _zero_row, seg_k = gather
@@ -109,7 +108,7 @@ def gemm(a, w, bias=None, res=None, act=ACT_NONE, swiglu=False, out_f32=False, o
             raise ValueError(f"gemm: a is [{a.shape[0]},{a.shape[1]}] but w is [{N},{K}]")
     ncol = N // 2 if swiglu else N
     if out is None:
-        out = torch.empty((M, ncol), dtype=torch.float32 if out_f32 else BF16, device=a.device)
+        out = torch.empty((M, ncol), dtype=torch.float32 if out_f32 else _lib.elem_dtype(), device=a.device)
     grp, grp_pad, row_off = out_map or (0, 0, 0)
     rmod, roff = res_map or (0, 0)
     ws = _ws(a.device)
@@ -153,7 +152,7 @@ def row_norm_finalize(stats, K, kind, eps, out=None):
 def row_stats(x, out=None):
     """(sum, sum of squares) per row and 64-column block of x [rows, C] bf16 -> fp32 [rows, C/64, 2]: seeds a norm-carrying
     GEMM chain for a tensor no GEMM wrote (same layout and summation order as `gemm(..., stats_out=)`)."""
-    _chk(x, BF16, "x")
+    _chk(x, _lib.elem_dtype(), "x")
     rows, C = x.shape
     out = torch.empty((rows, C // 64, 2), dtype=torch.float32, device=x.device) if out is None else out
     _lib.call("vl2_row_stats", _p(x), _p(out), rows, C, x.stride(0), _stream())
@@ -161,23 +160,23 @@ def row_stats(x, out=None):
 
 
 def layernorm(x, w, b, eps, res=None, silu=False, out=None):
-    _chk(x, BF16, "x"); _chk(w, torch.float32, "w"); _chk(b, torch.float32, "b"); _chk(res, BF16, "res")
+    _chk(x, _lib.elem_dtype(), "x"); _chk(w, torch.float32, "w"); _chk(b, torch.float32, "b"); _chk(res, _lib.elem_dtype(), "res")
     rows, C = x.shape
-    out = torch.empty((rows, C), dtype=BF16, device=x.device) if out is None else out
+    out = torch.empty((rows, C), dtype=_lib.elem_dtype(), device=x.device) if out is None else out
     _lib.call("vl2_layernorm", _p(x), _p(out), _p(w), _p(b), _p(res), rows, C, x.stride(0), out.stride(0),
               res.stride(0) if res is not None else 0, float(eps), int(silu), _stream())
     return out
 
 
 def rmsnorm(x, w, eps, out=None):
-    _chk(x, BF16, "x"); _chk(w, torch.float32, "w")
+    _chk(x, _lib.elem_dtype(), "x"); _chk(w, torch.float32, "w")
     rows, C = x.shape
-    out = torch.empty((rows, C), dtype=BF16, device=x.device) if out is None else out
+    out = torch.empty((rows, C), dtype=_lib.elem_dtype(), device=x.device) if out is None else out
     _lib.call("vl2_rmsnorm", _p(x), _p(out), _p(w), rows, C, x.stride(0), out.stride(0), float(eps), _stream())
     return out
 
 
-_DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+_DTYPE_CODE = {torch.float32: 0, torch.float16: 1, _lib.elem_dtype(): 2}
 
 
 def patchify(frames, patch, kp):
@@ -187,7 +186,7 @@ def patchify(frames, patch, kp):
     frames = frames.contiguous()
     T, C, H, W = frames.shape
     G = H // patch
-    out = torch.empty((T * G * G, kp), dtype=BF16, device=frames.device)
+    out = torch.empty((T * G * G, kp), dtype=_lib.elem_dtype(), device=frames.device)
     _lib.call("vl2_patchify", _p(frames), _DTYPE_CODE[frames.dtype], _p(out), T, H, W, patch, G, kp, _stream())
     return out
 
@@ -200,7 +199,7 @@ def patchify_u8(frames_thwc, patch, kp, rescale, mean, std):
     if C != 3:
         raise ValueError(f"expected uint8 frames [T,H,W,3], got {tuple(frames_thwc.shape)}")
     G = H // patch
-    out = torch.empty((T * G * G, kp), dtype=BF16, device=frames_thwc.device)
+    out = torch.empty((T * G * G, kp), dtype=_lib.elem_dtype(), device=frames_thwc.device)
     m, sd = [float(v) for v in mean], [float(v) for v in std]
     _lib.call("vl2_patchify_u8", _p(frames_thwc), _p(out), T, H, W, patch, G, kp, float(rescale), m[0], m[1], m[2], sd[0], sd[1], sd[2],
               _stream())
@@ -220,7 +219,7 @@ def attn_fwd(q, k, v, o, q_str, k_str, v_str, o_str, B, H, nq, nk, group, scale,
 
 
 def dwconv3x3_ln_silu(x, w9c, lnw, lnb, F, H, W, eps=1e-5):
-    _chk(x, BF16, "x")
+    _chk(x, _lib.elem_dtype(), "x")
     C = x.shape[-1]
     y = torch.empty_like(x)
     _lib.call("vl2_dwconv3x3_ln_silu", _p(x), _p(y), _p(w9c), _p(lnw), _p(lnb), F, H, W, C, float(eps), _stream())
@@ -235,7 +234,7 @@ def chan_mean(x, F, HW):
 
 
 def small_linear(x, w, b, act):
-    _chk(x, torch.float32, "x"); _chk(w, BF16, "w")
+    _chk(x, torch.float32, "x"); _chk(w, _lib.elem_dtype(), "w")
     F, K = x.shape
     N = w.shape[0]
     out = torch.empty((F, N), dtype=torch.float32, device=x.device)
@@ -255,11 +254,11 @@ def rope_kv(qkv, q_out, kcache, vcache, cos_t, sin_t, nh, nkv, pos0):
 
 
 def gemv(w, x, norm_w=None, eps=1e-5, res=None, swiglu=False, out_f32=False, out=None, bias=None):
-    _chk(w, BF16, "w"); _chk(x, BF16, "x"); _chk(bias, torch.float32, "bias")
+    _chk(w, _lib.elem_dtype(), "w"); _chk(x, _lib.elem_dtype(), "x"); _chk(bias, torch.float32, "bias")
     N, K = w.shape
     n_out = N // 2 if swiglu else N
     if out is None:
-        out = torch.empty((n_out,), dtype=torch.float32 if out_f32 else BF16, device=w.device)
+        out = torch.empty((n_out,), dtype=torch.float32 if out_f32 else _lib.elem_dtype(), device=w.device)
     flags = (GEMM_SWIGLU if swiglu else 0) | (GEMM_OUT_F32 if out_f32 else 0)
     _lib.call("vl2_gemv_bf16", _p(w), _p(x), _p(norm_w), _p(res), _p(bias), _p(out), N, K, w.stride(0), float(eps), flags, _stream())
     return out
@@ -268,12 +267,12 @@ def gemv(w, x, norm_w=None, eps=1e-5, res=None, swiglu=False, out_f32=False, out
 def gemm_skinny(a, w, bias=None, res=None, swiglu=False, out_f32=False, out=None):
     """C = epilogue(a @ w.T) for M = a.shape[0] <= 64 rows (batched decode): weights streamed once, GEMV-style, into MFMA.
     Needs `attach_workspace` (fp32 partial sums of the K split)."""
-    _chk(a, BF16, "a"); _chk(w, BF16, "w"); _chk(bias, torch.float32, "bias"); _chk(res, BF16, "res")
+    _chk(a, _lib.elem_dtype(), "a"); _chk(w, _lib.elem_dtype(), "w"); _chk(bias, torch.float32, "bias"); _chk(res, _lib.elem_dtype(), "res")
     M, K = a.shape
     N = w.shape[0]
     ncol = N // 2 if swiglu else N
     if out is None:
-        out = torch.empty((M, ncol), dtype=torch.float32 if out_f32 else BF16, device=a.device)
+        out = torch.empty((M, ncol), dtype=torch.float32 if out_f32 else _lib.elem_dtype(), device=a.device)
     flags = (GEMM_SWIGLU if swiglu else 0) | (GEMM_OUT_F32 if out_f32 else 0)
     ws = attach_workspace(a.device)
     _lib.call("vl2_gemm_skinny_bf16", _p(a), _p(w), _p(out), _p(bias), _p(res), M, N, K, a.stride(0), w.stride(0), out.stride(0),
@@ -283,12 +282,12 @@ def gemm_skinny(a, w, bias=None, res=None, swiglu=False, out_f32=False, out=None
 
 def gemv_batched(w, x, norm_w=None, eps=1e-5, res=None, swiglu=False, out_f32=False, out=None, bias=None):
     """y[b] = W x[b] for the rows of x [MB, K] in one pass over W (batched decode).  res / out are [MB, n_out]."""
-    _chk(w, BF16, "w"); _chk(x, BF16, "x"); _chk(bias, torch.float32, "bias")
+    _chk(w, _lib.elem_dtype(), "w"); _chk(x, _lib.elem_dtype(), "x"); _chk(bias, torch.float32, "bias")
     N, K = w.shape
     MB = x.shape[0]
     n_out = N // 2 if swiglu else N
     if out is None:
-        out = torch.empty((MB, n_out), dtype=torch.float32 if out_f32 else BF16, device=w.device)
+        out = torch.empty((MB, n_out), dtype=torch.float32 if out_f32 else _lib.elem_dtype(), device=w.device)
     flags = (GEMM_SWIGLU if swiglu else 0) | (GEMM_OUT_F32 if out_f32 else 0)
     _lib.call("vl2_gemv_batched_bf16", _p(w), _p(x), _p(norm_w), _p(res), _p(bias), _p(out), MB, N, K, w.stride(0), x.stride(0),
               out.stride(0), 0 if res is None else res.stride(0), float(eps), flags, _stream())
@@ -335,9 +334,9 @@ def embed_rows(ids_i32, table, out):
 def pack_fold_norm(w, g, beta=None, bias=None):
     """(W' bf16 [N,K], colsum fp32 [N], shift fp32 [N] or None) = weights.fold_norm(w, g, beta, bias)."""
     for t, n in ((w, "w"), (g, "g"), (beta, "beta"), (bias, "bias")):
-        _chk(t, BF16, n)
+        _chk(t, _lib.elem_dtype(), n)
     N, K = w.shape
-    wp = torch.empty((N, K), dtype=BF16, device=w.device)
+    wp = torch.empty((N, K), dtype=_lib.elem_dtype(), device=w.device)
     s = torch.empty((N,), dtype=torch.float32, device=w.device)
     t = torch.empty((N,), dtype=torch.float32, device=w.device) if beta is not None else None
     _lib.call("vl2_pack_fold_norm", _p(w), _p(g), _p(beta), _p(bias), _p(wp), _p(s), _p(t), N, K, w.stride(0), _stream())
@@ -345,32 +344,32 @@ def pack_fold_norm(w, g, beta=None, bias=None):
 
 
 def pack_gate_up(gate, up):
-    _chk(gate, BF16, "gate"); _chk(up, BF16, "up")
+    _chk(gate, _lib.elem_dtype(), "gate"); _chk(up, _lib.elem_dtype(), "up")
     I, D = gate.shape
-    out = torch.empty((2 * I, D), dtype=BF16, device=gate.device)
+    out = torch.empty((2 * I, D), dtype=_lib.elem_dtype(), device=gate.device)
     _lib.call("vl2_pack_gate_up", _p(gate), _p(up), _p(out), I, D, _stream())
     return out
 
 
 def pack_permute(x, out_f32=False):
     """[A, B, C] bf16 -> [A, C, B] (bf16, or fp32 with out_f32)."""
-    _chk(x, BF16, "x")
+    _chk(x, _lib.elem_dtype(), "x")
     A, B, C = x.shape
-    out = torch.empty((A, C, B), dtype=torch.float32 if out_f32 else BF16, device=x.device)
+    out = torch.empty((A, C, B), dtype=torch.float32 if out_f32 else _lib.elem_dtype(), device=x.device)
     _lib.call("vl2_pack_permute", _p(x), _p(out), A, B, C, int(out_f32), _stream())
     return out
 
 
 def pack_pad_rows(x, cols_dst):
-    _chk(x, BF16, "x")
+    _chk(x, _lib.elem_dtype(), "x")
     rows, cs = x.shape
-    out = torch.empty((rows, cols_dst), dtype=BF16, device=x.device)
+    out = torch.empty((rows, cols_dst), dtype=_lib.elem_dtype(), device=x.device)
     _lib.call("vl2_pack_pad_rows", _p(x), _p(out), rows, cs, cols_dst, _stream())
     return out
 
 
 def pack_cvt_f32(x):
-    _chk(x, BF16, "x")
+    _chk(x, _lib.elem_dtype(), "x")
     out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
     _lib.call("vl2_pack_cvt_f32", _p(x), _p(out), x.numel(), _stream())
     return out
@@ -406,7 +405,7 @@ def vit_desc(w, v, family, act):
 
 def vit_forward(desc, frames, T, out, u8_norm=None):
     """frames [T,3,S,S] fp32 / fp16 / bf16 or uint8 [T,S,S,3] -> out [T * tokens, D] bf16 (class-token row included)."""
-    code = 3 if frames.dtype == torch.uint8 else {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}[frames.dtype]
+    code = 3 if frames.dtype == torch.uint8 else {torch.float32: 0, torch.float16: 1, _lib.elem_dtype(): 2}[frames.dtype]
     n = int(_lib.load().vl2_vit_workspace_bytes(ctypes.byref(desc), T))
     if n < 0:
         raise _lib.Vl2HipError("vl2_vit_workspace_bytes: bad descriptor")
@@ -435,7 +434,7 @@ def stc_desc(w):
 
 def stc_forward(desc, x, T, hw, idx, dims, out):
     """x [T*hw*hw, cin] bf16 tower features -> out [To*Ho*Wo, C] bf16 (idx, dims from connector.conv3d_k2s2p1_index)."""
-    _chk(x, BF16, "x"); _chk(out, BF16, "out"); _chk(idx, torch.int32, "idx")
+    _chk(x, _lib.elem_dtype(), "x"); _chk(out, _lib.elem_dtype(), "out"); _chk(idx, torch.int32, "idx")
     To, Ho, Wo = dims
     n = int(_lib.load().vl2_stc_workspace_bytes(ctypes.byref(desc), T, hw, To * Ho * Wo))
     if n < 0:

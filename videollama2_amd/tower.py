@@ -8,7 +8,7 @@ import types
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import _lib, ops
 from .weights import pack_siglip_tower, pack_tower
 
 
@@ -60,7 +60,7 @@ class HipCLIPVisionTower(nn.Module):
             self._stage = ops.vit_desc(self.w, v, self._stage_family, self._stage_act)
         N1 = (v["image_size"] // v["patch_size"]) ** 2 + self._cls_tokens
         if out is None:
-            out = torch.empty((T * N1, v["hidden_size"]), dtype=torch.bfloat16, device=self._dev)
+            out = torch.empty((T * N1, v["hidden_size"]), dtype=_lib.elem_dtype(), device=self._dev)
         nrm = None
         if u8:
             ip = self.image_processor
@@ -94,7 +94,7 @@ class HipCLIPVisionTower(nn.Module):
     # ---- attributes the reference reads (encoder.py:55-81, videollama2_arch.py:66, model/__init__.py:186)
     @property
     def dtype(self):
-        return torch.bfloat16
+        return _lib.elem_dtype()
 
     @property
     def device(self):
@@ -130,7 +130,7 @@ class HipCLIPVisionTower(nn.Module):
         T = images.shape[0]
         N1 = (images.shape[2] // v["patch_size"]) ** 2 + self._cls_tokens
         images = images.to(self._dev)
-        out = torch.empty((T * N1, v["hidden_size"]), dtype=torch.bfloat16, device=self._dev)
+        out = torch.empty((T * N1, v["hidden_size"]), dtype=_lib.elem_dtype(), device=self._dev)
         cur = torch.cuda.current_stream(self._dev)
         if self._side is None or len(self._side) != ns:
             self._side = [torch.cuda.Stream(self._dev) for _ in range(ns)]
@@ -149,7 +149,7 @@ class HipCLIPVisionTower(nn.Module):
         if H != v["image_size"] or W != v["image_size"]:                          # HF:modeling_clip.py:203-207
             raise ValueError(f"Input image size ({H}*{W}) doesn't match model ({v['image_size']}*{v['image_size']}).")
         images = images.to(self._dev)
-        if ops.stage_enabled() and images.dtype in (torch.float32, torch.float16, torch.bfloat16, torch.uint8):
+        if ops.stage_enabled() and images.dtype in (torch.float32, torch.float16, _lib.elem_dtype(), torch.uint8):
             return self._hidden_stage(images, T, u8, out)
         w = self.w
         D, P = v["hidden_size"], v["patch_size"]
@@ -159,11 +159,11 @@ class HipCLIPVisionTower(nn.Module):
         hd = D // nh
         eps = v["layer_norm_eps"]
         a = self._patch_rows(images, u8, P, w["kp"])
-        x = torch.empty((T * N1, D), dtype=torch.bfloat16, device=self._dev)
+        x = torch.empty((T * N1, D), dtype=_lib.elem_dtype(), device=self._dev)
         ops.gemm(a, w["patch_w"], res=w["pos"], out=x, out_map=(G * G, 1, 1), res_map=(G * G, 1), flop_k=3 * P * P)
         ops.fill_cls(x, w["cls_pos"], T, N1)
         x = ops.layernorm(x, w["pre_w"], w["pre_b"], eps)
-        o = torch.empty((T * N1, D), dtype=torch.bfloat16, device=self._dev)
+        o = torch.empty((T * N1, D), dtype=_lib.elem_dtype(), device=self._dev)
         # layer_norm1 / layer_norm2 never run as kernels: every GEMM that writes the residual stream also emits its row
         # statistics (`stats_out`), and the q/k/v and fc1 GEMMs normalise in their epilogue (weights.fold_norm, csrc/k_gemm.h)
         # The K/64 partial statistics of a row are reduced ONCE per tensor (`row_norm_finalize`, a 2 us kernel) instead of in every
@@ -189,7 +189,7 @@ class HipCLIPVisionTower(nn.Module):
     def forward(self, images):
         if type(images) is list:                                                   # encoder.py:43-48
             return [self.forward(im.unsqueeze(0)) for im in images]
-        in_dtype = images.dtype if images.dtype != torch.uint8 else torch.bfloat16
+        in_dtype = images.dtype if images.dtype != torch.uint8 else _lib.elem_dtype()
         x, T, N1 = self.forward_hidden(images)
         x = x.view(T, N1, -1)
         if self.select_feature == "patch":                                         # encoder.py:33-34
@@ -230,7 +230,7 @@ class HipSiglipVisionTower(HipCLIPVisionTower):
         if H != v["image_size"] or W != v["image_size"]:                          # HF:modeling_siglip.py SiglipVisionEmbeddings
             raise ValueError(f"Input image size ({H}*{W}) doesn't match model ({v['image_size']}*{v['image_size']}).")
         images = images.to(self._dev)
-        if ops.stage_enabled() and images.dtype in (torch.float32, torch.float16, torch.bfloat16, torch.uint8):
+        if ops.stage_enabled() and images.dtype in (torch.float32, torch.float16, _lib.elem_dtype(), torch.uint8):
             return self._hidden_stage(images, T, u8, out)
         w = self.w
         D, P, nh = v["hidden_size"], v["patch_size"], v["num_attention_heads"]
@@ -239,9 +239,9 @@ class HipSiglipVisionTower(HipCLIPVisionTower):
         hdp, eps = w["hdp"], v["layer_norm_eps"]
         Hh = nh * hdp
         a = self._patch_rows(images, u8, P, w["kp"])
-        x = torch.empty((T * N, D), dtype=torch.bfloat16, device=self._dev)
+        x = torch.empty((T * N, D), dtype=_lib.elem_dtype(), device=self._dev)
         ops.gemm(a, w["patch_w"], bias=w["patch_b"], res=w["pos"], out=x, res_map=(N, 0), flop_k=3 * P * P)
-        o = torch.empty((T * N, Hh), dtype=torch.bfloat16, device=self._dev)
+        o = torch.empty((T * N, Hh), dtype=_lib.elem_dtype(), device=self._dev)
         rs = ops.row_stats(x)                                                      # norm-carrying chain, as in the CLIP tower
         rn = ops.row_norm_finalize(rs, D, ops.NORM_LN, eps)
         last = len(w["layers"]) - 1
@@ -263,4 +263,4 @@ class HipSiglipVisionTower(HipCLIPVisionTower):
         if type(images) is list:                                                   # encoder.py:113-118
             return [self.forward(im.unsqueeze(0)) for im in images]
         x, T, N = self.forward_hidden(images)
-        return x.view(T, N, -1).to(images.dtype if images.dtype != torch.uint8 else torch.bfloat16)   # encoder.py:121
+        return x.view(T, N, -1).to(images.dtype if images.dtype != torch.uint8 else _lib.elem_dtype())   # encoder.py:121

@@ -4,7 +4,7 @@ Accepts both transformers-5.x key names (`...vision_tower.vision_tower.embedding
 VideoLLaMA2 checkpoints carry (`...vision_tower.vision_tower.vision_model.embeddings...`); SURVEY.md 7.3-7."""
 import torch
 
-BF16 = torch.bfloat16
+from . import _lib
 
 
 def normalise_keys(sd):
@@ -20,12 +20,12 @@ def _aligned(t):
 
 
 def _bf(t, dev):
-    return _aligned(t.detach().to(device=dev, dtype=BF16).contiguous())
+    return _aligned(t.detach().to(device=dev, dtype=_lib.elem_dtype()).contiguous())
 
 
 def _f32(t, dev):
     # parameters are stored in bf16 by the reference's bf16 path; bf16 -> fp32 is exact
-    return _aligned(t.detach().to(dtype=BF16).to(device=dev, dtype=torch.float32).contiguous())
+    return _aligned(t.detach().to(dtype=_lib.elem_dtype()).to(device=dev, dtype=torch.float32).contiguous())
 
 
 def fold_norm(w, g, b=None, c=None, dev=None):
@@ -36,14 +36,14 @@ def fold_norm(w, g, b=None, c=None, dev=None):
     w [N, K], g / b [K], c [N] or None.  Returns (W' bf16 on dev, s fp32, t fp32 or None).  Parameters are taken as the bf16
     path stores them (rounded to bf16 first), so folding a real checkpoint and folding the oracle's seeded weights agree."""
     dev = w.device if dev is None else dev
-    wf = w.detach().to(device=dev, dtype=BF16).float()
-    wp = (wf * g.detach().to(device=dev, dtype=BF16).float()[None, :]).to(BF16).contiguous()
+    wf = w.detach().to(device=dev, dtype=_lib.elem_dtype()).float()
+    wp = (wf * g.detach().to(device=dev, dtype=_lib.elem_dtype()).float()[None, :]).to(_lib.elem_dtype()).contiguous()
     s = wp.float().sum(1).contiguous()
     t = None
     if b is not None:
-        t = wf @ b.detach().to(device=dev, dtype=BF16).float()
+        t = wf @ b.detach().to(device=dev, dtype=_lib.elem_dtype()).float()
         if c is not None:
-            t = t + c.detach().to(device=dev, dtype=BF16).float()
+            t = t + c.detach().to(device=dev, dtype=_lib.elem_dtype()).float()
         t = t.contiguous()
     return _aligned(wp), _aligned(s), (None if t is None else _aligned(t))
 
@@ -57,12 +57,12 @@ def pack_tower(sd, cfg, dev, prefix="model.vision_tower.vision_tower."):
     n_run = (L + 1 + sel) if sel < 0 else sel
     kreal = 3 * P * P
     kp = (kreal + 63) // 64 * 64
-    pw = torch.zeros((D, kp), dtype=BF16, device=dev)
+    pw = torch.zeros((D, kp), dtype=_lib.elem_dtype(), device=dev)
     pw[:, :kreal] = _bf(sd[prefix + "embeddings.patch_embedding.weight"].reshape(D, kreal), dev)
     pos = _bf(sd[prefix + "embeddings.position_embedding.weight"], dev)
     cls = _bf(sd[prefix + "embeddings.class_embedding"], dev)
     out = dict(kp=kp, n_run=n_run, patch_w=pw, pos=pos,
-               cls_pos=(cls.float() + pos[0].float()).to(BF16).contiguous(),
+               cls_pos=(cls.float() + pos[0].float()).to(_lib.elem_dtype()).contiguous(),
                pre_w=_f32(sd[prefix + "pre_layrnorm.weight"], dev), pre_b=_f32(sd[prefix + "pre_layrnorm.bias"], dev),
                layers=[])
     for i in range(n_run):
@@ -102,12 +102,12 @@ def pack_siglip_tower(sd, cfg, dev, prefix="model.vision_tower.vision_tower."):
     Ip = (I + 127) // 128 * 128
     kreal = 3 * P * P
     kp = (kreal + 63) // 64 * 64
-    pw = torch.zeros((D, kp), dtype=BF16, device=dev)
+    pw = torch.zeros((D, kp), dtype=_lib.elem_dtype(), device=dev)
     pw[:, :kreal] = _bf(sd[prefix + "embeddings.patch_embedding.weight"].reshape(D, kreal), dev)
 
     def pad_rows(w):                                # [H*hd, ...] -> [H*hdp, ...], zero rows after every head
-        w = w.detach().to(BF16)
-        out = torch.zeros((H, hdp) + tuple(w.shape[1:]), dtype=BF16)
+        w = w.detach().to(_lib.elem_dtype())
+        out = torch.zeros((H, hdp) + tuple(w.shape[1:]), dtype=_lib.elem_dtype())
         out[:, :hd] = w.reshape((H, hd) + tuple(w.shape[1:]))
         return out.reshape((H * hdp,) + tuple(w.shape[1:]))
 
@@ -116,11 +116,11 @@ def pack_siglip_tower(sd, cfg, dev, prefix="model.vision_tower.vision_tower."):
     for i in range(n_run):
         p = f"{prefix}encoder.layers.{i}."
         a = p + "self_attn."
-        wo = torch.zeros((D, H, hdp), dtype=BF16)
-        wo[:, :, :hd] = sd[a + "out_proj.weight"].detach().to(BF16).reshape(D, H, hd)
-        w1 = torch.zeros((Ip, D), dtype=BF16); w1[:I] = sd[p + "mlp.fc1.weight"].detach().to(BF16)
-        b1 = torch.zeros((Ip,), dtype=BF16); b1[:I] = sd[p + "mlp.fc1.bias"].detach().to(BF16)
-        w2 = torch.zeros((D, Ip), dtype=BF16); w2[:, :I] = sd[p + "mlp.fc2.weight"].detach().to(BF16)
+        wo = torch.zeros((D, H, hdp), dtype=_lib.elem_dtype())
+        wo[:, :, :hd] = sd[a + "out_proj.weight"].detach().to(_lib.elem_dtype()).reshape(D, H, hd)
+        w1 = torch.zeros((Ip, D), dtype=_lib.elem_dtype()); w1[:I] = sd[p + "mlp.fc1.weight"].detach().to(_lib.elem_dtype())
+        b1 = torch.zeros((Ip,), dtype=_lib.elem_dtype()); b1[:I] = sd[p + "mlp.fc1.bias"].detach().to(_lib.elem_dtype())
+        w2 = torch.zeros((D, Ip), dtype=_lib.elem_dtype()); w2[:, :I] = sd[p + "mlp.fc2.weight"].detach().to(_lib.elem_dtype())
         # layer norms folded into the q/k/v and fc1 GEMMs (fold_norm); the zero padding rows stay zero rows with zero shift
         wqkv, sqkv, bqkv = fold_norm(torch.cat([pad_rows(sd[a + n + "_proj.weight"]) for n in "qkv"], 0), sd[p + "layer_norm1.weight"],
                                      sd[p + "layer_norm1.bias"], torch.cat([pad_rows(sd[a + n + "_proj.bias"]) for n in "qkv"], 0), dev)
@@ -159,7 +159,7 @@ def pack_connector(sd, dev, prefix="model.mm_projector."):
         samp_b=_f32(sd[prefix + "sampler.0.bias"], dev), cin=cin,
         ro0_w=_bf(sd[prefix + "readout.0.weight"], dev), ro0_b=_f32(sd[prefix + "readout.0.bias"], dev),
         ro2_w=_bf(sd[prefix + "readout.2.weight"], dev), ro2_b=_f32(sd[prefix + "readout.2.bias"], dev),
-        zero_row=torch.zeros(cin, dtype=BF16, device=dev))
+        zero_row=torch.zeros(cin, dtype=_lib.elem_dtype(), device=dev))
 
 
 def pack_gate_up(gate, up):
@@ -301,7 +301,7 @@ def random_state_dict(cfg, device, seed=1234, n_llm_layers=None):
             x = x * (fan_in ** -0.5)
         else:
             x = 0.5 * x
-        sd[name] = x.to(BF16)
+        sd[name] = x.to(_lib.elem_dtype())
     return sd
 
 
@@ -350,4 +350,4 @@ class LazyRandomStateDict:
             x = x * (fan_in ** -0.5)
         else:
             x = 0.5 * x
-        return x.to(BF16)
+        return x.to(_lib.elem_dtype())
