@@ -69,6 +69,8 @@ int64_t vl2_workspace_bytes(void);
 #define VL2_STAGE_NO_MIX           2   /* ... with VL2_GEMM_NO_MIX */
 #define VL2_STAGE_SELF_REDUCE      4   /* ViT: the norm-carrying GEMMs reduce the row statistics themselves (no row_norm_finalize launches) */
 #define VL2_STAGE_FUSED_DECODE_ATTN 8  /* decode step: attention + combine as one launch (vl2_attn_decode_fused; measured slower) */
+#define VL2_STAGE_STC_UNFUSED      32   /* connector: the SE block as the five launches of rounds 1-3 (dwconv, chan_mean, 2 x small_linear, se_scale) instead of
+                                         * vl2_dwconv3x3_ln_silu_mean + small_linear + vl2_se_excite_scale */
 #define VL2_STAGE_DECODE_TAIL      16   /* decode step: o_proj / gate-up / down as ONE vl2_decode_tail launch instead of three vl2_gemv_bf16 launches
                                           (same bits; measured slower: 98.5 vs 66.7 us per layer, profiles/r04_experiments.md) */
 #define VL2_GEMV_RMS_PLAIN 32  /* vl2_gemv_bf16 `flags`: RMS-normalise x with NO weight vector (the norm weight is folded into W; `norm_w` is ignored):
@@ -169,6 +171,15 @@ int32_t vl2_chan_mean(const void* x, float* mean, int32_t F, int32_t HW, int32_t
 int32_t vl2_small_linear(const float* x, const void* W, const float* b, float* out, int32_t F, int32_t N, int32_t K,
                          int32_t act, void* stream);
 int32_t vl2_se_scale(void* x, const float* gate, int32_t F, int32_t HW, int32_t C, void* stream);
+/* The same depthwise conv + LayerNorm2d + SiLU with the SE squeeze folded in: also writes mean[F, C] = y.mean over (H, W) (timm SEModule,
+ * x.mean((2, 3))), from per-team partial sums added in a fixed order (a frame's result does not depend on F).  The taps `w9c` are held in the
+ * build's element type inside the kernel (exact for weights that came from a checkpoint of that type).  ws >= vl2_dwconv_mean_workspace_bytes. */
+int64_t vl2_dwconv_mean_workspace_bytes(int32_t F, int32_t C);
+int32_t vl2_dwconv3x3_ln_silu_mean(const void* x, void* y, const float* w9c, const float* lnw, const float* lnb, int32_t F, int32_t H, int32_t W,
+                                   int32_t C, float eps, float* mean, void* ws, int64_t ws_bytes, void* stream);
+/* SE excite + scale in one launch: x[f, :, c] *= sigmoid(W2[c, :rd] . g1[f, :rd] + b2[c])  (= vl2_small_linear(.., SIGMOID) then vl2_se_scale).
+ * g1 fp32 [F, rd] (the squeezed, reduced, SiLU'd vector), W2 [C, rd] in the element type, b2 fp32 [C] or NULL.  C%8==0, rd%16==0. */
+int32_t vl2_se_excite_scale(void* x, const float* g1, const void* W2, const float* b2, int32_t F, int32_t HW, int32_t C, int32_t rd, void* stream);
 
 /* Mistral RoPE (rotate-half) on q,k of the fused qkv rows + KV-cache append at positions pos0..pos0+S-1.
  * head_dim 128.  cos/sin fp32 [maxpos][64].  HF:modeling_mistral.py apply_rotary_pos_emb, DynamicCache.update. */

@@ -17,6 +17,9 @@ for name, Fr, H in (("s1 16x24x24", 16, 24), ("s2 9x13x13", 9, 13)):
     us = timeit(lambda: ops.dwconv3x3_ln_silu(x, wt, lnw, lnb, Fr, H, H))
     mb = 2 * Fr * H * H * C * 2 / 1e6
     print(f"dwconv_ln_silu {name}: {us:.1f} us, {mb / us * 1e-0:.2f} TB/s of x + y ({mb:.0f} MB)".replace("TB/s", "MB/us = TB/s"), flush=True)
+    wtr = wt.to(x.dtype).float()                # taps as a checkpoint of the element type holds them
+    us = timeit(lambda: ops.dwconv3x3_ln_silu_mean(x, wtr, lnw, lnb, Fr, H, H))
+    print(f"dwconv_strip + squeeze (2 launches) {name}: {us:.1f} us, {mb / us:.2f} MB/us = TB/s of x + y", flush=True)
     us = timeit(lambda: ops.chan_mean(x, Fr, H * H))
     print(f"chan_mean {name}: {us:.1f} us", flush=True)
     m = ops.chan_mean(x, Fr, H * H)
@@ -29,6 +32,8 @@ for name, Fr, H in (("s1 16x24x24", 16, 24), ("s2 9x13x13", 9, 13)):
     g2 = ops.small_linear(g1, w2, b2, ops.ACT_SIGMOID)
     us = timeit(lambda: ops.se_scale_(x, g2, Fr, H * H))
     print(f"se_scale {name}: {us:.1f} us", flush=True)
+    us = timeit(lambda: ops.se_excite_scale_(x, g1, w2, b2, Fr, H * H))
+    print(f"se_excite_scale (fc2 + sigmoid + scale, 1 launch) {name}: {us:.1f} us", flush=True)
     r = rnd(Fr * H * H, C)
     us = timeit(lambda: ops.layernorm(x, lnw, lnb, 1e-5, res=r, silu=True))
     print(f"layernorm+res+silu {name}: {us:.1f} us", flush=True)

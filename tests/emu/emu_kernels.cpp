@@ -269,6 +269,29 @@ extern "C" int32_t vl2_dwconv3x3_ln_silu(const void* x, void* y, const float* wt
     else emu::launch(g, blk, [=] { dwconv_ln_silu_kernel<4>((const bf16_t*)x, (bf16_t*)y, wt, lnw, lnb, H, W, C, eps); });
     return 0;
 }
+#define DWS_TPF_MAX 96
+static inline int dws_tpf(int H, int W) {
+    const int U = H * ((W + DWS_P - 1) / DWS_P);
+    return U <= DWS_TPF_MAX ? U : (U + (U + 63) / 64 - 1) / ((U + 63) / 64);
+}
+extern "C" int64_t vl2_dwconv_mean_workspace_bytes(int32_t F, int32_t C) { return F > 0 && C > 0 ? (int64_t)F * DWS_TPF_MAX * C * 4 : -1; }
+extern "C" int32_t vl2_dwconv3x3_ln_silu_mean(const void* x, void* y, const float* wt, const float* lnw, const float* lnb, int32_t F, int32_t H,
+                                              int32_t W, int32_t C, float eps, float* mean, void* ws, int64_t ws_bytes, void*) {
+    const int U = H * ((W + DWS_P - 1) / DWS_P), tpf = dws_tpf(H, W), iters = (U + tpf - 1) / tpf;
+    if (mean && (!ws || ws_bytes < (int64_t)F * tpf * C * 4)) return -1;
+    float* psum = mean ? (float*)ws : nullptr;
+    const dim3 g((F * tpf + 1) / 2), blk(512);
+    if (C <= 2048) emu::launch(g, blk, [=] { dwconv_strip_ln_silu_kernel<1>((const bf16_t*)x, (bf16_t*)y, wt, lnw, lnb, psum, F, H, W, C, eps, tpf, iters); });
+    else if (C <= 4096) emu::launch(g, blk, [=] { dwconv_strip_ln_silu_kernel<2>((const bf16_t*)x, (bf16_t*)y, wt, lnw, lnb, psum, F, H, W, C, eps, tpf, iters); });
+    else emu::launch(g, blk, [=] { dwconv_strip_ln_silu_kernel<4>((const bf16_t*)x, (bf16_t*)y, wt, lnw, lnb, psum, F, H, W, C, eps, tpf, iters); });
+    if (mean) emu::launch(dim3((C + 255) / 256, F), dim3(256), [=] { chan_psum_finish_kernel(psum, mean, tpf, C, 1.0f / (float)(H * W)); });
+    return 0;
+}
+extern "C" int32_t vl2_se_excite_scale(void* x, const float* g1, const void* W2, const float* b2, int32_t F, int32_t HW, int32_t C, int32_t rd, void*) {
+    if (C % 8 || rd % 16) return -2;
+    emu::launch(dim3((C + 127) / 128, F), dim3(256), [=] { se_excite_scale_kernel((bf16_t*)x, g1, (const bf16_t*)W2, b2, HW, C, rd); });
+    return 0;
+}
 extern "C" int32_t vl2_chan_mean(const void* x, float* mean, int32_t F, int32_t HW, int32_t C, void*) {
     emu::launch(dim3(C / 64, F), dim3(256), [=] { chan_mean_kernel((const bf16_t*)x, mean, HW, C); });
     return 0;

@@ -239,6 +239,35 @@ def test_emu_dwconv_ln_silu_odd_grids(emu, Fr, H, W, C):
     assert rel(y, ref) < TOL_BF16_OUT
 
 
+@pytest.mark.parametrize("Fr,H,W,C,rd", [(2, 5, 13, 512, 128), (1, 3, 6, 4096, 1024), (1, 2, 1, 256, 64), (2, 3, 18, 512, 48), (3, 24, 24, 128, 32), (1, 2, 3, 8192, 2048)])
+def test_emu_dwconv_strip_squeeze_and_fused_excite(emu, Fr, H, W, C, rd):
+    """The strip form of the depthwise kernel (taps in LDS, persistent teams, SE squeeze folded in) against the per-position forms, and the
+    one-launch excite + scale against small_linear + se_scale.  24x24 is the s1 grid (64 teams per frame, 3 units each)."""
+    from videollama2_amd import ops
+    x = bf(Fr * H * W, C)
+    wt = (torch.randn(C, 1, 3, 3, generator=torch.Generator().manual_seed(3)) * 0.3).bfloat16().float()
+    lnw, lnb = torch.randn(C, generator=torch.Generator().manual_seed(4)), torch.randn(C, generator=torch.Generator().manual_seed(5))
+    w9c = wt.view(C, 9).t().contiguous()
+    y0 = ops.dwconv3x3_ln_silu(x, w9c, lnw, lnb, Fr, H, W)
+    y, m = ops.dwconv3x3_ln_silu_mean(x, w9c, lnw, lnb, Fr, H, W)
+    if W >= 16:
+        assert torch.equal(y, y0)                     # same fmaf chain as the four-position kernel
+    else:
+        assert rel(y, y0) < 2e-3
+    assert rel(m, y.float().view(Fr, H * W, C).mean(1)) < 1e-5
+    if Fr > 1:                                        # a frame's bits do not depend on how many frames the launch holds
+        y1, m1 = ops.dwconv3x3_ln_silu_mean(x[H * W:2 * H * W].contiguous(), w9c, lnw, lnb, 1, H, W)
+        assert torch.equal(y1, y[H * W:2 * H * W]) and torch.equal(m1, m[1:2])
+    w1, b1 = bf(rd, C, scale=C ** -0.5), torch.randn(rd) * 0.1
+    w2, b2 = bf(C, rd, scale=rd ** -0.5), torch.randn(C) * 0.1
+    g1 = ops.small_linear(m, w1, b1, ops.ACT_SILU)
+    ya = ops.se_scale_(y.clone(), ops.small_linear(g1, w2, b2, ops.ACT_SIGMOID), Fr, H * W)
+    yb = ops.se_excite_scale_(y.clone(), g1, w2, b2, Fr, H * W)
+    gate = torch.sigmoid(F.linear(g1, w2.float(), b2))
+    assert rel(yb.view(Fr, H * W, C), y.float().view(Fr, H * W, C) * gate[:, None, :]) < TOL_BF16_OUT
+    assert rel(yb, ya) < 1e-3 and (yb != ya).float().mean() < 0.02      # the two differ only where a gate's last fp32 bit moves a bf16 rounding
+
+
 def test_emu_attention_ragged_and_causal(emu):
     from videollama2_amd import ops
     B, H, N, D = 2, 2, 150, 64

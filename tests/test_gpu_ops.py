@@ -340,6 +340,38 @@ def test_stc_direct_kernels_full_width(ops, C):
     assert rel(xs.view(Fr, H * H, C), x.float().view(Fr, H * H, C) * gref[:, None, :]) < TOL_BF16_OUT
 
 
+@pytest.mark.parametrize("Fr,H,W,C,rd", [(3, 24, 24, 4096, 1024), (2, 13, 13, 4096, 1024), (1, 5, 7, 1024, 256), (1, 2, 1, 256, 64), (2, 3, 18, 1024, 48),
+                                         (2, 27, 27, 3584, 896), (1, 24, 24, 8192, 2048)])
+def test_dwconv_strip_squeeze_and_fused_excite(ops, Fr, H, W, C, rd):
+    """Round 4: the strip form of the depthwise kernel (taps in LDS, persistent teams) with the SE squeeze folded in, and the one-launch
+    excite + scale, against the per-position kernels and small_linear + se_scale (timm SEModule as restated in oracle/shims/timm)."""
+    x = bf(Fr * H * W, C).to(DEV)
+    wt = (torch.randn(C, 1, 3, 3) * 0.3).bfloat16().float()
+    lnw, lnb = torch.randn(C).to(DEV), torch.randn(C).to(DEV)
+    w9c = wt.view(C, 9).t().contiguous().to(DEV)
+    y0 = ops.dwconv3x3_ln_silu(x, w9c, lnw, lnb, Fr, H, W)
+    y, m = ops.dwconv3x3_ln_silu_mean(x, w9c, lnw, lnb, Fr, H, W)
+    if W >= 16:
+        assert torch.equal(y, y0)                     # same fmaf chain as the four-position kernel
+    else:
+        assert rel(y, y0) < 2e-3
+    ref = F.conv2d(x.float().cpu().view(Fr, H, W, C).permute(0, 3, 1, 2), wt, padding=1, groups=C).permute(0, 2, 3, 1)
+    ref = F.silu(F.layer_norm(ref, (C,), lnw.cpu(), lnb.cpu(), 1e-5)).reshape(Fr * H * W, C)
+    assert rel(y, ref) < TOL_BF16_OUT
+    assert rel(m, y.float().view(Fr, H * W, C).mean(1)) < 1e-5
+    if Fr > 1:                                        # a frame's bits do not depend on how many frames the launch holds
+        y1, m1 = ops.dwconv3x3_ln_silu_mean(x[H * W:2 * H * W].contiguous(), w9c, lnw, lnb, 1, H, W)
+        assert torch.equal(y1, y[H * W:2 * H * W]) and torch.equal(m1, m[1:2])
+    w1, b1 = bf(rd, C, scale=C ** -0.5).to(DEV), (torch.randn(rd) * 0.1).to(DEV)
+    w2, b2 = bf(C, rd, scale=rd ** -0.5).to(DEV), (torch.randn(C) * 0.1).to(DEV)
+    g1 = ops.small_linear(m, w1, b1, ops.ACT_SILU)
+    ya = ops.se_scale_(y.clone(), ops.small_linear(g1, w2, b2, ops.ACT_SIGMOID), Fr, H * W)
+    yb = ops.se_excite_scale_(y.clone(), g1, w2, b2, Fr, H * W)
+    gate = torch.sigmoid(F.linear(g1, w2.float(), b2))
+    assert rel(yb.view(Fr, H * W, C), y.float().view(Fr, H * W, C) * gate[:, None, :]) < TOL_BF16_OUT
+    assert rel(yb, ya) < 1e-3 and (yb != ya).float().mean() < 0.02
+
+
 def test_rope_kv(ops):
     S, nh, nkv, HD, smax, pos0 = 77, 32, 8, 128, 256, 100
     qkv = bf(S, (nh + 2 * nkv) * HD)

@@ -84,6 +84,8 @@ SIGNATURES = {
     "vl2_chan_mean": [_vp, _vp, _i32, _i32, _i32, _vp],
     "vl2_small_linear": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
     "vl2_se_scale": [_vp, _vp, _i32, _i32, _i32, _vp],
+    "vl2_dwconv3x3_ln_silu_mean": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _i64, _vp],
+    "vl2_se_excite_scale": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
     "vl2_rope_kv": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "vl2_gemv_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _i32, _vp],
     "vl2_gemm_skinny_bf16": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp],
@@ -94,7 +96,7 @@ SIGNATURES = {
     "vl2_argmax": [_vp, _i32, _vp, _vp, _i32, _vp, _vp],
     "vl2_embed_rows": [_vp, _vp, _vp, _i32, _i32, _i32, _vp],
 }
-EXPORTS = ["vl2_version", "vl2_elem_name", "vl2_last_error_string", "vl2_workspace_bytes", "vl2_vit_workspace_bytes", "vl2_stc_workspace_bytes", "vl2_llm_workspace_bytes"] + list(SIGNATURES)
+EXPORTS = ["vl2_version", "vl2_elem_name", "vl2_last_error_string", "vl2_workspace_bytes", "vl2_vit_workspace_bytes", "vl2_stc_workspace_bytes", "vl2_llm_workspace_bytes", "vl2_dwconv_mean_workspace_bytes"] + list(SIGNATURES)
 
 _lib = None
 # ---- element type of the build in use: "bf16" (libvl2hip.so, the default: BASELINE.json configs[1]) or "fp16" (libvl2hip_f16.so = the same
@@ -151,6 +153,8 @@ def load():
     lib.vl2_vit_workspace_bytes.argtypes = [ctypes.POINTER(VitDesc), _i32]
     lib.vl2_stc_workspace_bytes.restype = _i64
     lib.vl2_stc_workspace_bytes.argtypes = [ctypes.POINTER(StcDesc), _i32, _i32, _i32]
+    lib.vl2_dwconv_mean_workspace_bytes.restype = _i64
+    lib.vl2_dwconv_mean_workspace_bytes.argtypes = [_i32, _i32]
     lib.vl2_llm_workspace_bytes.restype = _i64
     lib.vl2_llm_workspace_bytes.argtypes = [ctypes.POINTER(LlmDesc), _i32]
     for name, args in SIGNATURES.items():

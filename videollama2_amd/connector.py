@@ -67,11 +67,16 @@ class HipSTCConnector(nn.Module):
         HW = H * W
         h = ops.gemm(x, b["conv1_w"])
         h = ops.layernorm(h, b["bn1_w"], b["bn1_b"], 1e-5, silu=True)
-        h = ops.dwconv3x3_ln_silu(h, b["dw_w"], b["bn2_w"], b["bn2_b"], F, H, W, 1e-5)
-        g = ops.chan_mean(h, F, HW)
-        g = ops.small_linear(g, b["fc1_w"], b["fc1_b"], ops.ACT_SILU)
-        g = ops.small_linear(g, b["fc2_w"], b["fc2_b"], ops.ACT_SIGMOID)
-        ops.se_scale_(h, g, F, HW)
+        if ops.stage_flags() & ops.STAGE_STC_UNFUSED:
+            h = ops.dwconv3x3_ln_silu(h, b["dw_w"], b["bn2_w"], b["bn2_b"], F, H, W, 1e-5)
+            g = ops.chan_mean(h, F, HW)
+            g = ops.small_linear(g, b["fc1_w"], b["fc1_b"], ops.ACT_SILU)
+            g = ops.small_linear(g, b["fc2_w"], b["fc2_b"], ops.ACT_SIGMOID)
+            ops.se_scale_(h, g, F, HW)
+        else:                               # squeeze inside the depthwise kernel, excite + scale as one launch (the chain vl2_stc_forward issues)
+            h, g = ops.dwconv3x3_ln_silu_mean(h, b["dw_w"], b["bn2_w"], b["bn2_b"], F, H, W, 1e-5)
+            g = ops.small_linear(g, b["fc1_w"], b["fc1_b"], ops.ACT_SILU)
+            ops.se_excite_scale_(h, g, b["fc2_w"], b["fc2_b"], F, HW)
         h = ops.gemm(h, b["conv3_w"])
         sc = ops.layernorm(ops.gemm(x, b["ds_w"]), b["dsbn_w"], b["dsbn_b"], 1e-5) if "ds_w" in b else x
         return ops.layernorm(h, b["bn3_w"], b["bn3_b"], 1e-5, res=sc, silu=True)

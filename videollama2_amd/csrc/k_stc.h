@@ -201,6 +201,184 @@ __global__ __launch_bounds__(256, NVT <= 2 ? 4 : 2) void dwconv4_ln_silu_kernel(
     }
 }
 
+// ---- strip form (round 4).  What bounded the two kernels above was L2, not HBM: per output position they pull 9 x C fp32 taps (147 KB at C = 4096)
+// next to 4.5 - 9 activation rows, ~10 TB/s of L2 traffic for 2.2 TB/s of HBM.  Here the taps are staged ONCE per workgroup into LDS (packed to the
+// element type they came from: 9 x C x 2 B = 72 KB) and the workgroups are persistent: 512 threads = two TEAMS of four waves, two workgroups per CU
+// (16 waves, 144 KB of LDS), each team walking units of DWS_P = 3 consecutive positions of one image row (a 24-wide row = 8 units; 16 frames = 3072
+// units = exactly 3 per team of a 256-CU launch).  Teams are frame-aligned: team g serves frame g / TPF and the units j, j + TPF, ... of it, so the SE
+// squeeze (timm SEModule: x.mean((2, 3)), projector.py:133 via regnet Bottleneck) falls out as ONE [C] partial sum per team (`psum`, of the ROUNDED
+// outputs, as chan_mean_kernel reads them) that chan_psum_finish_kernel adds up in slot order -- deterministic, and a frame's bits do not depend on
+// how many frames the launch holds as long as TPF is the same (the launcher derives TPF from the grid, not from F: see vl2_dwconv3x3_ln_silu_mean).
+// Per output the taps accumulate in the same (ky, kx) order with the same fmaf chain as dwconv4_ln_silu_kernel, so the two agree bit for bit.
+#define DWS_P 3
+template <int NVT>
+__global__ __launch_bounds__(512, NVT <= 2 ? 4 : 2) void dwconv_strip_ln_silu_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, const float* __restrict__ wt,
+                                                                      const float* __restrict__ lnw, const float* __restrict__ lnb, float* __restrict__ psum,
+                                                                      int F, int H, int W, int C, float eps, int TPF, int iters) {
+#pragma clang fp reassociate(off)
+    extern __shared__ __attribute__((aligned(16))) unsigned char vl2_smem[];
+    u32x4* wl = (u32x4*)vl2_smem;                                 // [9][C/8] packed taps
+    __shared__ float red[2][DWS_P][4];
+    const int wv8 = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);     // wave-uniform: the team's unit walk stays in scalar registers
+    const int team = wv8 >> 2, wave = wv8 & 3, tt = threadIdx.x & 255, lane = tt & 63;
+    const int cv = C >> 3;
+    for (int v = threadIdx.x; v < 9 * cv; v += 512) {
+        const float* wp = wt + (size_t)v * 8;
+        const f32x4 a = *(const f32x4*)wp, b = *(const f32x4*)(wp + 4);
+        const float t[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+        wl[v] = pack8(t);
+    }
+    __syncthreads();
+    const int g = blockIdx.x * 2 + team, f = g / TPF, j = g - f * TPF;
+    const bool live = f < F;
+    const int upr = (W + DWS_P - 1) / DWS_P, U = H * upr;         // units per image row / per frame
+    const size_t fbase = (size_t)(live ? f : 0) * H * W * C;
+    float cs[NVT][8];
+#pragma unroll
+    for (int i = 0; i < NVT; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cs[i][e] = 0.f;
+    auto team_sums = [&](float (&v)[DWS_P]) {
+#pragma unroll
+        for (int p = 0; p < DWS_P; ++p) v[p] = wave_sum(v[p]);
+        __syncthreads();                                           // protect `red` against the previous use (both teams run the same sequence)
+        if (lane == 0) {
+#pragma unroll
+            for (int p = 0; p < DWS_P; ++p) red[team][p][wave] = v[p];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < DWS_P; ++p) v[p] = (red[team][p][0] + red[team][p][1]) + (red[team][p][2] + red[team][p][3]);
+    };
+    for (int it = 0; it < iters; ++it) {
+        const int u = j + it * TPF;
+        const bool valid = live && u < U;
+        const int h0 = valid ? u / upr : 0, w0 = valid ? (u - h0 * upr) * DWS_P : 0;
+        float acc[DWS_P][NVT][8];
+#pragma unroll
+        for (int p = 0; p < DWS_P; ++p)
+#pragma unroll
+            for (int i = 0; i < NVT; ++i)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[p][i][e] = 0.f;
+        if (valid) {
+            // channel slab outermost: 5 window vectors live at a time (the 4-position form keeps 12; with the team sums riding along that spills)
+#pragma unroll
+            for (int i = 0; i < NVT; ++i) {
+                const int c = (i * 256 + tt) * 8;
+                if (c >= C) continue;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int hh = h0 + ky - 1;
+                    if (hh < 0 || hh >= H) continue;               // zero padding: the whole input row contributes nothing
+                    u32x4 win[DWS_P + 2];
+#pragma unroll
+                    for (int q = 0; q < DWS_P + 2; ++q) {
+                        const int ww = w0 + q - 1;
+                        const u32x4 z = {0u, 0u, 0u, 0u};                // a padded column: a zero vector, fmaf(0, w, acc) == acc (no branch per tap)
+                        const u32x4 ld = *(const u32x4*)(x + fbase + (size_t)(hh * W + (ww < 0 ? 0 : ww >= W ? W - 1 : ww)) * C + c);
+                        win[q] = (ww >= 0 && ww < W) ? ld : z;
+                    }
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        float wv[8];
+                        unpack8(wl[(ky * 3 + kx) * cv + i * 256 + tt], wv);
+#pragma unroll
+                        for (int p = 0; p < DWS_P; ++p) {
+                            float xv[8];
+                            unpack8(win[p + kx], xv);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) acc[p][i][e] = __builtin_fmaf(xv[e], wv[e], acc[p][i][e]);
+                        }
+                    }
+                }
+            }
+        }
+        float st[DWS_P];
+#pragma unroll
+        for (int p = 0; p < DWS_P; ++p) {
+            float sm = 0.f;
+#pragma unroll
+            for (int i = 0; i < NVT; ++i)
+                if ((i * 256 + tt) * 8 < C) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) sm += acc[p][i][e];
+                }
+            st[p] = sm;
+        }
+        team_sums(st);
+        float mean[DWS_P];
+#pragma unroll
+        for (int p = 0; p < DWS_P; ++p) {
+            mean[p] = st[p] / (float)C;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < NVT; ++i)
+                if ((i * 256 + tt) * 8 < C) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { const float d = acc[p][i][e] - mean[p]; q = __builtin_fmaf(d, d, q); }
+                }
+            st[p] = q;
+        }
+        team_sums(st);
+        if (!valid) continue;
+#pragma unroll
+        for (int i = 0; i < NVT; ++i) {
+            const int c = (i * 256 + tt) * 8;
+            if (c >= C) continue;
+            const f32x4 g0 = *(const f32x4*)(lnw + c), g1 = *(const f32x4*)(lnw + c + 4);
+            const f32x4 b0 = *(const f32x4*)(lnb + c), b1 = *(const f32x4*)(lnb + c + 4);
+#pragma unroll
+            for (int p = 0; p < DWS_P; ++p) {
+                if (w0 + p >= W) continue;
+                const float rstd = rsqrtf(st[p] / (float)C + eps);
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    o[e] = silu_f(((acc[p][i][e] - mean[p]) * rstd) * (e < 4 ? g0[e] : g1[e - 4]) + (e < 4 ? b0[e] : b1[e - 4]));
+                const u32x4 pk = pack8(o);
+                *(u32x4*)(y + fbase + ((size_t)h0 * W + w0 + p) * C + c) = pk;
+                unpack8(pk, o);                                    // the squeeze sums what the tensor holds
+#pragma unroll
+                for (int e = 0; e < 8; ++e) cs[i][e] += o[e];
+            }
+        }
+    }
+    if (psum && live) {
+#pragma unroll
+        for (int i = 0; i < NVT; ++i) {
+            const int c = (i * 256 + tt) * 8;
+            if (c >= C) continue;
+            float* dst = psum + (size_t)g * C + c;
+            *(f32x4*)dst = f32x4{cs[i][0], cs[i][1], cs[i][2], cs[i][3]};
+            *(f32x4*)(dst + 4) = f32x4{cs[i][4], cs[i][5], cs[i][6], cs[i][7]};
+        }
+    }
+}
+
+// psum [F][NP][C] fp32 (one row per team of dwconv_strip_ln_silu_kernel) -> mean [F][C] = (sum over the NP rows, in slot order) * inv_hw.
+// grid = (C/256, F), block 256 = 64 channel quads x 4 slot phases.
+__global__ __launch_bounds__(256) void chan_psum_finish_kernel(const float* __restrict__ psum, float* __restrict__ mean, int NP, int C, float inv_hw) {
+#pragma clang fp reassociate(off)
+    __shared__ f32x4 part[4][64];
+    const int q = threadIdx.x & 63, ph = threadIdx.x >> 6, f = blockIdx.y;
+    const int c = blockIdx.x * 256 + q * 4;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    if (c < C)
+        for (int s = ph; s < NP; s += 4) {
+            const f32x4 v = *(const f32x4*)(psum + ((size_t)f * NP + s) * C + c);
+            a[0] += v[0]; a[1] += v[1]; a[2] += v[2]; a[3] += v[3];
+        }
+    part[ph][q] = a;
+    __syncthreads();
+    if (ph == 0 && c < C) {
+        f32x4 t;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t[e] = ((part[0][q][e] + part[1][q][e]) + (part[2][q][e] + part[3][q][e])) * inv_hw;
+        *(f32x4*)(mean + (size_t)f * C + c) = t;
+    }
+}
+
 // x [F, HW, C] bf16 -> mean [F, C] fp32; grid = (C/64, F), block 256 = 8 channel-vectors x 32 position lanes
 __global__ __launch_bounds__(256) void chan_mean_kernel(const bf16_t* __restrict__ x, float* __restrict__ mean, int HW, int C) {
     __shared__ float part[32][65];
@@ -323,5 +501,98 @@ __global__ __launch_bounds__(256) void se_scale_kernel(bf16_t* __restrict__ x, c
 #pragma unroll
         for (int j = 0; j < 4; ++j) { a[j] *= g0[j]; a[4 + j] *= g1[j]; }
         *(u32x4*)(x + v * 8) = pack8(a);
+    }
+}
+
+// SE excite (second 1x1 conv + sigmoid) and the channel scale in ONE launch: x[f, :, c] *= sigmoid(W2[c, :] . g1[f, :] + b2[c]).
+// grid = (C/128, F), block 256.  A workgroup owns 128 channels of one frame: wave w computes the 32 gates w*32 .. w*32+31, 16 at a time (each lane keeps its 16-wide
+// k slice of g1 per 1024-wide chunk in registers and streams the weight rows past it, four rows per batch; the 16 lane-partials meet in a
+// reduce-scatter butterfly), the gates go through LDS, then the 256 threads sweep the frame's H*W positions, 16 positions x 256 B per pass.  The
+// extra W2 traffic (128 rows x rd x 2 B per workgroup, L2 hits) rides in front of a sweep that moves 2 x HW x 256 B; it replaces a launch whose
+// 14 - 16 us were latency, not bytes (small_linear_kernel at [F, C] x [C, rd]).
+__global__ __launch_bounds__(256, 4) void se_excite_scale_kernel(bf16_t* __restrict__ x, const float* __restrict__ g1, const bf16_t* __restrict__ W2,
+                                                              const float* __restrict__ b2, int HW, int C, int rd) {
+#pragma clang fp reassociate(off)
+    __shared__ float gate_s[128];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, f = blockIdx.y;
+    const int c0 = blockIdx.x * 128;
+    for (int half16 = 0; half16 < 2; ++half16) {                   // 16 gates at a time: 16 accumulators + 8 weight vectors stay under 128 VGPRs
+        float tot[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tot[r] = 0.f;
+        for (int kc = 0; kc < rd; kc += 1024) {
+            const int k = kc + lane * 16;
+            const bool kin = k < rd;
+            f32x4 gv[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) gv[t] = kin ? *(const f32x4*)(g1 + (size_t)f * rd + k + t * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int rb = 0; rb < 16; rb += 4) {
+                u32x4 wr[4][2];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int c = c0 + wave * 32 + half16 * 16 + rb + r;
+                    const bf16_t* wp = W2 + (size_t)(c < C ? c : C - 1) * rd + (kin ? k : 0);
+                    wr[r][0] = *(const u32x4*)wp;
+                    wr[r][1] = *(const u32x4*)(wp + 8);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float w[16];
+                    unpack8(wr[r][0], w);
+                    unpack8(wr[r][1], w + 8);
+                    float a = tot[rb + r];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) a = __builtin_fmaf(w[e], gv[e >> 2][e & 3], a);
+                    tot[rb + r] = kin ? a : tot[rb + r];
+                }
+            }
+        }
+        // 16 lane-partials -> lanes 4r .. 4r+3 end up with the wave total of value r: reduce-scatter over lane bits 5..2, full steps over bits 1, 0
+#pragma unroll
+        for (int m = 32, half = 8; m >= 4; m >>= 1, half >>= 1) {
+            const bool up = lane & m;
+#pragma unroll
+            for (int k = 0; k < half; ++k) {
+                const float send = up ? tot[k] : tot[k + half];
+                const float keep = up ? tot[k + half] : tot[k];
+                tot[k] = keep + __shfl_xor(send, m);
+            }
+        }
+        tot[0] += __shfl_xor(tot[0], 2);
+        tot[0] += __shfl_xor(tot[0], 1);
+        if (!(lane & 3)) {
+            const int r = half16 * 16 + (lane >> 2), c = c0 + wave * 32 + r;
+            gate_s[wave * 32 + r] = c < C ? sigmoid_f(tot[0] + (b2 ? b2[c] : 0.f)) : 0.f;
+        }
+    }
+    __syncthreads();
+    const int cq = threadIdx.x & 15, pr = threadIdx.x >> 4;      // 16 lanes x 16 B = the 128 channels of one position; 16 positions per pass
+    const int c = c0 + cq * 8;
+    if (c >= C) return;
+    float gq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) gq[e] = gate_s[cq * 8 + e];
+    bf16_t* xf = x + (size_t)f * HW * C + c;
+    int p = pr;
+    for (; p + 48 < HW; p += 64) {                                 // four passes in flight
+        u32x4 v[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[t] = *(const u32x4*)(xf + (size_t)(p + t * 16) * C);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float a[8];
+            unpack8(v[t], a);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] *= gq[e];
+            *(u32x4*)(xf + (size_t)(p + t * 16) * C) = pack8(a);
+        }
+    }
+    for (; p < HW; p += 16) {
+        float a[8];
+        unpack8(*(const u32x4*)(xf + (size_t)p * C), a);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] *= gq[e];
+        *(u32x4*)(xf + (size_t)p * C) = pack8(a);
     }
 }

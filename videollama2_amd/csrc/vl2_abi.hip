@@ -687,6 +687,47 @@ extern "C" int32_t vl2_dwconv3x3_ln_silu(const void* x, void* y, const float* w9
     else hipLaunchKernelGGL((dwconv_ln_silu_kernel<4>), g, b, 0, ST(stream), (const bf16_t*)x, (bf16_t*)y, w9c, lnw, lnb, H, W, C, eps);
     return launched("vl2_dwconv3x3_ln_silu");
 }
+// strip form (k_stc.h): TPF teams per frame, a function of the grid (H, W) alone so that a frame's partial-sum grouping never depends on F
+#define DWS_TPF_MAX 96
+static inline int dws_tpf(int H, int W) {
+    const int U = H * ((W + DWS_P - 1) / DWS_P);
+    return U <= DWS_TPF_MAX ? U : (U + (U + 63) / 64 - 1) / ((U + 63) / 64);
+}
+template <int NVT>
+static void launch_dwconv_strip(const void* x, void* y, const float* w9c, const float* lnw, const float* lnb, float* psum, int F, int H, int W, int C,
+                                float eps, hipStream_t s) {
+    const int U = H * ((W + DWS_P - 1) / DWS_P), tpf = dws_tpf(H, W), iters = (U + tpf - 1) / tpf;
+    const size_t lds = (size_t)9 * C * 2;
+    lds_attr<dwconv_strip_ln_silu_kernel<NVT>>((int)lds);
+    hipLaunchKernelGGL((dwconv_strip_ln_silu_kernel<NVT>), dim3((F * tpf + 1) / 2), dim3(512), lds, s, (const bf16_t*)x, (bf16_t*)y, w9c, lnw, lnb, psum,
+                       F, H, W, C, eps, tpf, iters);
+}
+extern "C" int64_t vl2_dwconv_mean_workspace_bytes(int32_t F, int32_t C) {
+    if (F <= 0 || C <= 0) return -1;
+    return (int64_t)F * DWS_TPF_MAX * C * 4;
+}
+extern "C" int32_t vl2_dwconv3x3_ln_silu_mean(const void* x, void* y, const float* w9c, const float* lnw, const float* lnb, int32_t F, int32_t H,
+                                              int32_t W, int32_t C, float eps, float* mean, void* ws, int64_t ws_bytes, void* stream) {
+    if (!x || !y || !w9c || !lnw || !lnb || F <= 0 || H <= 0 || W <= 0) return fail(VL2_E_BADARG, "vl2_dwconv3x3_ln_silu_mean: bad args");
+    if (C % 8 || C > 8192) return fail(VL2_E_SHAPE, "vl2_dwconv3x3_ln_silu_mean: need C%%8==0 and C<=8192");
+    const int tpf = dws_tpf(H, W);
+    if (mean && (!ws || !ALIGNED16(ws) || ws_bytes < (int64_t)F * tpf * C * 4))
+        return fail(VL2_E_BADARG, "vl2_dwconv3x3_ln_silu_mean: workspace missing, unaligned or < %lld bytes", (long long)F * tpf * C * 4);
+    float* psum = mean ? (float*)ws : nullptr;
+    if (C <= 2048) launch_dwconv_strip<1>(x, y, w9c, lnw, lnb, psum, F, H, W, C, eps, ST(stream));
+    else if (C <= 4096) launch_dwconv_strip<2>(x, y, w9c, lnw, lnb, psum, F, H, W, C, eps, ST(stream));
+    else launch_dwconv_strip<4>(x, y, w9c, lnw, lnb, psum, F, H, W, C, eps, ST(stream));
+    if (mean)
+        hipLaunchKernelGGL(chan_psum_finish_kernel, dim3((C + 255) / 256, F), dim3(256), 0, ST(stream), (const float*)psum, mean, tpf, C, 1.0f / (float)(H * W));
+    return launched("vl2_dwconv3x3_ln_silu_mean");
+}
+extern "C" int32_t vl2_se_excite_scale(void* x, const float* g1, const void* W2, const float* b2, int32_t F, int32_t HW, int32_t C, int32_t rd,
+                                       void* stream) {
+    if (!x || !g1 || !W2 || F <= 0 || HW <= 0 || C <= 0 || rd <= 0) return fail(VL2_E_BADARG, "vl2_se_excite_scale: bad args");
+    if (C % 8 || rd % 16) return fail(VL2_E_SHAPE, "vl2_se_excite_scale: need C%%8==0 and rd%%16==0 (C=%d rd=%d)", C, rd);
+    hipLaunchKernelGGL(se_excite_scale_kernel, dim3((C + 127) / 128, F), dim3(256), 0, ST(stream), (bf16_t*)x, g1, (const bf16_t*)W2, b2, HW, C, rd);
+    return launched("vl2_se_excite_scale");
+}
 extern "C" int32_t vl2_chan_mean(const void* x, float* mean, int32_t F, int32_t HW, int32_t C, void* stream) {
     if (!x || !mean || F <= 0 || HW <= 0) return fail(VL2_E_BADARG, "vl2_chan_mean: bad args");
     if (C % 64) return fail(VL2_E_SHAPE, "vl2_chan_mean: need C%%64==0");

@@ -39,7 +39,7 @@ NORM_NONE, NORM_RMS, NORM_LN = 0, 1, 2
 _WORKSPACE = {}
 _CTL = dict(variant=0, splitk=False, attn_variant=0, stage_flags=0, gemm_flags=0)
 GEMM_PERSISTENT, GEMM_NO_MIX = 8, 16                                    # vl2_gemm_desc.flags (include/vl2hip.h)
-STAGE_PERSISTENT_GEMM, STAGE_NO_MIX, STAGE_SELF_REDUCE, STAGE_FUSED_DECODE_ATTN, STAGE_DECODE_TAIL = 1, 2, 4, 8, 16   # vl2_*_desc.flags of the stage calls
+STAGE_PERSISTENT_GEMM, STAGE_NO_MIX, STAGE_SELF_REDUCE, STAGE_FUSED_DECODE_ATTN, STAGE_DECODE_TAIL, STAGE_STC_UNFUSED = 1, 2, 4, 8, 16, 32   # vl2_*_desc.flags of the stage calls
 
 
 def attach_workspace(device):
@@ -77,6 +77,10 @@ def set_stage_flags(flags):
     (the library reads no environment variables and keeps no state)."""
     _CTL["stage_flags"] = int(flags)
     _CTL["gemm_flags"] = (GEMM_PERSISTENT if flags & STAGE_PERSISTENT_GEMM else 0) | (GEMM_NO_MIX if flags & STAGE_NO_MIX else 0)
+
+
+def stage_flags():
+    return _CTL["stage_flags"]
 
 
 def set_gemm_variant(v):
@@ -176,7 +180,7 @@ def rmsnorm(x, w, eps, out=None):
     return out
 
 
-_DTYPE_CODE = {torch.float32: 0, torch.float16: 1, _lib.elem_dtype(): 2}
+_DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}       # frame types of the patch-row kernels (any build reads all three)
 
 
 def patchify(frames, patch, kp):
@@ -224,6 +228,25 @@ def dwconv3x3_ln_silu(x, w9c, lnw, lnb, F, H, W, eps=1e-5):
     y = torch.empty_like(x)
     _lib.call("vl2_dwconv3x3_ln_silu", _p(x), _p(y), _p(w9c), _p(lnw), _p(lnb), F, H, W, C, float(eps), _stream())
     return y
+
+
+def dwconv3x3_ln_silu_mean(x, w9c, lnw, lnb, F, H, W, eps=1e-5):
+    """Depthwise 3x3 + LayerNorm2d + SiLU AND the SE squeeze of the result: returns (y [F*H*W, C], mean fp32 [F, C])."""
+    _chk(x, _lib.elem_dtype(), "x")
+    C = x.shape[-1]
+    y = torch.empty_like(x)
+    mean = torch.empty((F, C), dtype=torch.float32, device=x.device)
+    nb = _lib.load().vl2_dwconv_mean_workspace_bytes(F, C)
+    ws = torch.empty((nb,), dtype=torch.uint8, device=x.device)
+    _lib.call("vl2_dwconv3x3_ln_silu_mean", _p(x), _p(y), _p(w9c), _p(lnw), _p(lnb), F, H, W, C, float(eps), _p(mean), _p(ws), nb, _stream())
+    return y, mean
+
+
+def se_excite_scale_(x, g1, w2, b2, F, HW):
+    """x[f, :, c] *= sigmoid(w2[c] . g1[f] + b2[c]) in place (SE excite + scale, one launch)."""
+    _chk(x, _lib.elem_dtype(), "x"); _chk(g1, torch.float32, "g1"); _chk(w2, _lib.elem_dtype(), "w2"); _chk(b2, torch.float32, "b2")
+    _lib.call("vl2_se_excite_scale", _p(x), _p(g1), _p(w2), _p(b2), F, HW, x.shape[-1], w2.shape[1], _stream())
+    return x
 
 
 def chan_mean(x, F, HW):
@@ -405,7 +428,7 @@ def vit_desc(w, v, family, act):
 
 def vit_forward(desc, frames, T, out, u8_norm=None):
     """frames [T,3,S,S] fp32 / fp16 / bf16 or uint8 [T,S,S,3] -> out [T * tokens, D] bf16 (class-token row included)."""
-    code = 3 if frames.dtype == torch.uint8 else {torch.float32: 0, torch.float16: 1, _lib.elem_dtype(): 2}[frames.dtype]
+    code = 3 if frames.dtype == torch.uint8 else _DTYPE_CODE[frames.dtype]
     n = int(_lib.load().vl2_vit_workspace_bytes(ctypes.byref(desc), T))
     if n < 0:
         raise _lib.Vl2HipError("vl2_vit_workspace_bytes: bad descriptor")

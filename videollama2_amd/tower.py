@@ -149,7 +149,7 @@ class HipCLIPVisionTower(nn.Module):
         if H != v["image_size"] or W != v["image_size"]:                          # HF:modeling_clip.py:203-207
             raise ValueError(f"Input image size ({H}*{W}) doesn't match model ({v['image_size']}*{v['image_size']}).")
         images = images.to(self._dev)
-        if ops.stage_enabled() and images.dtype in (torch.float32, torch.float16, _lib.elem_dtype(), torch.uint8):
+        if ops.stage_enabled() and images.dtype in (torch.float32, torch.float16, torch.bfloat16, torch.uint8):
             return self._hidden_stage(images, T, u8, out)
         w = self.w
         D, P = v["hidden_size"], v["patch_size"]
@@ -230,7 +230,7 @@ class HipSiglipVisionTower(HipCLIPVisionTower):
         if H != v["image_size"] or W != v["image_size"]:                          # HF:modeling_siglip.py SiglipVisionEmbeddings
             raise ValueError(f"Input image size ({H}*{W}) doesn't match model ({v['image_size']}*{v['image_size']}).")
         images = images.to(self._dev)
-        if ops.stage_enabled() and images.dtype in (torch.float32, torch.float16, _lib.elem_dtype(), torch.uint8):
+        if ops.stage_enabled() and images.dtype in (torch.float32, torch.float16, torch.bfloat16, torch.uint8):
             return self._hidden_stage(images, T, u8, out)
         w = self.w
         D, P, nh = v["hidden_size"], v["patch_size"], v["num_attention_heads"]
