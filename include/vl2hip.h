@@ -67,7 +67,8 @@ int64_t vl2_workspace_bytes(void);
 /* stage-level descriptors (vl2_vit_desc / vl2_stc_desc / vl2_llm_desc) `flags`: experiment controls, all off by default */
 #define VL2_STAGE_PERSISTENT_GEMM  1   /* every GEMM of the stage with VL2_GEMM_PERSISTENT */
 #define VL2_STAGE_NO_MIX           2   /* ... with VL2_GEMM_NO_MIX */
-#define VL2_STAGE_SELF_REDUCE      4   /* ViT: the norm-carrying GEMMs reduce the row statistics themselves (no row_norm_finalize launches) */
+#define VL2_STAGE_SELF_REDUCE      4   /* ViT and LLM prefill: the norm-carrying GEMMs reduce the row statistics themselves (no row_norm_finalize launches;
+                                         * same bits, measured slower: LLM prefill 24.4 -> 26.0 ms, profiles/r04_experiments.md section 1) */
 #define VL2_STAGE_FUSED_DECODE_ATTN 8  /* decode step: attention + combine as one launch (vl2_attn_decode_fused; measured slower) */
 #define VL2_STAGE_STC_UNFUSED      32   /* connector: the SE block as the five launches of rounds 1-3 (dwconv, chan_mean, 2 x small_linear, se_scale) instead of
                                          * vl2_dwconv3x3_ln_silu_mean + small_linear + vl2_se_excite_scale */

@@ -271,3 +271,7 @@ def test_lazy_tower_key_layouts_and_never_loaded_guard(tmp_path):
     flat.check_loaded()
     ref.load_state_dict({k: p for k, p in flat.state_dict().items()}, strict=True)                  # 5.x keys into the 4.x host
     ref.check_loaded()
+    # tensors that arrive through load_state_dict are loaded by construction -- a synthetic tower of constants passes
+    ones = LazyHipVisionTower(str(tdir), args, key_layout="vision_model")
+    ones.load_state_dict({k: torch.ones_like(p) for k, p in ref.state_dict().items()}, strict=True)
+    ones.check_loaded()

@@ -70,8 +70,21 @@ class HipCausalLMLoader:
         import json
         import os
         cj = os.path.join(str(model_path), "config.json")
-        hfj = json.load(open(cj)) if os.path.isfile(cj) else {}
-        if cls._orig is not None and not (hfj.get("mm_vision_tower") and hfj.get("mm_projector_type")):
+        hfj = None
+        if os.path.isfile(cj):
+            with open(cj) as fh:
+                hfj = json.load(fh)
+        elif not os.path.isdir(str(model_path)):                      # a hub id: resolve its config.json through the hub cache
+            try:
+                from huggingface_hub import hf_hub_download
+                with open(hf_hub_download(str(model_path), "config.json")) as fh:
+                    hfj = json.load(fh)
+            except Exception as e:                                    # offline / unknown id: the reference class decides, and says so
+                import warnings
+                warnings.warn(f"HIP path: config.json of '{model_path}' is not readable ({type(e).__name__}); handing the checkpoint to "
+                              f"{getattr(cls._orig, '__name__', 'the reference class')} -- it will NOT run on the HIP kernels")
+        # delegate only on evidence: a readable config WITHOUT the multimodal keys (or no readable config at all, warned about above)
+        if cls._orig is not None and (hfj is None or not (hfj.get("mm_vision_tower") and hfj.get("mm_projector_type"))):
             return cls._orig.from_pretrained(model_path, *args, config=config, **kwargs)
         for k in ("load_in_4bit", "load_in_8bit", "quantization_config"):          # model/__init__.py:57-69: bitsandbytes loading
             if kwargs.get(k):
