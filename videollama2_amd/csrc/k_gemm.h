@@ -931,6 +931,13 @@ __device__ __forceinline__ void gemm4_body(const GemmArgs& p, int bid, int nwg) 
     // the rows' statistics are fetched (and, without a finalize table, reduced) BEHIND the first three slabs' LDS-DMA: their latency
     // rides on the ring fill (ahead of the DMAs it was exposed: the in-kernel reduction measured +0.26 ms per ViT pass that way).
     // The pins keep the optimiser from sinking the pure loads to their first use in the epilogue.
+    // NOTE: vmcnt retires in order and hipcc's wait for a pin behind this branchy prologue is `s_waitcnt vmcnt(0)`, so the
+    // first MFMA phase of a norm-carrying GEMM starts when all three slabs have landed, and the counted wait_dma(2) below only matters
+    // for GEMMs without a norm.  Three other forms were compiled and read in the ISA (round 4, profiles/r04_experiments.md section 10):
+    // loads between slab 0 and slabs 1 / 2 with the pin behind them, or behind the counted wait -> still vmcnt(0) (the waitcnt pass merges
+    // the branches' pending counts conservatively); a volatile load -> the memory legaliser waits for it at once, which would serialise
+    // slab 0 -> statistics -> slabs 1, 2.  An untracked inline-asm load with manual counts is the form left; not taken: the register
+    // allocator may copy its result before the data arrive.  The counted vmcnt values everywhere assume no other VMEM operation in flight.
     if constexpr (!TR) { rst = gemm_row_stats(p, m0, tid, BM); VL2_PIN2(rst[0], rst[1]); }
     else {
         gemm_tr_row_stats<MI>(p, m0 + wrow, lane, rowst);
