@@ -876,7 +876,7 @@ extern "C" int32_t vl2_attn_decode(const void* qkv, void* kcache, void* vcache, 
 // attention + combine of ONE decode token in one launch (k_decode.h attn_decode_kernel<true>): `cnt` = nkv int32 ticket counters,
 // zero when the launch starts (vl2_llm_decode_step clears the counters of all layers in its argmax launch).  Same bits as
 // vl2_attn_decode.  Measured 2.4 us per layer SLOWER than the two launches (profiles/r03_experiments.md section 5), so the stage-level
-// decode step takes it only under VL2_DECODE_FUSED_ATTN=1; exported as vl2_attn_decode_fused and kept under test.
+// decode step takes it only with VL2_STAGE_FUSED_DECODE_ATTN in the descriptor flags; exported as vl2_attn_decode_fused and kept under test.
 static int32_t attn_decode_fused(const void* qkv, void* kcache, void* vcache, const float* cos_t, const float* sin_t, float* partial, void* out,
                                  int32_t nh, int32_t nkv, int32_t smax, const int32_t* pos_dev, float scale, int32_t* cnt, void* stream) {
     const int group = nh / nkv, nsplit = (smax + 63) / 64;
