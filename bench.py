@@ -179,6 +179,9 @@ def main():
     ap.add_argument("--vit-streams", type=int, default=None, help="ViT frames as N chunks on N HIP streams (default: the tower's own, 3)")
     ap.add_argument("--dtype", choices=["bf16", "fp16"], default="bf16", help="16-bit element type = which build of the library runs "
                     "(bf16: libvl2hip.so, BASELINE.json configs[1]; fp16: libvl2hip_f16.so, the reference's own mm_infer dtype)")
+    ap.add_argument("--decode-weights", choices=["16bit", "fp8"], default="16bit",
+                    help="fp8: ALSO time the decode steps on e4m3fn row-scaled copies of the decoder weights (SURVEY 8f row 5; an optional "
+                         "arithmetic, reported under the `decode_fp8` key -- the headline decode numbers stay the 16-bit ones)")
     ap.add_argument("--stage-flags", type=int, default=0, help="experiment controls of the stage-level calls (include/vl2hip.h VL2_STAGE_*: 1 persistent GEMM, "
                     "2 no mixed launch, 4 in-GEMM statistics reduction (ViT), 8 fused decode attention); travel in the call descriptors")
     ap.add_argument("--tune", type=str, default="", help="debug: comma list of gemm=<variant>, splitk=<0|1>, attn=<variant> (videollama2_amd/ops.py launch controls)")
@@ -350,6 +353,45 @@ def main():
             except Exception as exc:               # noqa: BLE001
                 cuts[cut] = dict(error=f"{type(exc).__name__}: {exc}"[:300])
         model.sharder.cut = keep
+
+    # ---- optional: the same decode steps on fp8 (e4m3fn, one power-of-two scale per output row) copies of the decoder's weights
+    decode_fp8 = None
+    if args.decode_weights == "fp8" and world == 1 and tp_group is None:
+        dec = model.decoder
+        dec.enable_fp8_decode()
+        g8 = None if args.no_graph else dec.capture_graph()
+        best = None
+        for it in range(args.steps + 1):
+            _, _, _, emb, _ = model.prepare_inputs_labels_for_multimodal(ids, mask, None, None, [(frames, "video")])
+            dec.prefill(emb[0])
+            dec.state.copy_(torch.tensor([dec.pos - 1, 0], dtype=torch.int32), non_blocking=True)
+            a, b = ev(), ev()
+            a.record()
+            for s in range(n_new):
+                if g8 is not None:
+                    g8.replay()
+                else:
+                    ops.argmax(dec.logits, dec.tok)
+                    dec.decode_step()
+            b.record()
+            torch.cuda.synchronize()
+            if g8 is not None:
+                dec.pos += n_new
+            if it:
+                best = a.elapsed_time(b) if best is None else min(best, a.elapsed_time(b))
+        l = cfg["llm"]
+        kvd, qd = l["num_key_value_heads"] * l["head_dim"], l["num_attention_heads"] * l["head_dim"]
+        rows = l["num_hidden_layers"] * (qd + 2 * kvd + l["hidden_size"] + 2 * l["intermediate_size"] + l["hidden_size"]) + l["vocab_size"]
+        b16 = decode_bytes_per_token(cfg, S + n_new // 2)
+        kv = l["num_hidden_layers"] * 2 * kvd * 2 * (S + n_new // 2)
+        b8 = (b16 - kv) // 2 + rows * 4 + kv
+        decode_fp8 = {"ms_per_token": round(best / n_new, 4), "tokens_per_s": round(n_new / (best / 1e3), 2),
+                      "bytes_per_token": b8, "hbm_frac": round(b8 / (best / n_new / 1e3) / 1e9 / PEAK_HBM_GBS, 4),
+                      "what": "decode projections + lm_head on OCP e4m3fn copies of the packed weights, one power-of-two fp32 scale per output row, "
+                              "16-bit activations, fp32 accumulation (csrc/k_fp8.h; prefill keeps the 16-bit weights).  OPTIONAL arithmetic: not the "
+                              "reference's, not the headline (`decode_ms_per_token` is the 16-bit path); tests/test_gpu_fp8.py, profiles/r04_fp8_parity.json"}
+        dec.enable_fp8_decode(False)
+        graph = None if args.no_graph else dec.capture_graph()      # the 16-bit graph again for the passes below
 
     # ---- roofline of the dominant kernel (gemm_bf16_kernel, MFMA-bound): one extra profiled pass, every GEMM launch
     #      bracketed by HIP events on the launch stream; achieved = sum(algorithmic FLOPs) / sum(kernel time)
@@ -525,6 +567,8 @@ def main():
         if shard_check is not None:
             out["sharded_encoder_equals_unsharded"] = shard_check
             out["encoder_graphs"] = "replayed" if model.sharder.use_graph else f"eager ({model.sharder.graph_error or 'disabled'})"
+        if decode_fp8 is not None:
+            out["decode_fp8"] = decode_fp8
         if batched is not None:
             out["batched_decode"] = batched
         if bprefill is not None:

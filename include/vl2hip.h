@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define VL2_ABI_VERSION 3
+#define VL2_ABI_VERSION 4
 #define VL2_E_BADARG  (-1)   /* null pointer / non-positive size */
 #define VL2_E_SHAPE   (-2)   /* shape not supported by the gfx950 kernels (alignment / multiple-of constraints) */
 #define VL2_E_UNSUPP  (-3)   /* option combination not built */
@@ -74,6 +74,9 @@ int64_t vl2_workspace_bytes(void);
                                          * vl2_dwconv3x3_ln_silu_mean + small_linear + vl2_se_excite_scale */
 #define VL2_STAGE_DECODE_TAIL      16   /* decode step: o_proj / gate-up / down as ONE vl2_decode_tail launch instead of three vl2_gemv_bf16 launches
                                           (same bits; measured slower: 98.5 vs 66.7 us per layer, profiles/r04_experiments.md) */
+#define VL2_STAGE_DECODE_FP8       64   /* decode step: the five projections of every layer and lm_head read the fp8 copies of the weights
+                                         * (vl2_llm_desc.layers_w8 / lm_head_w8: vl2_gemv_fp8 instead of vl2_gemv_bf16).  A different arithmetic
+                                         * (weights rounded to e4m3fn): OPTIONAL, never the default, never the headline number */
 #define VL2_GEMV_RMS_PLAIN 32  /* vl2_gemv_bf16 `flags`: RMS-normalise x with NO weight vector (the norm weight is folded into W; `norm_w` is ignored):
                                  the same bits as a vector of ones, without every workgroup reading 4 K bytes of ones */
 #define VL2_NORM_NONE 0
@@ -191,6 +194,16 @@ int32_t vl2_rope_kv(const void* qkv, void* q_out, void* kcache, void* vcache, co
  * bias (fp32, may be NULL) is Qwen2's q/k/v bias (HF:models/qwen2/modeling_qwen2.py Qwen2Attention).  flags as vl2_gemm_desc.flags. */
 int32_t vl2_gemv_bf16(const void* W, const void* x, const float* norm_w, const void* res, const float* bias, void* y,
                       int32_t N, int32_t K, int32_t ldw, float eps, int32_t flags, void* stream);
+/* ---- fp8 weights for decode (the fp8 half of BASELINE.json configs[4]; csrc/k_fp8.h).  OCP e4m3fn bytes (gfx950's format,
+ * not MI300X's fnuz) with ONE power-of-two fp32 scale per output row: W[n][k] ~= scale[n] * q[n][k]; activations stay 16-bit (W8A16), fp32
+ * products and sums.  The reference has no fp8 path: the quantiser IS the definition, restated in oracle/fp8_oracle.py.
+ * vl2_pack_quant_fp8: w [N, ldw] 16-bit elements (K % 16 == 0) -> q [N, K] bytes, scale [N]: scale = 2^e, e the smallest integer with
+ *   max|row| <= 448 * 2^e (1 for a zero row), q = round-to-nearest-even e4m3fn of w * 2^-e (exact scaling: reproducible bit for bit anywhere).
+ * vl2_gemv_fp8: y[N] = scale[N] * (q[N,K] x[K]) (+ bias) (+ res), one token; norm_w / VL2_GEMV_RMS_PLAIN / VL2_GEMM_SWIGLU /
+ *   VL2_GEMM_OUT_F32 as vl2_gemv_bf16 (SWIGLU: q and scale in the packed 64-row block order).  N even, K % 16 == 0, K <= 32704. */
+int32_t vl2_pack_quant_fp8(const void* w, int64_t N, int64_t K, int64_t ldw, void* q, float* scale, void* stream);
+int32_t vl2_gemv_fp8(const void* q, const float* scale, const void* x, const float* norm_w, const void* res, const float* bias, void* y,
+                     int32_t N, int32_t K, int32_t ldq, float eps, int32_t flags, void* stream);
 /* Skinny-M GEMM for batched decode: C[M <= 64, N] = A[M,K] W[N,K]^T (+bias | +res | SwiGLU | fp32 out; flags as vl2_gemm_desc.flags).
  * The weights stream from HBM straight into the B operand of v_mfma_f32_16x16x32_bf16 (GEMV-style, once for all M rows), K is
  * split over workgroups, fp32 partial sums go through the caller's workspace `ws` (required, >= vl2_workspace_bytes()) and are reduced in order. */
@@ -327,6 +340,12 @@ typedef struct vl2_llm_layer {
     const void* wd;
     void* kcache; void* vcache;              /* [kv_heads][smax][128] bf16 */
 } vl2_llm_layer;
+typedef struct vl2_llm_layer_w8 {            /* fp8 copies of a layer's packed projections (vl2_pack_quant_fp8 of wqkv / wo / wgu / wd) */
+    const void* wqkv; const float* sqkv;
+    const void* wo;   const float* so;
+    const void* wgu;  const float* sgu;
+    const void* wd;   const float* sd;
+} vl2_llm_layer_w8;
 typedef struct vl2_llm_desc {
     uint32_t size;
     int32_t D, I, heads, kv_heads, n_layers, vocab, smax;        /* head_dim is 128; I as packed */
@@ -335,6 +354,8 @@ typedef struct vl2_llm_desc {
     const void* embed; const float* norm_w; const float* ones /* [D] of 1.0f */; const void* lm_head;
     const float* cos_t; const float* sin_t;                      /* fp32 [smax][64] */
     uint32_t flags;                /* VL2_STAGE_* */
+    const vl2_llm_layer_w8* layers_w8;                            /* host array [n_layers] or NULL; read only with VL2_STAGE_DECODE_FP8 */
+    const void* lm_head_w8; const float* lm_head_scale;          /* fp8 copy of lm_head (final norm weight NOT folded: norm_w is applied) */
 } vl2_llm_desc;
 int64_t vl2_llm_workspace_bytes(const vl2_llm_desc* w, int32_t S);
 /* Prefill: inputs_embeds x [S, D] bf16 -> K/V cache rows 0..S-1 of every layer, fp32 logits of the LAST position [vocab]. */

@@ -1,0 +1,86 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU restatement of the fp8 weight format of the optional decode path (the fp8 half of
+BASELINE.json configs[4]; product: videollama2_amd/csrc/k_fp8.h, include/vl2hip.h vl2_pack_quant_fp8 / vl2_gemv_fp8).
+
+PARITY UNPINNED against the reference: /root/reference has no fp8 path and no calibration recipe ("needs a calibration story
+the reference does not have"), so this file DEFINES the arithmetic and the kernels are held bit for bit (quantiser) / to fp32 rounding (GEMV)
+against it.  What it is pinned to instead: the OCP 8-bit floating point specification's e4m3fn encoding (OFP8 v1.0: bias 7, no infinities,
+S.1111.111 = NaN, max finite 448, subnormals in units of 2^-9) through (a) the known-answer table KNOWN_E4M3FN below, (b) PyTorch's
+independent implementation of the same format (`torch.float8_e4m3fn`), checked byte for byte over all 256 codes and over random inputs in
+tests/test_fp8.py, (c) a third independent implementation, the emulator's (tests/emu/hip_emu.h).
+
+Only tests/ and bench.py's checker legs may import this file (tests/test_host_logic.py::test_product_never_imports_oracle)."""
+import math
+
+import torch
+
+# (value, code): OFP8 e4m3fn known answers -- exact values, the two ends of the normal range, subnormals, round-half-even ties, saturation
+KNOWN_E4M3FN = [(0.0, 0x00), (1.0, 0x38), (-2.0, 0xC0), (0.5, 0x30), (448.0, 0x7E), (-448.0, 0xFE), (2.0 ** -6, 0x08), (2.0 ** -9, 0x01),
+                (7 * 2.0 ** -9, 0x07), (1.125, 0x39), (1.0625, 0x38), (1.1875, 0x3A), (17.0, 0x58), (19.0, 0x5A), (240.0, 0x77),
+                (3 * 2.0 ** -10, 0x02), (2.0 ** -10, 0x00), (0.75 * 2.0 ** -9, 0x01)]
+
+
+def e4m3fn_decode(code):
+    """One byte -> float (python arithmetic, from the specification)."""
+    s, e, m = code >> 7, (code >> 3) & 15, code & 7
+    if e == 15 and m == 7:
+        return math.nan
+    v = m * 2.0 ** -9 if e == 0 else (1 + m / 8) * 2.0 ** (e - 7)
+    return -v if s else v
+
+
+def e4m3fn_encode(x):
+    """float -> byte, round to nearest even, saturating to +-448 (python arithmetic, from the specification; exact for fp32 inputs)."""
+    if x != x:
+        return 0x7F
+    s = 0x80 if math.copysign(1.0, x) < 0 else 0
+    a = abs(x)
+    best, bd = 0, None
+    for c in range(0x7F):                      # the 127 finite non-negative codes are monotone: nearest value, ties to the even code
+        d = abs(e4m3fn_decode(c) - a)
+        if bd is None or d < bd or (d == bd and c % 2 == 0):
+            best, bd = c, d
+    return s | best
+
+
+def row_scale_exponent(amax):
+    """e = the smallest integer with amax <= 448 * 2^e (0 for amax = 0 or denormal amax), clamped to [-100, 100] -- k_fp8.h's bit arithmetic
+    restated with frexp: amax = m * 2^x, m in [0.5, 1); 448 = 0.875 * 2^9."""
+    amax = amax.float()
+    m, x = torch.frexp(amax)
+    e = x - 9 + (m > 0.875).to(x.dtype)
+    e = torch.where(amax < 2.0 ** -126, torch.zeros_like(e), e)
+    return e.clamp(-100, 100)
+
+
+def quant_rows(w):
+    """w [N, K] (any float dtype; the values are taken as they are) -> (q uint8 [N, K] e4m3fn codes, scale fp32 [N] = 2^e)."""
+    wf = w.detach().float().cpu()
+    e = row_scale_exponent(wf.abs().amax(dim=1))
+    scale = torch.exp2(e.float())
+    q = (wf * torch.exp2(-e.float())[:, None]).to(torch.float8_e4m3fn).view(torch.uint8)     # the scaling is exact (a power of two)
+    return q, scale
+
+
+def dequant(q, scale):
+    return q.view(torch.float8_e4m3fn).float() * scale[:, None]
+
+
+def gemv(q, scale, x, norm_w=None, eps=1e-5, res=None, bias=None, swiglu=False, rms=False, elem=torch.bfloat16):
+    """y = scale * (q x) (+ bias) (+ res) in fp32, x [K] in the 16-bit element type.  rms / norm_w: MistralRMSNorm on x first, its output
+    rounded to the element type (HF:modeling_mistral.py:46-48).  swiglu: rows in blocks of 64 = 32 gate rows then 32 up rows."""
+    xf = x.detach().float().cpu()
+    if rms or norm_w is not None:
+        xf = xf * torch.rsqrt((xf * xf).mean() + eps)
+        if norm_w is not None:
+            xf = xf * norm_w.float().cpu()
+        xf = xf.to(elem).float()
+    y = (q.view(torch.float8_e4m3fn).float() @ xf) * scale
+    if swiglu:
+        y = y.view(-1, 2, 32)
+        g, u = y[:, 0].reshape(-1), y[:, 1].reshape(-1)
+        y = torch.nn.functional.silu(g) * u
+    if bias is not None:
+        y = y + bias.float().cpu()
+    if res is not None:
+        y = y + res.float().cpu()
+    return y

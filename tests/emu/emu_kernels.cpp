@@ -13,6 +13,7 @@ alignas(64) unsigned char vl2_smem[160 * 1024];
 #include "k_stc.h"
 #include "k_decode.h"
 #include "k_decode_tail.h"
+#include "k_fp8.h"
 #include "k_skinny.h"
 #include "k_pack.h"
 #include <cstdint>
@@ -349,6 +350,23 @@ extern "C" int32_t vl2_gemv_bf16(const void* W, const void* x, const float* norm
     if (sw) emu::launch(g, blk, [=] { gemv_bf16_kernel<true, false, 2>(a); });
     else if (f32) emu::launch(g, blk, [=] { gemv_bf16_kernel<false, true, 2>(a); });
     else emu::launch(g, blk, [=] { gemv_bf16_kernel<false, false, 2>(a); });
+    return 0;
+}
+extern "C" int32_t vl2_pack_quant_fp8(const void* w, int64_t N, int64_t K, int64_t ldw, void* q, float* scale, void*) {
+    if (K % 16 || ldw % 8 || ldw < K) return -2;
+    emu::launch(dim3((unsigned)N), dim3(256), [=] { quant_fp8_rows_kernel((const bf16_t*)w, (uint8_t*)q, scale, (int)K, (long)ldw); });
+    return 0;
+}
+extern "C" int32_t vl2_gemv_fp8(const void* q, const float* scale, const void* x, const float* norm_w, const void* res, const float* bias, void* y,
+                                int32_t N, int32_t K, int32_t ldq, float eps, int32_t flags, void*) {
+    if (K % 16 || ldq % 16 || ldq < K || N % 2) return -2;
+    Gemv8Args a{(const uint8_t*)q, scale, (const bf16_t*)x, norm_w, (const bf16_t*)res, y, N, K, ldq, eps, bias, 0};
+    if (flags & VL2_GEMV_RMS_PLAIN) { a.norm_w = nullptr; a.rms_plain = 1; }
+    const bool sw = flags & 1, f32 = flags & 2;
+    dim3 g((N / 2 + 3) / 4), blk(256);
+    if (sw) emu::launch(g, blk, [=] { gemv_fp8_kernel<true, false>(a); });
+    else if (f32) emu::launch(g, blk, [=] { gemv_fp8_kernel<false, true>(a); });
+    else emu::launch(g, blk, [=] { gemv_fp8_kernel<false, false>(a); });
     return 0;
 }
 extern "C" int32_t vl2_gemm_skinny_bf16(const void* A, const void* W, void* C, const float* bias, const void* res, int32_t M, int32_t N,

@@ -345,6 +345,36 @@ template <class T> static inline void emu_permlane32_swap(T& vdst, T& src) {
 #define VL2_PIN2(a, b) ((void)0)
 #define VL2_PERMLANE32_SWAP_8(pk) do { emu_permlane32_swap(pk[0], pk[2]); emu_permlane32_swap(pk[1], pk[3]); \
                                        emu_permlane32_swap(pk[4], pk[6]); emu_permlane32_swap(pk[5], pk[7]); } while (0)
+// OCP e4m3fn (gfx950's fp8) in software, for csrc/k_fp8.h: v_cvt_pk_f32_fp8 / v_cvt_pk_fp8_f32 (round to nearest even, saturating)
+static inline float emu_e4m3fn_to_f32(unsigned b) {
+    const unsigned e = (b >> 3) & 15u, m = b & 7u;
+    float v = e == 0 ? ldexpf((float)m, -9) : (e == 15 && m == 7 ? NAN : ldexpf(1.0f + (float)m * 0.125f, (int)e - 7));
+    return (b & 0x80u) ? -v : v;
+}
+static inline unsigned emu_f32_to_e4m3fn(float f) {
+    if (f != f) return 0x7fu;
+    const unsigned sgn = std::signbit(f) ? 0x80u : 0u;
+    const float a = fabsf(f);
+    if (a >= 464.0f) return sgn | 0x7eu;                              // beyond the last rounding boundary: saturate to 448
+    if (a < 0.015625f) return sgn | (unsigned)nearbyintf(ldexpf(a, 9));   // subnormal range: units of 2^-9 (8 units = the first normal, 0x08)
+    int ex;
+    const float mant = frexpf(a, &ex) * 2.0f;                         // [1, 2)
+    ex -= 1;
+    unsigned q = (unsigned)nearbyintf((mant - 1.0f) * 8.0f);          // nearbyint: round-half-even in the default rounding mode
+    if (q == 8u) { q = 0u; ex += 1; }
+    return sgn | ((unsigned)(ex + 7) << 3) | q;
+}
+typedef float emu_f32x2 __attribute__((ext_vector_type(2)));
+static inline emu_f32x2 emu_cvt_pk_f32_fp8(unsigned w, bool hi) {
+    const unsigned h = hi ? (w >> 16) : w;
+    return emu_f32x2{emu_e4m3fn_to_f32(h & 0xffu), emu_e4m3fn_to_f32((h >> 8) & 0xffu)};
+}
+static inline int emu_cvt_pk_fp8_f32(float a, float b, int old, bool hi) {
+    const unsigned pk = emu_f32_to_e4m3fn(a) | (emu_f32_to_e4m3fn(b) << 8);
+    return hi ? (int)(((unsigned)old & 0x0000ffffu) | (pk << 16)) : (int)(((unsigned)old & 0xffff0000u) | pk);
+}
+#define VL2_CVT_PK_F32_FP8(w, hi) emu_cvt_pk_f32_fp8((unsigned)(w), (hi))
+#define VL2_CVT_PK_FP8_F32(a, b, old, hi) emu_cvt_pk_fp8_f32((a), (b), (old), (hi))
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 static inline int emu_fetch_add(int* p, int v) { int o = *p; *p = o + v; return o; }
 static inline unsigned emu_fetch_add(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }

@@ -50,11 +50,17 @@ class LlmLayer(ctypes.Structure):
     _fields_ = [(n, _vp) for n in ("wqkv", "bqkv", "wo", "wgu", "wd", "kcache", "vcache")]
 
 
+class LlmLayerW8(ctypes.Structure):
+    """include/vl2hip.h `vl2_llm_layer_w8` (fp8 copies of a layer's packed projections + their row scales)."""
+    _fields_ = [(n, _vp) for n in ("wqkv", "sqkv", "wo", "so", "wgu", "sgu", "wd", "sd")]
+
+
 class LlmDesc(ctypes.Structure):
     """include/vl2hip.h `vl2_llm_desc`."""
     _fields_ = [("size", ctypes.c_uint32), ("D", _i32), ("I", _i32), ("heads", _i32), ("kv_heads", _i32), ("n_layers", _i32), ("vocab", _i32),
                 ("smax", _i32), ("eps", _f32), ("layers", ctypes.POINTER(LlmLayer)), ("embed", _vp), ("norm_w", _vp), ("ones", _vp),
-                ("lm_head", _vp), ("cos_t", _vp), ("sin_t", _vp), ("flags", ctypes.c_uint32)]
+                ("lm_head", _vp), ("cos_t", _vp), ("sin_t", _vp), ("flags", ctypes.c_uint32),
+                ("layers_w8", ctypes.POINTER(LlmLayerW8)), ("lm_head_w8", _vp), ("lm_head_scale", _vp)]
 
 
 # name -> argtypes (all return int32 except the two below)
@@ -73,6 +79,8 @@ SIGNATURES = {
     "vl2_pack_permute": [_vp, _vp, _i32, _i32, _i32, _i32, _vp],
     "vl2_pack_pad_rows": [_vp, _vp, _i64, _i64, _i64, _vp],
     "vl2_pack_cvt_f32": [_vp, _vp, _i64, _vp],
+    "vl2_pack_quant_fp8": [_vp, _i64, _i64, _i64, _vp, _vp, _vp],
+    "vl2_gemv_fp8": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _i32, _vp],
     "vl2_layernorm": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp],
     "vl2_rmsnorm": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp],
     "vl2_patchify": [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
@@ -161,7 +169,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = _i32
         fn.argtypes = args
-    if lib.vl2_version() != 3:
+    if lib.vl2_version() != 4:
         raise Vl2HipError("libvl2hip.so ABI version mismatch")
     lib.vl2_elem_name.restype = ctypes.c_char_p
     lib.vl2_elem_name.argtypes = []

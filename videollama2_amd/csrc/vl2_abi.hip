@@ -10,6 +10,7 @@
 #include "k_attn2.h"
 #include "k_decode.h"
 #include "k_decode_tail.h"
+#include "k_fp8.h"
 #include "k_gemm.h"
 #include "k_gemm6.h"
 #include "k_norm.h"
@@ -819,6 +820,27 @@ extern "C" int32_t vl2_gemv_bf16(const void* W, const void* x, const float* norm
     else if (f32) launch_gemv<false, true>(a, N, ST(stream));
     else launch_gemv<false, false>(a, N, ST(stream));
     return launched("vl2_gemv_bf16");
+}
+extern "C" int32_t vl2_pack_quant_fp8(const void* w, int64_t N, int64_t K, int64_t ldw, void* q, float* scale, void* stream) {
+    if (!w || !q || !scale || N <= 0 || K <= 0) return fail(VL2_E_BADARG, "vl2_pack_quant_fp8: bad args");
+    if (K % 16 || ldw % 8 || ldw < K || N > 0x7fffffff || K > 0x7fffffff) return fail(VL2_E_SHAPE, "vl2_pack_quant_fp8: need K%%16==0, ldw%%8==0, ldw>=K");
+    hipLaunchKernelGGL(quant_fp8_rows_kernel, dim3((unsigned)N), dim3(256), 0, ST(stream), (const bf16_t*)w, (uint8_t*)q, scale, (int)K, (long)ldw);
+    return launched("vl2_pack_quant_fp8");
+}
+extern "C" int32_t vl2_gemv_fp8(const void* q, const float* scale, const void* x, const float* norm_w, const void* res, const float* bias, void* y,
+                                int32_t N, int32_t K, int32_t ldq, float eps, int32_t flags, void* stream) {
+    if (!q || !scale || !x || !y || N <= 0 || K <= 0) return fail(VL2_E_BADARG, "vl2_gemv_fp8: bad args");
+    if (K % 16 || ldq % 16 || ldq < K || K > 32704 || N % 2) return fail(VL2_E_SHAPE, "vl2_gemv_fp8: need N even, K%%16==0, ldq%%16==0, K<=32704 (x lives in LDS as fp32; K=%d)", K);
+    const bool sw = flags & VL2_GEMM_SWIGLU, f32 = flags & VL2_GEMM_OUT_F32;
+    if (sw && (N % 64 || f32 || bias)) return fail(VL2_E_SHAPE, "vl2_gemv_fp8: SWIGLU needs N%%64==0, 16-bit output, no bias");
+    Gemv8Args a{(const uint8_t*)q, scale, (const bf16_t*)x, norm_w, (const bf16_t*)res, y, N, K, ldq, eps, bias, 0};
+    if (flags & VL2_GEMV_RMS_PLAIN) { a.norm_w = nullptr; a.rms_plain = 1; }
+    const dim3 g((unsigned)((N / 2 + 3) / 4)), b(256);
+    const size_t lds = (size_t)K * 4;
+    if (sw) { lds_attr<gemv_fp8_kernel<true, false>>((int)lds); hipLaunchKernelGGL((gemv_fp8_kernel<true, false>), g, b, lds, ST(stream), a); }
+    else if (f32) { lds_attr<gemv_fp8_kernel<false, true>>((int)lds); hipLaunchKernelGGL((gemv_fp8_kernel<false, true>), g, b, lds, ST(stream), a); }
+    else { lds_attr<gemv_fp8_kernel<false, false>>((int)lds); hipLaunchKernelGGL((gemv_fp8_kernel<false, false>), g, b, lds, ST(stream), a); }
+    return launched("vl2_gemv_fp8");
 }
 template <bool SW, bool F32>
 static void launch_gemv_mr(const GemvArgs& a, int mb, int n_out, hipStream_t s) {

@@ -64,10 +64,26 @@ class HipMistralDecoder(nn.Module):
         # rank is the identity), so that the captured-RCCL decode graph can be exercised on hardware without a second GPU
         self.tp_always_reduce = False
 
+    @torch.no_grad()
+    def enable_fp8_decode(self, on=True):
+        """OPTIONAL arithmetic (the fp8 half of BASELINE.json configs[4]): the decode step's projections stream fp8
+        (OCP e4m3fn) copies of the packed weights with one power-of-two scale per output row (csrc/k_fp8.h; activations stay 16-bit).
+        Prefill keeps the 16-bit weights (it is MFMA-bound, decode is bound by the weight stream).  The copies are made once, here
+        (+7.2 GB for the 7B model).  Not the reference's arithmetic and never the default: oracle/fp8_oracle.py defines the quantiser."""
+        if self.tp > 1:
+            raise NotImplementedError("fp8 decode weights: single-rank decoders only")
+        if on and getattr(self, "w8", None) is None:
+            self.w8 = dict(layers=[{k: ops.quant_fp8(lw[k]) for k in ("wqkv", "wo", "wgu", "wd")} for lw in self.w["layers"]],
+                           lm_head=ops.quant_fp8(self.w["lm_head"]))
+            self._stage = None                                    # the descriptor is rebuilt with the fp8 pointers
+        self.decode_fp8 = bool(on)
+        self.graph = None                                         # a captured step holds the other projections
+        return self
+
     def _stage_desc(self):
         if self._stage is None:
             d, keep = ops.llm_desc(self.w, self.cfg["llm"], self.nh, self.nkv, self.max_seq_len, self.eps, self.kcache, self.vcache,
-                                   self.cos_t, self.sin_t)
+                                   self.cos_t, self.sin_t, w8=getattr(self, "w8", None))
             ws, _ = ops._llm_ws(d, 1, self._dev)
             self._stage = (d, keep, ws)
         return self._stage
@@ -149,6 +165,16 @@ class HipMistralDecoder(nn.Module):
         pos_dev = self.state[0:1] if dyn else None
         ops.embed_rows(self.tok, self.w["embed"], b["x0"])
         x = b["x0"][0]
+        if getattr(self, "decode_fp8", False):                  # the same step on the fp8 copies (vl2_gemv_fp8), operator by operator
+            for li, (lw, q) in enumerate(zip(self.w["layers"], self.w8["layers"])):
+                ops.gemv_fp8(*q["wqkv"], x, eps=self.eps, out=b["qkv"], bias=lw["bqkv"], rms_plain=True)
+                ops.attn_decode(b["qkv"], self.kcache[li], self.vcache[li], self.cos_t, self.sin_t, self.partial, b["o"], nh, nkv,
+                                self.pos, hd ** -0.5, pos_dev=pos_dev, ctx_cap=self.max_seq_len)
+                ops.gemv_fp8(*q["wo"], b["o"], res=x, out=b["x1"])
+                ops.gemv_fp8(*q["wgu"], b["x1"], eps=self.eps, swiglu=True, out=b["a"], rms_plain=True)
+                ops.gemv_fp8(*q["wd"], b["a"], res=b["x1"], out=x)
+            ops.gemv_fp8(*self.w8["lm_head"], x, norm_w=self.w["norm_w"], eps=self.eps, out_f32=True, out=self.logits)
+            return
         for li, lw in enumerate(self.w["layers"]):
             ops.gemv(lw["wqkv"], x, norm_w=self.w["ones"], eps=self.eps, out=b["qkv"], bias=lw["bqkv"])   # ln weight folded into wqkv
             ops.attn_decode(b["qkv"], self.kcache[li], self.vcache[li], self.cos_t, self.sin_t, self.partial, b["o"], nh, nkv,
@@ -186,7 +212,7 @@ class HipMistralDecoder(nn.Module):
         def one_step():                                       # argmax + the token's forward: ONE call into libvl2hip.so
             if self._use_stage():
                 d, _, ws = self._stage_desc()
-                ops.llm_decode_step(d, self.logits, self.tok, self.state, self.hist, self.partial, ws)
+                ops.llm_decode_step(d, self.logits, self.tok, self.state, self.hist, self.partial, ws, fp8=getattr(self, "decode_fp8", False))
             else:
                 ops.argmax(self.logits, self.tok, self.hist, 0, self.state)
                 self._decode_kernels(dyn=True)

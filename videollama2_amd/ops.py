@@ -39,7 +39,9 @@ NORM_NONE, NORM_RMS, NORM_LN = 0, 1, 2
 _WORKSPACE = {}
 _CTL = dict(variant=0, splitk=False, attn_variant=0, stage_flags=0, gemm_flags=0)
 GEMM_PERSISTENT, GEMM_NO_MIX = 8, 16                                    # vl2_gemm_desc.flags (include/vl2hip.h)
-STAGE_PERSISTENT_GEMM, STAGE_NO_MIX, STAGE_SELF_REDUCE, STAGE_FUSED_DECODE_ATTN, STAGE_DECODE_TAIL, STAGE_STC_UNFUSED = 1, 2, 4, 8, 16, 32   # vl2_*_desc.flags of the stage calls
+STAGE_PERSISTENT_GEMM, STAGE_NO_MIX, STAGE_SELF_REDUCE, STAGE_FUSED_DECODE_ATTN, STAGE_DECODE_TAIL, STAGE_STC_UNFUSED = 1, 2, 4, 8, 16, 32
+STAGE_DECODE_FP8 = 64                 # decode step on the fp8 copies of the weights (vl2_llm_desc.layers_w8); set by the decoder, not a lab switch
+GEMV_RMS_PLAIN = 32   # vl2_*_desc.flags of the stage calls
 
 
 def attach_workspace(device):
@@ -287,6 +289,28 @@ def gemv(w, x, norm_w=None, eps=1e-5, res=None, swiglu=False, out_f32=False, out
     return out
 
 
+def quant_fp8(w):
+    """include/vl2hip.h vl2_pack_quant_fp8: 16-bit weights [N, K] -> (e4m3fn bytes [N, K] as uint8, power-of-two row scales [N] fp32)."""
+    _chk(w, _lib.elem_dtype(), "w")
+    N, K = w.shape
+    q = torch.empty((N, K), dtype=torch.uint8, device=w.device)
+    sc = torch.empty((N,), dtype=torch.float32, device=w.device)
+    _lib.call("vl2_pack_quant_fp8", _p(w), N, K, w.stride(0), _p(q), _p(sc), _stream())
+    return q, sc
+
+
+def gemv_fp8(q, scale, x, norm_w=None, eps=1e-5, res=None, swiglu=False, out_f32=False, out=None, bias=None, rms_plain=False):
+    """y = scale * (q @ x) (+ bias) (+ res) for one token on fp8 weights (include/vl2hip.h vl2_gemv_fp8; W8A16)."""
+    _chk(q, torch.uint8, "q"); _chk(scale, torch.float32, "scale"); _chk(x, _lib.elem_dtype(), "x"); _chk(bias, torch.float32, "bias")
+    N, K = q.shape
+    n_out = N // 2 if swiglu else N
+    if out is None:
+        out = torch.empty((n_out,), dtype=torch.float32 if out_f32 else _lib.elem_dtype(), device=q.device)
+    flags = (GEMM_SWIGLU if swiglu else 0) | (GEMM_OUT_F32 if out_f32 else 0) | (GEMV_RMS_PLAIN if rms_plain else 0)
+    _lib.call("vl2_gemv_fp8", _p(q), _p(scale), _p(x), _p(norm_w), _p(res), _p(bias), _p(out), N, K, q.stride(0), float(eps), flags, _stream())
+    return out
+
+
 def gemm_skinny(a, w, bias=None, res=None, swiglu=False, out_f32=False, out=None):
     """C = epilogue(a @ w.T) for M = a.shape[0] <= 64 rows (batched decode): weights streamed once, GEMV-style, into MFMA.
     Needs `attach_workspace` (fp32 partial sums of the K split)."""
@@ -468,8 +492,8 @@ def stc_forward(desc, x, T, hw, idx, dims, out):
     return out
 
 
-def llm_desc(w, cfg_llm, nh, nkv, smax, eps, kcache, vcache, cos_t, sin_t):
-    """weights.pack_decoder dict + this decoder's caches -> (_lib.LlmDesc, keepalive)."""
+def llm_desc(w, cfg_llm, nh, nkv, smax, eps, kcache, vcache, cos_t, sin_t, w8=None):
+    """weights.pack_decoder dict + this decoder's caches -> (_lib.LlmDesc, keepalive).  w8: optional fp8 copies (decoder.enable_fp8_decode)."""
     layers = (_lib.LlmLayer * len(w["layers"]))()
     for i, lw in enumerate(w["layers"]):
         layers[i].wqkv, layers[i].bqkv, layers[i].wo = _p(lw["wqkv"]), _p(lw["bqkv"]), _p(lw["wo"])
@@ -478,7 +502,16 @@ def llm_desc(w, cfg_llm, nh, nkv, smax, eps, kcache, vcache, cos_t, sin_t):
     d = _lib.LlmDesc(ctypes.sizeof(_lib.LlmDesc), cfg_llm["hidden_size"], w["layers"][0]["wd"].shape[1], nh, nkv, len(w["layers"]),
                      w["lm_head"].shape[0], smax, float(eps), layers, _p(w["embed"]), _p(w["norm_w"]), _p(w["ones"]), _p(w["lm_head"]),
                      _p(cos_t), _p(sin_t))
-    return d, (layers, w, kcache, vcache)
+    l8 = None
+    if w8 is not None:
+        l8 = (_lib.LlmLayerW8 * len(w["layers"]))()
+        for i, q in enumerate(w8["layers"]):
+            for n in ("qkv", "o", "gu", "d"):
+                setattr(l8[i], "w" + n, _p(q["w" + n][0]))
+                setattr(l8[i], "s" + n, _p(q["w" + n][1]))
+        d.layers_w8 = l8
+        d.lm_head_w8, d.lm_head_scale = _p(w8["lm_head"][0]), _p(w8["lm_head"][1])
+    return d, (layers, w, kcache, vcache, l8, w8)
 
 
 def _llm_ws(desc, S, device):
@@ -495,6 +528,6 @@ def llm_prefill(desc, x, logits_out):
     return logits_out
 
 
-def llm_decode_step(desc, logits, tok, state, hist, partial, ws):
-    desc.flags = _CTL["stage_flags"]
+def llm_decode_step(desc, logits, tok, state, hist, partial, ws, fp8=False):
+    desc.flags = _CTL["stage_flags"] | (STAGE_DECODE_FP8 if fp8 else 0)
     _lib.call("vl2_llm_decode_step", ctypes.byref(desc), _p(logits), _p(tok), _p(state), _p(hist), _p(partial), _p(ws), ws.numel(), _stream())
