@@ -363,10 +363,11 @@ extern "C" int32_t vl2_gemv_fp8(const void* q, const float* scale, const void* x
     Gemv8Args a{(const uint8_t*)q, scale, (const bf16_t*)x, norm_w, (const bf16_t*)res, y, N, K, ldq, eps, bias, 0};
     if (flags & VL2_GEMV_RMS_PLAIN) { a.norm_w = nullptr; a.rms_plain = 1; }
     const bool sw = flags & 1, f32 = flags & 2;
-    dim3 g((N / 2 + 3) / 4), blk(256);
-    if (sw) emu::launch(g, blk, [=] { gemv_fp8_kernel<true, false>(a); });
-    else if (f32) emu::launch(g, blk, [=] { gemv_fp8_kernel<false, true>(a); });
-    else emu::launch(g, blk, [=] { gemv_fp8_kernel<false, false>(a); });
+    dim3 blk(256);
+#define EMU_G8(SW, F32, NP) emu::launch(dim3((N / 2 + 4 * NP - 1) / (4 * NP)), blk, [=] { gemv_fp8_kernel<SW, F32, NP>(a); })
+    if (K <= 4096) { if (sw) EMU_G8(true, false, 2); else if (f32) EMU_G8(false, true, 2); else EMU_G8(false, false, 2); }
+    else           { if (sw) EMU_G8(true, false, 1); else if (f32) EMU_G8(false, true, 1); else EMU_G8(false, false, 1); }
+#undef EMU_G8
     return 0;
 }
 extern "C" int32_t vl2_gemm_skinny_bf16(const void* A, const void* W, void* C, const float* bias, const void* res, int32_t M, int32_t N,

@@ -10,7 +10,7 @@
 //                           reproducible bit for bit on any machine -- no division, whose fast-math lowering on the GPU is a reciprocal);
 //                           q = RNE_e4m3fn(w * 2^-e).  A zero (or denormal-only) row gets scale 1.
 //   gemv_fp8_kernel       : y = scale * (q x) (+ bias) (+ res) for one token; fused RMSNorm prologue, SwiGLU pairing and residual epilogue
-//                           as gemv_bf16_kernel (k_decode.h), x staged in LDS as fp32 (after the same rounding to the element type)
+//                           as gemv_bf16_kernel (k_decode.h), x staged in LDS in the 16-bit element type exactly as there
 #pragma once
 #include "k_decode.h"
 
@@ -72,36 +72,48 @@ struct Gemv8Args {
     int rms_plain;          // RMS-normalise x without a weight vector (folded into W before quantisation)
 };
 
-// A wave owns ONE PAIR of weight rows per trip and keeps both rows' loads in flight (8 x 16 B per lane and row = 16 KiB per wave, the
-// 16-bit kernel's SwiGLU footprint): SWIGLU: (gate j, up j) -> one output; plain: rows (2 jp, 2 jp + 1) -> two outputs (N even).
-// grid = ceil(n_pairs / 4), block 256; dynamic LDS = K * 4 bytes (x as fp32).  K % 16 == 0, K <= 32704.
-template <bool SWIGLU, bool OUT_F32>
+// A wave owns NP PAIRS of weight rows per trip and keeps all their loads in flight: 8 x 16 B per lane and row array = 16 KiB per wave,
+// the 16-bit kernel's SwiGLU footprint -- the stream is bound by bytes in flight, so rows of K <= 4096 (four 16-B vectors per lane) run
+// two pairs at a time (NP = 2), longer rows one.  A pair = (gate j, up j) -> one output with SWIGLU, rows (2 jp, 2 jp + 1) -> two outputs
+// without (N even).  x lives in LDS in the 16-bit element type exactly as gemv_bf16_kernel stages it; a weight dword becomes two packed
+// element pairs (v_cvt_pk_f32_fp8 + the pack: every e4m3fn value is exact in bf16 and in half) and meets x in v_dot2: fp32 sums.
+// grid = ceil(n_pairs / (4 NP)), block 256; dynamic LDS = K * 2 bytes.  K % 16 == 0, K <= 32704; NP = 2 needs K <= 4096.
+template <bool SWIGLU, bool OUT_F32, int NP>
 __global__ __launch_bounds__(256) void gemv_fp8_kernel(Gemv8Args p) {
 #pragma clang fp reassociate(off)                  // the RMSNorm arithmetic in gemv_bf16_kernel's order: the staged x is the same bits
     extern __shared__ __attribute__((aligned(16))) unsigned char vl2_smem[];
     __shared__ float red[8];
-    float* xs = (float*)vl2_smem;
+    bf16_t* xs = (bf16_t*)vl2_smem;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_pairs = p.N / 2;
     const int nvec = p.K >> 4;                       // 16-B vectors (16 weights) per row
-    const bool one_pass = nvec <= 512;
+    constexpr int SL = 8 / NP;                       // load slots per pair and pass
+    const bool one_pass = nvec <= 64 * SL;
     u32x4 wv[8], uv[8];
-    const int jp = blockIdx.x * 4 + wave;            // this wave's pair
-    const int row0 = SWIGLU ? (jp >> 5) * 64 + (jp & 31) : 2 * jp;
-    const int row1 = SWIGLU ? row0 + 32 : row0 + 1;
+    const int jp0 = (blockIdx.x * 4 + wave) * NP;    // this wave's first pair
+    auto rows_of = [&](int jp, int& r0, int& r1) {
+        r0 = SWIGLU ? (jp >> 5) * 64 + (jp & 31) : 2 * jp;
+        r1 = SWIGLU ? r0 + 32 : r0 + 1;
+    };
     auto issue_rows = [&](int v0) {
-        const uint8_t* w0p = p.W + (size_t)row0 * p.ldw;
-        const uint8_t* w1p = p.W + (size_t)row1 * p.ldw;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int v = v0 + i * 64 + lane;
-            if (v < nvec) {
-                wv[i] = __builtin_nontemporal_load((const u32x4*)(w0p + (size_t)v * 16));
-                uv[i] = __builtin_nontemporal_load((const u32x4*)(w1p + (size_t)v * 16));
+        for (int pr = 0; pr < NP; ++pr) {
+            int r0, r1;
+            rows_of(jp0 + pr, r0, r1);
+            const uint8_t* w0p = p.W + (size_t)r0 * p.ldw;
+            const uint8_t* w1p = p.W + (size_t)r1 * p.ldw;
+            const bool live = jp0 + pr < n_pairs;
+#pragma unroll
+            for (int i = 0; i < SL; ++i) {
+                const int v = v0 + i * 64 + lane;
+                if (live && v < nvec) {
+                    wv[pr * SL + i] = __builtin_nontemporal_load((const u32x4*)(w0p + (size_t)v * 16));
+                    uv[pr * SL + i] = __builtin_nontemporal_load((const u32x4*)(w1p + (size_t)v * 16));
+                }
             }
         }
     };
-    if (one_pass && jp < n_pairs) issue_rows(0);     // the weights do not depend on x: their latency overlaps the staging of x
+    if (one_pass && jp0 < n_pairs) issue_rows(0);    // the weights do not depend on x: their latency overlaps the staging of x
     float rstd = 1.f;
     const bool norm = p.norm_w != nullptr || p.rms_plain;
     if (norm) {
@@ -118,58 +130,67 @@ __global__ __launch_bounds__(256) void gemv_fp8_kernel(Gemv8Args p) {
         rstd = rsqrtf(((red[0] + red[1]) + (red[2] + red[3])) / (float)p.K + p.eps);
     }
     for (int k = tid * 8; k < p.K; k += 2048) {
-        float v[8];
-        unpack8(*(const u32x4*)(p.x + k), v);
+        u32x4 raw = *(const u32x4*)(p.x + k);
         if (norm) {
+            float v[8];
+            unpack8(raw, v);
             f32x4 w0 = {1.f, 1.f, 1.f, 1.f}, w1 = w0;
             if (p.norm_w) { w0 = *(const f32x4*)(p.norm_w + k); w1 = *(const f32x4*)(p.norm_w + k + 4); }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = bf2f(f2bf((v[j] * rstd) * (j < 4 ? w0[j] : w1[j - 4])));   // HF: the norm's output is a 16-bit tensor
+            for (int j = 0; j < 8; ++j) v[j] = (v[j] * rstd) * (j < 4 ? w0[j] : w1[j - 4]);
+            raw = pack8(v);                          // HF: the norm's output is a 16-bit tensor
         }
-        *(f32x4*)(xs + k) = f32x4{v[0], v[1], v[2], v[3]};
-        *(f32x4*)(xs + k + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        *(u32x4*)(xs + k) = raw;
     }
     __syncthreads();
-    if (jp >= n_pairs) return;
-    float a0 = 0.f, a1 = 0.f;
-    for (int v0 = 0; v0 < nvec; v0 += 64 * 8) {
+    if (jp0 >= n_pairs) return;
+    float a0[NP], a1[NP];
+#pragma unroll
+    for (int pr = 0; pr < NP; ++pr) a0[pr] = a1[pr] = 0.f;
+    for (int v0 = 0; v0 < nvec; v0 += 64 * SL) {
         if (!one_pass) issue_rows(v0);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int v = v0 + i * 64 + lane;
-            if (v < nvec) {
+        for (int pr = 0; pr < NP; ++pr) {
+            if (jp0 + pr >= n_pairs) continue;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 xv = *(const f32x4*)(xs + (size_t)v * 16 + q * 4);
-                    const vl2_f32x2_t w0l = VL2_CVT_PK_F32_FP8(wv[i][q], false), w0h = VL2_CVT_PK_F32_FP8(wv[i][q], true);
-                    const vl2_f32x2_t w1l = VL2_CVT_PK_F32_FP8(uv[i][q], false), w1h = VL2_CVT_PK_F32_FP8(uv[i][q], true);
-                    a0 = __builtin_fmaf(w0l[0], xv[0], a0);
-                    a1 = __builtin_fmaf(w1l[0], xv[0], a1);
-                    a0 = __builtin_fmaf(w0l[1], xv[1], a0);
-                    a1 = __builtin_fmaf(w1l[1], xv[1], a1);
-                    a0 = __builtin_fmaf(w0h[0], xv[2], a0);
-                    a1 = __builtin_fmaf(w1h[0], xv[2], a1);
-                    a0 = __builtin_fmaf(w0h[1], xv[3], a0);
-                    a1 = __builtin_fmaf(w1h[1], xv[3], a1);
+            for (int i = 0; i < SL; ++i) {
+                const int v = v0 + i * 64 + lane;
+                if (v < nvec) {
+                    const u32x4 x0 = *(const u32x4*)(xs + (size_t)v * 16), x1 = *(const u32x4*)(xs + (size_t)v * 16 + 8);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const unsigned xl = q < 2 ? x0[2 * q] : x1[2 * q - 4], xh = q < 2 ? x0[2 * q + 1] : x1[2 * q - 3];
+                        const vl2_f32x2_t w0l = VL2_CVT_PK_F32_FP8(wv[pr * SL + i][q], false), w0h = VL2_CVT_PK_F32_FP8(wv[pr * SL + i][q], true);
+                        const vl2_f32x2_t w1l = VL2_CVT_PK_F32_FP8(uv[pr * SL + i][q], false), w1h = VL2_CVT_PK_F32_FP8(uv[pr * SL + i][q], true);
+                        a0[pr] = dot2_bf16(pack2bf(w0l[0], w0l[1]), xl, a0[pr]);
+                        a1[pr] = dot2_bf16(pack2bf(w1l[0], w1l[1]), xl, a1[pr]);
+                        a0[pr] = dot2_bf16(pack2bf(w0h[0], w0h[1]), xh, a0[pr]);
+                        a1[pr] = dot2_bf16(pack2bf(w1h[0], w1h[1]), xh, a1[pr]);
+                    }
                 }
             }
         }
     }
-    a0 = wave_sum(a0);
-    a1 = wave_sum(a1);
-    if (lane == 0) {
-        a0 *= p.scale[row0];
-        a1 *= p.scale[row1];
-        if (SWIGLU) {
-            float o = silu_f(a0) * a1;
-            if (p.res) o += bf2f(p.res[jp]);
-            ((bf16_t*)p.y)[jp] = f2bf(o);
-        } else {
-            float o0 = a0, o1 = a1;
-            if (p.bias) { o0 += p.bias[row0]; o1 += p.bias[row1]; }
-            if (p.res) { o0 += bf2f(p.res[row0]); o1 += bf2f(p.res[row1]); }
-            if (OUT_F32) { ((float*)p.y)[row0] = o0; ((float*)p.y)[row1] = o1; }
-            else { ((bf16_t*)p.y)[row0] = f2bf(o0); ((bf16_t*)p.y)[row1] = f2bf(o1); }
+#pragma unroll
+    for (int pr = 0; pr < NP; ++pr) {
+        const int jp = jp0 + pr;
+        if (jp >= n_pairs) continue;
+        int r0, r1;
+        rows_of(jp, r0, r1);
+        float s0 = wave_sum(a0[pr]), s1 = wave_sum(a1[pr]);
+        if (lane == 0) {
+            s0 *= p.scale[r0];
+            s1 *= p.scale[r1];
+            if (SWIGLU) {
+                float o = silu_f(s0) * s1;
+                if (p.res) o += bf2f(p.res[jp]);
+                ((bf16_t*)p.y)[jp] = f2bf(o);
+            } else {
+                if (p.bias) { s0 += p.bias[r0]; s1 += p.bias[r1]; }
+                if (p.res) { s0 += bf2f(p.res[r0]); s1 += bf2f(p.res[r1]); }
+                if (OUT_F32) { ((float*)p.y)[r0] = s0; ((float*)p.y)[r1] = s1; }
+                else { ((bf16_t*)p.y)[r0] = f2bf(s0); ((bf16_t*)p.y)[r1] = f2bf(s1); }
+            }
         }
     }
 }

@@ -835,11 +835,13 @@ extern "C" int32_t vl2_gemv_fp8(const void* q, const float* scale, const void* x
     if (sw && (N % 64 || f32 || bias)) return fail(VL2_E_SHAPE, "vl2_gemv_fp8: SWIGLU needs N%%64==0, 16-bit output, no bias");
     Gemv8Args a{(const uint8_t*)q, scale, (const bf16_t*)x, norm_w, (const bf16_t*)res, y, N, K, ldq, eps, bias, 0};
     if (flags & VL2_GEMV_RMS_PLAIN) { a.norm_w = nullptr; a.rms_plain = 1; }
-    const dim3 g((unsigned)((N / 2 + 3) / 4)), b(256);
-    const size_t lds = (size_t)K * 4;
-    if (sw) { lds_attr<gemv_fp8_kernel<true, false>>((int)lds); hipLaunchKernelGGL((gemv_fp8_kernel<true, false>), g, b, lds, ST(stream), a); }
-    else if (f32) { lds_attr<gemv_fp8_kernel<false, true>>((int)lds); hipLaunchKernelGGL((gemv_fp8_kernel<false, true>), g, b, lds, ST(stream), a); }
-    else { lds_attr<gemv_fp8_kernel<false, false>>((int)lds); hipLaunchKernelGGL((gemv_fp8_kernel<false, false>), g, b, lds, ST(stream), a); }
+    const size_t lds = (size_t)K * 2;
+    const dim3 b(256);
+    // rows of K <= 4096 are four 16-B vectors per lane: two pairs per wave and trip keep the 16-bit kernel's bytes in flight (k_fp8.h)
+#define VL2_G8(SW, F32, NP) hipLaunchKernelGGL((gemv_fp8_kernel<SW, F32, NP>), dim3((unsigned)((N / 2 + 4 * NP - 1) / (4 * NP))), b, lds, ST(stream), a)
+    if (K <= 4096) { if (sw) VL2_G8(true, false, 2); else if (f32) VL2_G8(false, true, 2); else VL2_G8(false, false, 2); }
+    else           { if (sw) VL2_G8(true, false, 1); else if (f32) VL2_G8(false, true, 1); else VL2_G8(false, false, 1); }
+#undef VL2_G8
     return launched("vl2_gemv_fp8");
 }
 template <bool SW, bool F32>
