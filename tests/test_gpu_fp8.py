@@ -145,3 +145,26 @@ def test_fp8_decode_kernels_equal_16bit_kernels_on_dequantised_weights(ops):
         assert e < 6e-3, (n, e)                                     # a 16-bit intermediate may round either way; fp32 logits stay together
         n += 1
     assert n >= 2
+
+
+def test_fp8_kernels_in_the_fp16_build():
+    """The fp16 build of the library (libvl2hip_f16.so): the quantiser reads half weights (every code of the same matrix as the bf16 case that
+    half holds exactly), the GEMV takes half activations -- both against the oracle with `elem=torch.float16`."""
+    from videollama2_amd import _lib, ops
+    _lib.set_elem("fp16")
+    try:
+        g = torch.Generator().manual_seed(11)
+        w = (torch.randn(512, 4096, generator=g) * 0.02).half()
+        w[3] = 0
+        w[5, 0] = 448.0
+        q, sc = ops.quant_fp8(w.to(DEV))
+        qo, so = F8.quant_rows(w)
+        assert torch.equal(sc.cpu(), so) and torch.equal(q.cpu(), qo)
+        x = (torch.randn(4096, generator=g)).half()
+        y = ops.gemv_fp8(q, sc, x.to(DEV), eps=1e-5, out_f32=True, rms_plain=True)
+        assert rel(y.cpu(), F8.gemv(qo, so, x, eps=1e-5, rms=True, elem=torch.float16)) < 2e-4
+        ysw = ops.gemv_fp8(q, sc, x.to(DEV), eps=1e-5, swiglu=True, rms_plain=True)
+        assert ysw.dtype == torch.float16
+        assert rel(ysw.float().cpu(), F8.gemv(qo, so, x, eps=1e-5, rms=True, swiglu=True, elem=torch.float16)) < 2e-3
+    finally:
+        _lib.set_elem("bf16")
