@@ -353,6 +353,9 @@ class HipMistralDecoder(nn.Module):
         projections run on the skinny-M MFMA kernel (weights streamed once, GEMV-style, for up to 64 rows; the tiled GEMMs
         beyond that; RMSNorm as its own kernel) -- prefill-style arithmetic, i.e. equal to the single-sequence step to bf16
         rounding, not to the bit."""
+        if getattr(self, "decode_fp8", False):
+            raise NotImplementedError("fp8 decode weights (enable_fp8_decode) cover the single-sequence decode step; batched decode streams "
+                                      "the 16-bit weights: call enable_fp8_decode(False) first")
         bb, nh, nkv, hd = self._bb, self.nh, self.nkv, self.hd
         x, x1, qkv, o, a = bb["x0"][:nb], bb["x1"][:nb], bb["qkv"][:nb], bb["o"][:nb], bb["a"][:nb]
         ops.embed_rows(bb["tok"][:nb], self.w["embed"], x)
