@@ -212,7 +212,7 @@ def test_configs1_full_depth_end_to_end():
     above, every stage consumes the previous stage's OWN output, so the numbers are end-to-end errors.  Decode is compared
     teacher-forced on the oracle's tokens (8 steps) and the free-running product `generate` must reproduce those tokens wherever
     the fp32 top-2 margin exceeds twice the logit error."""
-    run_end_to_end(O.config_videollama2_7b(16), 16, 32, 2048, min_decidable=3)
+    run_end_to_end(O.config_videollama2_7b(16), 16, 32, 2048, min_decidable=3, fp8_decode=True)
 
 
 @pytest.mark.gpu
@@ -264,7 +264,7 @@ def test_outlier_channels_tower_stc_four_decoder_layers():
     run_end_to_end(cfg, 4, 4, 1024, mutate=plant_outliers, tag="outliers ")
 
 
-def run_end_to_end(cfg, T, n_dec, max_seq_len, min_decidable=0, mutate=None, tag="", elem="bf16"):
+def run_end_to_end(cfg, T, n_dec, max_seq_len, min_decidable=0, mutate=None, tag="", elem="bf16", fp8_decode=False):
     """`elem` picks the library build (bf16 | fp16, include/vl2hip.h vl2_elem_name): the floor chain then runs in the SAME half type on torch-ROCm
     (the reference's mm_infer casts the frames with .half(), /root/reference/videollama2/__init__.py:60), the fp32 truth is shared."""
     from videollama2_amd import _lib
@@ -272,12 +272,12 @@ def run_end_to_end(cfg, T, n_dec, max_seq_len, min_decidable=0, mutate=None, tag
     half = torch.float16 if elem == "fp16" else torch.bfloat16
     _lib.set_elem(elem)
     try:
-        return _run_end_to_end(cfg, T, n_dec, max_seq_len, min_decidable, mutate, tag, half, VideoLLaMA2Hip)
+        return _run_end_to_end(cfg, T, n_dec, max_seq_len, min_decidable, mutate, tag, half, VideoLLaMA2Hip, fp8_decode)
     finally:
         _lib.set_elem("bf16")
 
 
-def _run_end_to_end(cfg, T, n_dec, max_seq_len, min_decidable, mutate, tag, half, VideoLLaMA2Hip):
+def _run_end_to_end(cfg, T, n_dec, max_seq_len, min_decidable, mutate, tag, half, VideoLLaMA2Hip, fp8_decode=False):
     side, V = cfg["vision"]["image_size"], cfg["llm"]["vocab_size"]
     grid = side // cfg["vision"]["patch_size"]
     torch.set_num_threads(min(os.cpu_count() or 8, 64))
@@ -366,4 +366,23 @@ def _run_end_to_end(cfg, T, n_dec, max_seq_len, min_decidable, mutate, tag, half
     assert got[:upto] == toks[:upto], (got, toks, first_tie)
     RECORD.append(dict(stage=f"{tag}e2e greedy tokens: product generate() vs fp32 oracle", ours=got, oracle=toks, teacher_forced_top1_agree=agree, steps=n_dec + 1,
                        first_unresolvable_tie=first_tie, decidable_steps=decidable, decidable_steps_agreeing=decided_ok))
+    if fp8_decode:
+        # OPTIONAL arithmetic (decoder.enable_fp8_decode): the same teacher-forced decode steps on the e4m3fn copies of the
+        # decoder weights, from the same (16-bit) prefill.  Reported against the fp32 oracle (whose weights are NOT quantised: this is the
+        # FORMAT's error at full depth, on seeded-normal weights) and against our own 16-bit steps; no bar beyond sanity -- never the default.
+        dec.prefill(memb[0])
+        dec.enable_fp8_decode()
+        agree8 = 0
+        for s in range(n_dec):
+            dec.tok.copy_(torch.tensor([toks[s]], dtype=torch.int32))
+            l8 = dec.decode_step().clone()
+            agree8 += int(l8.argmax()) == toks[s + 1]
+            if s < 4 or s == n_dec - 1:
+                row = dict(stage=f"{tag}fp8-weights decode step {s + 1} logits (teacher-forced; OPTIONAL arithmetic, no bar)", ours_rel_l2=float(rel(l8, lg[s + 1])),
+                           floor_rel_l2=float(rel(lg16[s + 1], lg[s + 1])), vs_our_16bit_step=float(rel(l8, mine[s + 1])), top1_agrees=int(l8.argmax()) == toks[s + 1])
+                RECORD.append(row)
+                print(f"[parity-full] {row['stage']}: vs fp32 oracle {row['ours_rel_l2']:.3e} (16-bit floor {row['floor_rel_l2']:.3e}), vs our 16-bit step {row['vs_our_16bit_step']:.3e}")
+            assert rel(l8, lg[s + 1]) < 0.5
+        dec.enable_fp8_decode(False)
+        RECORD.append(dict(stage=f"{tag}fp8-weights decode: teacher-forced top-1 agreement with the fp32 oracle", agree=agree8, steps=n_dec))
     _flush()
