@@ -940,6 +940,14 @@ def test_emu_parity_full_end_to_end_dry_run(emu):
     try:
         PF.run_end_to_end(O.config_small(4), 4, 3, 256)
         assert any(r.get("stage", "").startswith("e2e greedy tokens") for r in PF.RECORD)
+        # second run of the same case: the seeded weights come back from the 16-bit copy (what the fp16-build test of the GPU suite does),
+        # the fp32 truth from its cache, and the optional fp8-weights decode rows are appended
+        n0 = len(PF.RECORD)
+        PF.run_end_to_end(O.config_small(4), 4, 3, 256, fp8_decode=True)
+        again = PF.RECORD[n0:]
+        first = {r["stage"]: r.get("ours_rel_l2") for r in PF.RECORD[:n0] if "ours_rel_l2" in r}
+        assert all(first[r["stage"]] == r["ours_rel_l2"] for r in again if r["stage"] in first)      # same weights -> same numbers
+        assert any(r["stage"].startswith("fp8-weights decode:") for r in again)
         # massive-activation channels + shifted stream (ONE planted channel: the small config's streams are 64-256 wide, six channels
         # would be a tenth of it; the GPU test plants six in 1024 / 4096)
         PF.run_end_to_end(O.config_small(4), 4, 2, 256, mutate=lambda sd, cfg: PF.plant_outliers(sd, cfg, n_ch=1), tag="outliers ")

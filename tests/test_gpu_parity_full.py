@@ -282,7 +282,15 @@ def _run_end_to_end(cfg, T, n_dec, max_seq_len, min_decidable, mutate, tag, half
     grid = side // cfg["vision"]["patch_size"]
     torch.set_num_threads(min(os.cpu_count() or 8, 64))
     t0 = time.perf_counter()
-    sd = O.seeded_state_dict(cfg, 31)
+    # the seeded weights (64 s for the 7B case: sha256-keyed generators) are rounded once to the 16-bit grid, so a bf16 copy holds them
+    # exactly: the fp16-build run of the same case rebuilds its fp32 dict from that copy instead of generating 7.2 B numbers again
+    sd_key = ("e2e_weights", json.dumps(cfg, sort_keys=True, default=str))
+    if mutate is None and sd_key in _CACHE:
+        sd = {k: v.float() for k, v in _CACHE[sd_key].items()}
+    else:
+        sd = O.seeded_state_dict(cfg, 31)
+        if mutate is None and all(torch.equal(v.bfloat16().float(), v) for v in list(sd.values())[:8]):
+            _CACHE[sd_key] = {k: v.bfloat16() for k, v in sd.items()}
     planted = mutate(sd, cfg) if mutate is not None else None
     t_sd = time.perf_counter() - t0
     u8 = torch.randint(0, 256, (T, side, side, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(15))
