@@ -275,3 +275,41 @@ def test_lazy_tower_key_layouts_and_never_loaded_guard(tmp_path):
     ones = LazyHipVisionTower(str(tdir), args, key_layout="vision_model")
     ones.load_state_dict({k: torch.ones_like(p) for k, p in ref.state_dict().items()}, strict=True)
     ones.check_loaded()
+
+
+def test_loader_delegates_to_the_reference_class_only_on_evidence(tmp_path, monkeypatch):
+    """ADVICE r03 (install.py): `HipCausalLMLoader.from_pretrained` hands a checkpoint back to the class it replaced only when a READABLE
+    config lacks the multimodal keys (the LoRA / model_base branches of load_pretrained_model load plain LLM checkpoints); an unreadable
+    config (hub id, offline) is delegated WITH a warning; a multimodal checkpoint never is -- bitsandbytes kwargs are refused there."""
+    import json
+    import warnings
+    from videollama2_amd import install
+
+    calls = []
+
+    class Orig:
+        @classmethod
+        def from_pretrained(cls, path, *a, **kw):
+            calls.append(str(path))
+            return "reference-model"
+
+    class Loader(install.HipCausalLMLoader):
+        _orig = Orig
+
+    plain = tmp_path / "plain-llm"
+    plain.mkdir()
+    json.dump({"model_type": "mistral", "hidden_size": 64}, open(plain / "config.json", "w"))
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                             # readable config without mm keys: silent delegation
+        assert Loader.from_pretrained(str(plain)) == "reference-model"
+    monkeypatch.setenv("HF_HUB_OFFLINE", "1")
+    with pytest.warns(UserWarning, match="NOT run on the HIP kernels"):
+        assert Loader.from_pretrained("some-org/some-hub-id-that-is-not-cached") == "reference-model"
+    assert calls == [str(plain), "some-org/some-hub-id-that-is-not-cached"]
+    mm = tmp_path / "mm-ckpt"
+    mm.mkdir()
+    json.dump({"model_type": "videollama2_mistral", "mm_vision_tower": "openai/clip-vit-large-patch14-336", "mm_projector_type": "stc_connector"},
+              open(mm / "config.json", "w"))
+    with pytest.raises(NotImplementedError, match="bitsandbytes"):
+        Loader.from_pretrained(str(mm), load_in_4bit=True)         # a multimodal checkpoint stays on the HIP loader (and it refuses bnb kwargs)
+    assert len(calls) == 2
