@@ -15,6 +15,7 @@ respect to real timm; everything HF-side is pinned to transformers 5.15 eager ke
 Every function cites the reference (or HF / timm) code it follows.  HF: = site-packages/transformers.
 """
 import hashlib
+import os
 import math
 
 import numpy as np
@@ -235,13 +236,21 @@ def state_dict_names(cfg):
 def seeded_state_dict(cfg, seed=1234, lm_head_scale=1.0, only=None, round_bf16=True):
     """Build the synthetic weights.  `only`: optional predicate(name) to build a subset (full 7B is 29 GB fp32).
     round_bf16: round once to bf16 ('round to bf16 once; the same tensors feed oracle and kernels')."""
-    sd = {}
-    for name, shape in state_dict_names(cfg):
-        if only is not None and not only(name):
-            continue
-        t = seeded_tensor(name, shape, seed, lm_head_scale)
-        sd[name] = t.bfloat16().float() if round_bf16 else t
-    return sd
+    todo = [(name, shape) for name, shape in state_dict_names(cfg) if only is None or only(name)]
+
+    def make(item):
+        t = seeded_tensor(item[0], item[1], seed, lm_head_scale)
+        return t.bfloat16().float() if round_bf16 else t
+
+    # every tensor has its OWN name-keyed generator, so the tensors can be drawn in parallel without changing a bit (numpy's Generator
+    # releases the GIL): the 7.2 B numbers of the full-size case take ~65 s on one thread
+    if sum(int(np.prod(sh)) if len(sh) else 1 for _, sh in todo) > 50_000_000:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
+            vals = list(ex.map(make, todo))
+    else:
+        vals = [make(it) for it in todo]
+    return {name: v for (name, _), v in zip(todo, vals)}
 
 
 def normalise_keys(sd):
