@@ -60,6 +60,17 @@ def test_abi_argument_validation_without_gpu():
         _lib.call("vl2_attn_fwd", 16, 16, 16, 16, 0, 80, 80, 0, 80, 80, 0, 80, 80, 0, 80, 80, 1, 1, 4, 4, 1, 1.0, 0, 0, 80, 0, None)
     with pytest.raises(_lib.Vl2HipError, match="C%64"):
         _lib.call("vl2_row_stats", 16, 16, 4, 100, 104, None)
+    # fp8 entry points: shapes the kernels cannot take are refused before anything is launched
+    with pytest.raises(_lib.Vl2HipError, match="K%16"):
+        _lib.call("vl2_pack_quant_fp8", 16, 4, 40, 40, 16, 16, None)
+    with pytest.raises(_lib.Vl2HipError, match="N even"):
+        _lib.call("vl2_gemv_fp8", 16, 16, 16, None, None, None, 16, 7, 64, 64, 1e-5, 0, None)
+    with pytest.raises(_lib.Vl2HipError, match="SWIGLU"):
+        _lib.call("vl2_gemv_fp8", 16, 16, 16, None, None, None, 16, 96, 64, 64, 1e-5, 1, None)
+    d = _lib.LlmDesc()
+    d.size = ctypes.sizeof(_lib.LlmDesc) - 8                                # a caller built against the v3 descriptor (no fp8 fields)
+    with pytest.raises(_lib.Vl2HipError, match="another ABI"):
+        _lib.call("vl2_llm_decode_step", ctypes.byref(d), 16, 16, 16, 16, 16, 16, 64, None)
 
 
 def test_library_keeps_no_mutable_process_state():
