@@ -6,6 +6,7 @@
 alignas(64) unsigned char vl2_smem[160 * 1024];
 #include "k_gemm.h"
 #include "k_gemm6.h"
+#include "k_gemm7.h"
 #include "k_norm.h"
 #include "k_vit.h"
 #include "k_attn.h"
@@ -33,6 +34,15 @@ static int g_gemm_variant = 0;
 static bool g_gemm6_dynamic = false;       // gemm6: tiles handed out through the counter block (variants 70 / 71 = 60 / 61 dynamic)
 template <int ACT, bool SW, bool F32, bool G>
 static void run_gemm(GemmArgs a) {
+    if constexpr (!SW) {                                        // fill-the-round 224 x 128 / 192 x 128 tiles (k_gemm7.h), plain and gathered
+        if (g_gemm_variant == 224 || g_gemm_variant == 192) {
+            const int bm = g_gemm_variant;
+            a.tiles_m = (a.M + bm - 1) / bm; a.tiles_n = a.N / 128;
+            if (bm == 224) emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(512), [=] { gemm7_bf16_kernel<ACT, F32, G, 3>(a); });
+            else emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(512), [=] { gemm7_bf16_kernel<ACT, F32, G, 2>(a); });
+            return;
+        }
+    }
     if constexpr (!G) {
         if (g_gemm_variant == 4 && a.N % 256 == 0) {
             a.tiles_m = (a.M + 127) / 128; a.tiles_n = a.N / 256;

@@ -211,6 +211,49 @@ def test_emu_gemm_small_m_kernel_is_bit_identical(emu):
         ops.set_gemm_variant(0)
 
 
+def test_emu_gemm_fill_round_kernel_is_bit_identical(emu):
+    """csrc/k_gemm7.h (224 x 128 / 192 x 128 ping-pong tiles, knobs 224 / 192): two wave groups with DIFFERENT row ranges (2 x 2 and R1 x 1
+    blocks), 44 / 40 LDS-DMA pieces per stage dealt over 8 waves, the shared fp32 image epilogue -- same K order and epilogue arithmetic as
+    the 128 x 128 kernel, so the same bits: every epilogue the decoder's o / down projections and the connector use, ragged M over one
+    and several row tiles, K-tile counts 1 / 2 / 3 / 7 (below, at and above the ring depth), fp32 output, the norm-carrying forms, gather."""
+    from videollama2_amd import ops
+    from videollama2_amd.connector import conv3d_k2s2p1_index
+    for M, N, K in ((250, 256, 64), (225, 128, 128), (470, 128, 192), (193, 256, 448), (200, 128, 256)):
+        a, w, bias, res = bf(M, K), bf(N, K), torch.randn(N), bf(M, N)
+        st = torch.zeros((M, K // 64, 2), dtype=torch.float32)
+        xs = bf(M, K)
+        ops.row_stats(xs, out=st)
+        colsum = w.float().sum(1)
+        def run():
+            so = torch.zeros((M, N // 64, 2), dtype=torch.float32)
+            outs = (ops.gemm(a, w, bias=bias, res=res, act=ops.ACT_GELU), ops.gemm(a, w, bias=bias, act=ops.ACT_QGELU), ops.gemm(a, w, out_f32=True),
+                    ops.gemm(a, w, res=res, stats_out=so), so)
+            if K % 128 == 0:                                       # the statistics rows of a norm-carrying GEMM are read as 16-B vectors
+                outs += (ops.gemm(xs, w, bias=bias, norm=(ops.NORM_LN, st, 1e-5, colsum)), ops.gemm(xs, w, norm=(ops.NORM_RMS, st, 1e-5, None)))
+            return outs
+        try:
+            ops.set_gemm_variant(1)
+            ref = run()
+            for v in (224, 192):
+                ops.set_gemm_variant(v)
+                got = run()
+                assert all(torch.equal(x, y) for x, y in zip(got, ref)), (M, N, K, v)
+        finally:
+            ops.set_gemm_variant(0)
+    T, H, C = 4, 4, 128
+    pool, w3, b3 = bf(T * H * H, C), bf(128, 8 * C, scale=0.05), torch.randn(128)
+    idx, _ = conv3d_k2s2p1_index(T, H, H, "cpu")
+    zero = torch.zeros(C, dtype=torch.bfloat16)
+    try:
+        ops.set_gemm_variant(1)
+        refg = ops.gemm(pool, w3, bias=b3, act=ops.ACT_SILU, gather=(idx, zero, C))
+        for v in (224, 192):
+            ops.set_gemm_variant(v)
+            assert torch.equal(ops.gemm(pool, w3, bias=b3, act=ops.ACT_SILU, gather=(idx, zero, C)), refg), v
+    finally:
+        ops.set_gemm_variant(0)
+
+
 def test_emu_wide_rmsnorm_and_se_linear(emu):
     """The workgroup-per-row RMSNorm (C > 2048, several rows) and the K-split SE linear against torch."""
     from videollama2_amd import ops

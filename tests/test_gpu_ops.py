@@ -63,6 +63,53 @@ def test_gemm_pingpong_variant_is_bit_identical(ops, M, N, K):
         ops.set_gemm_variant(0)
 
 
+@pytest.mark.parametrize("M,N,K", [(1621, 4096, 14336), (1621, 4096, 4096), (1521, 4096, 4096), (1400, 4096, 1024), (225, 128, 64), (3000, 1024, 2048)])
+def test_gemm_fill_round_kernel_is_bit_identical(ops, M, N, K):
+    """csrc/k_gemm7.h (224 x 128 / 192 x 128 tiles, knobs 224 / 192; the automatic choice for the decoder's o / down projections at
+    S = 1621 and the connector's GEMMs on 1521 positions): same K order and epilogue arithmetic as the 128 x 128 kernel -> the same bits,
+    with every epilogue those callers use (residual + row statistics; bias + GELU; plain; fp32; the norm-carrying forms).  Repeated
+    launches screen the counted-vmcnt ring (5 / 6 pieces per wave) and the shared-image epilogue for races."""
+    a, w, bias, res = bf(M, K).to(DEV), bf(N, K, scale=K ** -0.5).to(DEV), torch.randn(N).to(DEV), bf(M, N).to(DEV)
+    xs = bf(M, K, seed=3).to(DEV)
+    st = ops.row_stats(xs)
+    colsum = w.float().sum(1)
+
+    def run():
+        so = torch.zeros((M, N // 64, 2), dtype=torch.float32, device=DEV)
+        outs = (ops.gemm(a, w, res=res, stats_out=so), so, ops.gemm(a, w, bias=bias, act=ops.ACT_GELU), ops.gemm(a, w), ops.gemm(a, w, out_f32=True))
+        if K % 128 == 0:
+            outs += (ops.gemm(xs, w, bias=bias, norm=(ops.NORM_LN, st, 1e-5, colsum)), ops.gemm(xs, w, norm=(ops.NORM_RMS, st, 1e-5, None)))
+        return outs
+    try:
+        ops.set_gemm_variant(1)
+        ref = run()
+        for v in (224, 192, 0):
+            ops.set_gemm_variant(v)
+            for _ in range(3):
+                assert all(torch.equal(x, y) for x, y in zip(run(), ref)), (M, N, K, v)
+    finally:
+        ops.set_gemm_variant(0)
+
+
+def test_gemm_fill_round_gathered_is_bit_identical(ops):
+    """The Conv3d(k2, s2, p1) taps as a gathered GEMM on the fill-the-round tiles (T = 16: 1521 x 4096 x 32768, the automatic choice) and on
+    a small grid with every border case, against the 128 x 128 gathered kernel."""
+    from videollama2_amd.connector import conv3d_k2s2p1_index
+    for T, H, C, N in ((16, 24, 4096, 4096), (4, 6, 1024, 256)):
+        x, wp, b = bf(T * H * H, C).to(DEV), bf(N, 8 * C, scale=(8 * C) ** -0.5).to(DEV), torch.randn(N, device=DEV)
+        idx, _ = conv3d_k2s2p1_index(T, H, H, DEV)
+        zero = torch.zeros(C, dtype=torch.bfloat16, device=DEV)
+        try:
+            ops.set_gemm_variant(1)
+            ref = ops.gemm(x, wp, bias=b, act=3, gather=(idx, zero, C))
+            for v in (192, 224, 0):
+                ops.set_gemm_variant(v)
+                for _ in range(2):
+                    assert torch.equal(ops.gemm(x, wp, bias=b, act=3, gather=(idx, zero, C)), ref), (T, v)
+        finally:
+            ops.set_gemm_variant(0)
+
+
 @pytest.mark.parametrize("M,N,K", [(1621, 28672, 4096), (1100, 16384, 2048)])
 def test_gemm_row_split_swiglu_is_bit_identical(ops, M, N, K):
     """Wide-N GEMMs whose M leaves the 256-row kernel a nearly empty last row tile run as two launches (256-row kernel on the

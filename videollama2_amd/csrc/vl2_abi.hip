@@ -13,6 +13,7 @@
 #include "k_fp8.h"
 #include "k_gemm.h"
 #include "k_gemm6.h"
+#include "k_gemm7.h"
 #include "k_norm.h"
 #include "k_pack.h"
 #include "k_skinny.h"
@@ -90,6 +91,7 @@ struct GemmCtl {
     bool no_persist = false;       // variant 24: the automatic choice without the persistent form
     bool persist = false;          // VL2_GEMM_PERSISTENT: the automatic choice may take the persistent form
     bool no_mix = false;           // VL2_GEMM_NO_MIX
+    bool no_fill = false;          // VL2_GEMM_NO_FILL
 };
 
 // ------------------------------------------------------------------------------------------------ GEMM
@@ -102,7 +104,8 @@ static bool want_stream_k(const GemmArgs& a, const GemmCtl& c) { return c.ws && 
 // 256x256 ping-pong 1.2: profiles/r01_gemm_experiments.md).  Fitted to the measured shapes of the T=16 workload: the LLM
 // o/gate-up/down projections and the STC 4096x4096 convs take 128x256, ViT qkv/wo/fc2 and the LLM qkv take 256x256,
 // short-K GEMMs (STC b1) stay on 128x128.  Returns 1, 4 (gemm3), 8 (gemm4) or 12 (gemm4 on 192-row tiles).
-static int choose_gemm_kernel(const GemmArgs& a) {
+static int choose_gemm_kernel(const GemmArgs& a, double* eff = nullptr) {
+    if (eff) *eff = 0.0;
     if (a.N % 256) return 1;
     // at most one 128x128 tile per CU: a bigger tile only halves the CUs in use and doubles the latency of the single round
     // (measured, T=8: 845x4096x4096 44.6 us here vs 50.2 us on 128x256; 945x4096x4096 47.2 vs 51.2)
@@ -124,7 +127,41 @@ static int choose_gemm_kernel(const GemmArgs& a) {
     const double m192 = (double)a.M / (((a.M + 191) / 192) * 192.0);
     const double e5 = fill((double)((a.M + 191) / 192) * (a.N / 256) / 256.0) * m192 * 1.13;
     if (a.K >= 512 && e5 > eb * 1.02) { best = 12; eb = e5; }
+    if (eff) *eff = best == 1 ? e1 : eb;
     return best;
+}
+
+// gemm7 (k_gemm7.h): 224 x 128 / 192 x 128 tiles for GEMMs that are ONE round of workgroups whatever the tile -- 0 = not this call, else R1
+// (3 = 224 rows, 2 = 192 rows).  Same efficiency model as choose_gemm_kernel: fill of the last round x rows wasted at the M edge x the
+// kernel's rate relative to the 128x128 kernel (GEMM7_RATE, measured: profiles/r05_experiments.md).  Only where the 128x128 grid is
+// more than one tile per CU (below that the one-round 128x128 / 64x64 kernels own the shape) and the K loop is long enough to pay for
+// the image epilogue.
+#define GEMM7_RATE 1.0
+static int choose_gemm7(const GemmArgs& a, bool gather) {
+    if (a.N % GEMM7_BN || a.K < 1024 || a.out_grp > 0 || a.res_row_mod > 0) return 0;
+    const long t128 = (long)((a.M + 127) / 128) * (a.N / 128);
+    if (t128 <= 256) return 0;
+    const auto fill = [](double rounds) { return rounds / (double)(long)(rounds + 0.999999); };
+    double eb = 0.0;
+    if (gather) eb = fill((double)t128 / 512.0) * ((double)a.M / (((a.M + 127) / 128) * 128.0));     // the gathered form has the 128x128 kernel only
+    else choose_gemm_kernel(a, &eb);
+    int best = 0;
+    for (int r1 = 3; r1 >= 2; --r1) {
+        const int bm = 128 + 32 * r1;
+        const long t7 = (long)((a.M + bm - 1) / bm) * (a.N / GEMM7_BN);
+        if (t7 > 256) continue;                                          // one round only: beyond it the 256-row kernels' rate wins
+        const double e7 = fill((double)t7 / 256.0) * ((double)a.M / (((a.M + bm - 1) / bm) * (double)bm)) * GEMM7_RATE;
+        if (e7 > eb * 1.03) { best = r1; eb = e7; }
+    }
+    return best;
+}
+template <int ACT, bool F32, bool G, int R1>
+static void launch_gemm7(const GemmArgs& a0, hipStream_t s) {
+    GemmArgs a = a0;
+    a.tiles_m = (a.M + Gemm7Geo<R1>::BM - 1) / Gemm7Geo<R1>::BM;
+    a.tiles_n = a.N / GEMM7_BN;
+    lds_attr<gemm7_bf16_kernel<ACT, F32, G, R1>>(Gemm7Geo<R1>::LDS_BYTES);
+    hipLaunchKernelGGL((gemm7_bf16_kernel<ACT, F32, G, R1>), dim3(a.tiles_m * a.tiles_n), dim3(512), Gemm7Geo<R1>::LDS_BYTES, s, a);
 }
 
 // Split-K factor for the 128x128 kernel (1 = do not split).  Only for grids that leave most resident slots empty: a lone
@@ -277,6 +314,12 @@ static GemmArgs gemm_rows(const GemmArgs& a0, int m0, int rows, bool f32) {
 
 template <int ACT, bool SW, bool F32, bool G>
 static void launch_gemm(const GemmArgs& a0, const GemmCtl& c, hipStream_t s) {
+    if constexpr (!SW) {
+        // fill-the-round tiles (k_gemm7.h): variants 224 / 192 on request (any shape with N % 128 == 0), or by the rule of choose_gemm7
+        const int r1 = c.variant == 224 ? 3 : c.variant == 192 ? 2 : (c.variant == 0 && !c.no_fill) ? choose_gemm7(a0, G) : 0;
+        if (r1 == 3) { launch_gemm7<ACT, F32, G, 3>(a0, s); return; }
+        if (r1 == 2) { launch_gemm7<ACT, F32, G, 2>(a0, s); return; }
+    }
     if constexpr (!G && !F32) {
         // persistent form: on request (variants 60 / 61; 62 = 192-row tiles with two accumulator sets, measured slower, kept for the lab) or
         // by the rule of choose_gemm6; a forced variant the call does not qualify for falls through to the automatic choice below
@@ -445,10 +488,11 @@ extern "C" int32_t vl2_gemm(const vl2_gemm_desc* d, void* stream) {
     if (d->stats_out && (sw || f32)) return fail(VL2_E_UNSUPP, "vl2_gemm: stats_out needs a plain bf16 output");
     if (d->ws && (d->ws_bytes < SK_WS_BYTES || !ALIGNED16(d->ws))) return fail(VL2_E_BADARG, "vl2_gemm: workspace needs >= %lld bytes, 16-byte aligned", (long long)SK_WS_BYTES);
     const int v = d->variant;
-    if (!(v == 0 || v == 1 || v == 2 || v == 4 || v == 8 || v == 12 || v == 32 || v == 24 || v == 60 || v == 61 || v == 62 || v == 70 || v == 71 || v == 80 || v == 81 || v == 256)) return fail(VL2_E_BADARG, "vl2_gemm: unknown variant %d", v);
+    if (!(v == 0 || v == 1 || v == 2 || v == 4 || v == 8 || v == 12 || v == 32 || v == 24 || v == 60 || v == 61 || v == 62 || v == 70 || v == 71 || v == 80 || v == 81 || v == 192 || v == 224 || v == 256)) return fail(VL2_E_BADARG, "vl2_gemm: unknown variant %d", v);
     GemmCtl ctl{d->ws, d->ws_bytes, v, (d->flags & VL2_GEMM_SPLITK) != 0};
     ctl.persist = (d->flags & VL2_GEMM_PERSISTENT) != 0;
     ctl.no_mix = (d->flags & VL2_GEMM_NO_MIX) != 0;
+    ctl.no_fill = (d->flags & VL2_GEMM_NO_FILL) != 0;
     GemmArgs a{};
     a.A = (const bf16_t*)d->A; a.W = (const bf16_t*)d->W; a.C = d->C; a.bias = d->bias; a.res = (const bf16_t*)d->res;
     a.a_idx = d->a_idx; a.zero_row = nullptr;
