@@ -59,6 +59,7 @@ int64_t vl2_workspace_bytes(void);
  * walks its tiles, csrc/k_gemm6.h: bf16 output without residual / statistics / gather, norm through `row_norm`, K >= 1024; a call that
  * does not qualify gets the automatic choice), 62 = 61 with two accumulator sets (the previous tile's epilogue drained under the next
  * tile's phases; measured slower than 61, kept for A/B), 24 = the automatic choice without the persistent form (A/B),
+ * 5 = variant 4 with the woven LDS-DMA issue whatever VL2_GEMM_NO_WEAVE says, 225 / 193 = 224 / 192 without it (A/B),
  * 224 / 192 = the fill-the-round 224x128 / 192x128 ping-pong kernel (csrc/k_gemm7.h; any N % 128 == 0, plain or gathered A, no SwiGLU; the
  * automatic choice takes it where its grid is one round of <= 256 workgroups and fills the chip better than the wider tiles:
  * the decoder's o / down projections at S = 1621, the STC convolutions on 1521 output positions).
@@ -68,10 +69,13 @@ int64_t vl2_workspace_bytes(void);
                                  and lost 1 ms per ViT pass on 3 of 11 boxes (profiles/r04_experiments.md) */
 #define VL2_GEMM_NO_MIX  16   /* a row-split call stays two launches instead of ONE mixed launch (A/B of gemm_mix_bf16_kernel) */
 #define VL2_GEMM_NO_FILL 32   /* the automatic choice does not take the fill-the-round kernel (variants 224 / 192): A/B of csrc/k_gemm7.h */
+#define VL2_GEMM_NO_WEAVE 64  /* the 128x256 / 224x128 / 192x128 ping-pong kernels issue their LDS-DMA from the load phases (the round 1-4 form) instead of
+                                 woven between the MFMAs of the matrix phases: A/B of the WEAVE template switch (same bits) */
 /* stage-level descriptors (vl2_vit_desc / vl2_stc_desc / vl2_llm_desc) `flags`: experiment controls, all off by default */
 #define VL2_STAGE_PERSISTENT_GEMM  1   /* every GEMM of the stage with VL2_GEMM_PERSISTENT */
 #define VL2_STAGE_NO_MIX           2   /* ... with VL2_GEMM_NO_MIX */
 #define VL2_STAGE_NO_FILL_TILES  128   /* ... with VL2_GEMM_NO_FILL */
+#define VL2_STAGE_NO_WEAVE       256   /* ... with VL2_GEMM_NO_WEAVE */
 #define VL2_STAGE_SELF_REDUCE      4   /* ViT and LLM prefill: the norm-carrying GEMMs reduce the row statistics themselves (no row_norm_finalize launches;
                                          * same bits, measured slower: LLM prefill 24.4 -> 26.0 ms, profiles/r04_experiments.md section 1) */
 #define VL2_STAGE_FUSED_DECODE_ATTN 8  /* decode step: attention + combine as one launch (vl2_attn_decode_fused; measured slower) */

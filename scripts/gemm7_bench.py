@@ -50,12 +50,12 @@ def main():
     idx, _ = conv3d_k2s2p1_index(T, H, H, dev)
     zero = torch.zeros(C, dtype=torch.bfloat16, device=dev)
     cases.append(("stc_conv3d_gather", 1521, 4096, 8 * C, lambda: ops.gemm(x, wp, bias=b, act=3, gather=(idx, zero, C))))
-    variants = (0, 1, 4, 8, 12, 192, 224)
+    variants = (0, 1, 4, 5, 8, 12, 192, 193, 224, 225)
     tab = {c[0]: {v: [] for v in variants} for c in cases}
     for _ in range(rounds):
         for name, M, N, K, fn in cases:
             for v in variants:
-                if name == "stc_conv3d_gather" and v in (4, 8, 12):
+                if name == "stc_conv3d_gather" and v in (4, 5, 8, 12, 193, 225):
                     continue
                 ops.set_gemm_variant(v)
                 try:

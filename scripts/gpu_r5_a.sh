@@ -4,7 +4,7 @@
 # power / clock files of the box (scripts/power_trace.py) for VERDICT r04 item 3.
 cd "$(dirname "$0")/.." || exit 1
 O=gpurun_out/r05a; mkdir -p $O
-timeout 900 python -m pytest tests/test_gpu_ops.py -x -q -k "fill_round" > $O/pytest_fill.log 2>&1; echo "pytest rc $?" >> $O/pytest_fill.log
+timeout 900 python -m pytest tests/test_gpu_ops.py -x -q -k "fill_round or pingpong" > $O/pytest_fill.log 2>&1; echo "pytest rc $?" >> $O/pytest_fill.log
 tail -5 $O/pytest_fill.log
 timeout 600 python scripts/gemm7_bench.py 3 > $O/gemm7_bench.txt 2>&1; cat $O/gemm7_bench.txt
 for rep in 1 2; do for f in 0 128; do

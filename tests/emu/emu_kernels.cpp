@@ -35,11 +35,13 @@ static bool g_gemm6_dynamic = false;       // gemm6: tiles handed out through th
 template <int ACT, bool SW, bool F32, bool G>
 static void run_gemm(GemmArgs a) {
     if constexpr (!SW) {                                        // fill-the-round 224 x 128 / 192 x 128 tiles (k_gemm7.h), plain and gathered
-        if (g_gemm_variant == 224 || g_gemm_variant == 192) {
-            const int bm = g_gemm_variant;
+        if (g_gemm_variant == 224 || g_gemm_variant == 192 || g_gemm_variant == 225 || g_gemm_variant == 193) {   // 225 / 193: LDS-DMA issued from the load phases
+            const bool weave = !(g_gemm_variant & 1);
+            const int bm = g_gemm_variant & ~1;
             a.tiles_m = (a.M + bm - 1) / bm; a.tiles_n = a.N / 128;
-            if (bm == 224) emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(512), [=] { gemm7_bf16_kernel<ACT, F32, G, 3>(a); });
-            else emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(512), [=] { gemm7_bf16_kernel<ACT, F32, G, 2>(a); });
+            const dim3 grid(a.tiles_m * a.tiles_n);
+            if (bm == 224) { if (weave) emu::launch(grid, dim3(512), [=] { gemm7_bf16_kernel<ACT, F32, G, 3, true>(a); }); else emu::launch(grid, dim3(512), [=] { gemm7_bf16_kernel<ACT, F32, G, 3, false>(a); }); }
+            else { if (weave) emu::launch(grid, dim3(512), [=] { gemm7_bf16_kernel<ACT, F32, G, 2, true>(a); }); else emu::launch(grid, dim3(512), [=] { gemm7_bf16_kernel<ACT, F32, G, 2, false>(a); }); }
             return;
         }
     }
@@ -50,6 +52,14 @@ static void run_gemm(GemmArgs a) {
                 if (a.res == nullptr) { emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(512), [=] { gemm3_bf16_kernel<ACT, SW, false, true>(a); }); return; }
             }
             emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(512), [=] { gemm3_bf16_kernel<ACT, SW, F32>(a); });
+            return;
+        }
+        if (g_gemm_variant == 5 && a.N % 256 == 0) {            // the same with the LDS-DMA issue woven into the MFMA phases (the library's default form)
+            a.tiles_m = (a.M + 127) / 128; a.tiles_n = a.N / 256;
+            if constexpr (!F32) {
+                if (a.res == nullptr) { emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(512), [=] { gemm3_bf16_kernel<ACT, SW, false, true, -1, true>(a); }); return; }
+            }
+            emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(512), [=] { gemm3_bf16_kernel<ACT, SW, F32, false, -1, true>(a); });
             return;
         }
         if (g_gemm_variant == 256) {

@@ -108,7 +108,7 @@ def test_emu_norm_carrying_gemms(emu):
     y2 = ops.gemm(x2, wl, bias=tl, norm=(ops.NORM_LN, st2, eps, sl))
     assert rel(y2, ref2) < TOL_BF16_OUT
     try:
-        for v in (1, 4, 8, 12, 32, 256):
+        for v in (1, 4, 5, 8, 12, 32, 256):
             ops.set_gemm_variant(v)
             stv = torch.zeros_like(st)
             assert torch.equal(ops.gemm(a, w, bias=bias, res=res, stats_out=stv), x) and torch.equal(stv, st), v
@@ -125,7 +125,7 @@ def test_emu_gemm_pingpong_variant(emu):
         a, w = bf(300, K), bf(512, K)
         ref = ops.gemm(a, w, out_f32=True)
         try:
-            for v in (4, 8, 256):
+            for v in (4, 5, 8, 256):
                 ops.set_gemm_variant(v)
                 assert torch.equal(ops.gemm(a, w, out_f32=True), ref)
         finally:
@@ -234,7 +234,7 @@ def test_emu_gemm_fill_round_kernel_is_bit_identical(emu):
         try:
             ops.set_gemm_variant(1)
             ref = run()
-            for v in (224, 192):
+            for v in (224, 192, 225, 193):
                 ops.set_gemm_variant(v)
                 got = run()
                 assert all(torch.equal(x, y) for x, y in zip(got, ref)), (M, N, K, v)
@@ -247,7 +247,7 @@ def test_emu_gemm_fill_round_kernel_is_bit_identical(emu):
     try:
         ops.set_gemm_variant(1)
         refg = ops.gemm(pool, w3, bias=b3, act=ops.ACT_SILU, gather=(idx, zero, C))
-        for v in (224, 192):
+        for v in (224, 192, 225, 193):
             ops.set_gemm_variant(v)
             assert torch.equal(ops.gemm(pool, w3, bias=b3, act=ops.ACT_SILU, gather=(idx, zero, C)), refg), v
     finally:

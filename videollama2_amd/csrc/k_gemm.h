@@ -1017,7 +1017,9 @@ __global__ __launch_bounds__(512, 2) void gemm4_bf16_kernel(GemmArgs p) {
 #define GEMM3_STAGE 49152
 #define GEMM3_LDS_BYTES (3 * GEMM3_STAGE)
 
-template <int ACT, bool SWIGLU, bool OUT_F32, bool TR = false, int EF = -1>
+// WEAVE (lab, variant 5): the six LDS-DMA pieces of K-tile t + 2 are issued from the wave's own MFMA(t) phase, one behind every second
+// MFMA, instead of from its LOAD(t) phase (see k_gemm7.h gemm7_loop); they are retired by vmcnt(0) at the end of the next LOAD phase.
+template <int ACT, bool SWIGLU, bool OUT_F32, bool TR = false, int EF = -1, bool WEAVE = false>
 __device__ __forceinline__ void gemm3_body(const GemmArgs& p, int bid, int nwg) {
     static_assert(!(TR && OUT_F32), "gemm_store_tr writes bf16");
     extern __shared__ __attribute__((aligned(16))) unsigned char vl2_smem[];
@@ -1054,16 +1056,18 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs& p, int bid, int nwg) 
         a_vo[i] = ((unsigned)am * (unsigned)p.lda + (sx & 7) * 8) * 2;
     }
     const unsigned w_step = 64u * (unsigned)p.ldw;
-    auto issue_dma = [&](int kt) {
+    auto issue_piece = [&](int kt, int i) {                     // piece i of this wave's share of K-tile kt: 0..3 = W, 4..5 = A
         const unsigned st = (unsigned)(kt % 3) * GEMM3_STAGE, kb = (unsigned)kt * (GEMM_BK * 2);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
+        if (i < 4)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(vl2_smem + st + 16384 + grp * 16384 + ((i * 4 + w4) << 10)),
                                                      16, w_vo, kb + i * w_step, 0, 0);
+        else
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(vl2_smem + st + (((grp * 2 + i - 4) * 4 + w4) << 10)),
+                                                     16, a_vo[i - 4], kb, 0, 0);
+    };
+    auto issue_dma = [&](int kt) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(vl2_smem + st + (((grp * 2 + i) * 4 + w4) << 10)),
-                                                     16, a_vo[i], kb, 0, 0);
+        for (int i = 0; i < 6; ++i) issue_piece(kt, i);
     };
 
     f32x16 acc[2][2];
@@ -1092,7 +1096,7 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs& p, int bid, int nwg) 
     for (int t = 0; t < nt; ++t) {
         // ---------------- LOAD(t)
         const bool more = t + 2 < nt;
-        if (more) issue_dma(t + 2);
+        if (!WEAVE && more) issue_dma(t + 2);
         const unsigned st = (unsigned)(t % 3) * GEMM3_STAGE;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -1103,7 +1107,7 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs& p, int bid, int nwg) 
                 fb[ks][i] = *(const bf16x8*)(vl2_smem + bb + i * 4096);
             }
         }
-        if (more) VL2_WAIT_VMCNT(6); else VL2_WAIT_VMCNT(0);      // tile t+1 landed; the 6 just issued stay in flight
+        if (!WEAVE && more) VL2_WAIT_VMCNT(6); else VL2_WAIT_VMCNT(0);      // tile t+1 landed; the 6 just issued stay in flight
         VL2_WAIT_LGKMCNT0();
         VL2_PHASE_BARRIER();
         // ---------------- MFMA(t)
@@ -1112,9 +1116,18 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs& p, int bid, int nwg) 
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < 2; ++j) {
                     acc[i][j] = TR ? VL2_MFMA32(fb[ks][j], fa[ks][i], acc[i][j])
                                    : VL2_MFMA32(fa[ks][i], fb[ks][j], acc[i][j]);
+                    if constexpr (WEAVE) {
+                        const int idx = ks * 4 + i * 2 + j;
+                        if ((idx & 1) && idx < 12) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (more) issue_piece(t + 2, idx >> 1);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                }
         VL2_PHASE_BARRIER();
     }
     if (grp == 0) VL2_PHASE_BARRIER();
@@ -1141,9 +1154,9 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs& p, int bid, int nwg) 
         __builtin_amdgcn_wave_barrier();
     }
 }
-template <int ACT, bool SWIGLU, bool OUT_F32, bool TR = false, int EF = -1>
+template <int ACT, bool SWIGLU, bool OUT_F32, bool TR = false, int EF = -1, bool WEAVE = false>
 __global__ __launch_bounds__(512, 2) void gemm3_bf16_kernel(GemmArgs p) {
-    gemm3_body<ACT, SWIGLU, OUT_F32, TR, EF>(p, blockIdx.x, gridDim.x);
+    gemm3_body<ACT, SWIGLU, OUT_F32, TR, EF, WEAVE>(p, blockIdx.x, gridDim.x);
 }
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -125,15 +125,21 @@ __device__ __forceinline__ void gemm7_store_rows(const GemmArgs& p, const float*
 }
 
 // one group's main loop.  G0: 2 x 2 blocks (frag[ks][0..1] = A, [2..3] = W); group 1: R1 x 1 blocks (frag[ks][0..R1-1] = A, [3] = W).
-template <int R1, bool G0, class Dma>
+// WEAVE: the LDS-DMA pieces of tile t + 2 are issued from the wave's own MFMA(t) phase, one piece behind every second MFMA (an in-order
+// wave that streams MFMAs has idle issue slots: a piece costs ~60 cycles there against 100-185 in a load phase that also carries 16
+// ds_read_b128 -- MI355X_MICROARCH.md "LDS-DMA piece issue cost"), and the load phase keeps the fragment reads only.  The pieces then have
+// one phase of flight (retired by vmcnt(0) at the end of the wave's next load phase) instead of two.
+template <int R1, bool G0, bool WEAVE, class Dma>
 __device__ __forceinline__ void gemm7_loop(unsigned char* smem, f32x16 (&acc)[4], const unsigned (&a_rd)[4], const unsigned (&b_rd)[4], int nt, int npw,
                                            Dma&& issue_dma) {
-    constexpr int STAGE = Gemm7Geo<R1>::STAGE;
+    constexpr int STAGE = Gemm7Geo<R1>::STAGE, NPW = Gemm7Geo<R1>::NPW;
+    constexpr int NM = G0 ? 16 : 4 * R1;                           // MFMAs of a phase
+    constexpr int WSTEP = NM >= 2 * NPW ? 2 : 1;                   // a piece behind every WSTEP-th MFMA
     bf16x8 frag[4][4];
     for (int t = 0; t < nt; ++t) {
         // ---------------- LOAD(t): memory work only
         const bool more = t + 2 < nt;
-        if (more) issue_dma(t + 2);
+        if constexpr (!WEAVE) { if (more) issue_dma(t + 2, 0, NPW); }
         const unsigned st = (unsigned)(t % 3) * STAGE;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -149,30 +155,37 @@ __device__ __forceinline__ void gemm7_loop(unsigned char* smem, f32x16 (&acc)[4]
                 frag[ks][3] = *(const bf16x8*)(smem + bb);
             }
         }
-        // tile t + 1 landed (this wave's pieces of it); the pieces just issued stay in flight
-        if (more) { if (npw == 6) VL2_WAIT_VMCNT(6); else VL2_WAIT_VMCNT(5); }
+        // tile t + 1 landed (this wave's pieces of it); without WEAVE the pieces just issued stay in flight
+        if (!WEAVE && more) { if (npw == 6) VL2_WAIT_VMCNT(6); else VL2_WAIT_VMCNT(5); }
         else VL2_WAIT_VMCNT(0);
         VL2_WAIT_LGKMCNT0();
         VL2_PHASE_BARRIER();
-        // ---------------- MFMA(t): matrix work only
+        // ---------------- MFMA(t): matrix work (+ the woven LDS-DMA issue)
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        for (int idx = 0; idx < NM; ++idx) {
             if constexpr (G0) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i * 2 + j] = VL2_MFMA32(frag[ks][i], frag[ks][2 + j], acc[i * 2 + j]);
+                const int ks = idx >> 2, i = (idx >> 1) & 1, j = idx & 1;
+                acc[i * 2 + j] = VL2_MFMA32(frag[ks][i], frag[ks][2 + j], acc[i * 2 + j]);
             } else {
-#pragma unroll
-                for (int i = 0; i < R1; ++i) acc[i] = VL2_MFMA32(frag[ks][i], frag[ks][3], acc[i]);
+                const int ks = idx / R1, i = idx % R1;
+                acc[i] = VL2_MFMA32(frag[ks][i], frag[ks][3], acc[i]);
+            }
+            if constexpr (WEAVE) {
+                if (idx % WSTEP == WSTEP - 1 && idx / WSTEP < NPW) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (more) issue_dma(t + 2, idx / WSTEP, idx / WSTEP + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
         VL2_PHASE_BARRIER();
     }
 }
 
-template <int ACT, bool OUT_F32, bool GATHER, int R1>
-__global__ __launch_bounds__(512, 2) void gemm7_bf16_kernel(GemmArgs p) {
+// (a __device__ body: the host pass of hipcc drops a __global__ template whose own body holds device-only inline asm -- VL2_PIN2 -- without
+//  a diagnostic, and the launch then fails to link)
+template <int ACT, bool OUT_F32, bool GATHER, int R1, bool WEAVE = false>
+__device__ __forceinline__ void gemm7_body(const GemmArgs& p) {
     static_assert(R1 == 2 || R1 == 3, "gemm7: 192- or 224-row tiles");
     using Geo = Gemm7Geo<R1>;
     constexpr int BM = Geo::BM, NA = Geo::NA, NPIECE = Geo::NPIECE, STAGE = Geo::STAGE, NPW = Geo::NPW;
@@ -216,13 +229,13 @@ __global__ __launch_bounds__(512, 2) void gemm7_bf16_kernel(GemmArgs p) {
         }
     }
     const int tps = GATHER ? p.seg_k / GEMM_BK : 1;                // K-tiles per gather segment
-    auto issue_dma = [&](int kt) {
+    auto issue_dma = [&](int kt, int i0, int i1) {              // pieces [i0, i1) of this wave's share of K-tile kt
         const unsigned st = (unsigned)(kt % 3) * STAGE, kw = (unsigned)kt * (GEMM_BK * 2);
         unsigned ka = kw;
         if constexpr (GATHER) {
             // the A row of (K segment, m) comes from the index table; a missing tap (index < 0) is an out-of-range buffer offset = zeros
             const int seg = kt / tps, kl = kt - seg * tps;
-            if (kl == 0 || kt == 0) {
+            if ((kl == 0 || kt == 0) && i0 == 0) {
 #pragma unroll
                 for (int i = 0; i < NPW; ++i)
                     if (wslot + 8 * i < NA) {
@@ -235,7 +248,7 @@ __global__ __launch_bounds__(512, 2) void gemm7_bf16_kernel(GemmArgs p) {
 #pragma unroll
         for (int i = 0; i < NPW; ++i) {
             const int q = wslot + 8 * i;
-            if (q < NPIECE) {
+            if (i >= i0 && i < i1 && q < NPIECE) {
                 if (q < NA)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(vl2_smem + st + (q << 10)), 16, vo[i], ka, 0, 0);
                 else
@@ -258,8 +271,8 @@ __global__ __launch_bounds__(512, 2) void gemm7_bf16_kernel(GemmArgs p) {
         a_rd[ks] = gemm_lds_off((grp == 0 ? (w4 >> 1) * 64 : 128) + frow, ks * 2 + fchk);
         b_rd[ks] = BM * 128 + gemm_lds_off((grp == 0 ? (w4 & 1) * 64 : w4 * 32) + frow, ks * 2 + fchk);
     }
-    issue_dma(0);
-    if (nt > 1) issue_dma(1);
+    issue_dma(0, 0, NPW);
+    if (nt > 1) issue_dma(1, 0, NPW);
     // the rows' (mean, rstd) (norm-carrying GEMMs) ride behind the ring fill, as in gemm4
     f32x2 rst = gemm_row_stats(p, m0, tid, BM);
     VL2_PIN2(rst[0], rst[1]);
@@ -268,11 +281,11 @@ __global__ __launch_bounds__(512, 2) void gemm7_bf16_kernel(GemmArgs p) {
     VL2_PHASE_BARRIER();
 
     if (grp == 0) {
-        gemm7_loop<R1, true>(vl2_smem, acc, a_rd, b_rd, nt, npw, issue_dma);
+        gemm7_loop<R1, true, WEAVE>(vl2_smem, acc, a_rd, b_rd, nt, npw, issue_dma);
         VL2_PHASE_BARRIER();
     } else {
         VL2_PHASE_BARRIER();
-        gemm7_loop<R1, false>(vl2_smem, acc, a_rd, b_rd, nt, npw, issue_dma);
+        gemm7_loop<R1, false, WEAVE>(vl2_smem, acc, a_rd, b_rd, nt, npw, issue_dma);
     }
 
     // ---- epilogue: every wave's blocks -> the fp32 image (the ring is dead: all operands were in registers before the last barrier)
@@ -299,4 +312,8 @@ __global__ __launch_bounds__(512, 2) void gemm7_bf16_kernel(GemmArgs p) {
     gemm_park_row_stats(p, rowtab, rst, tid, BM);
     __syncthreads();
     gemm7_store_rows<ACT, OUT_F32, BM / 32>(p, img, rowtab, m0, n0, wave, lane);
+}
+template <int ACT, bool OUT_F32, bool GATHER, int R1, bool WEAVE = false>
+__global__ __launch_bounds__(512, 2) void gemm7_bf16_kernel(GemmArgs p) {
+    gemm7_body<ACT, OUT_F32, GATHER, R1, WEAVE>(p);
 }

@@ -92,6 +92,7 @@ struct GemmCtl {
     bool persist = false;          // VL2_GEMM_PERSISTENT: the automatic choice may take the persistent form
     bool no_mix = false;           // VL2_GEMM_NO_MIX
     bool no_fill = false;          // VL2_GEMM_NO_FILL
+    bool no_weave = false;         // VL2_GEMM_NO_WEAVE
 };
 
 // ------------------------------------------------------------------------------------------------ GEMM
@@ -136,7 +137,7 @@ static int choose_gemm_kernel(const GemmArgs& a, double* eff = nullptr) {
 // kernel's rate relative to the 128x128 kernel (GEMM7_RATE, measured: profiles/r05_experiments.md).  Only where the 128x128 grid is
 // more than one tile per CU (below that the one-round 128x128 / 64x64 kernels own the shape) and the K loop is long enough to pay for
 // the image epilogue.
-#define GEMM7_RATE 1.0
+#define GEMM7_RATE 0.88
 static int choose_gemm7(const GemmArgs& a, bool gather) {
     if (a.N % GEMM7_BN || a.K < 1024 || a.out_grp > 0 || a.res_row_mod > 0) return 0;
     const long t128 = (long)((a.M + 127) / 128) * (a.N / 128);
@@ -155,13 +156,14 @@ static int choose_gemm7(const GemmArgs& a, bool gather) {
     }
     return best;
 }
-template <int ACT, bool F32, bool G, int R1>
+template <int ACT, bool F32, bool G, int R1, bool WEAVE = false>
 static void launch_gemm7(const GemmArgs& a0, hipStream_t s) {
     GemmArgs a = a0;
-    a.tiles_m = (a.M + Gemm7Geo<R1>::BM - 1) / Gemm7Geo<R1>::BM;
+    constexpr int bm = 128 + 32 * R1, lds = Gemm7Geo<R1>::LDS_BYTES;
+    a.tiles_m = (a.M + bm - 1) / bm;
     a.tiles_n = a.N / GEMM7_BN;
-    lds_attr<gemm7_bf16_kernel<ACT, F32, G, R1>>(Gemm7Geo<R1>::LDS_BYTES);
-    hipLaunchKernelGGL((gemm7_bf16_kernel<ACT, F32, G, R1>), dim3(a.tiles_m * a.tiles_n), dim3(512), Gemm7Geo<R1>::LDS_BYTES, s, a);
+    lds_attr<gemm7_bf16_kernel<ACT, F32, G, R1, WEAVE>>(lds);
+    hipLaunchKernelGGL((gemm7_bf16_kernel<ACT, F32, G, R1, WEAVE>), dim3(a.tiles_m * a.tiles_n), dim3(512), lds, s, a);
 }
 
 // Split-K factor for the 128x128 kernel (1 = do not split).  Only for grids that leave most resident slots empty: a lone
@@ -317,8 +319,11 @@ static void launch_gemm(const GemmArgs& a0, const GemmCtl& c, hipStream_t s) {
     if constexpr (!SW) {
         // fill-the-round tiles (k_gemm7.h): variants 224 / 192 on request (any shape with N % 128 == 0), or by the rule of choose_gemm7
         const int r1 = c.variant == 224 ? 3 : c.variant == 192 ? 2 : (c.variant == 0 && !c.no_fill) ? choose_gemm7(a0, G) : 0;
-        if (r1 == 3) { launch_gemm7<ACT, F32, G, 3>(a0, s); return; }
-        if (r1 == 2) { launch_gemm7<ACT, F32, G, 2>(a0, s); return; }
+        // (225 / 193 = 224 / 192 with the LDS-DMA issue of the load phases, as VL2_GEMM_NO_WEAVE selects it: the A/B of gemm7_loop's WEAVE)
+        const int r1v = c.variant == 225 ? 3 : c.variant == 193 ? 2 : r1;
+        const bool weave7 = !(c.no_weave || c.variant == 225 || c.variant == 193);
+        if (r1v == 3) { if (weave7) launch_gemm7<ACT, F32, G, 3, true>(a0, s); else launch_gemm7<ACT, F32, G, 3, false>(a0, s); return; }
+        if (r1v == 2) { if (weave7) launch_gemm7<ACT, F32, G, 2, true>(a0, s); else launch_gemm7<ACT, F32, G, 2, false>(a0, s); return; }
     }
     if constexpr (!G && !F32) {
         // persistent form: on request (variants 60 / 61; 62 = 192-row tiles with two accumulator sets, measured slower, kept for the lab) or
@@ -394,19 +399,33 @@ static void launch_gemm(const GemmArgs& a0, const GemmCtl& c, hipStream_t s) {
             return;
         }
         const int kern = c.variant == 0 ? choose_gemm_kernel(a0) : c.variant;
-        if (kern == 4 && a0.N % GEMM3_BN == 0) {
+        if ((kern == 4 || kern == 5) && a0.N % GEMM3_BN == 0) {
+            // the LDS-DMA issue woven into the MFMA phases (k_gemm.h gemm3_body WEAVE; same bits): measured -2...-5 % on the decoder's o / down
+            // projections and the STC convolutions (profiles/r05_experiments.md); VL2_GEMM_NO_WEAVE keeps the load-phase issue for A/B, variant 5 forces it
+            const bool weave = kern == 5 || !c.no_weave;
             GemmArgs a = a0;
             a.tiles_m = (a.M + GEMM3_BM - 1) / GEMM3_BM;
             a.tiles_n = a.N / GEMM3_BN;
+            const dim3 grid(a.tiles_m * a.tiles_n);
             if constexpr (!F32) {
                 if (want_tr_epilogue(a)) {
-                    lds_attr<gemm3_bf16_kernel<ACT, SW, false, true>>(GEMM3_LDS_BYTES);
-                    hipLaunchKernelGGL((gemm3_bf16_kernel<ACT, SW, false, true>), dim3(a.tiles_m * a.tiles_n), dim3(512), GEMM3_LDS_BYTES, s, a);
+                    if (weave) {
+                        lds_attr<gemm3_bf16_kernel<ACT, SW, false, true, -1, true>>(GEMM3_LDS_BYTES);
+                        hipLaunchKernelGGL((gemm3_bf16_kernel<ACT, SW, false, true, -1, true>), grid, dim3(512), GEMM3_LDS_BYTES, s, a);
+                    } else {
+                        lds_attr<gemm3_bf16_kernel<ACT, SW, false, true>>(GEMM3_LDS_BYTES);
+                        hipLaunchKernelGGL((gemm3_bf16_kernel<ACT, SW, false, true>), grid, dim3(512), GEMM3_LDS_BYTES, s, a);
+                    }
                     return;
                 }
             }
-            lds_attr<gemm3_bf16_kernel<ACT, SW, F32>>(GEMM3_LDS_BYTES);
-            hipLaunchKernelGGL((gemm3_bf16_kernel<ACT, SW, F32>), dim3(a.tiles_m * a.tiles_n), dim3(512), GEMM3_LDS_BYTES, s, a);
+            if (weave) {
+                lds_attr<gemm3_bf16_kernel<ACT, SW, F32, false, -1, true>>(GEMM3_LDS_BYTES);
+                hipLaunchKernelGGL((gemm3_bf16_kernel<ACT, SW, F32, false, -1, true>), grid, dim3(512), GEMM3_LDS_BYTES, s, a);
+            } else {
+                lds_attr<gemm3_bf16_kernel<ACT, SW, F32>>(GEMM3_LDS_BYTES);
+                hipLaunchKernelGGL((gemm3_bf16_kernel<ACT, SW, F32>), grid, dim3(512), GEMM3_LDS_BYTES, s, a);
+            }
             return;
         }
         if ((kern == 8 || (F32 && kern == 12)) && a0.N % GEMM4_BN == 0) {     // (the 192-row form is built for bf16 outputs only)
@@ -488,11 +507,12 @@ extern "C" int32_t vl2_gemm(const vl2_gemm_desc* d, void* stream) {
     if (d->stats_out && (sw || f32)) return fail(VL2_E_UNSUPP, "vl2_gemm: stats_out needs a plain bf16 output");
     if (d->ws && (d->ws_bytes < SK_WS_BYTES || !ALIGNED16(d->ws))) return fail(VL2_E_BADARG, "vl2_gemm: workspace needs >= %lld bytes, 16-byte aligned", (long long)SK_WS_BYTES);
     const int v = d->variant;
-    if (!(v == 0 || v == 1 || v == 2 || v == 4 || v == 8 || v == 12 || v == 32 || v == 24 || v == 60 || v == 61 || v == 62 || v == 70 || v == 71 || v == 80 || v == 81 || v == 192 || v == 224 || v == 256)) return fail(VL2_E_BADARG, "vl2_gemm: unknown variant %d", v);
+    if (!(v == 0 || v == 1 || v == 2 || v == 4 || v == 5 || v == 8 || v == 12 || v == 32 || v == 24 || v == 60 || v == 61 || v == 62 || v == 70 || v == 71 || v == 80 || v == 81 || v == 192 || v == 193 || v == 224 || v == 225 || v == 256)) return fail(VL2_E_BADARG, "vl2_gemm: unknown variant %d", v);
     GemmCtl ctl{d->ws, d->ws_bytes, v, (d->flags & VL2_GEMM_SPLITK) != 0};
     ctl.persist = (d->flags & VL2_GEMM_PERSISTENT) != 0;
     ctl.no_mix = (d->flags & VL2_GEMM_NO_MIX) != 0;
     ctl.no_fill = (d->flags & VL2_GEMM_NO_FILL) != 0;
+    ctl.no_weave = (d->flags & VL2_GEMM_NO_WEAVE) != 0;
     GemmArgs a{};
     a.A = (const bf16_t*)d->A; a.W = (const bf16_t*)d->W; a.C = d->C; a.bias = d->bias; a.res = (const bf16_t*)d->res;
     a.a_idx = d->a_idx; a.zero_row = nullptr;

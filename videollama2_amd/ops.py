@@ -38,8 +38,9 @@ NORM_NONE, NORM_RMS, NORM_LN = 0, 1, 2
 # call (vl2_gemm_desc.variant / flags / ws): the library itself holds no mutable state.
 _WORKSPACE = {}
 _CTL = dict(variant=0, splitk=False, attn_variant=0, stage_flags=0, gemm_flags=0)
-GEMM_PERSISTENT, GEMM_NO_MIX, GEMM_NO_FILL = 8, 16, 32                                    # vl2_gemm_desc.flags (include/vl2hip.h)
+GEMM_PERSISTENT, GEMM_NO_MIX, GEMM_NO_FILL, GEMM_NO_WEAVE = 8, 16, 32, 64                                    # vl2_gemm_desc.flags (include/vl2hip.h)
 STAGE_PERSISTENT_GEMM, STAGE_NO_MIX, STAGE_SELF_REDUCE, STAGE_FUSED_DECODE_ATTN, STAGE_DECODE_TAIL, STAGE_STC_UNFUSED = 1, 2, 4, 8, 16, 32
+STAGE_NO_WEAVE = 256                  # A/B of the woven LDS-DMA issue of the 128x256 / 224x128 / 192x128 ping-pong GEMMs
 STAGE_NO_FILL_TILES = 128             # A/B of the fill-the-round GEMM tiles (csrc/k_gemm7.h)
 STAGE_DECODE_FP8 = 64                 # decode step on the fp8 copies of the weights (vl2_llm_desc.layers_w8); set by the decoder, not a lab switch
 GEMV_RMS_PLAIN = 32   # vl2_*_desc.flags of the stage calls
@@ -80,7 +81,7 @@ def set_stage_flags(flags):
     (the library reads no environment variables and keeps no state)."""
     _CTL["stage_flags"] = int(flags)
     _CTL["gemm_flags"] = (GEMM_PERSISTENT if flags & STAGE_PERSISTENT_GEMM else 0) | (GEMM_NO_MIX if flags & STAGE_NO_MIX else 0) | \
-                         (GEMM_NO_FILL if flags & STAGE_NO_FILL_TILES else 0)
+                         (GEMM_NO_FILL if flags & STAGE_NO_FILL_TILES else 0) | (GEMM_NO_WEAVE if flags & STAGE_NO_WEAVE else 0)
 
 
 def stage_flags():
