@@ -23,6 +23,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+PEAK_MFMA_FP8_TFLOPS = 5000.0    # dense fp8 (MX K = 128 measured 4647 TF), same table
 PEAK_MFMA_BF16_TFLOPS = 2500.0   # dense, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
 PEAK_HBM_GBS = 8000.0
 
@@ -182,6 +183,9 @@ def main():
     ap.add_argument("--decode-weights", choices=["16bit", "fp8"], default="16bit",
                     help="fp8: ALSO time the decode steps on e4m3fn row-scaled copies of the decoder weights (SURVEY 8f row 5; an optional "
                          "arithmetic, reported under the `decode_fp8` key -- the headline decode numbers stay the 16-bit ones)")
+    ap.add_argument("--prefill-weights", choices=["16bit", "fp8"], default="16bit",
+                    help="fp8: ALSO time the prefill with its projections on the fp8 matrix pipe (W8A8: e4m3fn row-scaled weights, activations quantised "
+                         "per token row; BASELINE.json configs[4] 'fp8 MFMA on CDNA4'); reported under the `prefill_fp8` key -- never the headline")
     ap.add_argument("--stage-flags", type=int, default=0, help="experiment controls of the stage-level calls (include/vl2hip.h VL2_STAGE_*: 1 persistent GEMM, "
                     "2 no mixed launch, 4 in-GEMM statistics reduction (ViT), 8 fused decode attention); travel in the call descriptors")
     ap.add_argument("--tune", type=str, default="", help="debug: comma list of gemm=<variant>, splitk=<0|1>, attn=<variant> (videollama2_amd/ops.py launch controls)")
@@ -393,6 +397,49 @@ def main():
         dec.enable_fp8_decode(False)
         graph = None if args.no_graph else dec.capture_graph()      # the 16-bit graph again for the passes below
 
+    # ---- optional: the prefill with its four projections per layer on the fp8 matrix pipe (v_mfma_f32_32x32x64_f8f6f4; W8A8)
+    prefill_fp8 = None
+    if args.prefill_weights == "fp8" and world == 1 and tp_group is None:
+        dec = model.decoder
+        _, _, _, emb, _ = model.prepare_inputs_labels_for_multimodal(ids, mask, None, None, [(frames, "video")])
+        lref = dec.prefill(emb[0]).clone()
+        dec.enable_fp8_prefill()
+        l8 = dec.prefill(emb[0]).clone()
+        torch.cuda.synchronize()
+        best = None
+        for _ in range(5):
+            e0, e1 = ev(), ev()
+            e0.record()
+            dec.prefill(emb[0])
+            e1.record()
+            torch.cuda.synchronize()
+            t = e0.elapsed_time(e1)
+            best = t if best is None or t < best else best
+        ops.PROFILE = []
+        dec.prefill(emb[0])
+        torch.cuda.synchronize()
+        prof, ops.PROFILE = ops.PROFILE, None
+        by = {}
+        for pr in prof:
+            if pr[0] == "gemm_fp8":
+                e = by.setdefault(pr[4], [0, 0.0, 0.0])
+                e[0] += 1; e[1] += pr[1] / 1e9; e[2] += pr[2].elapsed_time(pr[3])
+        _, _, ptf, _ = algorithmic_tflop(cfg, T)
+        prefill_fp8 = {"prefill_ms": round(best, 3), "prefill_tokens_per_s": round(S / (best / 1e3), 1),
+                       "vs_16bit_prefill": round(pre_ms / best, 3),
+                       "mfma_frac_of_fp8_peak": round(ptf / (best / 1e3) / PEAK_MFMA_FP8_TFLOPS, 4), "peak_tflops": PEAK_MFMA_FP8_TFLOPS,
+                       "logits_rel_l2_vs_16bit_prefill": round(float((l8.float() - lref.float()).norm() / lref.float().norm()), 5),
+                       "top1_equal": bool(int(l8.argmax()) == int(lref.argmax())),
+                       "shapes": [dict(M=k[0], N=k[1], K=k[2], launches=v[0], avg_launch_us=round(1e3 * v[2] / v[0], 2), tflops=round(v[1] / v[2], 1))
+                                  for k, v in sorted(by.items(), key=lambda kv: -kv[1][2])],
+                       "arithmetic": "W8A8: OCP e4m3fn weights (one power-of-two scale per output row, the decode copies) x e4m3fn activations (one power-of-two "
+                                     "scale per token row, quantised on the fly by vl2_quant_act_fp8, which also computes the RMS rstd), fp32 accumulation on "
+                                     "v_mfma_f32_32x32x64_f8f6f4 (csrc/k_gemm.h gemm3 / gemm4 FP8); attention, RoPE, KV cache, lm_head 16-bit.  OPTIONAL "
+                                     "arithmetic: not the reference's, not the headline (`prefill_ms` is the 16-bit path); oracle/fp8_oracle.py gemm_w8a8, "
+                                     "tests/test_gpu_fp8.py"}
+        dec.enable_fp8_prefill(False)
+        dec.prefill(emb[0])
+
     # ---- roofline of the dominant kernel (gemm_bf16_kernel, MFMA-bound): one extra profiled pass, every GEMM launch
     #      bracketed by HIP events on the launch stream; achieved = sum(algorithmic FLOPs) / sum(kernel time)
     batched = None
@@ -569,6 +616,8 @@ def main():
             out["encoder_graphs"] = "replayed" if model.sharder.use_graph else f"eager ({model.sharder.graph_error or 'disabled'})"
         if decode_fp8 is not None:
             out["decode_fp8"] = decode_fp8
+        if prefill_fp8 is not None:
+            out["prefill_fp8"] = prefill_fp8
         if batched is not None:
             out["batched_decode"] = batched
         if bprefill is not None:

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define VL2_ABI_VERSION 4
+#define VL2_ABI_VERSION 5
 #define VL2_E_BADARG  (-1)   /* null pointer / non-positive size */
 #define VL2_E_SHAPE   (-2)   /* shape not supported by the gfx950 kernels (alignment / multiple-of constraints) */
 #define VL2_E_UNSUPP  (-3)   /* option combination not built */
@@ -59,7 +59,7 @@ int64_t vl2_workspace_bytes(void);
  * walks its tiles, csrc/k_gemm6.h: bf16 output without residual / statistics / gather, norm through `row_norm`, K >= 1024; a call that
  * does not qualify gets the automatic choice), 62 = 61 with two accumulator sets (the previous tile's epilogue drained under the next
  * tile's phases; measured slower than 61, kept for A/B), 24 = the automatic choice without the persistent form (A/B),
- * 5 = variant 4 with the woven LDS-DMA issue whatever VL2_GEMM_NO_WEAVE says, 225 / 193 = 224 / 192 without it (A/B),
+ * 5 = variant 4 with the woven LDS-DMA issue (VL2_GEMM_WEAVE), 225 / 193 = 224 / 192 with it (lab),
  * 224 / 192 = the fill-the-round 224x128 / 192x128 ping-pong kernel (csrc/k_gemm7.h; any N % 128 == 0, plain or gathered A, no SwiGLU; the
  * automatic choice takes it where its grid is one round of <= 256 workgroups and fills the chip better than the wider tiles:
  * the decoder's o / down projections at S = 1621, the STC convolutions on 1521 output positions).
@@ -69,13 +69,18 @@ int64_t vl2_workspace_bytes(void);
                                  and lost 1 ms per ViT pass on 3 of 11 boxes (profiles/r04_experiments.md) */
 #define VL2_GEMM_NO_MIX  16   /* a row-split call stays two launches instead of ONE mixed launch (A/B of gemm_mix_bf16_kernel) */
 #define VL2_GEMM_NO_FILL 32   /* the automatic choice does not take the fill-the-round kernel (variants 224 / 192): A/B of csrc/k_gemm7.h */
-#define VL2_GEMM_NO_WEAVE 64  /* the 128x256 / 224x128 / 192x128 ping-pong kernels issue their LDS-DMA from the load phases (the round 1-4 form) instead of
-                                 woven between the MFMAs of the matrix phases: A/B of the WEAVE template switch (same bits) */
+#define VL2_GEMM_FP8     128  /* W8A8 on the fp8 matrix pipe (v_mfma_f32_32x32x64_f8f6f4, twice the 16-bit MFMA rate; SURVEY 8f row 5 / BASELINE.json configs[4]
+                                 "fp8 MFMA on CDNA4"): A [M, lda] and W [N, ldw] hold OCP e4m3fn BYTES (K = elements = bytes, K % 128 == 0, N % 256 == 0),
+                                 `row_norm` [M][2] = (0, row multiplier) as vl2_quant_act_fp8 writes it (activation scale x RMS rstd), `col_scale` [N] = the
+                                 weight rows' scales (vl2_pack_quant_fp8).  C = epilogue(rowmul_m * colscale_n * sum_k A8 W8): bias / SiLU / SwiGLU / residual /
+                                 fp32 output as the 16-bit form.  An OPTIONAL arithmetic (both operands rounded to e4m3fn), never the default */
+#define VL2_GEMM_WEAVE   64   /* lab: the 128x256 / 224x128 / 192x128 ping-pong kernels issue their LDS-DMA woven between the MFMAs of the matrix phases instead of
+                                 from the load phases (same bits; faster back to back on warm operands, slower in the pipeline: profiles/r05_experiments.md) */
 /* stage-level descriptors (vl2_vit_desc / vl2_stc_desc / vl2_llm_desc) `flags`: experiment controls, all off by default */
 #define VL2_STAGE_PERSISTENT_GEMM  1   /* every GEMM of the stage with VL2_GEMM_PERSISTENT */
 #define VL2_STAGE_NO_MIX           2   /* ... with VL2_GEMM_NO_MIX */
 #define VL2_STAGE_NO_FILL_TILES  128   /* ... with VL2_GEMM_NO_FILL */
-#define VL2_STAGE_NO_WEAVE       256   /* ... with VL2_GEMM_NO_WEAVE */
+#define VL2_STAGE_WEAVE          256   /* ... with VL2_GEMM_WEAVE */
 #define VL2_STAGE_SELF_REDUCE      4   /* ViT and LLM prefill: the norm-carrying GEMMs reduce the row statistics themselves (no row_norm_finalize launches;
                                          * same bits, measured slower: LLM prefill 24.4 -> 26.0 ms, profiles/r04_experiments.md section 1) */
 #define VL2_STAGE_FUSED_DECODE_ATTN 8  /* decode step: attention + combine as one launch (vl2_attn_decode_fused; measured slower) */
@@ -83,6 +88,9 @@ int64_t vl2_workspace_bytes(void);
                                          * vl2_dwconv3x3_ln_silu_mean + small_linear + vl2_se_excite_scale */
 #define VL2_STAGE_DECODE_TAIL      16   /* decode step: o_proj / gate-up / down as ONE vl2_decode_tail launch instead of three vl2_gemv_bf16 launches
                                           (same bits; measured slower: 98.5 vs 66.7 us per layer, profiles/r04_experiments.md) */
+#define VL2_STAGE_PREFILL_FP8     512   /* vl2_llm_prefill: the four projections of every layer as VL2_GEMM_FP8 calls on the fp8 weight copies (layers_w8), their
+                                         * inputs quantised per row by vl2_quant_act_fp8 (which also computes the RMS rstd: no statistics launches).  Attention,
+                                         * RoPE, the KV cache and lm_head stay 16-bit.  OPTIONAL arithmetic (W8A8), never the default, never the headline */
 #define VL2_STAGE_DECODE_FP8       64   /* decode step: the five projections of every layer and lm_head read the fp8 copies of the weights
                                          * (vl2_llm_desc.layers_w8 / lm_head_w8: vl2_gemv_fp8 instead of vl2_gemv_bf16).  A different arithmetic
                                          * (weights rounded to e4m3fn): OPTIONAL, never the default, never the headline number */
@@ -126,6 +134,7 @@ typedef struct vl2_gemm_desc {
     const float* row_norm;         /* optional [M][2] (mean, rstd) from vl2_row_norm_finalize: replaces the per-tile reduction of stats_in */
     void* ws;  int64_t ws_bytes;   /* optional workspace (vl2_workspace_bytes()); NULL = no split-K / stream-K */
     int32_t variant;               /* 0 = auto */
+    const float* col_scale;        /* VL2_GEMM_FP8 only: [N] multipliers of the output columns (else NULL) */
     void* tile_ctr;                /* optional: 8 zeroed bytes (two uint32) through which the persistent GEMM hands out its tiles; the kernel
                                       re-arms them, so one block serves every GEMM of a stream (vl2_fill_zero once).  NULL: the block at the
                                       end of `ws` if that is given, else the persistent form is used on request only (static tile walk) */
@@ -211,6 +220,11 @@ int32_t vl2_gemv_bf16(const void* W, const void* x, const float* norm_w, const v
  * vl2_gemv_fp8: y[N] = scale[N] * (q[N,K] x[K]) (+ bias) (+ res), one token; norm_w / VL2_GEMV_RMS_PLAIN / VL2_GEMM_SWIGLU /
  *   VL2_GEMM_OUT_F32 as vl2_gemv_bf16 (SWIGLU: q and scale in the packed 64-row block order).  N even, K % 16 == 0, K <= 32704. */
 int32_t vl2_pack_quant_fp8(const void* w, int64_t N, int64_t K, int64_t ldw, void* q, float* scale, void* stream);
+/* fp8 ACTIVATIONS for vl2_gemm's VL2_GEMM_FP8 form (the prefill on the fp8 matrix pipe): x [M, ldx] 16-bit elements -> q [M, ldq] e4m3fn bytes with the
+ * power-of-two row scale rule of vl2_pack_quant_fp8, and row_tab [M][2] = (0, sa[m]) (norm = VL2_NORM_NONE) or (0, sa[m] * rsqrt(mean_k x^2 + eps))
+ * (VL2_NORM_RMS: the GEMM then computes RMSNorm(x) W'^T with the norm weight folded into W', HF:modeling_mistral.py:46-48) -- pass it as
+ * vl2_gemm_desc.row_norm.  K % 16 == 0.  Definition restated in oracle/fp8_oracle.py (quant_rows / gemm_w8a8). */
+int32_t vl2_quant_act_fp8(const void* x, int64_t ldx, void* q, int64_t ldq, float* row_tab, int32_t M, int32_t K, int32_t norm, float eps, void* stream);
 int32_t vl2_gemv_fp8(const void* q, const float* scale, const void* x, const float* norm_w, const void* res, const float* bias, void* y,
                      int32_t N, int32_t K, int32_t ldq, float eps, int32_t flags, void* stream);
 /* Skinny-M GEMM for batched decode: C[M <= 64, N] = A[M,K] W[N,K]^T (+bias | +res | SwiGLU | fp32 out; flags as vl2_gemm_desc.flags).
@@ -363,7 +377,7 @@ typedef struct vl2_llm_desc {
     const void* embed; const float* norm_w; const float* ones /* [D] of 1.0f */; const void* lm_head;
     const float* cos_t; const float* sin_t;                      /* fp32 [smax][64] */
     uint32_t flags;                /* VL2_STAGE_* */
-    const vl2_llm_layer_w8* layers_w8;                            /* host array [n_layers] or NULL; read only with VL2_STAGE_DECODE_FP8 */
+    const vl2_llm_layer_w8* layers_w8;                            /* host array [n_layers] or NULL; read only with VL2_STAGE_DECODE_FP8 / VL2_STAGE_PREFILL_FP8 */
     const void* lm_head_w8; const float* lm_head_scale;          /* fp8 copy of lm_head (final norm weight NOT folded: norm_w is applied) */
 } vl2_llm_desc;
 int64_t vl2_llm_workspace_bytes(const vl2_llm_desc* w, int32_t S);

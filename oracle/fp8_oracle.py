@@ -84,3 +84,33 @@ def gemv(q, scale, x, norm_w=None, eps=1e-5, res=None, bias=None, swiglu=False, 
     if res is not None:
         y = y + res.float().cpu()
     return y
+
+
+# ---- W8A8: the prefill projections on the fp8 matrix pipe (include/vl2hip.h VL2_GEMM_FP8, vl2_quant_act_fp8; csrc/k_fp8.h quant_act_fp8_kernel,
+# k_gemm.h gemm3 / gemm4 FP8).  PARITY UNPINNED against the reference for the same reason as above (BASELINE.json configs[4] names "fp8 MFMA on
+# CDNA4"; the reference holds no fp8 arithmetic to compare with): this restatement is the definition.
+def quant_act_rows(x, rms_eps=None):
+    """x [M, K] (16-bit activations) -> (q uint8 [M, K], row table fp32 [M, 2] = (0, sa[m]) or (0, sa[m] * rsqrt(mean_k x^2 + eps))): the weight
+    quantiser's power-of-two row scale rule applied to activation rows; the RMS factor is MistralRMSNorm's rstd of the RAW row
+    (HF:modeling_mistral.py:46-48; the norm weight is folded into the projection)."""
+    q, sa = quant_rows(x)
+    xf = x.detach().float().cpu()
+    rs = sa if rms_eps is None else sa * torch.rsqrt((xf * xf).mean(dim=1) + rms_eps)
+    return q, torch.stack([torch.zeros_like(rs), rs], dim=1)
+
+
+def gemm_w8a8(qa, tab, qw, sw, bias=None, res=None, act=None, swiglu=False):
+    """C = epilogue(tab[m, 1] * sw[n] * sum_k qa[m, k] qw[n, k]) in fp32 (the 16-bit rounding of the stored result is the caller's): products of
+    e4m3fn values are exact in fp32, the sum is fp32.  swiglu: columns in blocks of 64 = 32 gate then 32 up (weights.pack_gate_up)."""
+    y = (qa.view(torch.float8_e4m3fn).float() @ qw.view(torch.float8_e4m3fn).float().T) * tab[:, 1:2].float().cpu() * sw.float().cpu()[None, :]
+    if swiglu:
+        M = y.shape[0]
+        y = y.view(M, -1, 2, 32)
+        y = (torch.nn.functional.silu(y[:, :, 0]) * y[:, :, 1]).reshape(M, -1)
+    if bias is not None:
+        y = y + bias.float().cpu()[None, :]
+    if act == "silu":
+        y = torch.nn.functional.silu(y)
+    if res is not None:
+        y = y + res.float().cpu()
+    return y

@@ -35,8 +35,8 @@ static bool g_gemm6_dynamic = false;       // gemm6: tiles handed out through th
 template <int ACT, bool SW, bool F32, bool G>
 static void run_gemm(GemmArgs a) {
     if constexpr (!SW) {                                        // fill-the-round 224 x 128 / 192 x 128 tiles (k_gemm7.h), plain and gathered
-        if (g_gemm_variant == 224 || g_gemm_variant == 192 || g_gemm_variant == 225 || g_gemm_variant == 193) {   // 225 / 193: LDS-DMA issued from the load phases
-            const bool weave = !(g_gemm_variant & 1);
+        if (g_gemm_variant == 224 || g_gemm_variant == 192 || g_gemm_variant == 225 || g_gemm_variant == 193) {   // 225 / 193: LDS-DMA issue woven into the MFMA phases
+            const bool weave = (g_gemm_variant & 1) != 0;
             const int bm = g_gemm_variant & ~1;
             a.tiles_m = (a.M + bm - 1) / bm; a.tiles_n = a.N / 128;
             const dim3 grid(a.tiles_m * a.tiles_n);
@@ -54,7 +54,7 @@ static void run_gemm(GemmArgs a) {
             emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(512), [=] { gemm3_bf16_kernel<ACT, SW, F32>(a); });
             return;
         }
-        if (g_gemm_variant == 5 && a.N % 256 == 0) {            // the same with the LDS-DMA issue woven into the MFMA phases (the library's default form)
+        if (g_gemm_variant == 5 && a.N % 256 == 0) {            // the same with the LDS-DMA issue woven into the MFMA phases (lab form)
             a.tiles_m = (a.M + 127) / 128; a.tiles_n = a.N / 256;
             if constexpr (!F32) {
                 if (a.res == nullptr) { emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(512), [=] { gemm3_bf16_kernel<ACT, SW, false, true, -1, true>(a); }); return; }
@@ -173,6 +173,38 @@ extern "C" int32_t vl2_gemm(const vl2_gemm_desc* d, void*) {
     a.tile_ctr = (unsigned*)d->tile_ctr;
     g_gemm_variant = (d->flags & VL2_GEMM_SPLITK) ? 16 : d->variant;     // 16 = the emulator's split-K form of the 128x128 kernel
     const bool sw = d->flags & 1, f32 = d->flags & 2, g = a.a_idx != nullptr;
+    if (d->flags & VL2_GEMM_FP8) {          // W8A8 on the (emulated) fp8 matrix pipe: rows of K bytes seen as K / 2 16-bit elements (vl2_abi.hip)
+        if (N % 256 || K % 128 || !d->row_norm || !d->col_scale || g) return -2;
+        a.K = K / 2; a.lda = d->lda / 2; a.ldw = d->ldw / 2; a.norm = 1; a.row_norm = d->row_norm; a.col_scale = d->col_scale;
+        a.stats_in_np = a.K / 64; a.stats_out = nullptr; a.stats_in = nullptr; a.w_colsum = nullptr;
+        a.tiles_n = N / 256;
+        const int v = d->variant;
+        if (v == 0 || v == 4) {
+            a.tiles_m = (M + 127) / 128;
+            const dim3 grid(a.tiles_m * a.tiles_n);
+            if (sw) emu::launch(grid, dim3(512), [=] { gemm3_fp8_kernel<0, true, false>(a); });
+            else if (f32) emu::launch(grid, dim3(512), [=] { gemm3_fp8_kernel<0, false, true>(a); });
+            else if (act == 3) emu::launch(grid, dim3(512), [=] { gemm3_fp8_kernel<3, false, false>(a); });
+            else if (act == 0) emu::launch(grid, dim3(512), [=] { gemm3_fp8_kernel<0, false, false>(a); });
+            else return -3;
+        } else if (v == 8) {
+            a.tiles_m = (M + 255) / 256;
+            const dim3 grid(a.tiles_m * a.tiles_n);
+            if (sw) emu::launch(grid, dim3(512), [=] { gemm4_fp8_kernel<0, true, false, 256>(a); });
+            else if (f32) emu::launch(grid, dim3(512), [=] { gemm4_fp8_kernel<0, false, true, 256>(a); });
+            else if (act == 3) emu::launch(grid, dim3(512), [=] { gemm4_fp8_kernel<3, false, false, 256>(a); });
+            else if (act == 0) emu::launch(grid, dim3(512), [=] { gemm4_fp8_kernel<0, false, false, 256>(a); });
+            else return -3;
+        } else if (v == 12 && !f32) {
+            a.tiles_m = (M + 191) / 192;
+            const dim3 grid(a.tiles_m * a.tiles_n);
+            if (sw) emu::launch(grid, dim3(512), [=] { gemm4_fp8_kernel<0, true, false, 192>(a); });
+            else if (act == 3) emu::launch(grid, dim3(512), [=] { gemm4_fp8_kernel<3, false, false, 192>(a); });
+            else if (act == 0) emu::launch(grid, dim3(512), [=] { gemm4_fp8_kernel<0, false, false, 192>(a); });
+            else return -3;
+        } else return -1;
+        return 0;
+    }
     if (d->norm && ((!d->stats_in && !d->row_norm) || (d->norm == 2 && !d->w_colsum))) return -1;
     if (d->out_grp > 0 || d->res_row_mod > 0) {
         emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(256), [=] { gemm_bf16_kernel<0, false, false, false, true>(a); });
@@ -375,6 +407,11 @@ extern "C" int32_t vl2_gemv_bf16(const void* W, const void* x, const float* norm
 extern "C" int32_t vl2_pack_quant_fp8(const void* w, int64_t N, int64_t K, int64_t ldw, void* q, float* scale, void*) {
     if (K % 16 || ldw % 8 || ldw < K) return -2;
     emu::launch(dim3((unsigned)N), dim3(256), [=] { quant_fp8_rows_kernel((const bf16_t*)w, (uint8_t*)q, scale, (int)K, (long)ldw); });
+    return 0;
+}
+extern "C" int32_t vl2_quant_act_fp8(const void* x, int64_t ldx, void* q, int64_t ldq, float* row_tab, int32_t M, int32_t K, int32_t norm, float eps, void*) {
+    if (K % 16 || ldx % 8 || ldq % 16 || (norm != 0 && norm != 1)) return -2;
+    emu::launch(dim3((unsigned)M), dim3(256), [=] { quant_act_fp8_kernel((const bf16_t*)x, (long)ldx, (uint8_t*)q, (long)ldq, row_tab, K, norm == 1 ? 1 : 0, eps); });
     return 0;
 }
 extern "C" int32_t vl2_gemv_fp8(const void* q, const float* scale, const void* x, const float* norm_w, const void* res, const float* bias, void* y,

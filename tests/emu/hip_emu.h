@@ -197,6 +197,27 @@ inline f32x4 mfma_16x16x32_bf16(s16x8 a, s16x8 b, f32x4 c) {
     wave_sync();
     return c;
 }
+// v_mfma_f32_32x32x64_f8f6f4 with e4m3fn operands (the scaled builtin with zero scale operands = the unscaled instruction): a lane holds 32
+// bytes of A row (l & 31) and 32 bytes of B column (l & 31) for k half (l >> 5); D[i][j] = sum over both halves and the 32 bytes.  Which k a
+// byte is does not matter to the sum (the same index function for A and B); the products are exact in fp32, the sum order is this loop's.
+float emu_mx_e4m3(unsigned b);
+typedef int emu_i32x8 __attribute__((ext_vector_type(8)));
+inline f32x16 mfma_32x32x64_f8(emu_i32x8 a, emu_i32x8 b, f32x16 c) {
+    Wave& w = waves[cur->wave];
+    memcpy(w.scratch[cur->lane], &a, 32); memcpy(w.scratch[cur->lane] + 32, &b, 32);
+    wave_sync();
+    int l = cur->lane;
+    for (int r = 0; r < 16; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = l & 31;
+        float acc = c[r];
+        for (int h = 0; h < 2; ++h)
+            for (int k = 0; k < 32; ++k)
+                acc = fmaf(emu_mx_e4m3(w.scratch[row + 32 * h][k]), emu_mx_e4m3(w.scratch[col + 32 * h][32 + k]), acc);
+        c[r] = acc;
+    }
+    wave_sync();
+    return c;
+}
 // ds_read_b64_tr_b16 (gfx950 LDS transpose read), per 16-lane group: lane m supplies the 8-byte-aligned address of 4 consecutive
 // 16-bit elements; lane i receives element (i & 3) of lanes 4e + (i >> 2), e = 0..3 (guide: with linear addresses lane l, element j
 // = lds[(l & 15) + 16 j + 64 (l >> 4)]).  A misaligned address returns the 8-aligned address's data on hardware: refused here.
@@ -299,6 +320,7 @@ inline void buffer_load_lds(Rsrc r, void* lds, unsigned size, unsigned voff, uns
 #define __builtin_amdgcn_wave_barrier() emu::wave_sync()     /* hardware: no instruction (lanes of a wave run in lockstep); here the wave's fibers meet */
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) emu::mfma_32x32x16_bf16(a, b, c)
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) emu::mfma_16x16x32_bf16(a, b, c)
+#define __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, cbsz, blgp, oa, sa, ob, sb) emu::mfma_32x32x64_f8(a, b, c)
 #define __builtin_amdgcn_global_load_lds(g, l, sz, off, aux) emu::global_load_lds((const void*)(g), (void*)(l), sz, off, aux)
 #define __builtin_amdgcn_make_buffer_rsrc(p, stride, bytes, flags) emu::Rsrc{(const char*)(p), (unsigned)(bytes)}
 #define __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, aux) emu::buffer_load_b128((r), (unsigned)(voff), (unsigned)(soff))
@@ -351,6 +373,7 @@ static inline float emu_e4m3fn_to_f32(unsigned b) {
     float v = e == 0 ? ldexpf((float)m, -9) : (e == 15 && m == 7 ? NAN : ldexpf(1.0f + (float)m * 0.125f, (int)e - 7));
     return (b & 0x80u) ? -v : v;
 }
+namespace emu { inline float emu_mx_e4m3(unsigned b) { return emu_e4m3fn_to_f32(b & 0xffu); } }
 static inline unsigned emu_f32_to_e4m3fn(float f) {
     if (f != f) return 0x7fu;
     const unsigned sgn = std::signbit(f) ? 0x80u : 0u;

@@ -254,6 +254,33 @@ def test_emu_gemm_fill_round_kernel_is_bit_identical(emu):
         ops.set_gemm_variant(0)
 
 
+def test_emu_gemm_fp8_matrix_pipe_against_the_oracle(emu):
+    """VL2_GEMM_FP8 (W8A8 on v_mfma_f32_32x32x64_f8f6f4; k_gemm.h gemm3 / gemm4 FP8, k_fp8.h quant_act_fp8_kernel) on the emulator: the
+    activation quantiser bit for bit against oracle/fp8_oracle.py, the GEMM (all three tile shapes; plain, bias + SiLU, residual, SwiGLU,
+    fp32 output) against gemm_w8a8 to fp32 summation order."""
+    from oracle import fp8_oracle as F8
+    from videollama2_amd import ops
+    M, N, K = 200, 256, 256
+    x, w, bias, res = bf(M, K), bf(N, K, scale=K ** -0.5), torch.randn(N), bf(M, N)
+    x[3] = 0
+    x[5, 7] = 300.0                                                # an outlier row: the other elements land in the subnormal codes
+    qw, sw = ops.quant_fp8(w)
+    for eps in (None, 1e-5):
+        qa, tab = ops.quant_act_fp8(x, rms_eps=eps)
+        qo, to = F8.quant_act_rows(x, rms_eps=eps)
+        assert torch.equal(qa, qo) and rel(tab, to) < 1e-6 and torch.equal(tab[:, 0], to[:, 0])
+        try:
+            for v in (4, 8, 12):
+                ops.set_gemm_variant(v)
+                if v != 12:
+                    assert rel(ops.gemm_fp8(qa, tab, qw, sw, out_f32=True), F8.gemm_w8a8(qa, tab, qw, sw)) < 1e-5, v
+                assert rel(ops.gemm_fp8(qa, tab, qw, sw, bias=bias, act=ops.ACT_SILU), F8.gemm_w8a8(qa, tab, qw, sw, bias=bias, act="silu")) < TOL_BF16_OUT
+                assert rel(ops.gemm_fp8(qa, tab, qw, sw, res=res), F8.gemm_w8a8(qa, tab, qw, sw, res=res)) < TOL_BF16_OUT
+                assert rel(ops.gemm_fp8(qa, tab, qw, sw, swiglu=True), F8.gemm_w8a8(qa, tab, qw, sw, swiglu=True)) < TOL_BF16_OUT
+        finally:
+            ops.set_gemm_variant(0)
+
+
 def test_emu_wide_rmsnorm_and_se_linear(emu):
     """The workgroup-per-row RMSNorm (C > 2048, several rows) and the K-split SE linear against torch."""
     from videollama2_amd import ops
@@ -772,6 +799,33 @@ def test_emu_stage_level_entry_points_equal_the_per_operator_path(emu, golden_sm
         d, _, ws = m.decoder._stage_desc()
         with pytest.raises(Vl2HipError, match="exceeds the KV cache"):
             ops.llm_prefill(d, torch.zeros(65, cfg["llm"]["hidden_size"], dtype=torch.bfloat16), m.decoder.logits)
+    finally:
+        ops.STAGE_ABI = True
+
+
+def test_emu_fp8_prefill_stage_equals_the_per_operator_path(emu, golden_small):
+    """VL2_STAGE_PREFILL_FP8 (vl2_llm_prefill with the projections on the fp8 matrix pipe, W8A8): the C++ layer loop and decoder.prefill's
+    per-operator loop issue the same kernels -> the same logits bit for bit; against the 16-bit prefill the difference is the format's
+    (an OPTIONAL arithmetic): only bounded here."""
+    from videollama2_amd import ops
+    from videollama2_amd.decoder import HipMistralDecoder
+    g = golden_small
+    cfg = g["cfg"]
+    keep = lambda n: n.startswith(("model.layers.", "model.norm", "model.embed_tokens", "lm_head"))
+    dec = HipMistralDecoder(cfg, O.seeded_state_dict(cfg, g["seed"], only=keep), "cpu", max_seq_len=64)
+    l16 = dec.prefill(g["inputs_embeds"]).clone()
+    dec.enable_fp8_prefill()
+    try:
+        outs = {}
+        for stage in (True, False):
+            ops.STAGE_ABI = stage
+            outs[stage] = dec.prefill(g["inputs_embeds"]).clone()
+        assert torch.equal(outs[True], outs[False])
+        e = rel(outs[True], l16)
+        print(f"[emu] small config: fp8 (W8A8) prefill logits vs 16-bit prefill rel-L2 {e:.3e}")
+        assert 1e-4 < e < 0.3
+        dec.enable_fp8_prefill(False)
+        assert torch.equal(dec.prefill(g["inputs_embeds"]), l16)
     finally:
         ops.STAGE_ABI = True
 

@@ -168,3 +168,82 @@ def test_fp8_kernels_in_the_fp16_build():
         assert rel(ysw.float().cpu(), F8.gemv(qo, so, x, eps=1e-5, rms=True, swiglu=True, elem=torch.float16)) < 2e-3
     finally:
         _lib.set_elem("bf16")
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# W8A8 on the fp8 matrix pipe (v_mfma_f32_32x32x64_f8f6f4): VL2_GEMM_FP8 / vl2_quant_act_fp8 / VL2_STAGE_PREFILL_FP8 -- the MFMA half of
+# BASELINE.json configs[4] ("fp8 MFMA on CDNA4").  Definition: oracle/fp8_oracle.py quant_act_rows / gemm_w8a8.
+def test_activation_quantiser_on_device_matches_the_oracle(ops):
+    """Token rows through vl2_quant_act_fp8: the bytes bit for bit (the weight quantiser's rule on activation rows: outliers, a zero row, tiny
+    and huge rows), the row table (0, scale [x RMS rstd]) to fp32 rounding of the sum of squares."""
+    x = bf(333, 4096, seed=7)
+    x[0] = 0
+    x[1, 5] = 200.0
+    x[2] *= 1e-20
+    x[3] *= 1e20
+    for K in (4096, 14336):
+        xx = x if K == 4096 else bf(97, K, seed=8)
+        for eps in (None, 1e-5):
+            q, tab = ops.quant_act_fp8(xx.to(DEV), rms_eps=eps)
+            qo, to = F8.quant_act_rows(xx, rms_eps=eps)
+            assert torch.equal(q.cpu(), qo), f"{int((q.cpu() != qo).sum())} codes differ (K={K})"
+            assert torch.equal(tab[:, 0].cpu(), to[:, 0]) and rel(tab[:, 1].cpu(), to[:, 1]) < 1e-6
+
+
+@pytest.mark.parametrize("name,M,N,K,kw", [("qkv", 1621, 6144, 4096, dict(rms=True, bias=True)), ("o", 1621, 4096, 4096, dict(res=True)),
+                                           ("gate_up", 1621, 28672, 4096, dict(rms=True, swiglu=True)), ("down", 1621, 4096, 14336, dict(res=True)),
+                                           ("down_ragged", 333, 4096, 14336, dict(res=True, variants=(4, 8, 12))),
+                                           ("f32", 700, 1024, 2048, dict(f32=True, variants=(4, 8)))])
+def test_gemm_fp8_at_decoder_shapes(ops, name, M, N, K, kw):
+    """The four prefill projections at S = 1621 (and a ragged M on every tile shape) on the fp8 matrix pipe against gemm_w8a8: the same e4m3fn
+    operands, exact products, fp32 sums in another order; a 16-bit output adds its one rounding."""
+    x, w = bf(M, K, seed=1), bf(N, K, scale=K ** -0.5, seed=2)
+    qw, sw = ops.quant_fp8(w.to(DEV))
+    qa, tab = ops.quant_act_fp8(x.to(DEV), rms_eps=1e-5 if kw.get("rms") else None)
+    n_out = N // 2 if kw.get("swiglu") else N
+    bias = torch.randn(N) if kw.get("bias") else None
+    res = bf(M, n_out, seed=4) if kw.get("res") else None
+    ref = F8.gemm_w8a8(qa.cpu(), tab.cpu(), qw.cpu(), sw.cpu(), bias=bias, res=res, swiglu=bool(kw.get("swiglu")))
+    try:
+        for v in kw.get("variants", (0,)):
+            ops.set_gemm_variant(v)
+            y = ops.gemm_fp8(qa, tab, qw, sw, bias=None if bias is None else bias.to(DEV), res=None if res is None else res.to(DEV),
+                             swiglu=bool(kw.get("swiglu")), out_f32=bool(kw.get("f32")))
+            e = rel(y.float().cpu(), ref)
+            assert e < (1e-5 if kw.get("f32") else 3e-3), (name, v, e)
+    finally:
+        ops.set_gemm_variant(0)
+
+
+def test_fp8_prefill_full_width_stage_equals_operators_and_tracks_the_16bit_prefill(ops):
+    """Mistral-7B widths, 2 layers, S = 300: the prefill with VL2_STAGE_PREFILL_FP8 (one C call) == decoder.prefill's operator loop bit for
+    bit; against the 16-bit prefill the logits differ by the FORMAT (both operands rounded to e4m3fn): reported in
+    profiles/r05_fp8_prefill_parity.json, bounded here, and switching the option off restores the 16-bit bits."""
+    from videollama2_amd import ops as O_
+    from videollama2_amd.decoder import HipMistralDecoder
+    cfg = O.config_videollama2_7b(16)
+    cfg["llm"]["num_hidden_layers"] = 2
+    keep = lambda n: n.startswith(("model.layers.", "model.norm", "model.embed_tokens", "lm_head"))
+    sd = O.seeded_state_dict(cfg, 5, only=keep)
+    x = (torch.randn(300, 4096, generator=torch.Generator().manual_seed(2)).bfloat16().float() * 0.5).to(DEV)
+    dec = HipMistralDecoder(cfg, sd, DEV, max_seq_len=512)
+    l16 = dec.prefill(x).clone()
+    dec.enable_fp8_prefill()
+    try:
+        outs = {}
+        for stage in (True, False):
+            O_.STAGE_ABI = stage
+            outs[stage] = dec.prefill(x).clone()
+    finally:
+        O_.STAGE_ABI = True
+    assert torch.equal(outs[True], outs[False])
+    e = rel(outs[True].cpu(), l16.cpu())
+    top1 = bool(int(outs[True].argmax()) == int(l16.argmax()))
+    print(f"[fp8] full-width 2-layer prefill, W8A8 vs 16-bit: last-position logits rel-L2 {e:.3e}, top-1 equal {top1}")
+    assert 1e-4 < e < 0.2
+    dec.enable_fp8_prefill(False)
+    assert torch.equal(dec.prefill(x), l16)
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "r05_fp8_prefill_parity.json")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    json.dump(dict(config="Mistral-7B widths, 2 layers, S=300: prefill projections W8A8 on v_mfma_f32_32x32x64_f8f6f4 vs the 16-bit prefill",
+                   stage_equals_operator_loop=True, logits_rel_l2_vs_16bit=e, top1_equal=top1), open(out, "w"), indent=1)

@@ -17,7 +17,7 @@ class GemmDesc(ctypes.Structure):
                 ("a_idx", _vp), ("seg_k", _i32),
                 ("out_grp", _i32), ("out_grp_pad", _i32), ("out_row_off", _i32), ("res_row_mod", _i32), ("res_row_off", _i32),
                 ("stats_out", _vp), ("stats_in", _vp), ("norm", _i32), ("norm_eps", _f32), ("w_colsum", _vp), ("row_norm", _vp),
-                ("ws", _vp), ("ws_bytes", _i64), ("variant", _i32), ("tile_ctr", _vp)]
+                ("ws", _vp), ("ws_bytes", _i64), ("variant", _i32), ("col_scale", _vp), ("tile_ctr", _vp)]
 
 
 class VitLayer(ctypes.Structure):
@@ -80,6 +80,7 @@ SIGNATURES = {
     "vl2_pack_pad_rows": [_vp, _vp, _i64, _i64, _i64, _vp],
     "vl2_pack_cvt_f32": [_vp, _vp, _i64, _vp],
     "vl2_pack_quant_fp8": [_vp, _i64, _i64, _i64, _vp, _vp, _vp],
+    "vl2_quant_act_fp8": [_vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _f32, _vp],
     "vl2_gemv_fp8": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _i32, _vp],
     "vl2_layernorm": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp],
     "vl2_rmsnorm": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp],
@@ -169,7 +170,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = _i32
         fn.argtypes = args
-    if lib.vl2_version() != 4:
+    if lib.vl2_version() != 5:
         raise Vl2HipError("libvl2hip.so ABI version mismatch")
     lib.vl2_elem_name.restype = ctypes.c_char_p
     lib.vl2_elem_name.argtypes = []

@@ -50,6 +50,21 @@ __device__ __forceinline__ float e_hi(uint32_t u) { return __builtin_bit_cast(fl
 #define VL2_ELEM_NAME "bf16"
 #endif
 
+// ---- fp8 (OCP e4m3fn) operands on the matrix pipe: v_mfma_f32_32x32x64_f8f6f4, 64 k per instruction = twice the bf16 rate per byte of
+// operand (MI355X_MICROARCH.md: 4.6 PF measured on the MX form).  The builtin is the block-scaled one with zero scale operands, which the
+// backend selects as the unscaled instruction (as composable_kernel's intrin_mfma_f32_32x32x64f8f6f4 does).  A lane supplies 32 bytes per
+// operand = two 16-B fragments as the 16-bit kernels read them (k chunks c and c + 2 of a 64-byte row slab for lane half c): the k index
+// function of the instruction is the same for A and B, and the dot product does not care which k a byte is, so the 16-bit kernels' LDS
+// image and fragment reads carry fp8 rows unchanged -- a row of 2 K' bytes is a row of K' 16-bit "elements".
+typedef int vl2_i32x8 __attribute__((ext_vector_type(8)));
+typedef int vl2_i32x4 __attribute__((ext_vector_type(4)));
+#ifndef VL2_MFMA32_F8
+#define VL2_MFMA32_F8(a_lo, a_hi, b_lo, b_hi, c)                                                                                                  \
+    __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(                                                                                              \
+        __builtin_shufflevector(__builtin_bit_cast(vl2_i32x4, a_lo), __builtin_bit_cast(vl2_i32x4, a_hi), 0, 1, 2, 3, 4, 5, 6, 7),                \
+        __builtin_shufflevector(__builtin_bit_cast(vl2_i32x4, b_lo), __builtin_bit_cast(vl2_i32x4, b_hi), 0, 1, 2, 3, 4, 5, 6, 7), c, 0, 0, 0, 0, 0, 0)
+#endif
+
 __device__ __forceinline__ void unpack8(const u32x4& v, float* f) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {

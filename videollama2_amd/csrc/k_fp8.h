@@ -59,6 +59,54 @@ __global__ __launch_bounds__(256) void quant_fp8_rows_kernel(const bf16_t* __res
     }
 }
 
+// ---- fp8 ACTIVATIONS for the prefill GEMMs on the fp8 matrix pipe (VL2_GEMM_FP8: v_mfma_f32_32x32x64_f8f6f4, k_gemm.h gemm3 / gemm4 FP8):
+// row m of a 16-bit activation -> e4m3fn bytes with the same power-of-two row scale rule as the weights (sa[m] = 2^e, e the smallest integer
+// with max|x[m][:]| <= 448 * 2^e; exact to apply and to remove), and the row's entry of the GEMM's row table (GemmArgs.row_norm, [M][2]):
+// (0, sa[m]) or, for an RMS-norm-carrying GEMM (HF:modeling_mistral.py:46-48 with the weight folded into W), (0, sa[m] * rsqrt(mean x^2 + eps))
+// -- the quantiser reads the whole row anyway, so the norm needs no statistics from the producer.  grid = M rows, block 256, K % 16 == 0.
+__global__ __launch_bounds__(256) void quant_act_fp8_kernel(const bf16_t* __restrict__ x, long ldx, uint8_t* __restrict__ q, long ldq,
+                                                            float* __restrict__ rowtab, int K, int rms, float eps) {
+#pragma clang fp reassociate(off)
+    __shared__ float red[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bf16_t* row = x + (size_t)blockIdx.x * ldx;
+    float amax = 0.f, ss = 0.f;
+    for (int k = tid * 8; k < K; k += 2048) {
+        float v[8];
+        unpack8(*(const u32x4*)(row + k), v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { amax = fmaxf(amax, fabsf(v[j])); ss = __builtin_fmaf(v[j], v[j], ss); }
+    }
+    amax = wave_max(amax);
+    ss = wave_sum(ss);
+    if (lane == 0) { red[wave] = amax; red[4 + wave] = ss; }
+    __syncthreads();
+    amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    ss = (red[4] + red[5]) + (red[6] + red[7]);
+    const unsigned ab = __builtin_bit_cast(unsigned, amax);             // the scale exponent: quant_fp8_rows_kernel's bit arithmetic
+    const int E = (int)((ab >> 23) & 0xffu);
+    int e = E == 0 ? 0 : (E - 127) - 8 + ((ab & 0x7fffffu) > 0x600000u ? 1 : 0);
+    e = e < -100 ? -100 : (e > 100 ? 100 : e);
+    const float sc = __builtin_bit_cast(float, (unsigned)(127 + e) << 23), inv = __builtin_bit_cast(float, (unsigned)(127 - e) << 23);
+    if (tid == 0) {
+        rowtab[2 * (size_t)blockIdx.x] = 0.f;
+        rowtab[2 * (size_t)blockIdx.x + 1] = rms ? sc * rsqrtf(ss / (float)K + eps) : sc;
+    }
+    uint8_t* qrow = q + (size_t)blockIdx.x * ldq;
+    for (int k = tid * 8; k < K; k += 2048) {
+        float v[8];
+        unpack8(*(const u32x4*)(row + k), v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = v[j] * inv;
+        int lo = 0, hi = 0;
+        lo = VL2_CVT_PK_FP8_F32(v[0], v[1], lo, false);
+        lo = VL2_CVT_PK_FP8_F32(v[2], v[3], lo, true);
+        hi = VL2_CVT_PK_FP8_F32(v[4], v[5], hi, false);
+        hi = VL2_CVT_PK_FP8_F32(v[6], v[7], hi, true);
+        *(u32x2*)(qrow + k) = u32x2{(unsigned)lo, (unsigned)hi};
+    }
+}
+
 struct Gemv8Args {
     const uint8_t* W;       // [N, ldw] e4m3fn bytes (SWIGLU: packed blocks of 64 rows = 32 gate rows then 32 up rows, like the 16-bit layout)
     const float* scale;     // [N] one per (packed) row

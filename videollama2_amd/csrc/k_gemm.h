@@ -48,6 +48,7 @@ struct GemmArgs {
     float norm_eps;
     const float* w_colsum;   // LayerNorm: s[n] = sum_k W[n][k] (fp32, of the bf16 weights as packed) [N]
     const float* row_norm;   // [rows][2] = (mean, rstd) of the A rows, already reduced (row_norm_finalize_kernel); overrides stats_in
+    const float* col_scale;  // fp8 form: [N] one multiplier per output column (the weight rows' scales), applied behind the row scale; else null
     unsigned* tile_ctr;      // persistent form (k_gemm6.h): two zeroed words {tiles handed out, workgroups finished}, re-armed by the kernel; null = static walk
     int tile_first_dyn;      // persistent form: 1 = the FIRST tile of a workgroup is drawn from the counter too (a workgroup that starts late finds no work)
 };
@@ -153,6 +154,12 @@ __device__ __forceinline__ void gemm_store_patch(const GemmArgs& p0, const float
         f32x4 bias0 = {0.f, 0.f, 0.f, 0.f}, bias1 = bias0, cs0 = bias0, cs1 = bias0;
         if (!SWIGLU && p.bias) { bias0 = *(const f32x4*)(p.bias + nfull); bias1 = *(const f32x4*)(p.bias + nfull + 4); }
         if (!SWIGLU && p.norm == 2) { cs0 = *(const f32x4*)(p.w_colsum + nfull); cs1 = *(const f32x4*)(p.w_colsum + nfull + 4); }
+        // fp8 form only (null otherwise: the 16-bit paths keep their bits): the weight rows' scales of this lane's 8 columns (SwiGLU: gate | up)
+        f32x4 sc0 = {1.f, 1.f, 1.f, 1.f}, sc1 = sc0, sc2 = sc0, sc3 = sc0;
+        if (p.col_scale) {
+            sc0 = *(const f32x4*)(p.col_scale + nfull); sc1 = *(const f32x4*)(p.col_scale + nfull + 4);
+            if (SWIGLU) { sc2 = *(const f32x4*)(p.col_scale + nfull + 32); sc3 = *(const f32x4*)(p.col_scale + nfull + 36); }
+        }
         // Round 3 (profiles/r03_experiments.md): the epilogue was 7-12 us of every tile (22-36 % of a K = 1024 GEMM), a chain of
         // LDS write -> read -> RESIDUAL LOAD (an L2 / HBM round trip under `if (live)`, so never hoisted) -> store per row pass.
         // The residual rows of all passes are now requested up front, unconditionally (rows past M clamp to M - 1 and are dropped
@@ -185,6 +192,7 @@ __device__ __forceinline__ void gemm_store_patch(const GemmArgs& p0, const float
                     for (int j = 0; j < 8; ++j) {
                         float g = ep[row * 68 + cg + j], u = ep[row * 68 + 32 + cg + j];
                         if (p.norm) { g *= rs; u *= rs; }                     // RMSNorm only (no mean / shift term)
+                        if (p.col_scale) { g *= (j < 4 ? sc0[j & 3] : sc1[j & 3]); u *= (j < 4 ? sc2[j & 3] : sc3[j & 3]); }
                         v[j] = silu_f(g) * u;
                     }
                 } else {
@@ -197,6 +205,10 @@ __device__ __forceinline__ void gemm_store_patch(const GemmArgs& p0, const float
                     } else if (p.norm == 1) {
 #pragma unroll
                         for (int j = 0; j < 8; ++j) v[j] *= rs;
+                    }
+                    if (p.col_scale) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { v[j] *= sc0[j]; v[4 + j] *= sc1[j]; }
                     }
                     if (p.bias) {
 #pragma unroll
@@ -847,9 +859,13 @@ __device__ __forceinline__ int gemm4_lds_off(int row, int chunk) {
 //   16 frames: 37 x 4 = 148 tiles of 256 rows on 256 CUs, 49 x 4 = 196 tiles of 192 rows): group g owns rows [96g, +96), its four
 //   waves side by side (wave tile 96 x 64 = 3 x 2 accumulators, 5 fragment reads per 6 MFMAs), the A slab is 12 LDS-DMA pieces
 //   (waves 0, 1 of a group issue two, waves 2, 3 one: counted vmcnt per wave).  Same slabs, same k order -> same bits per element.
-template <int ACT, bool SWIGLU, bool OUT_F32, bool TR = false, int EF = -1, int BM = 256>
+// FP8: A and W rows hold e4m3fn bytes (a slab = 64 k per row in the same 64 bytes); one v_mfma_f32_32x32x64_f8f6f4 per accumulator block
+//   and slab from the two fragments the 16-bit form feeds to two MFMAs (dev_common.h VL2_MFMA32_F8); epilogue = gemm_store_patch with the
+//   row / column scales (GemmArgs.row_norm, col_scale).
+template <int ACT, bool SWIGLU, bool OUT_F32, bool TR = false, int EF = -1, int BM = 256, bool FP8 = false>
 __device__ __forceinline__ void gemm4_body(const GemmArgs& p, int bid, int nwg) {
     static_assert(!(TR && OUT_F32), "gemm_store_tr writes bf16");
+    static_assert(!(FP8 && TR), "the fp8 form stores through gemm_store_patch");
     static_assert(BM == 256 || BM == 192, "gemm4: 256- or 192-row tiles");
     constexpr int GR = BM / 2;                                     // rows of a wave group
     constexpr int MI = BM == 256 ? 2 : 3, NJ = BM == 256 ? 4 : 2;  // 32 x 32 accumulator blocks of a wave
@@ -965,14 +981,21 @@ __device__ __forceinline__ void gemm4_body(const GemmArgs& p, int bid, int nwg) 
         VL2_WAIT_LGKMCNT0();
         VL2_PHASE_BARRIER();
         // ---------------- MFMA(t): matrix work only
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        if constexpr (FP8) {
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < NJ; ++j)
-                    acc[i][j] = TR ? VL2_MFMA32(fb[ks][j], fa[ks][i], acc[i][j])
-                                   : VL2_MFMA32(fa[ks][i], fb[ks][j], acc[i][j]);
+                for (int j = 0; j < NJ; ++j) acc[i][j] = VL2_MFMA32_F8(fa[0][i], fa[1][i], fb[0][j], fb[1][j], acc[i][j]);
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+                        acc[i][j] = TR ? VL2_MFMA32(fb[ks][j], fa[ks][i], acc[i][j])
+                                       : VL2_MFMA32(fa[ks][i], fb[ks][j], acc[i][j]);
+        }
         VL2_PHASE_BARRIER();
     }
     if (grp == 0) VL2_PHASE_BARRIER();
@@ -1006,6 +1029,10 @@ template <int ACT, bool SWIGLU, bool OUT_F32, bool TR = false, int EF = -1, int 
 __global__ __launch_bounds__(512, 2) void gemm4_bf16_kernel(GemmArgs p) {
     gemm4_body<ACT, SWIGLU, OUT_F32, TR, EF, BM>(p, blockIdx.x, gridDim.x);
 }
+template <int ACT, bool SWIGLU, bool OUT_F32, int BM>
+__global__ __launch_bounds__(512, 2) void gemm4_fp8_kernel(GemmArgs p) {
+    gemm4_body<ACT, SWIGLU, OUT_F32, false, -1, BM, true>(p, blockIdx.x, gridDim.x);
+}
 
 // ------------------------------------------------------------------------------------------------------------------
 // gemm3: 128 (M) x 256 (N) ping-pong kernel (see gemm4) for GEMMs whose M granularity matters (the M = 1621 prefill):
@@ -1019,9 +1046,11 @@ __global__ __launch_bounds__(512, 2) void gemm4_bf16_kernel(GemmArgs p) {
 
 // WEAVE (lab, variant 5): the six LDS-DMA pieces of K-tile t + 2 are issued from the wave's own MFMA(t) phase, one behind every second
 // MFMA, instead of from its LOAD(t) phase (see k_gemm7.h gemm7_loop); they are retired by vmcnt(0) at the end of the next LOAD phase.
-template <int ACT, bool SWIGLU, bool OUT_F32, bool TR = false, int EF = -1, bool WEAVE = false>
+// FP8: see gemm4_body -- two v_mfma_f32_32x32x64_f8f6f4 per accumulator block and K-tile (128 k per row in the tile's 128 bytes).
+template <int ACT, bool SWIGLU, bool OUT_F32, bool TR = false, int EF = -1, bool WEAVE = false, bool FP8 = false>
 __device__ __forceinline__ void gemm3_body(const GemmArgs& p, int bid, int nwg) {
     static_assert(!(TR && OUT_F32), "gemm_store_tr writes bf16");
+    static_assert(!(FP8 && (TR || WEAVE)), "the fp8 form: LDS epilogue, load-phase DMA issue");
     extern __shared__ __attribute__((aligned(16))) unsigned char vl2_smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1111,6 +1140,15 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs& p, int bid, int nwg) 
         VL2_WAIT_LGKMCNT0();
         VL2_PHASE_BARRIER();
         // ---------------- MFMA(t)
+        if constexpr (FP8) {
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = VL2_MFMA32_F8(fa[2 * k2][i], fa[2 * k2 + 1][i], fb[2 * k2][j], fb[2 * k2 + 1][j], acc[i][j]);
+        } else
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -1157,6 +1195,10 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs& p, int bid, int nwg) 
 template <int ACT, bool SWIGLU, bool OUT_F32, bool TR = false, int EF = -1, bool WEAVE = false>
 __global__ __launch_bounds__(512, 2) void gemm3_bf16_kernel(GemmArgs p) {
     gemm3_body<ACT, SWIGLU, OUT_F32, TR, EF, WEAVE>(p, blockIdx.x, gridDim.x);
+}
+template <int ACT, bool SWIGLU, bool OUT_F32>
+__global__ __launch_bounds__(512, 2) void gemm3_fp8_kernel(GemmArgs p) {
+    gemm3_body<ACT, SWIGLU, OUT_F32, false, -1, false, true>(p, blockIdx.x, gridDim.x);
 }
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -92,7 +92,7 @@ struct GemmCtl {
     bool persist = false;          // VL2_GEMM_PERSISTENT: the automatic choice may take the persistent form
     bool no_mix = false;           // VL2_GEMM_NO_MIX
     bool no_fill = false;          // VL2_GEMM_NO_FILL
-    bool no_weave = false;         // VL2_GEMM_NO_WEAVE
+    bool weave = false;            // VL2_GEMM_WEAVE
 };
 
 // ------------------------------------------------------------------------------------------------ GEMM
@@ -319,9 +319,9 @@ static void launch_gemm(const GemmArgs& a0, const GemmCtl& c, hipStream_t s) {
     if constexpr (!SW) {
         // fill-the-round tiles (k_gemm7.h): variants 224 / 192 on request (any shape with N % 128 == 0), or by the rule of choose_gemm7
         const int r1 = c.variant == 224 ? 3 : c.variant == 192 ? 2 : (c.variant == 0 && !c.no_fill) ? choose_gemm7(a0, G) : 0;
-        // (225 / 193 = 224 / 192 with the LDS-DMA issue of the load phases, as VL2_GEMM_NO_WEAVE selects it: the A/B of gemm7_loop's WEAVE)
+        // (225 / 193 = 224 / 192 with the LDS-DMA issue woven into the MFMA phases, as VL2_GEMM_WEAVE selects it: lab form, see gemm3 below)
         const int r1v = c.variant == 225 ? 3 : c.variant == 193 ? 2 : r1;
-        const bool weave7 = !(c.no_weave || c.variant == 225 || c.variant == 193);
+        const bool weave7 = c.weave || c.variant == 225 || c.variant == 193;
         if (r1v == 3) { if (weave7) launch_gemm7<ACT, F32, G, 3, true>(a0, s); else launch_gemm7<ACT, F32, G, 3, false>(a0, s); return; }
         if (r1v == 2) { if (weave7) launch_gemm7<ACT, F32, G, 2, true>(a0, s); else launch_gemm7<ACT, F32, G, 2, false>(a0, s); return; }
     }
@@ -400,9 +400,11 @@ static void launch_gemm(const GemmArgs& a0, const GemmCtl& c, hipStream_t s) {
         }
         const int kern = c.variant == 0 ? choose_gemm_kernel(a0) : c.variant;
         if ((kern == 4 || kern == 5) && a0.N % GEMM3_BN == 0) {
-            // the LDS-DMA issue woven into the MFMA phases (k_gemm.h gemm3_body WEAVE; same bits): measured -2...-5 % on the decoder's o / down
-            // projections and the STC convolutions (profiles/r05_experiments.md); VL2_GEMM_NO_WEAVE keeps the load-phase issue for A/B, variant 5 forces it
-            const bool weave = kern == 5 || !c.no_weave;
+            // WEAVE (k_gemm.h gemm3_body; same bits): the LDS-DMA issue woven into the MFMA phases.  Measured round 5 (profiles/r05_experiments.md):
+            // -2...-9 % back to back with the operands warm in the Infinity Cache, but +4...+12 % IN THE PIPELINE (down 206 -> 218 us, o 66 -> 69,
+            // Conv3d on the 192-row tiles 425 -> 476): the woven pieces have 1.5 phases of flight instead of 3, which cold weights do not forgive.
+            // So it is a lab switch: variant 5 or VL2_GEMM_WEAVE.
+            const bool weave = kern == 5 || c.weave;
             GemmArgs a = a0;
             a.tiles_m = (a.M + GEMM3_BM - 1) / GEMM3_BM;
             a.tiles_n = a.N / GEMM3_BN;
@@ -456,6 +458,34 @@ static void launch_gemm(const GemmArgs& a0, const GemmCtl& c, hipStream_t s) {
     hipLaunchKernelGGL((gemm_bf16_kernel<ACT, SW, F32, G>), dim3(a0.tiles_m * a0.tiles_n), dim3(256), GEMM_LDS_BYTES, s, a0);
 }
 
+// ---- fp8 form (VL2_GEMM_FP8): A and W are e4m3fn bytes; the kernels see a row of K bytes as K / 2 16-bit "elements" (k_gemm.h gemm3 / gemm4 FP8),
+// so `a` arrives with K, lda, ldw already halved.  128 x 256, 256 x 256 or 192 x 256 ping-pong tiles by the efficiency model of the 16-bit choice
+// (the 128 x 128 kernels are not built for fp8), LDS epilogue with the row table and the column scales.
+template <int ACT, bool SW, bool F32>
+static int32_t launch_gemm_fp8(const GemmArgs& a0, int variant, hipStream_t s) {
+    GemmArgs a = a0;
+    int kern = variant ? variant : choose_gemm_kernel(a);
+    if (kern != 4 && kern != 8 && kern != 12) kern = 4;
+    if (F32 && kern == 12) kern = 8;
+    a.tiles_n = a.N / 256;
+    if (kern == 4) {
+        a.tiles_m = (a.M + GEMM3_BM - 1) / GEMM3_BM;
+        lds_attr<gemm3_fp8_kernel<ACT, SW, F32>>(GEMM3_LDS_BYTES);
+        hipLaunchKernelGGL((gemm3_fp8_kernel<ACT, SW, F32>), dim3(a.tiles_m * a.tiles_n), dim3(512), GEMM3_LDS_BYTES, s, a);
+    } else if (kern == 8) {
+        a.tiles_m = (a.M + 255) / 256;
+        lds_attr<gemm4_fp8_kernel<ACT, SW, F32, 256>>(GEMM4_LDS_BYTES);
+        hipLaunchKernelGGL((gemm4_fp8_kernel<ACT, SW, F32, 256>), dim3(a.tiles_m * a.tiles_n), dim3(512), GEMM4_LDS_BYTES, s, a);
+    } else {
+        if constexpr (!F32) {
+            a.tiles_m = (a.M + 191) / 192;
+            lds_attr<gemm4_fp8_kernel<ACT, SW, false, 192>>(GEMM4_LDS_BYTES);
+            hipLaunchKernelGGL((gemm4_fp8_kernel<ACT, SW, false, 192>), dim3(a.tiles_m * a.tiles_n), dim3(512), GEMM4_LDS_BYTES, s, a);
+        }
+    }
+    return 0;
+}
+
 // one chunk (every operand within the kernels' 32-bit buffer offsets) -> the right instantiation
 static int32_t gemm_dispatch(const GemmArgs& a, const GemmCtl& c, int act, bool sw, bool f32, hipStream_t s) {
     const bool g = a.a_idx != nullptr;
@@ -492,6 +522,33 @@ extern "C" int32_t vl2_gemm(const vl2_gemm_desc* d, void* stream) {
         (d->stats_in && !ALIGNED16(d->stats_in)))
         return fail(VL2_E_SHAPE, "vl2_gemm: pointers / leading dims must be 16-byte aligned");
     const bool sw = d->flags & VL2_GEMM_SWIGLU, f32 = d->flags & VL2_GEMM_OUT_F32, g = d->a_idx != nullptr;
+    if (d->flags & VL2_GEMM_FP8) {
+        // W8A8 on the fp8 matrix pipe: K counts e4m3fn elements = bytes; row scales through `row_norm` (vl2_quant_act_fp8), column scales `col_scale`
+        if (g || d->out_grp > 0 || d->res_row_mod > 0 || d->stats_out || d->stats_in || d->w_colsum || (d->flags & (VL2_GEMM_SPLITK | VL2_GEMM_PERSISTENT)))
+            return fail(VL2_E_UNSUPP, "vl2_gemm: the fp8 form supports plain rows with bias / activation / SwiGLU / residual only");
+        if (!d->row_norm || !d->col_scale) return fail(VL2_E_BADARG, "vl2_gemm: the fp8 form needs row_norm (vl2_quant_act_fp8) and col_scale (vl2_pack_quant_fp8)");
+        if (N % 256 || K % 128 || (d->lda % 16) || (d->ldw % 16)) return fail(VL2_E_SHAPE, "vl2_gemm: the fp8 form needs N%%256==0, K%%128==0, 16-byte rows (N=%d K=%d)", N, K);
+        if (sw && (f32 || act != VL2_ACT_NONE || d->bias)) return fail(VL2_E_UNSUPP, "vl2_gemm: SWIGLU excludes bias/act/f32");
+        if (f32 && act != VL2_ACT_NONE) return fail(VL2_E_UNSUPP, "vl2_gemm: f32 output supports act none");
+        if (!ALIGNED16(d->col_scale) || (((uintptr_t)d->row_norm) & 7)) return fail(VL2_E_SHAPE, "vl2_gemm: col_scale must be 16-byte, row_norm 8-byte aligned");
+        if ((int64_t)(M - 1) * d->lda + K >= ((int64_t)1 << 31) - 65536 || (int64_t)(N - 1) * d->ldw + K >= ((int64_t)1 << 31) - 65536)
+            return fail(VL2_E_UNSUPP, "vl2_gemm: fp8 operands of 2 GiB or more are not chunked");
+        const int v8 = d->variant;
+        if (!(v8 == 0 || v8 == 4 || v8 == 8 || v8 == 12)) return fail(VL2_E_BADARG, "vl2_gemm: the fp8 form has variants 0 / 4 / 8 / 12 (got %d)", v8);
+        GemmArgs a{};
+        a.A = (const bf16_t*)d->A; a.W = (const bf16_t*)d->W; a.C = d->C; a.bias = d->bias; a.res = (const bf16_t*)d->res;
+        a.M = M; a.N = N; a.K = K / 2; a.lda = d->lda / 2; a.ldw = d->ldw / 2; a.ldc = d->ldc; a.ldres = d->ldres;
+        a.norm = VL2_NORM_RMS; a.row_norm = d->row_norm; a.col_scale = d->col_scale;
+        a.stats_out_np = N / 64; a.stats_in_np = a.K / 64; a.idx_ld = M;
+        hipStream_t s8 = ST(stream);
+        if (sw) launch_gemm_fp8<ACT_NONE, true, false>(a, v8, s8);
+        else if (f32) launch_gemm_fp8<ACT_NONE, false, true>(a, v8, s8);
+        else if (act == VL2_ACT_NONE) launch_gemm_fp8<ACT_NONE, false, false>(a, v8, s8);
+        else if (act == VL2_ACT_SILU) launch_gemm_fp8<ACT_SILU, false, false>(a, v8, s8);
+        else return fail(VL2_E_UNSUPP, "vl2_gemm: the fp8 form supports act none / silu");
+        return launched("vl2_gemm (fp8)");
+    }
+    if (d->col_scale) return fail(VL2_E_BADARG, "vl2_gemm: col_scale without VL2_GEMM_FP8");
     if (g && (d->seg_k <= 0 || d->seg_k % 64 || K % d->seg_k)) return fail(VL2_E_SHAPE, "vl2_gemm: bad gather segments");
     const bool remap = d->out_grp > 0 || d->res_row_mod > 0;
     if (remap && (sw || g || f32 || act != VL2_ACT_NONE || d->norm || d->stats_out)) return fail(VL2_E_UNSUPP, "vl2_gemm: row remap supports plain bf16 output only");
@@ -512,7 +569,7 @@ extern "C" int32_t vl2_gemm(const vl2_gemm_desc* d, void* stream) {
     ctl.persist = (d->flags & VL2_GEMM_PERSISTENT) != 0;
     ctl.no_mix = (d->flags & VL2_GEMM_NO_MIX) != 0;
     ctl.no_fill = (d->flags & VL2_GEMM_NO_FILL) != 0;
-    ctl.no_weave = (d->flags & VL2_GEMM_NO_WEAVE) != 0;
+    ctl.weave = (d->flags & VL2_GEMM_WEAVE) != 0;
     GemmArgs a{};
     a.A = (const bf16_t*)d->A; a.W = (const bf16_t*)d->W; a.C = d->C; a.bias = d->bias; a.res = (const bf16_t*)d->res;
     a.a_idx = d->a_idx; a.zero_row = nullptr;
@@ -890,6 +947,15 @@ extern "C" int32_t vl2_pack_quant_fp8(const void* w, int64_t N, int64_t K, int64
     if (K % 16 || ldw % 8 || ldw < K || N > 0x7fffffff || K > 0x7fffffff) return fail(VL2_E_SHAPE, "vl2_pack_quant_fp8: need K%%16==0, ldw%%8==0, ldw>=K");
     hipLaunchKernelGGL(quant_fp8_rows_kernel, dim3((unsigned)N), dim3(256), 0, ST(stream), (const bf16_t*)w, (uint8_t*)q, scale, (int)K, (long)ldw);
     return launched("vl2_pack_quant_fp8");
+}
+extern "C" int32_t vl2_quant_act_fp8(const void* x, int64_t ldx, void* q, int64_t ldq, float* row_tab, int32_t M, int32_t K, int32_t norm, float eps, void* stream) {
+    if (!x || !q || !row_tab || M <= 0 || K <= 0) return fail(VL2_E_BADARG, "vl2_quant_act_fp8: bad args");
+    if (norm != VL2_NORM_NONE && norm != VL2_NORM_RMS) return fail(VL2_E_BADARG, "vl2_quant_act_fp8: norm must be none or RMS");
+    if (K % 16 || ldx % 8 || ldq % 16 || ldx < K || ldq < K || !ALIGNED16(x) || !ALIGNED16(q) || (((uintptr_t)row_tab) & 7))
+        return fail(VL2_E_SHAPE, "vl2_quant_act_fp8: need K%%16==0, 16-byte aligned rows");
+    hipLaunchKernelGGL(quant_act_fp8_kernel, dim3((unsigned)M), dim3(256), 0, ST(stream), (const bf16_t*)x, (long)ldx, (uint8_t*)q, (long)ldq, row_tab, K,
+                       norm == VL2_NORM_RMS ? 1 : 0, eps);
+    return launched("vl2_quant_act_fp8");
 }
 extern "C" int32_t vl2_gemv_fp8(const void* q, const float* scale, const void* x, const float* norm_w, const void* res, const float* bias, void* y,
                                 int32_t N, int32_t K, int32_t ldq, float eps, int32_t flags, void* stream) {

@@ -80,6 +80,22 @@ class HipMistralDecoder(nn.Module):
         self.graph = None                                         # a captured step holds the other projections
         return self
 
+    @torch.no_grad()
+    def enable_fp8_prefill(self, on=True):
+        """OPTIONAL arithmetic (BASELINE.json configs[4] "fp8 MFMA on CDNA4"): the four projections of every layer of the
+        PREFILL run on the fp8 matrix pipe (v_mfma_f32_32x32x64_f8f6f4, twice the 16-bit MFMA rate and half the operand bytes): weights = the
+        row-scaled e4m3fn copies of enable_fp8_decode, activations quantised per token row on the fly (W8A8; csrc/k_fp8.h quant_act_fp8_kernel,
+        k_gemm.h gemm3 / gemm4 FP8).  Attention, RoPE, the KV cache and lm_head stay 16-bit.  Not the reference's arithmetic, never the
+        default: oracle/fp8_oracle.py (gemm_w8a8) defines it."""
+        if self.tp > 1:
+            raise NotImplementedError("fp8 prefill: single-rank decoders only")
+        if on and getattr(self, "w8", None) is None:
+            self.w8 = dict(layers=[{k: ops.quant_fp8(lw[k]) for k in ("wqkv", "wo", "wgu", "wd")} for lw in self.w["layers"]],
+                           lm_head=ops.quant_fp8(self.w["lm_head"]))
+            self._stage = None
+        self.prefill_fp8 = bool(on)
+        return self
+
     def _stage_desc(self):
         if self._stage is None:
             d, keep = ops.llm_desc(self.w, self.cfg["llm"], self.nh, self.nkv, self.max_seq_len, self.eps, self.kcache, self.vcache,
@@ -130,7 +146,7 @@ class HipMistralDecoder(nn.Module):
         x = x.to(device=self._dev, dtype=_lib.elem_dtype()).contiguous()
         if self._use_stage(cache) and not return_all_logits:      # the whole prefill as one call into libvl2hip.so (vl2_llm_prefill)
             out = self.logits if logits_out is None else logits_out
-            ops.llm_prefill(self._stage_desc()[0], x, out)
+            ops.llm_prefill(self._stage_desc()[0], x, out, fp8=getattr(self, "prefill_fp8", False))
             self.pos = S
             self.last_hidden = None
             return out
@@ -138,6 +154,26 @@ class HipMistralDecoder(nn.Module):
         q = torch.empty((S, nh * hd), dtype=_lib.elem_dtype(), device=self._dev)
         o = torch.empty((S, nh * hd), dtype=_lib.elem_dtype(), device=self._dev)
         smax = self.max_seq_len
+        if getattr(self, "prefill_fp8", False):                   # the same pass operator by operator on the fp8 matrix pipe (vl2_stage.inc)
+            for li, (lw, w8) in enumerate(zip(self.w["layers"], self.w8["layers"])):
+                a8, tab = ops.quant_act_fp8(x, rms_eps=self.eps)
+                qkv = ops.gemm_fp8(a8, tab, *w8["wqkv"], bias=lw["bqkv"])
+                ops.rope_kv(qkv, q, kcache[li], vcache[li], self.cos_t, self.sin_t, nh, nkv, 0)
+                ops.attn_fwd(q, kcache[li], vcache[li], o, (0, hd, nh * hd), (0, smax * hd, hd), (0, smax * hd, hd),
+                             (0, hd, nh * hd), 1, nh, S, S, nh // nkv, hd ** -0.5, True, 0, hd)
+                a8, tab = ops.quant_act_fp8(o)
+                x1 = ops.gemm_fp8(a8, tab, *w8["wo"], res=x)
+                a8, tab = ops.quant_act_fp8(x1, rms_eps=self.eps)
+                a = ops.gemm_fp8(a8, tab, *w8["wgu"], swiglu=True)
+                a8, tab = ops.quant_act_fp8(a)
+                x = ops.gemm_fp8(a8, tab, *w8["wd"], res=x1)
+            self.pos = S
+            self.last_hidden = x
+            if return_all_logits:
+                h = ops.rmsnorm(x, self.w["norm_w"], self.eps)
+                return ops.gemm(h, self.w["lm_head"], out_f32=True)
+            return ops.gemv(self.w["lm_head"], x[S - 1], norm_w=self.w["norm_w"], eps=self.eps, out_f32=True,
+                            out=self.logits if logits_out is None else logits_out)
         rs = ops.row_stats(x)          # RMSNorm rides in the q/k/v and gate/up GEMMs (weights.fold_norm): this seeds the statistics
         rn = ops.row_norm_finalize(rs, D, ops.NORM_RMS, self.eps)       # [S, 2] (0, rstd): reduced once, not in every column tile
         for li, lw in enumerate(self.w["layers"]):

@@ -38,10 +38,11 @@ NORM_NONE, NORM_RMS, NORM_LN = 0, 1, 2
 # call (vl2_gemm_desc.variant / flags / ws): the library itself holds no mutable state.
 _WORKSPACE = {}
 _CTL = dict(variant=0, splitk=False, attn_variant=0, stage_flags=0, gemm_flags=0)
-GEMM_PERSISTENT, GEMM_NO_MIX, GEMM_NO_FILL, GEMM_NO_WEAVE = 8, 16, 32, 64                                    # vl2_gemm_desc.flags (include/vl2hip.h)
+GEMM_PERSISTENT, GEMM_NO_MIX, GEMM_NO_FILL, GEMM_WEAVE, GEMM_FP8 = 8, 16, 32, 64, 128                                    # vl2_gemm_desc.flags (include/vl2hip.h)
 STAGE_PERSISTENT_GEMM, STAGE_NO_MIX, STAGE_SELF_REDUCE, STAGE_FUSED_DECODE_ATTN, STAGE_DECODE_TAIL, STAGE_STC_UNFUSED = 1, 2, 4, 8, 16, 32
-STAGE_NO_WEAVE = 256                  # A/B of the woven LDS-DMA issue of the 128x256 / 224x128 / 192x128 ping-pong GEMMs
+STAGE_WEAVE = 256                     # lab: LDS-DMA issue woven into the MFMA phases of the 128x256 / 224x128 / 192x128 ping-pong GEMMs
 STAGE_NO_FILL_TILES = 128             # A/B of the fill-the-round GEMM tiles (csrc/k_gemm7.h)
+STAGE_PREFILL_FP8 = 512               # prefill projections on the fp8 matrix pipe (W8A8, vl2_llm_desc.layers_w8); set by the decoder, not a lab switch
 STAGE_DECODE_FP8 = 64                 # decode step on the fp8 copies of the weights (vl2_llm_desc.layers_w8); set by the decoder, not a lab switch
 GEMV_RMS_PLAIN = 32   # vl2_*_desc.flags of the stage calls
 
@@ -81,7 +82,7 @@ def set_stage_flags(flags):
     (the library reads no environment variables and keeps no state)."""
     _CTL["stage_flags"] = int(flags)
     _CTL["gemm_flags"] = (GEMM_PERSISTENT if flags & STAGE_PERSISTENT_GEMM else 0) | (GEMM_NO_MIX if flags & STAGE_NO_MIX else 0) | \
-                         (GEMM_NO_FILL if flags & STAGE_NO_FILL_TILES else 0) | (GEMM_NO_WEAVE if flags & STAGE_NO_WEAVE else 0)
+                         (GEMM_NO_FILL if flags & STAGE_NO_FILL_TILES else 0) | (GEMM_WEAVE if flags & STAGE_WEAVE else 0)
 
 
 def stage_flags():
@@ -300,6 +301,44 @@ def quant_fp8(w):
     sc = torch.empty((N,), dtype=torch.float32, device=w.device)
     _lib.call("vl2_pack_quant_fp8", _p(w), N, K, w.stride(0), _p(q), _p(sc), _stream())
     return q, sc
+
+
+def quant_act_fp8(x, rms_eps=None, out=None, row_tab=None):
+    """include/vl2hip.h vl2_quant_act_fp8: 16-bit activation rows [M, K] -> (e4m3fn bytes [M, K] as uint8, row table [M, 2] fp32 = (0, row scale
+    [x RMS rstd when rms_eps is given])), the A operand and `row_norm` of gemm_fp8."""
+    _chk(x, _lib.elem_dtype(), "x")
+    M, K = x.shape
+    q = torch.empty((M, K), dtype=torch.uint8, device=x.device) if out is None else out
+    tab = torch.empty((M, 2), dtype=torch.float32, device=x.device) if row_tab is None else row_tab
+    _lib.call("vl2_quant_act_fp8", _p(x), x.stride(0), _p(q), q.stride(0), _p(tab), M, K, NORM_NONE if rms_eps is None else NORM_RMS,
+              0.0 if rms_eps is None else float(rms_eps), _stream())
+    return q, tab
+
+
+def gemm_fp8(a8, row_tab, w8, col_scale, bias=None, res=None, act=ACT_NONE, swiglu=False, out_f32=False, out=None):
+    """C = epilogue(row_tab[m, 1] * col_scale[n] * (a8 @ w8.T)) on the fp8 matrix pipe (vl2_gemm with VL2_GEMM_FP8; W8A8, an OPTIONAL
+    arithmetic): a8 [M, K] / w8 [N, K] e4m3fn bytes (quant_act_fp8 / quant_fp8), K % 128 == 0, N % 256 == 0."""
+    _chk(a8, torch.uint8, "a8"); _chk(w8, torch.uint8, "w8"); _chk(row_tab, torch.float32, "row_tab"); _chk(col_scale, torch.float32, "col_scale")
+    _chk(bias, torch.float32, "bias"); _chk(res, _lib.elem_dtype(), "res")
+    M, K = a8.shape
+    N = w8.shape[0]
+    if w8.shape[1] != K or row_tab.shape[0] < M or col_scale.shape[0] != N:
+        raise ValueError("gemm_fp8: shapes of a8 / w8 / row_tab / col_scale do not agree")
+    ncol = N // 2 if swiglu else N
+    if out is None:
+        out = torch.empty((M, ncol), dtype=torch.float32 if out_f32 else _lib.elem_dtype(), device=a8.device)
+    flags = GEMM_FP8 | (GEMM_SWIGLU if swiglu else 0) | (GEMM_OUT_F32 if out_f32 else 0)
+    d = _lib.GemmDesc(ctypes.sizeof(_lib.GemmDesc), M, N, K, _p(a8), a8.stride(0), _p(w8), w8.stride(0), _p(out), out.stride(0),
+                      _p(bias), _p(res), res.stride(0) if res is not None else 0, act, flags, None, 0, 0, 0, 0, 0, 0, None, None, NORM_NONE, 0.0, None,
+                      _p(row_tab), None, 0, _CTL["variant"] if _CTL["variant"] in (4, 8, 12) else 0, _p(col_scale))
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.call("vl2_gemm", ctypes.byref(d), _stream())
+    if PROFILE is not None:
+        e1.record()
+        PROFILE.append(("gemm_fp8", 2.0 * M * N * K, e0, e1, (M, N, K)))
+    return out
 
 
 def gemv_fp8(q, scale, x, norm_w=None, eps=1e-5, res=None, swiglu=False, out_f32=False, out=None, bias=None, rms_plain=False):
@@ -524,9 +563,9 @@ def _llm_ws(desc, S, device):
     return torch.empty((n,), dtype=torch.uint8, device=device), n
 
 
-def llm_prefill(desc, x, logits_out):
+def llm_prefill(desc, x, logits_out, fp8=False):
     ws, n = _llm_ws(desc, x.shape[0], x.device)
-    desc.flags = _CTL["stage_flags"]
+    desc.flags = _CTL["stage_flags"] | (STAGE_PREFILL_FP8 if fp8 else 0)
     _lib.call("vl2_llm_prefill", ctypes.byref(desc), _p(x), x.shape[0], _p(logits_out), _p(ws), n, _stream())
     return logits_out
 
