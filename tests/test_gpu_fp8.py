@@ -196,7 +196,9 @@ def test_activation_quantiser_on_device_matches_the_oracle(ops):
                                            ("f32", 700, 1024, 2048, dict(f32=True, variants=(4, 8)))])
 def test_gemm_fp8_at_decoder_shapes(ops, name, M, N, K, kw):
     """The four prefill projections at S = 1621 (and a ragged M on every tile shape) on the fp8 matrix pipe against gemm_w8a8: the same e4m3fn
-    operands, exact products, fp32 sums in another order; a 16-bit output adds its one rounding."""
+    operands, exact products, fp32 sums in another order; a 16-bit output adds its one rounding.  The fp32-output bar is 5e-5, not the 1e-6 of
+    a re-ordered IEEE sum: v_mfma_f32_32x32x64_f8f6f4 adds its 64 products per lane with a shared-exponent alignment that drops low bits
+    (measured on MI355X at K = 2048: 1.45e-5 rel-L2 to the fp32 sum of the exact products, profiles/r05_experiments.md)."""
     x, w = bf(M, K, seed=1), bf(N, K, scale=K ** -0.5, seed=2)
     qw, sw = ops.quant_fp8(w.to(DEV))
     qa, tab = ops.quant_act_fp8(x.to(DEV), rms_eps=1e-5 if kw.get("rms") else None)
@@ -210,7 +212,7 @@ def test_gemm_fp8_at_decoder_shapes(ops, name, M, N, K, kw):
             y = ops.gemm_fp8(qa, tab, qw, sw, bias=None if bias is None else bias.to(DEV), res=None if res is None else res.to(DEV),
                              swiglu=bool(kw.get("swiglu")), out_f32=bool(kw.get("f32")))
             e = rel(y.float().cpu(), ref)
-            assert e < (1e-5 if kw.get("f32") else 3e-3), (name, v, e)
+            assert e < (5e-5 if kw.get("f32") else 3e-3), (name, v, e)
     finally:
         ops.set_gemm_variant(0)
 

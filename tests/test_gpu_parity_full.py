@@ -1,6 +1,6 @@
 """Parity on BASELINE.json configs[1] ITSELF (VideoLLaMA2-7B widths and depths, 16 frames, S = 1621), on MI355X.
 
-For every stage three numbers are produced in the same test and written to gpurun_out/r03_parity.json (copied to
+For every stage three numbers are produced in the same test and written to gpurun_out/r05_parity.json (copied to
 profiles/ by the round's GPU script):
     ours   = rel-L2( HIP path            , fp32 oracle )      the oracle runs in fp32 on the HOST cores of the GPU box
     floor  = rel-L2( reference-bf16 path , fp32 oracle )      the same restatement run in bf16 with torch-ROCm ops on the GPU --
@@ -47,7 +47,7 @@ def _flush():
         return
     out = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out, exist_ok=True)
-    with open(os.path.join(out, "r04_parity.json"), "w") as f:
+    with open(os.path.join(out, "r05_parity.json"), "w") as f:
         json.dump(dict(config="BASELINE.json configs[1]: VideoLLaMA2-7B widths, bf16, MI355X; fp32 oracle on the host cores, "
                               "reference-bf16 floor = the same restatement in bf16 on torch-ROCm", host_cores=os.cpu_count(),
                        rows=RECORD), f, indent=1)

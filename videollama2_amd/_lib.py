@@ -125,6 +125,14 @@ def elem_dtype():
     return torch.float16 if _ELEM == "fp16" else torch.bfloat16
 
 
+def check_elem(built_in, what):
+    """A module's packed weights, caches and stage descriptors are in the element type that was current when it was BUILT; the kernels
+    cannot tell bf16 bits from fp16 bits, so a module called after `set_elem` switched the process to the other build refuses loudly."""
+    if built_in != _ELEM:
+        raise RuntimeError(f"{what} was built with element type {built_in!r} but the library in use is {_ELEM!r} "
+                           f"(_lib.set_elem): rebuild the module, or switch back with _lib.set_elem({built_in!r})")
+
+
 def set_elem(name):
     """Select the 16-bit element type ("bf16" | "fp16") of every kernel call that follows."""
     global _ELEM, _lib

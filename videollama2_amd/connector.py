@@ -45,6 +45,7 @@ class HipSTCConnector(nn.Module):
         super().__init__()
         self.padding = int(padding)
         self._dev = torch.device(device)
+        self._elem = _lib.elem()
         self.w = pack_connector(state_dict, self._dev, prefix)
         if self._dev.type == "cuda":
             ops.attach_workspace(self._dev)       # split-K (opt-in, ops.set_splitk): Conv3d taps, s2 on few output frames
@@ -109,6 +110,7 @@ class HipSTCConnector(nn.Module):
 
     @torch.no_grad()
     def forward(self, x, return_stages=False):
+        _lib.check_elem(self._elem, type(self).__name__)
         if x.dim() == 5:                                              # [b, t, h, w, d]  (projector.py:200-201)
             b, t, hh, ww, d = x.shape
             x = x.reshape(b, t, hh * ww, d)

@@ -960,7 +960,7 @@ extern "C" int32_t vl2_quant_act_fp8(const void* x, int64_t ldx, void* q, int64_
 extern "C" int32_t vl2_gemv_fp8(const void* q, const float* scale, const void* x, const float* norm_w, const void* res, const float* bias, void* y,
                                 int32_t N, int32_t K, int32_t ldq, float eps, int32_t flags, void* stream) {
     if (!q || !scale || !x || !y || N <= 0 || K <= 0) return fail(VL2_E_BADARG, "vl2_gemv_fp8: bad args");
-    if (K % 16 || ldq % 16 || ldq < K || K > 32704 || N % 2) return fail(VL2_E_SHAPE, "vl2_gemv_fp8: need N even, K%%16==0, ldq%%16==0, K<=32704 (x lives in LDS as fp32; K=%d)", K);
+    if (K % 16 || ldq % 16 || ldq < K || K > 32704 || N % 2) return fail(VL2_E_SHAPE, "vl2_gemv_fp8: need N even, K%%16==0, ldq%%16==0, K<=32704 (x lives in LDS as 16-bit elements; K=%d)", K);
     const bool sw = flags & VL2_GEMM_SWIGLU, f32 = flags & VL2_GEMM_OUT_F32;
     if (sw && (N % 64 || f32 || bias)) return fail(VL2_E_SHAPE, "vl2_gemv_fp8: SWIGLU needs N%%64==0, 16-bit output, no bias");
     Gemv8Args a{(const uint8_t*)q, scale, (const bf16_t*)x, norm_w, (const bf16_t*)res, y, N, K, ldq, eps, bias, 0};

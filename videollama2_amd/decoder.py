@@ -42,6 +42,7 @@ class HipMistralDecoder(nn.Module):
         fr = torch.arange(max_seq_len, dtype=torch.float32)[:, None] * inv[None, :]
         self.cos_t = fr.cos().contiguous().to(self._dev)
         self.sin_t = fr.sin().contiguous().to(self._dev)
+        self._elem = _lib.elem()
         bf = dict(dtype=_lib.elem_dtype(), device=self._dev)
         self.kcache = [torch.zeros((self.nkv, max_seq_len, self.hd), **bf) for _ in range(self.n_layers)]
         self.vcache = [torch.zeros((self.nkv, max_seq_len, self.hd), **bf) for _ in range(self.n_layers)]
@@ -139,6 +140,7 @@ class HipMistralDecoder(nn.Module):
         """x: inputs_embeds [S, D] (any float dtype, device).  Fills the KV cache for positions 0..S-1 and returns
         fp32 logits of the last position [V] (or all positions [S, V]).  cache = (k per layer, v per layer) overrides the
         decoder's own single-sequence cache (batched decode gives every sequence its slice)."""
+        _lib.check_elem(self._elem, type(self).__name__)
         kcache, vcache = cache if cache is not None else (self.kcache, self.vcache)
         S = x.shape[0]
         if S > self.max_seq_len:
@@ -224,6 +226,7 @@ class HipMistralDecoder(nn.Module):
     @torch.no_grad()
     def decode_step(self, tok_dev=None):
         """Eager step: feed the token in self.tok (or tok_dev) at position self.pos -> fp32 logits [V] (self.logits)."""
+        _lib.check_elem(self._elem, type(self).__name__)
         if self.pos >= self.max_seq_len:
             raise ValueError("KV cache exhausted")
         if tok_dev is not None and tok_dev.data_ptr() != self.tok.data_ptr():

@@ -36,6 +36,7 @@ class HipCLIPVisionTower(nn.Module):
             raise ValueError(f"Unexpected select feature: {select_feature}")      # encoder.py:38
         self.image_processor = image_processor
         self._dev = torch.device(device)
+        self._elem = _lib.elem()            # the element type the weights are packed in (checked on every call: _lib.check_elem)
         self.w = self._pack(state_dict, cfg, self._dev, prefix)
         if self._dev.type == "cuda":
             ops.attach_workspace(self._dev)       # split-K (opt-in, ops.set_splitk) for small per-rank grids
@@ -121,6 +122,7 @@ class HipCLIPVisionTower(nn.Module):
         """Returns hidden_states[select_layer] INCLUDING the CLS row: bf16 [T*(N+1), D] (flat token-major).
         With `self.streams` > 1 the (independent) frames run as that many interleaved chunks on separate HIP streams,
         so one chunk's partial last round of GEMM tiles overlaps the other chunk's kernels."""
+        _lib.check_elem(self._elem, type(self).__name__)
         ns = min(int(self.streams), images.shape[0] // 4 if images.dim() == 4 else 1)    # >= 4 frames per chunk
         if images.dtype == torch.uint8:
             ns = 1
