@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define VL2_ABI_VERSION 5
+#define VL2_ABI_VERSION 6
 #define VL2_E_BADARG  (-1)   /* null pointer / non-positive size */
 #define VL2_E_SHAPE   (-2)   /* shape not supported by the gfx950 kernels (alignment / multiple-of constraints) */
 #define VL2_E_UNSUPP  (-3)   /* option combination not built */
@@ -74,6 +74,8 @@ int64_t vl2_workspace_bytes(void);
                                  `row_norm` [M][2] = (0, row multiplier) as vl2_quant_act_fp8 writes it (activation scale x RMS rstd), `col_scale` [N] = the
                                  weight rows' scales (vl2_pack_quant_fp8).  C = epilogue(rowmul_m * colscale_n * sum_k A8 W8): bias / SiLU / SwiGLU / residual /
                                  fp32 output as the 16-bit form.  An OPTIONAL arithmetic (both operands rounded to e4m3fn), never the default */
+#define VL2_GEMM_NO_TICKET 256 /* `row_norm_out` is filled by a separate vl2_row_norm_finalize launch behind the GEMM (rounds 3-4) instead of by the GEMM's last
+                                 column tile: A/B of the producer-side finalize (same bits) */
 #define VL2_GEMM_WEAVE   64   /* lab: the 128x256 / 224x128 / 192x128 ping-pong kernels issue their LDS-DMA woven between the MFMAs of the matrix phases instead of
                                  from the load phases (same bits; faster back to back on warm operands, slower in the pipeline: profiles/r05_experiments.md) */
 /* stage-level descriptors (vl2_vit_desc / vl2_stc_desc / vl2_llm_desc) `flags`: experiment controls, all off by default */
@@ -81,6 +83,10 @@ int64_t vl2_workspace_bytes(void);
 #define VL2_STAGE_NO_MIX           2   /* ... with VL2_GEMM_NO_MIX */
 #define VL2_STAGE_NO_FILL_TILES  128   /* ... with VL2_GEMM_NO_FILL */
 #define VL2_STAGE_WEAVE          256   /* ... with VL2_GEMM_WEAVE */
+#define VL2_STAGE_ROW_TICKET    1024   /* ViT and LLM prefill: the statistics-producing GEMMs (out_proj / fc2, o / down) finalize their own output rows
+                                         * (vl2_gemm_desc.row_norm_out: producer-side ticket, csrc/k_gemm.h gemm_rows_ticket) instead of a vl2_row_norm_finalize launch
+                                         * behind each of them.  Same bits; measured round 5: neutral in the tower (-0.03 ms), SLOWER in the prefill (+0.12 ms: every
+                                         * tile drains its stores and pays an agent-scope atomic round trip), profiles/r05_experiments.md -- off by default */
 #define VL2_STAGE_SELF_REDUCE      4   /* ViT and LLM prefill: the norm-carrying GEMMs reduce the row statistics themselves (no row_norm_finalize launches;
                                          * same bits, measured slower: LLM prefill 24.4 -> 26.0 ms, profiles/r04_experiments.md section 1) */
 #define VL2_STAGE_FUSED_DECODE_ATTN 8  /* decode step: attention + combine as one launch (vl2_attn_decode_fused; measured slower) */
@@ -138,6 +144,12 @@ typedef struct vl2_gemm_desc {
     void* tile_ctr;                /* optional: 8 zeroed bytes (two uint32) through which the persistent GEMM hands out its tiles; the kernel
                                       re-arms them, so one block serves every GEMM of a stream (vl2_fill_zero once).  NULL: the block at the
                                       end of `ws` if that is given, else the persistent form is used on request only (static tile walk) */
+    float* row_norm_out;           /* optional, with stats_out: [M][2] (mean, rstd) of the OUTPUT rows for the GEMM that consumes them (its `row_norm`), written by
+                                      this call -- by the workgroup that stores the last column tile of a row block (csrc/k_gemm.h gemm_rows_ticket: the bits of
+                                      vl2_row_norm_finalize, no launch between producer and consumer), or by an appended vl2_row_norm_finalize launch where the
+                                      chosen kernel has no such epilogue (64 x 64 tiles, split-K, column chunks) or VL2_GEMM_NO_TICKET is set */
+    uint32_t* row_ticket;          /* with row_norm_out: M / 64 + 2 zeroed words (vl2_fill_zero once; the kernels re-arm them, so one block serves a stream) */
+    int32_t norm_out;  float norm_out_eps;   /* with row_norm_out: VL2_NORM_RMS / VL2_NORM_LN of the output rows and its epsilon */
 } vl2_gemm_desc;
 int32_t vl2_gemm(const vl2_gemm_desc* d, void* stream);
 /* (sum, sum of squares) per row and 64-column block of a bf16 activation x [rows, C] -> stats fp32 [rows][C/64][2], in the

@@ -581,11 +581,12 @@ def mistral_forward(sd, cfg, x, start_pos=0, caches=None, n_layers=None, last_on
     return F.linear(x, sd["lm_head.weight"]), new
 
 
-def greedy_generate(sd, cfg, inputs_embeds, max_new_tokens, eos_token_id=None, n_layers=None):
+def greedy_generate(sd, cfg, inputs_embeds, max_new_tokens, eos_token_id=None, n_layers=None, return_prefill_caches=False):
     """HF GenerationMixin._sample with do_sample=False as mm_infer drives it (videollama2/__init__.py:99-110):
     prefill on inputs_embeds, argmax, feed embed_tokens(next) one token at a time; stop at EOS (the semantic
     content of KeywordsStoppingCriteria, mm_utils.py:329-339).  Returns (new token ids list, per-step logits)."""
     logits, caches = mistral_forward(sd, cfg, inputs_embeds, 0, None, n_layers)
+    prefill_caches = caches            # (a layer's cache grows by concatenation into NEW tensors: this list keeps the prefill state)
     pos = inputs_embeds.shape[0]
     toks, all_logits = [], []
     for _ in range(max_new_tokens):
@@ -597,6 +598,8 @@ def greedy_generate(sd, cfg, inputs_embeds, max_new_tokens, eos_token_id=None, n
         x = F.embedding(torch.tensor([nxt], device=inputs_embeds.device), sd["model.embed_tokens.weight"]).to(inputs_embeds.dtype)
         logits, caches = mistral_forward(sd, cfg, x, pos, caches, n_layers)
         pos += 1
+    if return_prefill_caches:          # test harness: teacher-forced decode of ANOTHER weight set (fp8-dequantised) from the same prefill
+        return toks, torch.stack(all_logits), prefill_caches
     return toks, torch.stack(all_logits)
 
 

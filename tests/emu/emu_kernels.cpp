@@ -31,6 +31,7 @@ extern "C" int32_t vl2_fill_zero(void* p, int64_t bytes, void*) { if (!p || byte
 
 // per-call controls (vl2_gemm_desc.variant, VL2_GEMM_SPLITK, vl2_attn_fwd variant): set by the entry points below
 static int g_gemm_variant = 0;
+static bool g_need_fin = false;     // a GEMM path without the producer-side finalize ran: append the row_norm_finalize launch (vl2_abi.hip GemmCtl.fin)
 static bool g_gemm6_dynamic = false;       // gemm6: tiles handed out through the counter block (variants 70 / 71 = 60 / 61 dynamic)
 template <int ACT, bool SW, bool F32, bool G>
 static void run_gemm(GemmArgs a) {
@@ -85,6 +86,7 @@ static void run_gemm(GemmArgs a) {
             if (a.stats_out) tail.stats_out = a.stats_out + (size_t)M1 * a.stats_out_np * 2;
             if (a.stats_in) tail.stats_in = a.stats_in + (size_t)M1 * a.stats_in_np * 2;
             if (a.row_norm) tail.row_norm = a.row_norm + (size_t)M1 * 2;
+            if (a.row_norm_out) { tail.row_norm_out = a.row_norm_out + (size_t)M1 * 2; tail.row_ticket = a.row_ticket + M1 / 64; }
             tail.tiles_m = (tail.M + 127) / 128; tail.tiles_n = a.N / 128;
             const int n_big = big.tiles_m * big.tiles_n, n_all = n_big + tail.tiles_m * tail.tiles_n;
             if (a.res == nullptr) emu::launch(dim3(n_all), dim3(512), [=] { gemm_mix_bf16_kernel<ACT, SW, true>(big, tail, n_big); });
@@ -139,6 +141,7 @@ static void run_gemm(GemmArgs a) {
     }
     if constexpr (!SW && !F32) {
         if (g_gemm_variant == 32) {                             // small-M 64x64 form (plain and gathered)
+            if (a.row_norm_out) g_need_fin = true;                // no producer-side finalize in this kernel: vl2_gemm appends the launch
             a.tiles_m = (a.M + 63) / 64; a.tiles_n = a.N / 64;
             emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(128), [=] { gemm_s_bf16_kernel<ACT, G>(a); });
             return;
@@ -148,6 +151,7 @@ static void run_gemm(GemmArgs a) {
         const int nt = a.K / 64;
         const int split = nt % 4 == 0 && nt >= 8 ? 4 : nt % 3 == 0 && nt >= 6 ? 3 : nt % 2 == 0 ? 2 : 1;
         if (split > 1) {
+            if (a.row_norm_out) g_need_fin = true;
             static std::vector<float> ws;
             static std::vector<int> cnt;
             ws.assign((size_t)a.tiles_m * a.tiles_n * split * 64 * 256, 0.f);
@@ -171,6 +175,20 @@ extern "C" int32_t vl2_gemm(const vl2_gemm_desc* d, void*) {
     a.idx_ld = M; a.stats_out = d->stats_out; a.stats_out_np = N / 64; a.stats_in = d->stats_in; a.stats_in_np = K / 64;
     a.norm = d->norm; a.norm_eps = d->norm_eps; a.w_colsum = d->w_colsum; a.row_norm = d->row_norm;
     a.tile_ctr = (unsigned*)d->tile_ctr;
+    g_need_fin = d->row_norm_out && (d->flags & VL2_GEMM_NO_TICKET);
+    if (d->row_norm_out) {
+        if (!d->stats_out || !d->row_ticket || (d->norm_out != 1 && d->norm_out != 2)) return -1;
+        if (!g_need_fin) { a.row_norm_out = d->row_norm_out; a.row_ticket = (unsigned*)d->row_ticket; a.norm_out = d->norm_out; a.norm_out_eps = d->norm_out_eps; }
+    }
+    struct Fin {           // runs when vl2_gemm returns, whichever branch: the appended row_norm_finalize launch of vl2_abi.hip
+        const vl2_gemm_desc* d;
+        ~Fin() {
+            if (!g_need_fin) return;
+            const vl2_gemm_desc* q = d;
+            emu::launch(dim3((q->M + 31) / 32), dim3(256), [=] { row_norm_finalize_kernel(q->stats_out, q->row_norm_out, q->M, q->N / 64, q->N, q->norm_out, q->norm_out_eps); });
+            g_need_fin = false;
+        }
+    } fin{d};
     g_gemm_variant = (d->flags & VL2_GEMM_SPLITK) ? 16 : d->variant;     // 16 = the emulator's split-K form of the 128x128 kernel
     const bool sw = d->flags & 1, f32 = d->flags & 2, g = a.a_idx != nullptr;
     if (d->flags & VL2_GEMM_FP8) {          // W8A8 on the (emulated) fp8 matrix pipe: rows of K bytes seen as K / 2 16-bit elements (vl2_abi.hip)

@@ -119,6 +119,51 @@ def test_emu_norm_carrying_gemms(emu):
         ops.set_gemm_variant(0)
 
 
+def test_emu_gemm_producer_side_finalize_equals_the_launch(emu):
+    """k_gemm.h gemm_rows_ticket (round 5): a statistics-producing GEMM leaves (mean, rstd) of its output rows in `row_norm_out` itself -- the
+    workgroup that stores the last column tile of a row block reduces the block's partials.  On every tile shape (128x128, 128x256, 256x256,
+    192x256, 224x128, 192x128, the 8-wave 128x128, the mixed launch) and both epilogue forms, ragged M: the same bits as
+    row_norm_finalize(stats_out), LayerNorm and RMSNorm; the tickets come back zeroed (one block serves a stream of GEMMs); kernels without the
+    epilogue (64x64 tiles, split-K) and VL2_GEMM_NO_TICKET get the launch appended by vl2_gemm -- same result."""
+    from videollama2_amd import ops
+    M, N, K = 700, 512, 256
+    a, w, bias, res = bf(M, K), bf(N, K, scale=K ** -0.5), torch.randn(N), bf(M, N)
+    try:
+        for kind, eps in ((ops.NORM_LN, 1e-5), (ops.NORM_RMS, 1e-6)):
+            ops.set_gemm_variant(1)
+            st_ref = torch.zeros(M, N // 64, 2)
+            y_ref = ops.gemm(a, w, bias=bias, res=res, stats_out=st_ref)
+            rn_ref = ops.row_norm_finalize(st_ref, N, kind, eps)
+            for v, use_res in ((1, True), (4, True), (4, False), (8, True), (8, False), (12, True), (12, False), (224, True), (192, True), (256, True),
+                               (24, True), (24, False), (32, True), (0, True)):
+                ops.set_gemm_variant(v)
+                st, rn, tick = torch.zeros(M, N // 64, 2), torch.full((M, 2), -7.0), torch.zeros(M // 64 + 2, dtype=torch.int32)
+                r = res if use_res else None
+                y = ops.gemm(a, w, bias=bias, res=r, stats_out=st, norm_out=(kind, eps, rn, tick))
+                if use_res:
+                    assert torch.equal(y, y_ref) and torch.equal(st, st_ref), v
+                    assert torch.equal(rn, rn_ref), (v, kind, (rn - rn_ref).abs().max())
+                else:
+                    assert torch.equal(rn, ops.row_norm_finalize(st, N, kind, eps)), (v, kind)
+                assert int(tick.abs().sum()) == 0, f"variant {v}: tickets not re-armed"
+            ops.set_gemm_variant(0)
+            ops.set_stage_flags(ops.STAGE_NO_TICKET_OPS)                       # the launch appended by vl2_gemm (A/B form)
+            st, rn, tick = torch.zeros(M, N // 64, 2), torch.zeros(M, 2), torch.zeros(M // 64 + 2, dtype=torch.int32)
+            ops.gemm(a, w, bias=bias, res=res, stats_out=st, norm_out=(kind, eps, rn, tick))
+            assert torch.equal(rn, rn_ref) and int(tick.abs().sum()) == 0
+            ops.set_stage_flags(0)
+            ops.set_splitk(True)                                            # split-K kernel: no ticket epilogue -> appended launch
+            ops.set_gemm_variant(1)
+            st, rn = torch.zeros(M, N // 64, 2), torch.zeros(M, 2)
+            ops.gemm(a, w, bias=bias, res=res, stats_out=st, norm_out=(kind, eps, rn, tick))
+            assert torch.equal(rn, ops.row_norm_finalize(st, N, kind, eps))
+            ops.set_splitk(False)
+    finally:
+        ops.set_gemm_variant(0)
+        ops.set_stage_flags(0)
+        ops.set_splitk(False)
+
+
 def test_emu_gemm_pingpong_variant(emu):
     from videollama2_amd import ops
     for K in (64, 128, 448):
@@ -795,12 +840,17 @@ def test_emu_stage_level_entry_points_equal_the_per_operator_path(emu, golden_sm
         assert all(torch.equal(x[1], y[1]) for x, y in zip(a[3], b[3])) and torch.equal(a[4], b[4]) and torch.equal(a[5], b[5])
         assert torch.equal(a[6], b[6]) and rel(a[6][0], g["mm_features"]) < 2.5e-2
         assert rel(a[0], g["tower_out"]) < 1.2e-2
+        ops.STAGE_ABI = True
+        ops.set_stage_flags(ops.STAGE_ROW_TICKET)                  # producer-side finalize of the row statistics (k_gemm.h gemm_rows_ticket): same bits
+        assert torch.equal(m.vision_tower(g["frames"]), a[0]) and torch.equal(m.decoder.prefill(g["inputs_embeds"]), a[2])
+        ops.set_stage_flags(0)
         from videollama2_amd._lib import Vl2HipError
         d, _, ws = m.decoder._stage_desc()
         with pytest.raises(Vl2HipError, match="exceeds the KV cache"):
             ops.llm_prefill(d, torch.zeros(65, cfg["llm"]["hidden_size"], dtype=torch.bfloat16), m.decoder.logits)
     finally:
         ops.STAGE_ABI = True
+        ops.set_stage_flags(0)
 
 
 def test_emu_fp8_prefill_stage_equals_the_per_operator_path(emu, golden_small):

@@ -41,6 +41,40 @@ def test_gemm_bias_act_res(ops, act):
     assert rel(c, y) < TOL_BF16_OUT
 
 
+@pytest.mark.parametrize("M,N,K,kind,variants", [(9232, 1024, 1024, 2, (0, 1, 8, 12)), (9232, 1024, 4096, 2, (0, 12)), (1621, 4096, 4096, 1, (0, 1, 4, 224, 192, 256)),
+                                                 (1621, 4096, 14336, 1, (0, 4, 224)), (945, 4096, 4096, 1, (0, 1)), (333, 4096, 4096, 1, (0, 32))])
+def test_gemm_producer_side_finalize_equals_the_launch(ops, M, N, K, kind, variants):
+    """k_gemm.h gemm_rows_ticket (round 5): the statistics-producing GEMMs of the step (ViT out_proj / fc2, decoder o / down at S = 1621 and at the
+    T = 8 length, a small-M shape that falls back to the appended launch) leave (mean, rstd) of their output rows in `row_norm_out` -- bit for bit
+    what vl2_row_norm_finalize computes from `stats_out`, on every tile shape, repeatedly on ONE ticket block (the kernels re-arm it), racing
+    workgroups on eight XCDs included (write-through partials, agent-scope loads in the electing workgroup)."""
+    a, w, bias, res = bf(M, K), bf(N, K, scale=K ** -0.5), torch.randn(N), bf(M, N)
+    ad, wd, bd, rd = a.to(DEV), w.to(DEV), bias.to(DEV), res.to(DEV)
+    eps = 1e-5
+    tick = torch.zeros(M // 64 + 2, dtype=torch.int32, device=DEV)
+    try:
+        ops.set_gemm_variant(1)
+        st_ref = torch.zeros(M, N // 64, 2, device=DEV)
+        y_ref = ops.gemm(ad, wd, bias=bd, res=rd, stats_out=st_ref)
+        rn_ref = ops.row_norm_finalize(st_ref, N, kind, eps)
+        for v in variants:
+            ops.set_gemm_variant(v)
+            for rep in range(4):
+                st, rn = torch.zeros(M, N // 64, 2, device=DEV), torch.full((M, 2), -7.0, device=DEV)
+                y = ops.gemm(ad, wd, bias=bd, res=rd, stats_out=st, norm_out=(kind, eps, rn, tick))
+                assert torch.equal(y, y_ref) and torch.equal(st, st_ref), (v, rep)
+                assert torch.equal(rn, rn_ref), (v, rep, float((rn - rn_ref).abs().max()))
+                assert int(tick.abs().sum().item()) == 0, f"variant {v}: tickets not re-armed"
+        ops.set_gemm_variant(0)
+        ops.set_stage_flags(ops.STAGE_NO_TICKET_OPS)                       # the launch appended by vl2_gemm (A/B form)
+        st, rn = torch.zeros(M, N // 64, 2, device=DEV), torch.zeros(M, 2, device=DEV)
+        ops.gemm(ad, wd, bias=bd, res=rd, stats_out=st, norm_out=(kind, eps, rn, tick))
+        assert torch.equal(rn, rn_ref)
+    finally:
+        ops.set_gemm_variant(0)
+        ops.set_stage_flags(0)
+
+
 @pytest.mark.parametrize("M,N,K", [(300, 512, 448), (9232, 4096, 1024), (1621, 28672, 4096)])
 def test_gemm_pingpong_variant_is_bit_identical(ops, M, N, K):
     """The ping-pong kernels (128x256: knob 4, 256x256: knob 8, 192x256: knob 12) accumulate in the same order as the 128x128 kernel:

@@ -48,6 +48,15 @@ def test_stage_calls_equal_per_operator_path_on_device(golden_small, golden_smal
     assert [t for t, _ in a[4]] == [t for t, _ in b[4]]
     assert all(torch.equal(x[1], y[1]) for x, y in zip(a[4], b[4]))
     assert rel(a[0].float().cpu(), g["tower_out"]) < 1.2e-2 and rel(a[2][0].float().cpu(), g["mm_features"]) < 2.5e-2
+    # the producer-side finalize (VL2_STAGE_ROW_TICKET: out_proj / fc2 / o / down write (mean, rstd) of their rows themselves, k_gemm.h
+    # gemm_rows_ticket) is the same arithmetic as the launches: tower and prefill logits bit for bit, twice on the self-re-arming ticket block
+    try:
+        ops.set_stage_flags(ops.STAGE_ROW_TICKET)
+        for _ in range(2):
+            assert torch.equal(m.vision_tower(g["frames"].to(DEV)), a[0])
+            assert torch.equal(dec.prefill(g["inputs_embeds"].to(DEV)), a[3])
+    finally:
+        ops.set_stage_flags(0)
     # the graph decoder.generate uses replays the same entry point: tokens equal to eager generate
     ids = g["input_ids"][None].to(DEV)
     kw = dict(attention_mask=torch.ones_like(ids), images=[(g["frames"].to(DEV), "video")], do_sample=False, max_new_tokens=6)

@@ -22,7 +22,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert _lib.load().vl2_version() == 5
+    assert _lib.load().vl2_version() == 6
     assert _lib.load().vl2_elem_name() == b"bf16"
     f16 = ctypes.CDLL(_lib.LIB_PATHS["fp16"])               # the fp16 build: same export table, other element type
     for name in declared:

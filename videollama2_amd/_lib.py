@@ -17,7 +17,8 @@ class GemmDesc(ctypes.Structure):
                 ("a_idx", _vp), ("seg_k", _i32),
                 ("out_grp", _i32), ("out_grp_pad", _i32), ("out_row_off", _i32), ("res_row_mod", _i32), ("res_row_off", _i32),
                 ("stats_out", _vp), ("stats_in", _vp), ("norm", _i32), ("norm_eps", _f32), ("w_colsum", _vp), ("row_norm", _vp),
-                ("ws", _vp), ("ws_bytes", _i64), ("variant", _i32), ("col_scale", _vp), ("tile_ctr", _vp)]
+                ("ws", _vp), ("ws_bytes", _i64), ("variant", _i32), ("col_scale", _vp), ("tile_ctr", _vp),
+                ("row_norm_out", _vp), ("row_ticket", _vp), ("norm_out", _i32), ("norm_out_eps", _f32)]
 
 
 class VitLayer(ctypes.Structure):
@@ -178,7 +179,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = _i32
         fn.argtypes = args
-    if lib.vl2_version() != 5:
+    if lib.vl2_version() != 6:
         raise Vl2HipError("libvl2hip.so ABI version mismatch")
     lib.vl2_elem_name.restype = ctypes.c_char_p
     lib.vl2_elem_name.argtypes = []

@@ -51,6 +51,12 @@ struct GemmArgs {
     const float* col_scale;  // fp8 form: [N] one multiplier per output column (the weight rows' scales), applied behind the row scale; else null
     unsigned* tile_ctr;      // persistent form (k_gemm6.h): two zeroed words {tiles handed out, workgroups finished}, re-armed by the kernel; null = static walk
     int tile_first_dyn;      // persistent form: 1 = the FIRST tile of a workgroup is drawn from the counter too (a workgroup that starts late finds no work)
+    // ---- producer-side finalize (gemm_rows_ticket below): with stats_out, the workgroup that stores the LAST column tile of a row block reduces the
+    // block's partials to (mean, rstd) itself -- the row_norm_finalize launch between a producer and its consumer disappears
+    float* row_norm_out;     // [rows][2] (mean, rstd) of the OUTPUT rows, or null
+    unsigned* row_ticket;    // one zeroed word per row tile of THIS launch (index = the kernel's tile row), re-armed by the last arriver
+    int norm_out;            // 1 RMSNorm (mean = 0), 2 LayerNorm
+    float norm_out_eps;
 };
 
 // ---- norm-carrying GEMMs ------------------------------------------------------------------------------------------------
@@ -117,6 +123,68 @@ __device__ __forceinline__ f32x2 gemm_row_stats(const GemmArgs& p, int m0, int t
 // (mean, rstd) of the tile's rows -> LDS table `tab` [BM][2]; call before the barrier that precedes the first gemm_store_patch
 __device__ __forceinline__ void gemm_park_row_stats(const GemmArgs& p, float* tab, const f32x2& r, int t, int BM) {
     if (p.norm && t < BM) { tab[2 * t] = r[0]; tab[2 * t + 1] = r[1]; }
+}
+
+// One (sum, sum of squares) partial of `stats_out`.  With the producer-side finalize the partial goes out WRITE-THROUGH (an agent-scope relaxed
+// atomic store = `global_store_dwordx2 ... sc1`): the workgroup that reduces it may sit on another XCD, whose L2 is not coherent with this one's,
+// and a release fence (buffer_wbl2) in every tile was measured to lose against the launch it replaces (k_decode.h attn_decode_kernel<FUSED>).
+__device__ __forceinline__ void gemm_stat_put(const GemmArgs& p, float* dst, float s, float q) {
+    if (p.row_norm_out) {
+        const f32x2 v = {s, q};
+        __hip_atomic_store((uint64_t*)dst, __builtin_bit_cast(uint64_t, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        dst[0] = s;
+        dst[1] = q;
+    }
+}
+// ---- producer-side finalize.  Called by every thread of the workgroup at the very end of a tile whose epilogue emitted `stats_out` partials
+// (tile row `tm`, rows m0 .. m0 + BM - 1, NT threads).  Every wave drains its write-through partial stores (s_waitcnt vmcnt(0): acknowledged =
+// visible at the memory side), the workgroup takes a ticket on its row tile's counter, and the one that draws the LAST ticket of the row block
+// (tiles_n of them) reduces the block's N / 64 partials per row to (mean, rstd) -- eight lanes per row, lane i sums partials i, i + 8, ... and
+// octet_sum folds them: row_norm_finalize_kernel's (k_norm.h) association and expressions, i.e. the SAME bits as the separate launch -- reading
+// them past its own L2 (agent-scope loads).  The counter is re-armed by that workgroup (every other arrival has happened), so one zeroed block
+// of counters serves every GEMM of a stream.  No spin anywhere: nobody waits for anybody.
+template <int NT>
+__device__ __forceinline__ void gemm_rows_ticket(const GemmArgs& p, int tm, int m0, int BM, int tid) {
+#pragma clang fp reassociate(off)
+    if (!p.row_norm_out || !p.stats_out) return;
+    __shared__ int s_rows_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned t = __hip_atomic_fetch_add(p.row_ticket + tm, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = t == (unsigned)p.tiles_n - 1u;
+        if (last) __hip_atomic_store(p.row_ticket + tm, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_rows_last = last;
+    }
+    __syncthreads();
+    if (!s_rows_last) return;
+    const int np = p.stats_out_np, i8 = tid & 7;
+    const float inv = 1.0f / (float)(np * 64);
+    for (int r0 = 0; r0 < BM; r0 += NT / 8) {
+        const int r = r0 + (tid >> 3), m = m0 + r;
+        const int mc = m < p.M ? m : p.M - 1;                       // whole octets stay active for the DPP reduction
+        const float* sp = p.stats_out + (size_t)mc * np * 2;
+        float sum = 0.f, sq = 0.f;
+        for (int i = i8; i < np; i += 8) {
+            const f32x2 v = __builtin_bit_cast(f32x2, __hip_atomic_load((const uint64_t*)(sp + 2 * i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            sum += v[0];
+            sq += v[1];
+        }
+        sum = octet_sum(sum);
+        sq = octet_sum(sq);
+        if (r < BM && m < p.M && i8 == 0) {
+            float mean = 0.f, rstd;
+            if (p.norm_out == 2) {
+                mean = sum * inv;
+                rstd = rsqrtf(fmaxf(__builtin_fmaf(-mean, mean, sq * inv), 0.f) + p.norm_out_eps);
+            } else {
+                rstd = rsqrtf(sq * inv + p.norm_out_eps);
+            }
+            p.row_norm_out[2 * (size_t)m] = mean;
+            p.row_norm_out[2 * (size_t)m + 1] = rstd;
+        }
+    }
 }
 
 enum { ACT_NONE = 0, ACT_QGELU = 1, ACT_GELU = 2, ACT_SILU = 3, ACT_GELU_TANH = 5 };
@@ -250,9 +318,7 @@ __device__ __forceinline__ void gemm_store_patch(const GemmArgs& p0, const float
                 st_s = octet_sum(st_s);
                 st_q = octet_sum(st_q);
                 if (live && (lane % LPR) == 0) {
-                    float* dst = p.stats_out + ((size_t)orow * p.stats_out_np + (n_base >> 6)) * 2;
-                    dst[0] = st_s;
-                    dst[1] = st_q;
+                    gemm_stat_put(p, p.stats_out + ((size_t)orow * p.stats_out_np + (n_base >> 6)) * 2, st_s, st_q);
                 }
             }
         }
@@ -408,9 +474,7 @@ __device__ __forceinline__ void gemm_store_tr(const GemmArgs& p, f32x16 (&acc)[M
                 // lane hi = 0: ts = (t0, t2, t4, t6) with t4 = t3, t6 = t1  ->  (t0 + t1) + (t2 + t3) = (ts0 + ts3) + (ts1 + ts2)
                 const float tot_s = (ts[0] + ts[3]) + (ts[1] + ts[2]), tot_q = (tq[0] + tq[3]) + (tq[1] + tq[2]);
                 if (live && hi == 0) {
-                    float* dst = p.stats_out + ((size_t)m * p.stats_out_np + ((n_w0 + cb * 64) >> 6)) * 2;
-                    dst[0] = tot_s;
-                    dst[1] = tot_q;
+                    gemm_stat_put(p, p.stats_out + ((size_t)m * p.stats_out_np + ((n_w0 + cb * 64) >> 6)) * 2, tot_s, tot_q);
                 }
             }
         }
@@ -670,6 +734,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
         gemm_store_patch<ACT, SWIGLU, OUT_F32, REMAP>(p, ep, m0 + wm * 64 + mi * 32, n0 + wn * 64, lane, rowtab, wm * 64 + mi * 32);
         __builtin_amdgcn_wave_barrier();    // complete in order); pins the write / read order for the compiler and the CPU emulator
     }
+    if constexpr (!SWIGLU && !OUT_F32 && !REMAP && !SPLITK) gemm_rows_ticket<256>(p, tm, m0, GEMM_BM, tid);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1002,6 +1067,7 @@ __device__ __forceinline__ void gemm4_body(const GemmArgs& p, int bid, int nwg) 
 
     if constexpr (TR) {       // ---- register-resident epilogue: the accumulators hold C^T, rows are lane-local
         gemm_store_tr<ACT, SWIGLU, MI, NJ, EF>(p, acc, m0 + wrow, n0 + wcol, lane, rowst);
+        if constexpr (!SWIGLU && !FP8) gemm_rows_ticket<512>(p, tm, m0, BM, tid);
         return;
     }
     // ---- epilogue: 32 x 64 patches (BM = 256: 2 row blocks x 2 column halves per wave; BM = 192: 3 row blocks)
@@ -1024,6 +1090,7 @@ __device__ __forceinline__ void gemm4_body(const GemmArgs& p, int bid, int nwg) 
             gemm_store_patch<ACT, SWIGLU, OUT_F32>(p, ep, m0 + wrow + mi * 32, n0 + wcol + nh * 64, lane, rowtab, wrow + mi * 32);
             __builtin_amdgcn_wave_barrier();
         }
+    if constexpr (!SWIGLU && !OUT_F32 && !FP8) gemm_rows_ticket<512>(p, tm, m0, BM, tid);
 }
 template <int ACT, bool SWIGLU, bool OUT_F32, bool TR = false, int EF = -1, int BM = 256>
 __global__ __launch_bounds__(512, 2) void gemm4_bf16_kernel(GemmArgs p) {
@@ -1172,6 +1239,7 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs& p, int bid, int nwg) 
 
     if constexpr (TR) {       // register-resident epilogue (the accumulators hold C^T)
         gemm_store_tr<ACT, SWIGLU, 2, 2, EF>(p, acc, m0 + wm * 64, n0 + grp * 128 + wn * 64, lane, rowst);
+        if constexpr (!SWIGLU && !FP8) gemm_rows_ticket<512>(p, tm, m0, GEMM3_BM, tid);
         return;
     }
     float* ep = (float*)vl2_smem + wave * (32 * 68);
@@ -1191,6 +1259,7 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs& p, int bid, int nwg) 
         gemm_store_patch<ACT, SWIGLU, OUT_F32>(p, ep, m0 + wm * 64 + mi * 32, n0 + grp * 128 + wn * 64, lane, rowtab, wm * 64 + mi * 32);
         __builtin_amdgcn_wave_barrier();
     }
+    if constexpr (!SWIGLU && !OUT_F32 && !FP8) gemm_rows_ticket<512>(p, tm, m0, GEMM3_BM, tid);
 }
 template <int ACT, bool SWIGLU, bool OUT_F32, bool TR = false, int EF = -1, bool WEAVE = false>
 __global__ __launch_bounds__(512, 2) void gemm3_bf16_kernel(GemmArgs p) {
@@ -1419,6 +1488,7 @@ __device__ __forceinline__ void gemm_l8_body(const GemmArgs& p, int bid, int nwg
     gemm_park_row_stats(p, rowtab, rst, tid, GEMM_BM);
     __syncthreads();
     gemm_store_patch<ACT, SWIGLU, OUT_F32>(p, ep, m0 + wm * 32, n0 + wn * 64, lane, rowtab, wm * 32);
+    if constexpr (!SWIGLU && !OUT_F32) gemm_rows_ticket<512>(p, tm, m0, GEMM_BM, tid);
 }
 template <int ACT, bool SWIGLU, bool OUT_F32>
 __global__ __launch_bounds__(512, 1) void gemm_l8_bf16_kernel(GemmArgs p) {

@@ -116,9 +116,7 @@ __device__ __forceinline__ void gemm7_store_rows(const GemmArgs& p, const float*
             st_s = octet_sum(st_s);
             st_q = octet_sum(st_q);
             if (live && (lane & 7) == 0) {
-                float* dst = p.stats_out + ((size_t)m * p.stats_out_np + ((n0 + ch * 64) >> 6)) * 2;
-                dst[0] = st_s;
-                dst[1] = st_q;
+                gemm_stat_put(p, p.stats_out + ((size_t)m * p.stats_out_np + ((n0 + ch * 64) >> 6)) * 2, st_s, st_q);
             }
         }
     }
@@ -312,6 +310,7 @@ __device__ __forceinline__ void gemm7_body(const GemmArgs& p) {
     gemm_park_row_stats(p, rowtab, rst, tid, BM);
     __syncthreads();
     gemm7_store_rows<ACT, OUT_F32, BM / 32>(p, img, rowtab, m0, n0, wave, lane);
+    if constexpr (!OUT_F32) gemm_rows_ticket<512>(p, tm, m0, BM, tid);
 }
 template <int ACT, bool OUT_F32, bool GATHER, int R1, bool WEAVE = false>
 __global__ __launch_bounds__(512, 2) void gemm7_bf16_kernel(GemmArgs p) {

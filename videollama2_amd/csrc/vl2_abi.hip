@@ -93,6 +93,8 @@ struct GemmCtl {
     bool no_mix = false;           // VL2_GEMM_NO_MIX
     bool no_fill = false;          // VL2_GEMM_NO_FILL
     bool weave = false;            // VL2_GEMM_WEAVE
+    bool* fin = nullptr;           // set to true by a launch path whose kernel has no producer-side finalize (gemm_rows_ticket): vl2_gemm then
+                                   // appends the row_norm_finalize launch itself, so `row_norm_out` is filled whichever kernel ran
 };
 
 // ------------------------------------------------------------------------------------------------ GEMM
@@ -310,6 +312,7 @@ static GemmArgs gemm_rows(const GemmArgs& a0, int m0, int rows, bool f32) {
     if (a0.stats_out) a.stats_out = a0.stats_out + (size_t)m0 * a0.stats_out_np * 2;
     if (a0.stats_in) a.stats_in = a0.stats_in + (size_t)m0 * a0.stats_in_np * 2;
     if (a0.row_norm) a.row_norm = a0.row_norm + (size_t)m0 * 2;
+    if (a0.row_norm_out) { a.row_norm_out = a0.row_norm_out + (size_t)m0 * 2; a.row_ticket = a0.row_ticket + m0 / 64; }   // 64 = the smallest tile height
     a.tiles_m = (rows + GEMM_BM - 1) / GEMM_BM;
     return a;
 }
@@ -375,6 +378,7 @@ static void launch_gemm(const GemmArgs& a0, const GemmCtl& c, hipStream_t s) {
     }
     if constexpr (!SW && !F32) {
         if (choose_splitk(a0, c) <= 1 && want_small_m(a0, c)) {
+            if (a0.row_norm_out && c.fin) *c.fin = true;
             lds_attr<gemm_s_bf16_kernel<ACT, G>>(GEMMS_LDS_BYTES);
             GemmArgs a = a0;
             a.tiles_m = (a.M + GEMMS_BM - 1) / GEMMS_BM;
@@ -384,6 +388,7 @@ static void launch_gemm(const GemmArgs& a0, const GemmCtl& c, hipStream_t s) {
         }
     }
     if (const int split = choose_splitk(a0, c); split > 1) {
+        if (a0.row_norm_out && c.fin) *c.fin = true;
         lds_attr<gemm_bf16_kernel<ACT, SW, F32, G, false, true>>(GEMM_LDS_BYTES);
         GemmArgs a = a0;
         a.sk_ws = (float*)c.ws;
@@ -562,6 +567,11 @@ extern "C" int32_t vl2_gemm(const vl2_gemm_desc* d, void* stream) {
         if (d->norm == VL2_NORM_LN && (!d->w_colsum || sw)) return fail(VL2_E_BADARG, "vl2_gemm: fused LayerNorm needs w_colsum (and excludes SWIGLU)");
     }
     if (d->stats_out && (sw || f32)) return fail(VL2_E_UNSUPP, "vl2_gemm: stats_out needs a plain bf16 output");
+    if (d->row_norm_out) {
+        if (!d->stats_out || !d->row_ticket) return fail(VL2_E_BADARG, "vl2_gemm: row_norm_out needs stats_out and row_ticket");
+        if (d->norm_out != VL2_NORM_RMS && d->norm_out != VL2_NORM_LN) return fail(VL2_E_BADARG, "vl2_gemm: unknown norm_out %d", d->norm_out);
+        if ((((uintptr_t)d->row_norm_out) & 7) || (((uintptr_t)d->row_ticket) & 3)) return fail(VL2_E_SHAPE, "vl2_gemm: row_norm_out must be 8-byte, row_ticket 4-byte aligned");
+    }
     if (d->ws && (d->ws_bytes < SK_WS_BYTES || !ALIGNED16(d->ws))) return fail(VL2_E_BADARG, "vl2_gemm: workspace needs >= %lld bytes, 16-byte aligned", (long long)SK_WS_BYTES);
     const int v = d->variant;
     if (!(v == 0 || v == 1 || v == 2 || v == 4 || v == 5 || v == 8 || v == 12 || v == 32 || v == 24 || v == 60 || v == 61 || v == 62 || v == 70 || v == 71 || v == 80 || v == 81 || v == 192 || v == 193 || v == 224 || v == 225 || v == 256)) return fail(VL2_E_BADARG, "vl2_gemm: unknown variant %d", v);
@@ -570,6 +580,8 @@ extern "C" int32_t vl2_gemm(const vl2_gemm_desc* d, void* stream) {
     ctl.no_mix = (d->flags & VL2_GEMM_NO_MIX) != 0;
     ctl.no_fill = (d->flags & VL2_GEMM_NO_FILL) != 0;
     ctl.weave = (d->flags & VL2_GEMM_WEAVE) != 0;
+    bool need_fin = d->row_norm_out && (d->flags & VL2_GEMM_NO_TICKET);      // A/B: the separate launch as in rounds 3-4
+    ctl.fin = &need_fin;
     GemmArgs a{};
     a.A = (const bf16_t*)d->A; a.W = (const bf16_t*)d->W; a.C = d->C; a.bias = d->bias; a.res = (const bf16_t*)d->res;
     a.a_idx = d->a_idx; a.zero_row = nullptr;
@@ -581,6 +593,7 @@ extern "C" int32_t vl2_gemm(const vl2_gemm_desc* d, void* stream) {
     a.stats_out = d->stats_out; a.stats_out_np = N / 64;
     a.stats_in = d->stats_in; a.stats_in_np = K / 64;
     a.norm = d->norm; a.norm_eps = d->norm_eps; a.w_colsum = d->w_colsum; a.row_norm = d->row_norm;
+    if (d->row_norm_out && !need_fin) { a.row_norm_out = d->row_norm_out; a.row_ticket = (unsigned*)d->row_ticket; a.norm_out = d->norm_out; a.norm_out_eps = d->norm_out_eps; }
     a.tile_ctr = d->tile_ctr ? (unsigned*)d->tile_ctr : d->ws ? (unsigned*)((char*)d->ws + GEMM6_CTR_OFF) : nullptr;
     if (d->tile_ctr && ((uintptr_t)d->tile_ctr & 7)) return fail(VL2_E_BADARG, "vl2_gemm: tile_ctr must be 8-byte aligned");
     hipStream_t s = ST(stream);
@@ -609,11 +622,14 @@ extern "C" int32_t vl2_gemm(const vl2_gemm_desc* d, void* stream) {
                 c.C = f32 ? (void*)((float*)c.C + ccol) : (void*)((bf16_t*)c.C + ccol);
                 if (c.res) c.res = c.res + ccol;
                 if (c.stats_out) c.stats_out = c.stats_out + (size_t)(n0 / 64) * 2;
+                if (c.row_norm_out) { c.row_norm_out = nullptr; need_fin = true; }      // a column chunk sees a part of the row's partials only
             }
             const int32_t rc = gemm_dispatch(c, ctl, act, sw, f32, s);
             if (rc) return rc;
         }
     }
+    if (need_fin)      // a kernel without the producer-side finalize ran (64 x 64 tiles, split-K, column chunks), or VL2_GEMM_NO_TICKET asked for the launch
+        hipLaunchKernelGGL(row_norm_finalize_kernel, dim3((M + 31) / 32), dim3(256), 0, s, (const float*)d->stats_out, d->row_norm_out, M, N / 64, N, d->norm_out, d->norm_out_eps);
     return launched("vl2_gemm");
 }
 

@@ -42,6 +42,8 @@ GEMM_PERSISTENT, GEMM_NO_MIX, GEMM_NO_FILL, GEMM_WEAVE, GEMM_FP8 = 8, 16, 32, 64
 STAGE_PERSISTENT_GEMM, STAGE_NO_MIX, STAGE_SELF_REDUCE, STAGE_FUSED_DECODE_ATTN, STAGE_DECODE_TAIL, STAGE_STC_UNFUSED = 1, 2, 4, 8, 16, 32
 STAGE_WEAVE = 256                     # lab: LDS-DMA issue woven into the MFMA phases of the 128x256 / 224x128 / 192x128 ping-pong GEMMs
 STAGE_NO_FILL_TILES = 128             # A/B of the fill-the-round GEMM tiles (csrc/k_gemm7.h)
+STAGE_NO_TICKET_OPS = 2048            # ops.gemm(norm_out=...) only: the appended launch instead of the in-kernel ticket (test / A/B control of the operator path)
+STAGE_ROW_TICKET, GEMM_NO_TICKET = 1024, 256  # stage calls: producer-side finalize (k_gemm.h gemm_rows_ticket) instead of the row_norm_finalize launches (lab: not faster)
 STAGE_PREFILL_FP8 = 512               # prefill projections on the fp8 matrix pipe (W8A8, vl2_llm_desc.layers_w8); set by the decoder, not a lab switch
 STAGE_DECODE_FP8 = 64                 # decode step on the fp8 copies of the weights (vl2_llm_desc.layers_w8); set by the decoder, not a lab switch
 GEMV_RMS_PLAIN = 32   # vl2_*_desc.flags of the stage calls
@@ -82,7 +84,8 @@ def set_stage_flags(flags):
     (the library reads no environment variables and keeps no state)."""
     _CTL["stage_flags"] = int(flags)
     _CTL["gemm_flags"] = (GEMM_PERSISTENT if flags & STAGE_PERSISTENT_GEMM else 0) | (GEMM_NO_MIX if flags & STAGE_NO_MIX else 0) | \
-                         (GEMM_NO_FILL if flags & STAGE_NO_FILL_TILES else 0) | (GEMM_WEAVE if flags & STAGE_WEAVE else 0)
+                         (GEMM_NO_FILL if flags & STAGE_NO_FILL_TILES else 0) | (GEMM_WEAVE if flags & STAGE_WEAVE else 0) | \
+                         (GEMM_NO_TICKET if flags & STAGE_NO_TICKET_OPS else 0)
 
 
 def stage_flags():
@@ -96,13 +99,15 @@ def set_gemm_variant(v):
 
 
 def gemm(a, w, bias=None, res=None, act=ACT_NONE, swiglu=False, out_f32=False, out=None, M=None,
-         gather=None, out_map=None, res_map=None, flop_k=None, stats_out=None, norm=None):
+         gather=None, out_map=None, res_map=None, flop_k=None, stats_out=None, norm=None, norm_out=None):
     """C = epilogue(a @ w.T).  a [M,K] bf16 (or row pool when `gather`), w [N,K] bf16, bias fp32 [N], res bf16 rows.
     gather = (a_idx int32 [nseg, M], zero_row (unused), seg_k).  out_map = (grp, grp_pad, row_off),
     res_map = (row_mod, row_off) -- see include/vl2hip.h.
     stats_out: fp32 [M, N/64, 2] buffer the epilogue fills with (sum, sum of squares) per row and 64-column block of the
     stored output.  norm = (kind, stats_in, eps, w_colsum): Norm(a) @ w.T computed on the raw rows of `a` from the statistics
-    the GEMM that wrote `a` emitted (NORM_RMS / NORM_LN; w must carry the norm weight folded in, bias the folded shift)."""
+    the GEMM that wrote `a` emitted (NORM_RMS / NORM_LN; w must carry the norm weight folded in, bias the folded shift).
+    norm_out = (kind, eps, row_norm_out fp32 [M, 2], tickets uint32 [>= M/64 + 2], zeroed once): with stats_out, the call also leaves
+    (mean, rstd) of its OUTPUT rows in row_norm_out -- what row_norm_finalize(stats_out) would compute, without the launch."""
     _chk(a, _lib.elem_dtype(), "a"); _chk(w, _lib.elem_dtype(), "w"); _chk(bias, torch.float32, "bias"); _chk(res, _lib.elem_dtype(), "res")
     N = w.shape[0]
     if gather is not None:
@@ -139,6 +144,12 @@ def gemm(a, w, bias=None, res=None, act=ACT_NONE, swiglu=False, out_f32=False, o
                       _p(bias), _p(res), res.stride(0) if res is not None else 0, act, flags, _p(a_idx), seg_k,
                       grp, grp_pad, row_off, rmod, roff, _p(stats_out), _p(stats_in), kind, float(eps), _p(colsum), _p(row_norm),
                       _p(ws), ws.numel() if ws is not None else 0, _CTL["variant"])
+    if norm_out is not None:
+        ko, eo, rn_out, tick = norm_out
+        _chk(rn_out, torch.float32, "row_norm_out")
+        if stats_out is None or rn_out.shape[0] < M or tick.numel() < M // 64 + 2 or tick.dtype not in (torch.int32, torch.uint32):
+            raise ValueError("gemm: norm_out needs stats_out, row_norm_out [>= M, 2] and >= M/64 + 2 zeroed 32-bit tickets")
+        d.row_norm_out, d.row_ticket, d.norm_out, d.norm_out_eps = _p(rn_out), _p(tick), ko, float(eo)
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
