@@ -358,6 +358,36 @@ def main():
                 cuts[cut] = dict(error=f"{type(exc).__name__}: {exc}"[:300])
         model.sharder.cut = keep
 
+    # ---- N > 1: what every rank saw and did, each on its OWN clock (the headline numbers are max-over-ranks): a first multi-GPU run explains itself
+    per_rank = None
+    if world > 1:
+        def local_ms(fn, iters):
+            fn()
+            torch.cuda.synchronize()
+            a, b = ev(), ev()
+            a.record()
+            for _ in range(iters):
+                fn()
+            b.record()
+            torch.cuda.synchronize()
+            return a.elapsed_time(b) / iters
+        me = {"rank": rank, "device": torch.cuda.get_device_name(dev), "device_index": dev_index, "frames": c0, "backend": backend}
+        try:
+            tower, conn = model.vision_tower, model.mm_projector
+            me["vit_ms"] = round(local_ms(lambda: tower(frames[s0:s0 + c0]), enc_iters), 3) if c0 > 0 else 0.0
+            if model.sharder.can_shard_connector(T):          # the rank-local piece of the sharded-connector cut: ViT + RegStage s1 on its frames
+                me["vit_s1_ms"] = round(local_ms(lambda: model.sharder.local_s1_of(tower, conn, frames[s0:s0 + c0]), enc_iters), 3)
+            maxc = max(pc for _, pc in parts)
+            send = torch.zeros((maxc, tower.num_patches, tower.hidden_size), dtype=_lib.elem_dtype(), device=dev)
+            recv = torch.empty((world * maxc, tower.num_patches, tower.hidden_size), dtype=_lib.elem_dtype(), device=dev)
+            dist.barrier()
+            me["gather_us"] = round(local_ms(lambda: model.sharder._all_gather(recv, send), 10) * 1e3, 1)     # the ONE collective of the north_star cut, alone
+            me["gather_mb"] = round(recv.numel() * recv.element_size() / 1e6, 2)
+        except Exception as exc:                               # noqa: BLE001  (diagnostics never fail the run)
+            me["error"] = f"{type(exc).__name__}: {exc}"[:300]
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, me)
+
     # ---- optional: the same decode steps on fp8 (e4m3fn, one power-of-two scale per output row) copies of the decoder's weights
     decode_fp8 = None
     if args.decode_weights == "fp8" and world == 1 and tp_group is None:
@@ -608,6 +638,11 @@ def main():
                          "what": f"CLIP tower alone on the rank's {c0} of {T} frames (no collective, no connector), max over ranks"},
         }
         if world > 1:
+            out["ranks_seen"] = sorted(r["rank"] for r in per_rank if r) if per_rank else None
+            out["per_rank"] = per_rank
+            out["targets"] = ("`value` (frames/s through ViT + collective + connector) answers BASELINE.json's metric; the >= 6x frame-parallel target of north_star can "
+                              "only be met by the frame-parallel part -- `vit_only.frames_per_s` (no collective, no connector) -- because the connector is not frame-parallel "
+                              "beyond the sharded_connector cut (SURVEY 8e); both cuts are timed below, `cut` names the one `value` used")
             out["cut"] = model.sharder.cut
             out["north_star_cut"] = cuts["north_star"]
             out["sharded_connector_cut"] = cuts["sharded_connector"]

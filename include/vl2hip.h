@@ -80,6 +80,8 @@ int64_t vl2_workspace_bytes(void);
                                  from the load phases (same bits; faster back to back on warm operands, slower in the pipeline: profiles/r05_experiments.md) */
 /* stage-level descriptors (vl2_vit_desc / vl2_stc_desc / vl2_llm_desc) `flags`: experiment controls, all off by default */
 #define VL2_STAGE_PERSISTENT_GEMM  1   /* every GEMM of the stage with VL2_GEMM_PERSISTENT */
+#define VL2_STAGE_VIT_NO_PERSISTENT 4096 /* vl2_vit_forward only: its GEMMs WITHOUT VL2_GEMM_PERSISTENT (the tower's default since round 5: -0.15 ... -0.27 ms per 16-frame pass
+                                          * on 7 of 7 boxes, profiles/r05_experiments.md section 5); A/B switch */
 #define VL2_STAGE_NO_MIX           2   /* ... with VL2_GEMM_NO_MIX */
 #define VL2_STAGE_NO_FILL_TILES  128   /* ... with VL2_GEMM_NO_FILL */
 #define VL2_STAGE_WEAVE          256   /* ... with VL2_GEMM_WEAVE */
@@ -289,6 +291,16 @@ int32_t vl2_attn_decode_batched(const void* qkv, void* kcache, void* vcache, con
  * state != NULL (device int32[2] = {position, step}): hist index = state[1], then both counters advance by one, so the
  * whole decode step is replayable from a hipGraph.  HF:generation/utils.py _sample with do_sample=False. */
 int32_t vl2_argmax(const float* logits, int32_t V, int32_t* tok, int32_t* hist, int32_t step, int32_t* state, void* stream);
+/* do_sample=True (videollama2/__init__.py:93-106 -> HF GenerationMixin._sample): the logits warpers of HF:generation/logits_process.py in HF's order --
+ * scores / temperature; top_k > 0: scores below the k-th largest removed (ties stay; HF's generation_config default is 50); top_p < 1: ascending
+ * softmax cumsum <= 1 - top_p removed, the largest always stays -- then ONE draw from softmax(kept scores): the token whose interval of the cumulative
+ * distribution, taken in token-index order, contains u[step] (u in [0, 1), device fp32; with `state` the index is state[1]).  torch.multinomial's own
+ * consumption of its random stream is not reproducible outside torch, so parity = the kept set and the probabilities (oracle/sampling_oracle.py,
+ * pinned to the live HF warpers).  tok / hist / step / state exactly as vl2_argmax (the call takes its place in a decode loop or captured graph).
+ * dbg: optional 4 floats {tokens kept, kept mass / top-k mass, threshold score, largest score}.  One 1024-thread workgroup, no sort (radix descent over
+ * the float keys; probability mass in 2^-40 fixed point: deterministic). */
+int32_t vl2_sample_token(const float* logits, int32_t V, float temperature, int32_t top_k, float top_p, const float* u, int32_t* tok, int32_t* hist,
+                         int32_t step, int32_t* state, float* dbg, void* stream);
 /* out[i,:] = table[ids[i],:]; ids int32 device.  embed_tokens in videollama2/model/videollama2_arch.py:203-220. */
 int32_t vl2_embed_rows(const int32_t* ids, const void* table, void* out, int32_t n, int32_t D, int32_t ldo, void* stream);
 

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=2.5)
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--frames", type=int, default=16)
+    ap.add_argument("--phases", default="vit,stc,prefill")
     args = ap.parse_args()
     flags = [int(f) for f in args.flags.split(",")]
     from videollama2_amd import ops
@@ -48,6 +49,7 @@ def main():
     S = vis.shape[1] + 100
     emb = (torch.randn((S, cfg["llm"]["hidden_size"]), device=dev) * 0.02).to(feats.dtype)
     phases = {"vit": lambda: model.vision_tower(frames), "stc": lambda: model.mm_projector(feats), "prefill": lambda: model.decoder.prefill(emb)}
+    phases = {k: v for k, v in phases.items() if k in args.phases.split(",")}
     card, hw = find_sysfs()
     samples, stop = [], threading.Event()
 

@@ -17,6 +17,7 @@ alignas(64) unsigned char vl2_smem[160 * 1024];
 #include "k_fp8.h"
 #include "k_skinny.h"
 #include "k_pack.h"
+#include "k_sample.h"
 #include <cstdint>
 #include <algorithm>
 #include <vector>
@@ -550,6 +551,13 @@ extern "C" int32_t vl2_attn_decode_batched(const void* qkv, void* kc, void* vc, 
 }
 extern "C" int32_t vl2_argmax(const float* logits, int32_t V, int32_t* tok, int32_t* hist, int32_t step, int32_t* state, void*) {
     emu::launch(dim3(1), dim3(1024), [=] { argmax_kernel(logits, V, tok, hist, step, state, (int*)nullptr, 0, (const bf16_t*)nullptr, (bf16_t*)nullptr, 0); });
+    return 0;
+}
+extern "C" int32_t vl2_sample_token(const float* logits, int32_t V, float temperature, int32_t top_k, float top_p, const float* u, int32_t* tok,
+                                    int32_t* hist, int32_t step, int32_t* state, float* dbg, void*) {
+    if (!logits || !tok || !u || V <= 0 || !(temperature > 0.f) || top_k < 0 || !(top_p > 0.f)) return -1;
+    SampleArgs a{logits, V, temperature, top_k, top_p, u, tok, hist, step, state, dbg};
+    emu::launch(dim3(1), dim3(1024), [=] { sample_token_kernel(a); });
     return 0;
 }
 extern "C" int32_t vl2_embed_rows(const int32_t* ids, const void* table, void* out, int32_t n, int32_t D, int32_t ldo, void*) {

@@ -404,5 +404,6 @@ static inline unsigned emu_fetch_add(unsigned* p, unsigned v) { unsigned o = *p;
 static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
 static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
+static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }
 // the harness defines the dynamic LDS array that kernels declare `extern __shared__ ... vl2_smem[]`
 // (the build step rewrites `extern __shared__` -> `extern`)

@@ -259,7 +259,7 @@ def test_full_depth_end_to_end_other_frame_counts(T):
     run_end_to_end(O.config_videollama2_7b(T), T, 8, 4096, tag=f"T={T} ")
 
 
-def plant_outliers(sd, cfg, seed=7, n_ch=6):
+def plant_outliers(sd, cfg, seed=7, n_ch=6, llm_layers=None, llm_mult=40.0):
     """Massive activations, as real CLIP-L / Mistral checkpoints have them and seeded-normal weights do not: six channels of the tower's and
     six of the decoder's residual stream carry a value ~60-100 x the typical one (planted through the biases / extra weight rows of the layers
     that WRITE the stream), the LayerNorm / RMSNorm gains of those channels are x 8, and the whole tower stream is shifted by +4 sigma --
@@ -278,8 +278,8 @@ def plant_outliers(sd, cfg, seed=7, n_ch=6):
             elif k.endswith(("layer_norm1.weight", "layer_norm2.weight", "pre_layrnorm.weight")):
                 v = v.clone(); v[cv] = v[cv] * 8.0
                 sd[k] = v.bfloat16().float()
-        elif k.startswith("model.layers.") and k.endswith(("o_proj.weight", "down_proj.weight")):
-            v = v.clone(); v[cl] = v[cl] * 40.0                     # rows of the projections that write the stream: channels cl get x 40 outputs
+        elif k.startswith("model.layers.") and k.endswith(("o_proj.weight", "down_proj.weight")) and (llm_layers is None or int(k.split(".")[2]) in llm_layers):
+            v = v.clone(); v[cl] = v[cl] * llm_mult                 # rows of the projections that write the stream: channels cl get x 40 outputs
             sd[k] = v.bfloat16().float()
         elif k.startswith("model.layers.") and k.endswith(("input_layernorm.weight", "post_attention_layernorm.weight")):
             v = v.clone(); v[cl] = v[cl] * 8.0
@@ -297,6 +297,15 @@ def test_outlier_channels_tower_stc_four_decoder_layers():
     run_end_to_end(cfg, 4, 4, 1024, mutate=plant_outliers, tag="outliers ")
 
 
+def plant_outliers_stationary(sd, cfg):
+    """The deep fixture's mutation: the decoder's massive channels are written ONCE (layer 0's o_proj / down_proj rows x 60) and then ride the residual
+    stream, as they do in real checkpoints (a few channels written by an early MLP, ~constant through the depth); every layer's norm gains of those
+    channels stay x 8.  Planting x 40 rows in EVERY layer -- the 4-layer fixture's recipe -- compounds with depth: at 8 layers the problem itself is
+    ill-conditioned (measured on the build box, fp32 vs torch-bf16 of the oracle alone: logits 0.1-0.7 apart from step to step; first GPU run of this
+    test: floor 0.11-1.1), i.e. it tests nothing.  This form measures 2.4-3.8e-2 for the bf16 floor at 8 layers, stable over the steps."""
+    return plant_outliers(sd, cfg, llm_layers=(0,), llm_mult=60.0)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("elem", ["bf16", "fp16"])
 def test_outlier_channels_twelve_tower_eight_decoder_layers(elem):
@@ -307,7 +316,7 @@ def test_outlier_channels_twelve_tower_eight_decoder_layers(elem):
     cfg = O.config_videollama2_7b(4)
     cfg["vision"]["num_hidden_layers"] = 13                        # hidden_states[-2] = the output of layer 12
     cfg["llm"]["num_hidden_layers"] = 8
-    run_end_to_end(cfg, 4, 31, 1024, min_decidable=3 if elem == "bf16" else 16, mutate=plant_outliers, tag=f"outliers 12+8 {elem} ", elem=elem)
+    run_end_to_end(cfg, 4, 31, 1024, min_decidable=3 if elem == "bf16" else 16, mutate=plant_outliers_stationary, tag=f"outliers 12+8 {elem} ", elem=elem)
 
 
 def run_end_to_end(cfg, T, n_dec, max_seq_len, min_decidable=0, mutate=None, tag="", elem="bf16", fp8_decode=False):

@@ -104,6 +104,7 @@ SIGNATURES = {
     "vl2_attn_decode_fused": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _f32, _vp, _vp],
     "vl2_attn_decode_batched": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _i64, _i32, _i32, _i32, _vp, _i32, _f32, _vp],
     "vl2_argmax": [_vp, _i32, _vp, _vp, _i32, _vp, _vp],
+    "vl2_sample_token": [_vp, _i32, _f32, _i32, _f32, _vp, _vp, _vp, _i32, _vp, _vp, _vp],
     "vl2_embed_rows": [_vp, _vp, _vp, _i32, _i32, _i32, _vp],
 }
 EXPORTS = ["vl2_version", "vl2_elem_name", "vl2_last_error_string", "vl2_workspace_bytes", "vl2_vit_workspace_bytes", "vl2_stc_workspace_bytes", "vl2_llm_workspace_bytes", "vl2_dwconv_mean_workspace_bytes"] + list(SIGNATURES)

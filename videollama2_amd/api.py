@@ -111,8 +111,8 @@ def model_init(model_path, device="cuda", max_seq_len=4096, tokenizer=None, **kw
 def mm_infer(image_or_video, instruct, model, tokenizer, modal="video", **kwargs):
     """videollama2/__init__.py:32-114: tag + chat-template the instruction, put the modal sentinel in the ids, greedy-generate
     with the keyword stopping criterion, decode.  Frames go to the device as the reference sends them (`tensor.half()`,
-    __init__.py:60; the patch-row kernel reads fp16 / bf16 / fp32 / uint8 frames alike); sampling is not built
-    (`do_sample=True` raises, the reference default is greedy)."""
+    __init__.py:60; the patch-row kernel reads fp16 / bf16 / fp32 / uint8 frames alike).  do_sample / temperature / top_p are read
+    from kwargs with the reference's defaults (__init__.py:93-95: temperature 0.2 when sampling, top_p 0.9) and handed to generate."""
     if modal == "image":
         modal_token = DEFAULT_IMAGE_TOKEN
     elif modal == "video":
@@ -137,9 +137,11 @@ def mm_infer(image_or_video, instruct, model, tokenizer, modal="video", **kwargs
     attention_masks = input_ids.ne(tokenizer.pad_token_id).long()
     stopping_criteria = KeywordsStoppingCriteria([tokenizer.eos_token], tokenizer, input_ids)
     do_sample = kwargs.get("do_sample", False)
+    temperature = kwargs.get("temperature", 0.2 if do_sample else 0.0)         # __init__.py:94 (unused by greedy decoding)
+    top_p = kwargs.get("top_p", 0.9)                                           # __init__.py:95
     with torch.inference_mode():
         output_ids = model.generate(input_ids, attention_mask=attention_masks, images=tensor, do_sample=do_sample,
-                                    max_new_tokens=kwargs.get("max_new_tokens", 2048), use_cache=True,
+                                    temperature=temperature, top_p=top_p, max_new_tokens=kwargs.get("max_new_tokens", 2048), use_cache=True,
                                     stopping_criteria=[stopping_criteria], pad_token_id=tokenizer.eos_token_id,
                                     eos_token_id=tokenizer.eos_token_id)
     return tokenizer.batch_decode(output_ids, skip_special_tokens=True)[0].strip()

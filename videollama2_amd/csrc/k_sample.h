@@ -1,0 +1,202 @@
+// Sampled next token: temperature -> top-k -> top-p -> softmax -> one draw, on the fp32 logits of the decode step, ONE workgroup.
+//
+// Replaces what HF `GenerationMixin._sample` does with torch ops when the reference calls `model.generate(..., do_sample=True, temperature=,
+// top_p=)` (videollama2/__init__.py:93-106; the gradio demo uses temperature 0.2): the logits warpers of HF:generation/logits_process.py
+//   TemperatureLogitsWarper   scores / temperature
+//   TopKLogitsWarper          remove scores < the k-th largest (ties with it stay)                      (generation_config default top_k = 50)
+//   TopPLogitsWarper          sort ascending, softmax, cumsum; remove where cumsum <= 1 - top_p; the largest always stays
+// then probs = softmax(scores) and torch.multinomial(probs, 1).  The draw itself cannot be the reference's bit for bit (torch.multinomial
+// consumes its Philox stream in an implementation-defined way), so the contract is: the KEPT SET and the renormalised probabilities are the
+// warpers', and the token is the inverse CDF of those probabilities, in token-index order, at the uniform number `u` the host hands over
+// (oracle/sampling_oracle.py restates exactly this and is pinned to the live HF warpers).
+//
+// No sort: floats are compared through their order-preserving 32-bit keys, and both thresholds are found by radix descent over the key bits,
+// 8 bits per pass -- counts for top-k, probability MASS for top-p.  Mass is summed in 2^-40 fixed point (64-bit integer LDS atomics): integer
+// addition is associative, so every histogram is the same whatever order the lanes arrive in, and the kernel is deterministic.  The logits
+// (128 KB at V = 32000, 600 KB at 152064) stay in L2; a pass is V / 1024 coalesced loads per thread.
+#pragma once
+#include "dev_common.h"
+
+__device__ __forceinline__ uint32_t sample_key(float x) {          // monotonic: a < b  <=>  key(a) < key(b)  (no NaNs in logits)
+    const uint32_t b = __builtin_bit_cast(uint32_t, x);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+// `scores / temperature` as torch computes it (correctly rounded fp32 division) whatever -ffast-math turns a float division into: the quotient of
+// two floats formed in double and rounded once more is the correctly rounded float quotient (53 >= 2 * 24 + 2 bits: the double rounding is innocuous)
+#define VL2_FDIV_RN(a, b) ((float)((double)(a) / (double)(b)))
+#define SAMPLE_FIX 1099511627776.0f                                // 2^40: a probability relative to the maximum, as a 64-bit integer
+
+struct SampleArgs {
+    const float* logits;   // [V] fp32
+    int V;
+    float temperature;     // > 0
+    int top_k;             // 0 (or >= V) = off
+    float top_p;           // >= 1 = off
+    const float* u;        // uniform numbers in [0, 1): u[step] is consumed
+    int* tok;              // -> the sampled token
+    int* hist;             // optional: hist[step] = token
+    int step;              // used when state == null
+    int* state;            // optional (hipGraph-replayable decode): step = state[1]; afterwards state[0] (position) and state[1] advance by one
+    float* dbg;            // optional [4]: {kept tokens, kept mass / total mass, threshold score, max score} of the call
+};
+
+__global__ __launch_bounds__(1024) void sample_token_kernel(SampleArgs p) {
+    __shared__ unsigned long long hist64[256];
+    __shared__ float s_red[16];
+    __shared__ uint32_t s_prefix;
+    __shared__ unsigned long long s_base, s_target, s_thr;
+    __shared__ int s_sel, s_tok, s_kept;
+    __shared__ unsigned long long s_m[1024];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int V = p.V;
+    const float T = p.temperature;
+    if (tid == 0) { s_kept = 0; s_tok = -1; }
+    // ---- pass A: the maximum score (the softmax shift; also the last key of every descent)
+    float mx = -3.4e38f;
+    for (int i = tid; i < V; i += 1024) mx = fmaxf(mx, VL2_FDIV_RN(p.logits[i], T));
+    mx = wave_max(mx);
+    if (lane == 0) s_red[wave] = mx;
+    __syncthreads();
+    mx = s_red[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) mx = fmaxf(mx, s_red[w]);
+    __syncthreads();
+    // ---- top-k: the key of the k-th largest score by radix descent over COUNTS (from the top bin downwards)
+    uint32_t key_lo = 0;                                            // kept: key >= key_lo
+    if (p.top_k > 0 && p.top_k < V) {
+        uint32_t prefix = 0;
+        unsigned long long need = (unsigned long long)p.top_k;     // rank still to be found inside the current prefix
+        for (int lvl = 3; lvl >= 0; --lvl) {
+            if (tid < 256) hist64[tid] = 0ull;
+            __syncthreads();
+            const int sh = lvl * 8;
+            for (int i = tid; i < V; i += 1024) {
+                const uint32_t k = sample_key(VL2_FDIV_RN(p.logits[i], T));
+                if (lvl == 3 || (k >> (sh + 8)) == (prefix >> (sh + 8))) atomicAdd(&hist64[(k >> sh) & 255u], 1ull);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                unsigned long long acc = 0;
+                int d = 255;
+                for (; d > 0; --d) {
+                    if (acc + hist64[d] >= need) break;
+                    acc += hist64[d];
+                }
+                s_prefix = prefix | ((uint32_t)d << sh);
+                s_base = need - acc;
+            }
+            __syncthreads();
+            prefix = s_prefix;
+            need = s_base;
+            __syncthreads();
+        }
+        key_lo = prefix;
+    }
+    // ---- top-p: ascending cumulative mass; removed while cumulative <= (1 - top_p) * Z.  Level 3 also yields Z (the total of its bins).
+    unsigned long long Z = 0;
+    {
+        uint32_t prefix = 0;
+        unsigned long long below = 0;                              // mass of the survivors with keys below the current prefix range
+        const bool want_p = p.top_p < 1.0f;
+        for (int lvl = 3; lvl >= (want_p ? 0 : 3); --lvl) {
+            if (tid < 256) hist64[tid] = 0ull;
+            __syncthreads();
+            const int sh = lvl * 8;
+            for (int i = tid; i < V; i += 1024) {
+                const float s = VL2_FDIV_RN(p.logits[i], T);
+                const uint32_t k = sample_key(s);
+                if (k >= key_lo && (lvl == 3 || (k >> (sh + 8)) == (prefix >> (sh + 8))))
+                    atomicAdd(&hist64[(k >> sh) & 255u], (unsigned long long)(__expf(s - mx) * SAMPLE_FIX));
+            }
+            __syncthreads();
+            if (tid == 0) {
+                if (lvl == 3) {
+                    unsigned long long z = 0;
+                    for (int d = 0; d < 256; ++d) z += hist64[d];
+                    s_target = z;
+                    // (1 - top_p) in fp32 as HF forms it, times Z in double: the largest integer mass that still counts as "<= threshold"
+                    s_thr = want_p ? (unsigned long long)((double)(1.0f - p.top_p) * (double)z) : 0ull;
+                }
+                const unsigned long long r = s_thr;
+                unsigned long long acc = below;
+                int d = 0;
+                for (; d < 255; ++d) {
+                    if (acc + hist64[d] > r) break;                 // the first bin whose cumulative mass exceeds the threshold: its keys are (partly) kept
+                    acc += hist64[d];
+                }
+                s_prefix = prefix | ((uint32_t)d << sh);
+                s_base = acc;
+            }
+            __syncthreads();
+            if (lvl == 3) Z = s_target;
+            prefix = s_prefix;
+            below = s_base;
+            __syncthreads();
+        }
+        if (want_p && prefix > key_lo) key_lo = prefix;             // kept: cumulative mass up to and including the key exceeds the threshold
+    }
+    // ---- the draw: inverse CDF over the kept tokens in INDEX order.  Thread t owns the contiguous chunk [t * c, (t + 1) * c)
+    const int c = (V + 1023) / 1024;
+    const int i0 = tid * c, i1 = i0 + c < V ? i0 + c : V;
+    unsigned long long mine = 0;
+    int cnt = 0;
+    for (int i = i0; i < i1; ++i) {
+        const float s = VL2_FDIV_RN(p.logits[i], T);
+        if (sample_key(s) >= key_lo) { mine += (unsigned long long)(__expf(s - mx) * SAMPLE_FIX); ++cnt; }
+    }
+    // the chunk that holds the target: the 1024 chunk masses through LDS, walked by thread 0 (a few microseconds; the kernel runs once per token)
+    s_m[tid] = mine;
+    if (cnt) atomicAdd(&s_kept, cnt);
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long tot = 0;
+        for (int t = 0; t < 1024; ++t) tot += s_m[t];
+        const int step = p.state ? p.state[1] : p.step;
+        float u = p.u[step];
+        u = u < 0.f ? 0.f : (u >= 1.f ? 0.99999994f : u);
+        unsigned long long tgt = (unsigned long long)((double)u * (double)tot);
+        if (tgt >= tot) tgt = tot - 1;
+        unsigned long long acc = 0;
+        int t = 0;
+        for (; t < 1023; ++t) {
+            if (tgt < acc + s_m[t]) break;
+            acc += s_m[t];
+        }
+        s_sel = t;                                                   // the owning chunk; its exclusive prefix in s_base
+        s_base = acc;
+        s_target = tgt;
+        if (p.dbg) { p.dbg[0] = (float)s_kept; p.dbg[1] = Z ? (float)((double)tot / (double)Z) : 1.f; p.dbg[3] = mx; }
+    }
+    __syncthreads();
+    if (tid == s_sel) {
+        const unsigned long long tgt = s_target;
+        unsigned long long acc = s_base;
+        int sel = -1, last = -1;
+        for (int i = i0; i < i1; ++i) {
+            const float s = VL2_FDIV_RN(p.logits[i], T);
+            if (sample_key(s) >= key_lo) {
+                const unsigned long long f = (unsigned long long)(__expf(s - mx) * SAMPLE_FIX);
+                if (f > 0) last = i;
+                if (f > 0 && tgt < acc + f) { sel = i; break; }
+                acc += f;
+            }
+        }
+        s_tok = sel >= 0 ? sel : last;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const int sel = s_tok;
+        *p.tok = sel;
+        if (p.dbg) {
+            const uint32_t kb = (key_lo & 0x80000000u) ? (key_lo & 0x7fffffffu) : ~key_lo;
+            p.dbg[2] = key_lo ? __builtin_bit_cast(float, kb) : -3.4e38f;
+        }
+        if (p.state) {
+            if (p.hist) p.hist[p.state[1]] = sel;
+            p.state[0] += 1;
+            p.state[1] += 1;
+        } else if (p.hist) {
+            p.hist[p.step] = sel;
+        }
+    }
+}

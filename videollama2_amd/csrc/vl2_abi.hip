@@ -16,6 +16,7 @@
 #include "k_gemm7.h"
 #include "k_norm.h"
 #include "k_pack.h"
+#include "k_sample.h"
 #include "k_skinny.h"
 #include "k_stc.h"
 #include "k_vit.h"
@@ -1085,6 +1086,17 @@ extern "C" int32_t vl2_argmax(const float* logits, int32_t V, int32_t* tok, int3
     if (!logits || !tok || V <= 0) return fail(VL2_E_BADARG, "vl2_argmax: bad args");
     hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(1024), 0, ST(stream), logits, V, tok, hist, step, state, (int*)nullptr, 0, (const bf16_t*)nullptr, (bf16_t*)nullptr, 0);
     return launched("vl2_argmax");
+}
+// do_sample=True: temperature -> top-k -> top-p -> one draw at the host's uniform number (k_sample.h; HF:generation/logits_process.py warpers +
+// GenerationMixin._sample).  Same token / history / state protocol as vl2_argmax, so it takes the argmax launch's place in a decode loop or graph.
+extern "C" int32_t vl2_sample_token(const float* logits, int32_t V, float temperature, int32_t top_k, float top_p, const float* u, int32_t* tok,
+                                    int32_t* hist, int32_t step, int32_t* state, float* dbg, void* stream) {
+    if (!logits || !tok || !u || V <= 0) return fail(VL2_E_BADARG, "vl2_sample_token: null pointer or empty vocabulary");
+    if (!(temperature > 0.f) || top_k < 0 || !(top_p > 0.f)) return fail(VL2_E_BADARG, "vl2_sample_token: need temperature > 0, top_k >= 0, top_p > 0 (got %g, %d, %g)", (double)temperature, top_k, (double)top_p);
+    if (!state && step < 0) return fail(VL2_E_BADARG, "vl2_sample_token: negative step");
+    SampleArgs a{logits, V, temperature, top_k, top_p, u, tok, hist, step, state, dbg};
+    hipLaunchKernelGGL(sample_token_kernel, dim3(1), dim3(1024), 0, ST(stream), a);
+    return launched("vl2_sample_token");
 }
 // the decode step's argmax, which also clears `nzero` int32 words (the fused attention launches' ticket counters)
 static int32_t argmax_and_clear(const float* logits, int32_t V, int32_t* tok, int32_t* hist, int32_t* state, int32_t* zero, int32_t nzero,

@@ -236,20 +236,27 @@ class HipMistralDecoder(nn.Module):
         return self.logits
 
     @torch.no_grad()
-    def capture_graph(self):
-        """Capture {argmax -> decode step} once as a hipGraph (torch.cuda.CUDAGraph records the launches libvl2hip.so
+    def capture_graph(self, sampler=None):
+        """sampler = (temperature, top_k, top_p): the sampled-token launch (ops.sample_token, reading its uniform number u[step] from
+        self.u_buf on the device) takes the argmax's place in the captured step; one graph per sampler setting.
+        Capture {argmax -> decode step} once as a hipGraph (torch.cuda.CUDAGraph records the launches libvl2hip.so
         enqueues on the capture stream).  Replays read token / position / step from device memory.
         Tensor-parallel decoders: the two all-reduces per layer are RCCL kernels on the capture stream and become graph nodes
         like every other launch (ProcessGroupNCCL supports stream capture); the host-staged gloo debug path cannot be captured."""
         if (self.tp > 1 or self.tp_always_reduce) and (self.tp_group is None or dist.get_backend(self.tp_group) != "nccl"):
             raise NotImplementedError("hipGraph decode under tensor parallelism needs the nccl (RCCL) backend: gloo stages through the host")
-        if self.graph is not None:
+        if sampler is None and self.graph is not None:
             return self.graph
+        if sampler is not None and getattr(self, "_graph_sample", (None, None))[0] == tuple(sampler):
+            return self._graph_sample[1]
         saved = (self.state.clone(), self.tok.clone(), self.logits.clone(), self.hist[:2].clone())
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         def one_step():                                       # argmax + the token's forward: ONE call into libvl2hip.so
-            if self._use_stage():
+            if sampler is not None:                           # (the stage call opens with its own argmax: the sampled step is the operator sequence)
+                ops.sample_token(self.logits, self.tok, self.u_buf, sampler[0], sampler[1], sampler[2], hist=self.hist, state=self.state)
+                self._decode_kernels(dyn=True)
+            elif self._use_stage():
                 d, _, ws = self._stage_desc()
                 ops.llm_decode_step(d, self.logits, self.tok, self.state, self.hist, self.partial, ws, fp8=getattr(self, "decode_fp8", False))
             else:
@@ -266,18 +273,24 @@ class HipMistralDecoder(nn.Module):
             one_step()
         self.state.copy_(saved[0]); self.tok.copy_(saved[1]); self.logits.copy_(saved[2]); self.hist[:2].copy_(saved[3])
         torch.cuda.synchronize()
-        self.graph = g
+        if sampler is not None:
+            self._graph_sample = (tuple(sampler), g)
+        else:
+            self.graph = g
         return g
 
     @torch.no_grad()
     def generate(self, inputs_embeds, max_new_tokens=2048, eos_token_id=None, stopping_criteria=None,
-                 return_logits=False, use_graph=False, streamer=None):
+                 return_logits=False, use_graph=False, streamer=None, sampler=None):
         """Greedy decode (HF GenerationMixin._sample, do_sample=False): returns LongTensor [1, n_new] of NEW tokens.
         Stops at `eos_token_id` (int or list), when `stopping_criteria(output_ids, None)` is truthy
         (KeywordsStoppingCriteria semantics, videollama2/mm_utils.py:341-345), or at max_new_tokens / cache end.
         use_graph=True replays one captured hipGraph per token (argmax + the whole decode step).
         streamer: optional object with put(LongTensor[1, n]) / end() (the HF `BaseStreamer` protocol the reference's worker
-        uses with TextIteratorStreamer, serve/model_worker.py:263-300): every new token is handed over as soon as it is known."""
+        uses with TextIteratorStreamer, serve/model_worker.py:263-300): every new token is handed over as soon as it is known.
+        sampler = (temperature, top_k, top_p[, generator]): HF `_sample` with do_sample=True -- the logits warpers in HF's order and one draw per
+        step (ops.sample_token, csrc/k_sample.h) instead of the argmax; the uniform numbers come from torch's generator for this device (or the
+        given one), so `torch.manual_seed` makes a run repeatable like it does for the reference."""
         eos = set()
         if eos_token_id is not None:
             eos = set(eos_token_id) if isinstance(eos_token_id, (list, tuple, set)) else {int(eos_token_id)}
@@ -293,8 +306,15 @@ class HipMistralDecoder(nn.Module):
         # max_seq_len (the kernels now ignore such a step, but there is nothing to replay either) -> plain last-step path
         tp_ok = self.tp == 1 or (self.tp_group is not None and dist.get_backend(self.tp_group) == "nccl")
         use_graph = use_graph and tp_ok and self._dev.type == "cuda" and self.pos < self.max_seq_len
+        if sampler is not None:
+            T, tk, tp = float(sampler[0]), int(sampler[1]), float(sampler[2])
+            gen = sampler[3] if len(sampler) > 3 else None
+            if getattr(self, "u_buf", None) is None:
+                self.u_buf = torch.zeros((self.max_seq_len + 1,), dtype=torch.float32, device=self._dev)
+            self.u_buf[:max_new_tokens].copy_(torch.rand((max_new_tokens,), device=self._dev, generator=gen))
+            sampler = (T, tk, tp)
         if use_graph:
-            g = self.capture_graph()
+            g = self.capture_graph(sampler)
             self.state.copy_(torch.tensor([self.pos - 1, 0], dtype=torch.int32))
         for step in range(max_new_tokens):
             if return_logits:
@@ -303,6 +323,8 @@ class HipMistralDecoder(nn.Module):
             if use_graph and not last:
                 g.replay()                           # argmax(step) + forward of the new token -> logits(step+1)
                 self.pos += 1
+            elif sampler is not None:
+                ops.sample_token(self.logits, self.tok, self.u_buf, sampler[0], sampler[1], sampler[2], hist=self.hist, step=step)
             else:
                 ops.argmax(self.logits, self.tok, self.hist, step)
             t = int(self.tok.item())                 # one 4-byte D2H per token (the reference syncs per token too)

@@ -229,8 +229,18 @@ class VideoLLaMA2Hip(nn.Module):
         attention_mask = kwargs.pop("attention_mask", None)
         if "inputs_embeds" in kwargs:
             raise NotImplementedError("`inputs_embeds` is not supported")                # videollama2_mistral.py:119-120
+        sampler = None
         if kwargs.get("do_sample", False):
-            raise NotImplementedError("HIP path implements greedy decoding (do_sample=False, the reference default)")
+            # HF GenerationMixin.generate -> _get_logits_processor: temperature (default 1.0), top_k (generation_config default 50), top_p (default
+            # 1.0) as warpers in that order, then one multinomial draw per step (videollama2/__init__.py:93-106 passes temperature and top_p)
+            temperature, top_k, top_p = kwargs.get("temperature", 1.0), kwargs.get("top_k", 50), kwargs.get("top_p", 1.0)
+            temperature = 1.0 if temperature is None else float(temperature)
+            top_k, top_p = (0 if top_k is None else int(top_k)), (1.0 if top_p is None else float(top_p))
+            if not temperature > 0.0:
+                raise ValueError(f"`temperature` (={temperature}) has to be a strictly positive float")       # HF TemperatureLogitsWarper.__init__
+            if top_k < 0 or not 0.0 < top_p <= 1.0:
+                raise ValueError(f"`top_k` has to be >= 0 and `top_p` a float > 0 and <= 1, but are {top_k} / {top_p}")
+            sampler = (temperature, top_k, top_p, kwargs.get("generator", None))
         if inputs.dim() == 1:
             inputs = inputs[None]
         emb, lens = self._inputs_embeds(inputs, attention_mask, images)
@@ -238,14 +248,14 @@ class VideoLLaMA2Hip(nn.Module):
         if emb.shape[0] == 1:
             return self.decoder.generate(emb[0, :lens[0]], max_new_tokens=max_new, eos_token_id=eos,
                                          stopping_criteria=kwargs.get("stopping_criteria", None),
-                                         return_logits=kwargs.get("return_logits", False), streamer=kwargs.get("streamer", None),
+                                         return_logits=kwargs.get("return_logits", False), streamer=kwargs.get("streamer", None), sampler=sampler,
                                          # one captured hipGraph per token by default (what bench.py measures); `use_graph=False`
                                          # keeps the eager launch loop
                                          use_graph=kwargs.get("use_graph", self._dev.type == "cuda" and self.decoder.tp == 1))
         # batch > 1 (right-padded, arch.py:227-261): the sequences decode together, each on its own cache / position; finished rows
         # are filled with pad_token_id like HF's generate does
-        if kwargs.get("stopping_criteria") is not None or kwargs.get("streamer") is not None or kwargs.get("return_logits"):
-            raise NotImplementedError("HIP path: stopping_criteria / streamer / return_logits are built for batch 1")
+        if kwargs.get("stopping_criteria") is not None or kwargs.get("streamer") is not None or kwargs.get("return_logits") or sampler is not None:
+            raise NotImplementedError("HIP path: stopping_criteria / streamer / return_logits / do_sample are built for batch 1")
         outs = self.decoder.generate_batch([emb[bi, :lens[bi]] for bi in range(emb.shape[0])], max_new_tokens=max_new, eos_token_id=eos)
         pad = kwargs.get("pad_token_id", None)
         pad = 0 if pad is None else int(pad)

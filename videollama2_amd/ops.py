@@ -42,6 +42,7 @@ GEMM_PERSISTENT, GEMM_NO_MIX, GEMM_NO_FILL, GEMM_WEAVE, GEMM_FP8 = 8, 16, 32, 64
 STAGE_PERSISTENT_GEMM, STAGE_NO_MIX, STAGE_SELF_REDUCE, STAGE_FUSED_DECODE_ATTN, STAGE_DECODE_TAIL, STAGE_STC_UNFUSED = 1, 2, 4, 8, 16, 32
 STAGE_WEAVE = 256                     # lab: LDS-DMA issue woven into the MFMA phases of the 128x256 / 224x128 / 192x128 ping-pong GEMMs
 STAGE_NO_FILL_TILES = 128             # A/B of the fill-the-round GEMM tiles (csrc/k_gemm7.h)
+STAGE_VIT_NO_PERSISTENT = 4096        # vl2_vit_forward without the persistent GEMM form (its default since round 5): A/B
 STAGE_NO_TICKET_OPS = 2048            # ops.gemm(norm_out=...) only: the appended launch instead of the in-kernel ticket (test / A/B control of the operator path)
 STAGE_ROW_TICKET, GEMM_NO_TICKET = 1024, 256  # stage calls: producer-side finalize (k_gemm.h gemm_rows_ticket) instead of the row_norm_finalize launches (lab: not faster)
 STAGE_PREFILL_FP8 = 512               # prefill projections on the fp8 matrix pipe (W8A8, vl2_llm_desc.layers_w8); set by the decoder, not a lab switch
@@ -421,6 +422,14 @@ def attn_decode_batched(qkv, kcache, vcache, cos_t, sin_t, partial, out, nh, nkv
 
 def argmax(logits, tok, hist=None, step=0, state=None):
     _lib.call("vl2_argmax", _p(logits), logits.numel(), _p(tok), _p(hist), step, _p(state), _stream())
+
+
+def sample_token(logits, tok, u, temperature, top_k=50, top_p=1.0, hist=None, step=0, state=None, dbg=None):
+    """One sampled token from fp32 logits (include/vl2hip.h vl2_sample_token): temperature -> top-k -> top-p (HF's warpers, HF's order), then the
+    inverse CDF of the kept, renormalised probabilities at u[step] (u: device fp32 uniforms in [0, 1)).  tok / hist / step / state as `argmax`."""
+    _chk(logits, torch.float32, "logits"); _chk(u, torch.float32, "u"); _chk(dbg, torch.float32, "dbg")
+    _lib.call("vl2_sample_token", _p(logits), logits.numel(), float(temperature), int(top_k), float(top_p), _p(u), _p(tok), _p(hist), int(step),
+              _p(state), _p(dbg), _stream())
 
 
 def embed_rows(ids_i32, table, out):
