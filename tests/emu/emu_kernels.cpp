@@ -7,6 +7,7 @@ alignas(64) unsigned char vl2_smem[160 * 1024];
 #include "k_gemm.h"
 #include "k_gemm6.h"
 #include "k_gemm7.h"
+#include "k_gemm8.h"
 #include "k_norm.h"
 #include "k_vit.h"
 #include "k_attn.h"
@@ -66,6 +67,14 @@ static void run_gemm(GemmArgs a) {
         }
         if (g_gemm_variant == 256) {
             emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(512), [=] { gemm_l8_bf16_kernel<ACT, SW, F32>(a); });
+            return;
+        }
+        if (g_gemm_variant == 9 && a.N % 256 == 0) {            // gemm8: the 256 x 256 tile on four waves (128 x 128 wave tiles)
+            a.tiles_m = (a.M + 255) / 256; a.tiles_n = a.N / 256;
+            if constexpr (!F32) {
+                if (a.res == nullptr) { emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(256), [=] { gemm8_bf16_kernel<ACT, SW, false, true>(a); }); return; }
+            }
+            emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(256), [=] { gemm8_bf16_kernel<ACT, SW, F32>(a); });
             return;
         }
         if (g_gemm_variant == 8 && a.N % 256 == 0) {
@@ -225,6 +234,7 @@ extern "C" int32_t vl2_gemm(const vl2_gemm_desc* d, void*) {
         return 0;
     }
     if (d->norm && ((!d->stats_in && !d->row_norm) || (d->norm == 2 && !d->w_colsum))) return -1;
+    if (d->norm && !d->row_norm && (K % 128)) return -2;          // vl2_abi.hip: the in-GEMM reduction reads the partials as 16-byte pairs
     if (d->out_grp > 0 || d->res_row_mod > 0) {
         emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(256), [=] { gemm_bf16_kernel<0, false, false, false, true>(a); });
         return 0;

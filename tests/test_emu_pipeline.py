@@ -170,9 +170,27 @@ def test_emu_gemm_pingpong_variant(emu):
         a, w = bf(300, K), bf(512, K)
         ref = ops.gemm(a, w, out_f32=True)
         try:
-            for v in (4, 5, 8, 256):
+            for v in (4, 5, 8, 9, 256):                             # 9 = gemm8: the 256 x 256 tile on four waves (k_gemm8.h)
                 ops.set_gemm_variant(v)
                 assert torch.equal(ops.gemm(a, w, out_f32=True), ref)
+        finally:
+            ops.set_gemm_variant(0)
+    # gemm8 through every epilogue form: LDS patches (residual, statistics + producer-side finalize) and the register-resident C^T form (bias /
+    # activation, SwiGLU, LayerNorm carried), ragged M, K from one slab to a full ring and beyond
+    from videollama2_amd.weights import pack_gate_up
+    for M, K in ((300, 64), (257, 192), (520, 576)):
+        a, w, bias, res = bf(M, K), bf(512, K, scale=K ** -0.5), torch.randn(512), bf(M, 512)
+        wgu = pack_gate_up(bf(256, K, seed=3), bf(256, K, seed=4))
+        rn_in = ops.row_norm_finalize(ops.row_stats(a), K, ops.NORM_LN, 1e-5)
+        outs = {}
+        try:
+            for v in (1, 9):
+                ops.set_gemm_variant(v)
+                st, rn, tick = torch.zeros(M, 8, 2), torch.zeros(M, 2), torch.zeros(M // 64 + 2, dtype=torch.int32)
+                outs[v] = [ops.gemm(a, w, bias=bias, res=res, stats_out=st, norm_out=(ops.NORM_LN, 1e-5, rn, tick)), st, rn,
+                           ops.gemm(a, w, bias=bias, act=ops.ACT_QGELU), ops.gemm(a, wgu, swiglu=True)]
+                outs[v].append(ops.gemm(a, w, bias=bias, norm=(ops.NORM_LN, rn_in, 1e-5, torch.randn(512, generator=torch.Generator().manual_seed(1)))))
+            assert all(torch.equal(x, y) for x, y in zip(outs[1], outs[9])), (M, K)
         finally:
             ops.set_gemm_variant(0)
 

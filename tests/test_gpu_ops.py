@@ -84,13 +84,13 @@ def test_gemm_pingpong_variant_is_bit_identical(ops, M, N, K):
     try:
         ops.set_gemm_variant(1)
         ref = ops.gemm(ad, wd, bias=bd, res=rd, act=ops.ACT_QGELU)
-        for v in (4, 5, 8, 12, 0):                                   # 5 = the 128x256 kernel with its LDS-DMA issue woven into the MFMA phases (lab)
+        for v in (4, 5, 8, 9, 12, 0):                                # 5 = the 128x256 kernel with its LDS-DMA issue woven into the MFMA phases (lab); 9 = gemm8 (four waves)
             ops.set_gemm_variant(v)
             for _ in range(3):
                 assert torch.equal(ops.gemm(ad, wd, bias=bd, res=rd, act=ops.ACT_QGELU), ref)
         ops.set_gemm_variant(1)
         ref = ops.gemm(ad, wd, bias=bd, act=ops.ACT_QGELU)           # no residual: the register-resident C^T epilogue of 4 / 8 / 12
-        for v in (4, 8, 12, 0):
+        for v in (4, 8, 9, 12, 0):
             ops.set_gemm_variant(v)
             assert torch.equal(ops.gemm(ad, wd, bias=bd, act=ops.ACT_QGELU), ref)
     finally:

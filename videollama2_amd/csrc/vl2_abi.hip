@@ -14,6 +14,7 @@
 #include "k_gemm.h"
 #include "k_gemm6.h"
 #include "k_gemm7.h"
+#include "k_gemm8.h"
 #include "k_norm.h"
 #include "k_pack.h"
 #include "k_sample.h"
@@ -204,6 +205,23 @@ static bool want_small_m(const GemmArgs& a, const GemmCtl& c) {
 // 16-B loads, all requested up front, beat the 8-B pieces the C^T layout needs: 31.2 vs 35.8 us on the ViT out_proj).  Both forms
 // produce the same bits (hash-checked per shape), so the choice is invisible to every caller.
 static bool want_tr_epilogue(const GemmArgs& a) { return a.res == nullptr; }
+
+// gemm8 (k_gemm8.h): the 256 x 256 tile on four waves, one per SIMD, 128 x 128 wave tiles
+template <int ACT, bool SW, bool F32>
+static void launch_gemm8(const GemmArgs& a0, hipStream_t s) {
+    GemmArgs a = a0;
+    a.tiles_m = (a.M + 255) / 256;
+    a.tiles_n = a.N / GEMM4_BN;
+    if constexpr (!F32) {
+        if (want_tr_epilogue(a)) {
+            lds_attr<gemm8_bf16_kernel<ACT, SW, false, true>>(GEMM8_LDS_BYTES);
+            hipLaunchKernelGGL((gemm8_bf16_kernel<ACT, SW, false, true>), dim3(a.tiles_m * a.tiles_n), dim3(256), GEMM8_LDS_BYTES, s, a);
+            return;
+        }
+    }
+    lds_attr<gemm8_bf16_kernel<ACT, SW, F32, false>>(GEMM8_LDS_BYTES);
+    hipLaunchKernelGGL((gemm8_bf16_kernel<ACT, SW, F32, false>), dim3(a.tiles_m * a.tiles_n), dim3(256), GEMM8_LDS_BYTES, s, a);
+}
 
 template <int ACT, bool SW, bool F32, int BM = GEMM4_BM>
 static void launch_gemm4(const GemmArgs& a0, hipStream_t s) {
@@ -436,6 +454,10 @@ static void launch_gemm(const GemmArgs& a0, const GemmCtl& c, hipStream_t s) {
             }
             return;
         }
+        if (kern == 9 && a0.N % GEMM4_BN == 0) {                              // lab / forced: the four-wave 256 x 256 kernel (k_gemm8.h)
+            launch_gemm8<ACT, SW, F32>(a0, s);
+            return;
+        }
         if ((kern == 8 || (F32 && kern == 12)) && a0.N % GEMM4_BN == 0) {     // (the 192-row form is built for bf16 outputs only)
             launch_gemm4<ACT, SW, F32>(a0, s);
             return;
@@ -566,6 +588,7 @@ extern "C" int32_t vl2_gemm(const vl2_gemm_desc* d, void* stream) {
         if (d->norm != VL2_NORM_RMS && d->norm != VL2_NORM_LN) return fail(VL2_E_BADARG, "vl2_gemm: unknown norm %d", d->norm);
         if ((!d->stats_in && !d->row_norm) || g || remap) return fail(VL2_E_BADARG, "vl2_gemm: a fused norm needs stats_in (or row_norm) and plain A rows");
         if (d->norm == VL2_NORM_LN && (!d->w_colsum || sw)) return fail(VL2_E_BADARG, "vl2_gemm: fused LayerNorm needs w_colsum (and excludes SWIGLU)");
+        if (!d->row_norm && (K % 128)) return fail(VL2_E_SHAPE, "vl2_gemm: reducing stats_in in the GEMM needs K %% 128 == 0 (16-byte pairs of partials; K=%d): pass row_norm (vl2_row_norm_finalize)", K);
     }
     if (d->stats_out && (sw || f32)) return fail(VL2_E_UNSUPP, "vl2_gemm: stats_out needs a plain bf16 output");
     if (d->row_norm_out) {
@@ -575,7 +598,7 @@ extern "C" int32_t vl2_gemm(const vl2_gemm_desc* d, void* stream) {
     }
     if (d->ws && (d->ws_bytes < SK_WS_BYTES || !ALIGNED16(d->ws))) return fail(VL2_E_BADARG, "vl2_gemm: workspace needs >= %lld bytes, 16-byte aligned", (long long)SK_WS_BYTES);
     const int v = d->variant;
-    if (!(v == 0 || v == 1 || v == 2 || v == 4 || v == 5 || v == 8 || v == 12 || v == 32 || v == 24 || v == 60 || v == 61 || v == 62 || v == 70 || v == 71 || v == 80 || v == 81 || v == 192 || v == 193 || v == 224 || v == 225 || v == 256)) return fail(VL2_E_BADARG, "vl2_gemm: unknown variant %d", v);
+    if (!(v == 0 || v == 1 || v == 2 || v == 4 || v == 5 || v == 8 || v == 9 || v == 12 || v == 32 || v == 24 || v == 60 || v == 61 || v == 62 || v == 70 || v == 71 || v == 80 || v == 81 || v == 192 || v == 193 || v == 224 || v == 225 || v == 256)) return fail(VL2_E_BADARG, "vl2_gemm: unknown variant %d", v);
     GemmCtl ctl{d->ws, d->ws_bytes, v, (d->flags & VL2_GEMM_SPLITK) != 0};
     ctl.persist = (d->flags & VL2_GEMM_PERSISTENT) != 0;
     ctl.no_mix = (d->flags & VL2_GEMM_NO_MIX) != 0;
