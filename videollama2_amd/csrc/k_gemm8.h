@@ -12,6 +12,14 @@
 //                                      MFMA(t, ks1) || ds_read fragments (t+1, ks0)
 // ONE barrier per slab (32 MFMAs = 1024 matrix-pipe cycles): at it every wave has finished reading slab t-1 (its fragments were in registers before
 // its MFMAs issued) and has seen its own pieces of slab t+1 land.
+//
+// MEASURED (round 5, profiles/r05_experiments.md section 7; variant 9, never the automatic choice): bit-identical to the family; 8192^3 832.6 us against
+// 850.0 for gemm4 and 677.6 for the vendor kernel on the same box (8192 x 4096 x 4096: 217.2 / 218.2 / 176.7) -- within 2 % of the ping-pong kernel, not
+// the vendor's 20 %.  What holds it: an LDS-DMA piece costs the lone wave of a SIMD 60-100 cycles of issue (no partner wave to issue it under the MFMAs),
+// eight pieces per 32-MFMA slab.  The vendor kernels stage through registers (plain loads + ds_write_b128, each of which fits an MFMA gap); that form was
+// built here too: with ONE register set (one slab of global-load latency) it stalls on the loads (925 us), and with the two or three sets that cover the
+// latency hipcc's allocator shuffles accumulators between the register files inside the loop (hundreds of v_accvgpr moves and scratch traffic per
+// iteration; three formulations tried) -- that pipeline needs hand-written assembly, which this library does not carry.
 #pragma once
 #include "k_gemm.h"
 
