@@ -565,7 +565,7 @@ def main():
         # HBM-side bytes per launch come from a separate rocprofv3 --pmc run (scripts/gpu_traffic.sh; PMC cannot be
         # collected inside this process); only quoted for the workload it was collected on (T=16, 241 GEMM launches).
         traffic, tsrc = None, None
-        for tname in ("r04_gemm_traffic.json", "r03_gemm_traffic.json", "r02_gemm_traffic.json"):     # PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs) of this round's kernels first
+        for tname in ("r05_gemm_traffic.json", "r04_gemm_traffic.json", "r03_gemm_traffic.json", "r02_gemm_traffic.json"):     # PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs) of this round's kernels first
             tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", tname)
             if os.path.exists(tpath):
                 tj = json.load(open(tpath))

@@ -60,6 +60,7 @@ int64_t vl2_workspace_bytes(void);
  * does not qualify gets the automatic choice), 62 = 61 with two accumulator sets (the previous tile's epilogue drained under the next
  * tile's phases; measured slower than 61, kept for A/B), 24 = the automatic choice without the persistent form (A/B),
  * 5 = variant 4 with the woven LDS-DMA issue (VL2_GEMM_WEAVE), 225 / 193 = 224 / 192 with it (lab),
+ * 9 = lab: the 256x256 tile on FOUR waves (one per SIMD, 128x128 wave tiles, csrc/k_gemm8.h; measured within 2 % of variant 8, never the automatic choice),
  * 224 / 192 = the fill-the-round 224x128 / 192x128 ping-pong kernel (csrc/k_gemm7.h; any N % 128 == 0, plain or gathered A, no SwiGLU; the
  * automatic choice takes it where its grid is one round of <= 256 workgroups and fills the chip better than the wider tiles:
  * the decoder's o / down projections at S = 1621, the STC convolutions on 1521 output positions).
@@ -74,6 +75,9 @@ int64_t vl2_workspace_bytes(void);
                                  `row_norm` [M][2] = (0, row multiplier) as vl2_quant_act_fp8 writes it (activation scale x RMS rstd), `col_scale` [N] = the
                                  weight rows' scales (vl2_pack_quant_fp8).  C = epilogue(rowmul_m * colscale_n * sum_k A8 W8): bias / SiLU / SwiGLU / residual /
                                  fp32 output as the 16-bit form.  An OPTIONAL arithmetic (both operands rounded to e4m3fn), never the default */
+#define VL2_GEMM_WEAVE4  512  /* the 256x256 / 192x256 ping-pong kernels (and the big-tile part of the mixed launch) issue the LDS-DMA of slab t+3 from their MATRIX
+                                 phases, one piece behind every fourth MFMA, instead of from the load phases (csrc/k_gemm.h gemm4_body WEAVE4; same bits) */
+#define VL2_GEMM_NO_WEAVE4 1024 /* the 192x256 tiles (variant 12) WITHOUT the woven issue they take by default since round 5: A/B (ViT fc2 / out_proj, decoder q/k/v: -0.4 ... -3.7 %) */
 #define VL2_GEMM_NO_TICKET 256 /* `row_norm_out` is filled by a separate vl2_row_norm_finalize launch behind the GEMM (rounds 3-4) instead of by the GEMM's last
                                  column tile: A/B of the producer-side finalize (same bits) */
 #define VL2_GEMM_WEAVE   64   /* lab: the 128x256 / 224x128 / 192x128 ping-pong kernels issue their LDS-DMA woven between the MFMAs of the matrix phases instead of
@@ -85,6 +89,8 @@ int64_t vl2_workspace_bytes(void);
 #define VL2_STAGE_NO_MIX           2   /* ... with VL2_GEMM_NO_MIX */
 #define VL2_STAGE_NO_FILL_TILES  128   /* ... with VL2_GEMM_NO_FILL */
 #define VL2_STAGE_WEAVE          256   /* ... with VL2_GEMM_WEAVE */
+#define VL2_STAGE_WEAVE4        8192   /* ... with VL2_GEMM_WEAVE4 */
+#define VL2_STAGE_NO_WEAVE4    16384   /* ... with VL2_GEMM_NO_WEAVE4 */
 #define VL2_STAGE_ROW_TICKET    1024   /* ViT and LLM prefill: the statistics-producing GEMMs (out_proj / fc2, o / down) finalize their own output rows
                                          * (vl2_gemm_desc.row_norm_out: producer-side ticket, csrc/k_gemm.h gemm_rows_ticket) instead of a vl2_row_norm_finalize launch
                                          * behind each of them.  Same bits; measured round 5: neutral in the tower (-0.03 ms), SLOWER in the prefill (+0.12 ms: every
@@ -259,6 +265,10 @@ int32_t vl2_gemv_batched_bf16(const void* W, const void* x, const float* norm_w,
  *   split in 64-key slices (flash-decoding), and combines the slices into out [nh*128] bf16.
  *   pos_dev != NULL: the position is read from device memory (*pos_dev) so a captured hipGraph replays as it moves; the
  *   launch then covers positions < ctx_cap.  partial: fp32 workspace >= nh*ceil(cap/64)*130 floats (cap = ctx_cap or pos+1). */
+#ifdef VL2_EXPERIMENTAL
+/* ---- EXPERIMENTAL SURFACE (not permanent ABI).  The two entry points below are exported for the A/B tests and the lab scripts that
+ * measured them SLOWER than the launches they replace; a host sees their declarations only with -DVL2_EXPERIMENTAL, nothing in the product calls
+ * them by default, and they may disappear with any ABI version.  (Their stage flags: VL2_STAGE_FUSED_DECODE_ATTN, VL2_STAGE_DECODE_TAIL.) */
 /* The same attention + combine in ONE launch (the workgroup that finishes a kv head's last slice combines its q heads): position from
  * device memory only, partial sized for smax (nh*ceil(smax/64)*130 floats), cnt = nkv int32 ticket counters that must be ZERO when the
  * launch starts (the caller clears them; NOT with a hipMemsetAsync node of a few bytes inside a captured hipGraph -- that did not replay
@@ -272,12 +282,14 @@ int32_t vl2_attn_decode_fused(const void* qkv, void* kcache, void* vcache, const
  * workgroup per CU, two grid barriers, the next phase's first weight rows in flight across each barrier) instead of three vl2_gemv_bf16
  * launches; the same bits as those.  o [QD], x0 / x1 / xout [D], act [I] bf16 (xout may be x0); Wo [D, QD], Wgu [2 I, D], Wd [D, I].
  * bar: 32 int32 words that must be ZERO when the launch starts (it re-arms them; vl2_llm_decode_step clears them in its argmax launch).
- * Every spin is bounded: on a timeout bar[24] is set and the outputs are garbage.  D, QD, I <= 32704, multiples of 8 (I of 32).
+ * Every spin is bounded: on a timeout bar[24] is set and the outputs are garbage (the caller must read bar[24]; vl2_llm_decode_step does not).
+ * D, QD, I <= 32512 (the staged vector shares the 64 KiB of LDS a kernel may take without the opt-in attribute with 512 B of static LDS), multiples of 8 (I of 32).
  * MEASURED SLOWER than the three launches on MI355X (scripts/ubench/tail_lab.hip: 98.5 vs 66.7 us per Mistral-7B layer -- a grid barrier
  * with its write-through hand-off costs ~11 us against ~3.6 us of fixed cost per GEMV launch, and one 16-wave workgroup per CU streams the
  * gate/up rows at 5 TB/s instead of 6.4): nothing takes it by default (VL2_STAGE_DECODE_TAIL). */
 int32_t vl2_decode_tail(const void* Wo, const void* Wgu, const void* Wd, int32_t ldwo, int32_t ldwgu, int32_t ldwd, const void* o, const void* x0,
                         void* x1, void* act, void* xout, int32_t D, int32_t QD, int32_t I, float eps, int32_t* bar, void* stream);
+#endif /* VL2_EXPERIMENTAL */
 int32_t vl2_attn_decode(const void* qkv, void* kcache, void* vcache, const float* cos_t, const float* sin_t, float* partial,
                         void* out, int32_t nh, int32_t nkv, int32_t smax, int32_t pos, const int32_t* pos_dev,
                         int32_t ctx_cap, float scale, void* stream);

@@ -22,10 +22,14 @@ def run(M, N, K, kw):
     bias = torch.randn(N, device=dev) if kw.get("bias") else None
     res = rnd(M, ncol) if kw.get("res") else None
     c = torch.empty(M, ncol, dtype=torch.bfloat16, device=dev)
+    ops.attach_workspace(dev)
+    # round 5: the tower's q/k/v and fc1 take the persistent form by default (vl2_vit_forward): the same per-call flag here
+    ops.set_stage_flags(ops.STAGE_PERSISTENT_GEMM if (M == 9232 and K == 1024 and N >= 3072) else 0)
     for _ in range(2):      # launch 1 = warm-up (L2/MALL state), launch 2 = the one post-processing reads
         ops.gemm(a, w, bias=bias, res=res, act=kw.get("act", 0), swiglu=bool(kw.get("swiglu")), out=c)
         SEP.fill_(1.0)      # separator kernel: a vl2_gemm call may be two kernels back to back (row split), the post-processor groups by it
     torch.cuda.synchronize()
+    ops.set_stage_flags(0)
 for M, N, K, cnt, kw in SHAPES:
     run(M, N, K, kw)
 # Conv3d as the gathered GEMM

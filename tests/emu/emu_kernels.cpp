@@ -22,6 +22,7 @@ alignas(64) unsigned char vl2_smem[160 * 1024];
 #include <cstdint>
 #include <algorithm>
 #include <vector>
+#define VL2_EXPERIMENTAL 1      // this translation unit DEFINES the experimental entry points too
 #include "../../include/vl2hip.h"
 
 static char g_err[256] = "emu";
@@ -33,6 +34,8 @@ extern "C" int32_t vl2_fill_zero(void* p, int64_t bytes, void*) { if (!p || byte
 
 // per-call controls (vl2_gemm_desc.variant, VL2_GEMM_SPLITK, vl2_attn_fwd variant): set by the entry points below
 static int g_gemm_variant = 0;
+static bool g_no_weave4 = false;
+static bool g_weave4 = false;       // VL2_GEMM_WEAVE4: the 256-/192-row ping-pong bodies with the woven LDS-DMA issue
 static bool g_need_fin = false;     // a GEMM path without the producer-side finalize ran: append the row_norm_finalize launch (vl2_abi.hip GemmCtl.fin)
 static bool g_gemm6_dynamic = false;       // gemm6: tiles handed out through the counter block (variants 70 / 71 = 60 / 61 dynamic)
 template <int ACT, bool SW, bool F32, bool G>
@@ -80,6 +83,11 @@ static void run_gemm(GemmArgs a) {
         if (g_gemm_variant == 8 && a.N % 256 == 0) {
             a.tiles_m = (a.M + 255) / 256; a.tiles_n = a.N / 256;
             if constexpr (!F32) {
+                if (g_weave4) {
+                    if (a.res == nullptr) emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(512), [=] { gemm4_bf16_kernel<ACT, SW, false, true, -1, 256, true>(a); });
+                    else emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(512), [=] { gemm4_bf16_kernel<ACT, SW, false, false, -1, 256, true>(a); });
+                    return;
+                }
                 if (a.res == nullptr) { emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(512), [=] { gemm4_bf16_kernel<ACT, SW, false, true>(a); }); return; }
             }
             emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(512), [=] { gemm4_bf16_kernel<ACT, SW, F32>(a); });
@@ -99,6 +107,11 @@ static void run_gemm(GemmArgs a) {
             if (a.row_norm_out) { tail.row_norm_out = a.row_norm_out + (size_t)M1 * 2; tail.row_ticket = a.row_ticket + M1 / 64; }
             tail.tiles_m = (tail.M + 127) / 128; tail.tiles_n = a.N / 128;
             const int n_big = big.tiles_m * big.tiles_n, n_all = n_big + tail.tiles_m * tail.tiles_n;
+            if (g_weave4) {
+                if (a.res == nullptr) emu::launch(dim3(n_all), dim3(512), [=] { gemm_mix_bf16_kernel<ACT, SW, true, true>(big, tail, n_big); });
+                else emu::launch(dim3(n_all), dim3(512), [=] { gemm_mix_bf16_kernel<ACT, SW, false, true>(big, tail, n_big); });
+                return;
+            }
             if (a.res == nullptr) emu::launch(dim3(n_all), dim3(512), [=] { gemm_mix_bf16_kernel<ACT, SW, true>(big, tail, n_big); });
             else emu::launch(dim3(n_all), dim3(512), [=] { gemm_mix_bf16_kernel<ACT, SW, false>(big, tail, n_big); });
             return;
@@ -123,6 +136,11 @@ static void run_gemm(GemmArgs a) {
         }
         if (g_gemm_variant == 12 && a.N % 256 == 0) {            // gemm4 on 192 x 256 tiles
             a.tiles_m = (a.M + 191) / 192; a.tiles_n = a.N / 256;
+            if (!g_no_weave4) {                                 // the 192-row tiles' default since round 5 (vl2_abi.hip)
+                if (a.res == nullptr) emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(512), [=] { gemm4_bf16_kernel<ACT, SW, false, true, -1, 192, true>(a); });
+                else emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(512), [=] { gemm4_bf16_kernel<ACT, SW, false, false, -1, 192, true>(a); });
+                return;
+            }
             if (a.res == nullptr) { emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(512), [=] { gemm4_bf16_kernel<ACT, SW, false, true, -1, 192>(a); }); return; }
             emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(512), [=] { gemm4_bf16_kernel<ACT, SW, false, false, -1, 192>(a); });
             return;
@@ -185,6 +203,8 @@ extern "C" int32_t vl2_gemm(const vl2_gemm_desc* d, void*) {
     a.idx_ld = M; a.stats_out = d->stats_out; a.stats_out_np = N / 64; a.stats_in = d->stats_in; a.stats_in_np = K / 64;
     a.norm = d->norm; a.norm_eps = d->norm_eps; a.w_colsum = d->w_colsum; a.row_norm = d->row_norm;
     a.tile_ctr = (unsigned*)d->tile_ctr;
+    g_weave4 = (d->flags & VL2_GEMM_WEAVE4) != 0;
+    g_no_weave4 = (d->flags & VL2_GEMM_NO_WEAVE4) != 0;
     g_need_fin = d->row_norm_out && (d->flags & VL2_GEMM_NO_TICKET);
     if (d->row_norm_out) {
         if (!d->stats_out || !d->row_ticket || (d->norm_out != 1 && d->norm_out != 2)) return -1;

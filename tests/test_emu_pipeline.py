@@ -175,6 +175,21 @@ def test_emu_gemm_pingpong_variant(emu):
                 assert torch.equal(ops.gemm(a, w, out_f32=True), ref)
         finally:
             ops.set_gemm_variant(0)
+    # WEAVE4: the 256 x 256 / 192 x 256 bodies (and the mixed launch's big tiles) with the LDS-DMA of slab t+3 issued from the matrix phases
+    for M, K in ((300, 64), (520, 192), (700, 576)):
+        a, w, bias, res = bf(M, K), bf(512, K, scale=K ** -0.5), torch.randn(512), bf(M, 512)
+        try:
+            ops.set_gemm_variant(1)
+            refs = (ops.gemm(a, w, bias=bias, res=res), ops.gemm(a, w, bias=bias, act=ops.ACT_QGELU))
+            for v in (8, 12, 24):
+                ops.set_gemm_variant(v)
+                for fl in (ops.STAGE_WEAVE4, ops.STAGE_NO_WEAVE4, 0):             # woven everywhere | nowhere | the default (192-row tiles only)
+                    ops.set_stage_flags(fl)
+                    assert torch.equal(ops.gemm(a, w, bias=bias, res=res), refs[0]) and torch.equal(ops.gemm(a, w, bias=bias, act=ops.ACT_QGELU), refs[1]), (M, K, v, fl)
+                ops.set_stage_flags(0)
+        finally:
+            ops.set_gemm_variant(0)
+            ops.set_stage_flags(0)
     # gemm8 through every epilogue form: LDS patches (residual, statistics + producer-side finalize) and the register-resident C^T form (bias /
     # activation, SwiGLU, LayerNorm carried), ragged M, K from one slab to a full ring and beyond
     from videollama2_amd.weights import pack_gate_up

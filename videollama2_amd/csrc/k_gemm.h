@@ -927,7 +927,12 @@ __device__ __forceinline__ int gemm4_lds_off(int row, int chunk) {
 // FP8: A and W rows hold e4m3fn bytes (a slab = 64 k per row in the same 64 bytes); one v_mfma_f32_32x32x64_f8f6f4 per accumulator block
 //   and slab from the two fragments the 16-bit form feeds to two MFMAs (dev_common.h VL2_MFMA32_F8); epilogue = gemm_store_patch with the
 //   row / column scales (GemmArgs.row_norm, col_scale).
-template <int ACT, bool SWIGLU, bool OUT_F32, bool TR = false, int EF = -1, int BM = 256, bool FP8 = false>
+// WEAVE4 (round 5): the LDS-DMA pieces of slab t+3 are issued from the wave's own MFMA(t) phase, one behind every fourth MFMA, instead of from its
+//   LOAD(t) phase.  The load phase of a group must fit under its partner's matrix phase (16 MFMAs = 512 cycles) and does not: four LDS-DMA pieces cost
+//   60-100 cycles of issue each (MI355X_MICROARCH.md) next to 12 fragment reads and two barriers.  Unlike the 3-stage kernels' weave (one phase of flight
+//   for the woven pieces: lost on cold operands) the 4-stage ring leaves them 2.5 slab times.  The slot of slab t+3 is slab t-1's, dead for both groups
+//   by MFMA(t).  Same slabs, same k order -> same bits.
+template <int ACT, bool SWIGLU, bool OUT_F32, bool TR = false, int EF = -1, int BM = 256, bool FP8 = false, bool WEAVE4 = false>
 __device__ __forceinline__ void gemm4_body(const GemmArgs& p, int bid, int nwg) {
     static_assert(!(TR && OUT_F32), "gemm_store_tr writes bf16");
     static_assert(!(FP8 && TR), "the fp8 form stores through gemm_store_patch");
@@ -981,6 +986,17 @@ __device__ __forceinline__ void gemm4_body(const GemmArgs& p, int bid, int nwg) 
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(vl2_smem + st + 16384 + ((grp * 8 + i * 4 + w4) << 10)),
                                                      16, w_vo[i], kb, 0, 0);
     };
+    auto issue_piece = [&](int t, int tk, int i) {    // piece i of this wave's share of slab tk, into the ring slot of slab t: 0, 1 = A (1 only if two_a), 2, 3 = W
+        const unsigned st = (unsigned)(t & 3) * GEMM4_STAGE, kb = (unsigned)tk * (GEMM4_BK * 2);
+        if (i == 0)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(vl2_smem + st + ((grp * APG + w4) << 10)), 16, a_vo[0], kb, 0, 0);
+        else if (i == 1) {
+            if (two_a)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(vl2_smem + st + ((grp * APG + 4 + w4) << 10)), 16, a_vo[1], kb, 0, 0);
+        } else
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(vl2_smem + st + 16384 + ((grp * 8 + (i - 2) * 4 + w4) << 10)),
+                                                     16, w_vo[i - 2], kb, 0, 0);
+    };
     // counted waits: `slabs` newer slabs of this wave's LDS-DMA stay in flight (4 or 3 pieces per slab)
     auto wait_dma = [&](int slabs) {
         if (slabs >= 2) { if (two_a) VL2_WAIT_VMCNT(8); else VL2_WAIT_VMCNT(6); }
@@ -1031,7 +1047,7 @@ __device__ __forceinline__ void gemm4_body(const GemmArgs& p, int bid, int nwg) 
     if (grp == 1) VL2_PHASE_BARRIER();
     for (int t = 0; t < nt; ++t) {
         // ---------------- LOAD(t): memory work only
-        if (t + 3 < nt) issue_dma(t + 3);
+        if (!WEAVE4 && t + 3 < nt) issue_dma(t + 3);
         const unsigned st = (unsigned)(t & 3) * GEMM4_STAGE;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -1041,8 +1057,10 @@ __device__ __forceinline__ void gemm4_body(const GemmArgs& p, int bid, int nwg) 
 #pragma unroll
             for (int j = 0; j < NJ; ++j) fb[ks][j] = *(const bf16x8*)(vl2_smem + bb + j * 2048);
         }
-        // slab t+1 must have landed before the barrier below; the (up to) two newer slabs stay in flight
-        wait_dma(nt - 2 - t);                      // slabs issued after t+1
+        // slab t+1 must have landed before the barrier below; the (up to) two newer slabs stay in flight (woven form: slab t+3 is not issued yet)
+        // (woven form: ONE newer slab is in flight in every iteration -- past the end of K the matrix phases re-issue the last slab into the dead
+        //  slot, so the loop has no tail case and no branch; the stray pieces are drained behind the loop)
+        if constexpr (WEAVE4) wait_dma(1); else wait_dma(nt - 2 - t);                      // slabs issued after t+1
         VL2_WAIT_LGKMCNT0();
         VL2_PHASE_BARRIER();
         // ---------------- MFMA(t): matrix work only
@@ -1057,12 +1075,23 @@ __device__ __forceinline__ void gemm4_body(const GemmArgs& p, int bid, int nwg) 
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
-                    for (int j = 0; j < NJ; ++j)
+                    for (int j = 0; j < NJ; ++j) {
                         acc[i][j] = TR ? VL2_MFMA32(fb[ks][j], fa[ks][i], acc[i][j])
                                        : VL2_MFMA32(fa[ks][i], fb[ks][j], acc[i][j]);
+                        if constexpr (WEAVE4) {
+                            constexpr int NM = 2 * MI * NJ;                  // MFMAs of the phase: 16 (256 rows) or 12 (192 rows)
+                            const int idx = (ks * MI + i) * NJ + j;
+                            if (idx % (NM / 4) == 1) {                       // behind MFMA 1, 5, 9, 13 (1, 4, 7, 10): one piece each
+                                __builtin_amdgcn_sched_barrier(0);
+                                issue_piece(t + 3, t + 3 < nt ? t + 3 : nt - 1, idx / (NM / 4));
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
+                    }
         }
         VL2_PHASE_BARRIER();
     }
+    if constexpr (WEAVE4) VL2_WAIT_VMCNT(0);                      // the stray pieces of the last three matrix phases have landed (the epilogue reuses the ring)
     if (grp == 0) VL2_PHASE_BARRIER();
 
     if constexpr (TR) {       // ---- register-resident epilogue: the accumulators hold C^T, rows are lane-local
@@ -1092,9 +1121,9 @@ __device__ __forceinline__ void gemm4_body(const GemmArgs& p, int bid, int nwg) 
         }
     if constexpr (!SWIGLU && !OUT_F32 && !FP8) gemm_rows_ticket<512>(p, tm, m0, BM, tid);
 }
-template <int ACT, bool SWIGLU, bool OUT_F32, bool TR = false, int EF = -1, int BM = 256>
+template <int ACT, bool SWIGLU, bool OUT_F32, bool TR = false, int EF = -1, int BM = 256, bool WEAVE4 = false>
 __global__ __launch_bounds__(512, 2) void gemm4_bf16_kernel(GemmArgs p) {
-    gemm4_body<ACT, SWIGLU, OUT_F32, TR, EF, BM>(p, blockIdx.x, gridDim.x);
+    gemm4_body<ACT, SWIGLU, OUT_F32, TR, EF, BM, false, WEAVE4>(p, blockIdx.x, gridDim.x);
 }
 template <int ACT, bool SWIGLU, bool OUT_F32, int BM>
 __global__ __launch_bounds__(512, 2) void gemm4_fp8_kernel(GemmArgs p) {
@@ -1500,8 +1529,8 @@ __global__ __launch_bounds__(512, 1) void gemm_l8_bf16_kernel(GemmArgs p) {
 // leading rows (`pb`), workgroups [n_big, grid) the one-round 128 x 128 body on the tail rows (`ps`).  Workgroups are dispatched in
 // index order, so the small tiles start on the CUs that run out of big tiles during the last, partially filled round of big tiles
 // (gate/up at S = 1621: 672 big tiles = 2.625 rounds, 224 tail tiles) instead of in a second launch behind it.  Same bodies -> same bits.
-template <int ACT, bool SWIGLU, bool TR>
+template <int ACT, bool SWIGLU, bool TR, bool WEAVE4 = false>
 __global__ __launch_bounds__(512, 2) void gemm_mix_bf16_kernel(GemmArgs pb, GemmArgs ps, int n_big) {
-    if ((int)blockIdx.x < n_big) gemm4_body<ACT, SWIGLU, false, TR>(pb, blockIdx.x, n_big);
+    if ((int)blockIdx.x < n_big) gemm4_body<ACT, SWIGLU, false, TR, -1, 256, false, WEAVE4>(pb, blockIdx.x, n_big);
     else gemm_l8_body<ACT, SWIGLU, false>(ps, (int)blockIdx.x - n_big, (int)gridDim.x - n_big);
 }

@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdio>
 
+#define VL2_EXPERIMENTAL 1      // this translation unit DEFINES the experimental entry points too
 #include "../../include/vl2hip.h"
 #include "k_attn.h"
 #include "k_attn2.h"
@@ -95,6 +96,8 @@ struct GemmCtl {
     bool no_mix = false;           // VL2_GEMM_NO_MIX
     bool no_fill = false;          // VL2_GEMM_NO_FILL
     bool weave = false;            // VL2_GEMM_WEAVE
+    bool no_weave4 = false;        // VL2_GEMM_NO_WEAVE4: the 192-row tiles with the load-phase issue of rounds 3-4 (A/B)
+    bool weave4 = false;           // VL2_GEMM_WEAVE4: the 256 x 256 / 192 x 256 ping-pong bodies issue their LDS-DMA from the matrix phases (k_gemm.h gemm4_body WEAVE4)
     bool* fin = nullptr;           // set to true by a launch path whose kernel has no producer-side finalize (gemm_rows_ticket): vl2_gemm then
                                    // appends the row_norm_finalize launch itself, so `row_norm_out` is filled whichever kernel ran
 };
@@ -224,19 +227,30 @@ static void launch_gemm8(const GemmArgs& a0, hipStream_t s) {
 }
 
 template <int ACT, bool SW, bool F32, int BM = GEMM4_BM>
-static void launch_gemm4(const GemmArgs& a0, hipStream_t s) {
+static void launch_gemm4(const GemmArgs& a0, hipStream_t s, bool weave4 = false) {
     GemmArgs a = a0;
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = a.N / GEMM4_BN;
+    const dim3 grid(a.tiles_m * a.tiles_n);
     if constexpr (!F32) {
         if (want_tr_epilogue(a)) {
-            lds_attr<gemm4_bf16_kernel<ACT, SW, false, true, -1, BM>>(GEMM4_LDS_BYTES);
-            hipLaunchKernelGGL((gemm4_bf16_kernel<ACT, SW, false, true, -1, BM>), dim3(a.tiles_m * a.tiles_n), dim3(512), GEMM4_LDS_BYTES, s, a);
+            if (weave4) {
+                lds_attr<gemm4_bf16_kernel<ACT, SW, false, true, -1, BM, true>>(GEMM4_LDS_BYTES);
+                hipLaunchKernelGGL((gemm4_bf16_kernel<ACT, SW, false, true, -1, BM, true>), grid, dim3(512), GEMM4_LDS_BYTES, s, a);
+            } else {
+                lds_attr<gemm4_bf16_kernel<ACT, SW, false, true, -1, BM>>(GEMM4_LDS_BYTES);
+                hipLaunchKernelGGL((gemm4_bf16_kernel<ACT, SW, false, true, -1, BM>), grid, dim3(512), GEMM4_LDS_BYTES, s, a);
+            }
+            return;
+        }
+        if (weave4) {
+            lds_attr<gemm4_bf16_kernel<ACT, SW, false, false, -1, BM, true>>(GEMM4_LDS_BYTES);
+            hipLaunchKernelGGL((gemm4_bf16_kernel<ACT, SW, false, false, -1, BM, true>), grid, dim3(512), GEMM4_LDS_BYTES, s, a);
             return;
         }
     }
     lds_attr<gemm4_bf16_kernel<ACT, SW, F32, false, -1, BM>>(GEMM4_LDS_BYTES);
-    hipLaunchKernelGGL((gemm4_bf16_kernel<ACT, SW, F32, false, -1, BM>), dim3(a.tiles_m * a.tiles_n), dim3(512), GEMM4_LDS_BYTES, s, a);
+    hipLaunchKernelGGL((gemm4_bf16_kernel<ACT, SW, F32, false, -1, BM>), grid, dim3(512), GEMM4_LDS_BYTES, s, a);
 }
 
 // ---- persistent ping-pong GEMM (k_gemm6.h): ONE workgroup per CU walks its tiles, the LDS ring runs across tile boundaries, the stores
@@ -379,17 +393,26 @@ static void launch_gemm(const GemmArgs& a0, const GemmCtl& c, hipStream_t s) {
             const long t_big = (long)(M1 / GEMM4_BM) * (a0.N / GEMM4_BN), t_tail = (long)tail.tiles_m * tail.tiles_n;
             if (!no_mix && t_tail > 128 && t_tail <= 512) {
                 big.tiles_m = M1 / GEMM4_BM; big.tiles_n = a0.N / GEMM4_BN;
+                const dim3 gmix((unsigned)(t_big + t_tail));
                 if (want_tr_epilogue(big)) {
-                    lds_attr<gemm_mix_bf16_kernel<ACT, SW, true>>(GEMM4_LDS_BYTES);
-                    hipLaunchKernelGGL((gemm_mix_bf16_kernel<ACT, SW, true>), dim3((unsigned)(t_big + t_tail)), dim3(512), GEMM4_LDS_BYTES, s, big, tail, (int)t_big);
+                    if (c.weave4) {
+                        lds_attr<gemm_mix_bf16_kernel<ACT, SW, true, true>>(GEMM4_LDS_BYTES);
+                        hipLaunchKernelGGL((gemm_mix_bf16_kernel<ACT, SW, true, true>), gmix, dim3(512), GEMM4_LDS_BYTES, s, big, tail, (int)t_big);
+                    } else {
+                        lds_attr<gemm_mix_bf16_kernel<ACT, SW, true>>(GEMM4_LDS_BYTES);
+                        hipLaunchKernelGGL((gemm_mix_bf16_kernel<ACT, SW, true>), gmix, dim3(512), GEMM4_LDS_BYTES, s, big, tail, (int)t_big);
+                    }
+                } else if (c.weave4) {
+                    lds_attr<gemm_mix_bf16_kernel<ACT, SW, false, true>>(GEMM4_LDS_BYTES);
+                    hipLaunchKernelGGL((gemm_mix_bf16_kernel<ACT, SW, false, true>), gmix, dim3(512), GEMM4_LDS_BYTES, s, big, tail, (int)t_big);
                 } else {
                     lds_attr<gemm_mix_bf16_kernel<ACT, SW, false>>(GEMM4_LDS_BYTES);
-                    hipLaunchKernelGGL((gemm_mix_bf16_kernel<ACT, SW, false>), dim3((unsigned)(t_big + t_tail)), dim3(512), GEMM4_LDS_BYTES, s, big, tail, (int)t_big);
+                    hipLaunchKernelGGL((gemm_mix_bf16_kernel<ACT, SW, false>), gmix, dim3(512), GEMM4_LDS_BYTES, s, big, tail, (int)t_big);
                 }
                 return;
             }
             if (a0.K >= 2048) {                       // two launches (measured wins at K >= 2048 only: profiles/r02_experiments.md section 3)
-                launch_gemm4<ACT, SW, F32>(big, s);
+                launch_gemm4<ACT, SW, F32>(big, s, c.weave4);
                 launch_gemm<ACT, SW, F32, G>(tail, c, s);
                 return;
             }
@@ -459,12 +482,15 @@ static void launch_gemm(const GemmArgs& a0, const GemmCtl& c, hipStream_t s) {
             return;
         }
         if ((kern == 8 || (F32 && kern == 12)) && a0.N % GEMM4_BN == 0) {     // (the 192-row form is built for bf16 outputs only)
-            launch_gemm4<ACT, SW, F32>(a0, s);
+            launch_gemm4<ACT, SW, F32>(a0, s, c.weave4);
             return;
         }
         if constexpr (!F32) {
             if (kern == 12 && a0.N % GEMM4_BN == 0) {
-                launch_gemm4<ACT, SW, false, 192>(a0, s);
+                // 192-row tiles take the woven LDS-DMA issue by default (round 5, scripts/weave4_bench.py, interleaved on one box, same bits): their load
+                // phase carries 3-4 pieces + 10 fragment reads under a partner's TWELVE MFMAs -- ViT fc2 82.5 -> 79.4 us, out_proj 30.1 -> 29.3, the
+                // decoder's q/k/v 82.0 -> 81.6; the 256-row bodies measure the same either way (16 MFMAs cover the load phase) and keep the load-phase issue
+                launch_gemm4<ACT, SW, false, 192>(a0, s, !c.no_weave4);
                 return;
             }
         }
@@ -604,6 +630,8 @@ extern "C" int32_t vl2_gemm(const vl2_gemm_desc* d, void* stream) {
     ctl.no_mix = (d->flags & VL2_GEMM_NO_MIX) != 0;
     ctl.no_fill = (d->flags & VL2_GEMM_NO_FILL) != 0;
     ctl.weave = (d->flags & VL2_GEMM_WEAVE) != 0;
+    ctl.weave4 = (d->flags & VL2_GEMM_WEAVE4) != 0;
+    ctl.no_weave4 = (d->flags & VL2_GEMM_NO_WEAVE4) != 0;
     bool need_fin = d->row_norm_out && (d->flags & VL2_GEMM_NO_TICKET);      // A/B: the separate launch as in rounds 3-4
     ctl.fin = &need_fin;
     GemmArgs a{};
@@ -1132,8 +1160,8 @@ extern "C" int32_t vl2_decode_tail(const void* Wo, const void* Wgu, const void* 
                                    const void* x0, void* x1, void* act, void* xout, int32_t D, int32_t QD, int32_t I, float eps, int32_t* bar,
                                    void* stream) {
     if (!Wo || !Wgu || !Wd || !o || !x0 || !x1 || !act || !xout || !bar) return fail(VL2_E_BADARG, "vl2_decode_tail: null pointer");
-    if (D <= 0 || QD <= 0 || I <= 0 || D % 8 || QD % 8 || I % 32 || ldwo % 8 || ldwgu % 8 || ldwd % 8 || D > 32704 || QD > 32704 || I > 32704)
-        return fail(VL2_E_SHAPE, "vl2_decode_tail: need D, QD %% 8 == 0, I %% 32 == 0, all <= 32704 (D %d QD %d I %d)", D, QD, I);
+    if (D <= 0 || QD <= 0 || I <= 0 || D % 8 || QD % 8 || I % 32 || ldwo % 8 || ldwgu % 8 || ldwd % 8 || D > 32512 || QD > 32512 || I > 32512)
+        return fail(VL2_E_SHAPE, "vl2_decode_tail: need D, QD %% 8 == 0, I %% 32 == 0, all <= 32512 (D %d QD %d I %d)", D, QD, I);
     if ((uintptr_t)bar & 3) return fail(VL2_E_BADARG, "vl2_decode_tail: bar must be 4-byte aligned");
     TailArgs a{(const bf16_t*)Wo, (const bf16_t*)Wgu, (const bf16_t*)Wd, ldwo, ldwgu, ldwd, (const bf16_t*)o, (const bf16_t*)x0, (bf16_t*)x1,
                (bf16_t*)act, (bf16_t*)xout, D, QD, I, eps, (unsigned*)bar};

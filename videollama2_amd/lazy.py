@@ -134,8 +134,9 @@ class LazyHipVisionTower(nn.Module):
         """`load_state_dict` of a checkpoint written in the OTHER key layout (4.x <-> 5.x): rename its keys to the hosted ones.
         Also records which tensors arrived through `load_state_dict` (check_loaded trusts those: a synthetic or freshly initialised
         tower with constant LayerNorm scales is a legitimate load)."""
-        self._seen_in_load = getattr(self, "_seen_in_load", set()) | {k[len(prefix):].split("vision_model.")[-1].split("vision_tower.")[-1]
-                                                                      for k in state_dict if k.startswith(prefix + "vision_tower.")}
+        norm = lambda k: k.split("vision_model.")[-1].split("vision_tower.")[-1]
+        hosted = {norm(k) for k in self.vision_tower.state_dict()}       # only keys that land in a hosted parameter count as loaded (ADVICE r04)
+        self._seen_in_load = getattr(self, "_seen_in_load", set()) | ({norm(k[len(prefix):]) for k in state_dict if k.startswith(prefix + "vision_tower.")} & hosted)
         old = prefix + "vision_tower.vision_model."
         if self.key_layout == "flat":
             for k in [k for k in state_dict if k.startswith(old)]:
@@ -143,6 +144,12 @@ class LazyHipVisionTower(nn.Module):
         elif not any(k.startswith(old) for k in state_dict):
             for k in [k for k in state_dict if k.startswith(prefix + "vision_tower.")]:
                 state_dict[old + k[len(prefix + "vision_tower."):]] = state_dict.pop(k)
+
+    def to_empty(self, *args, **kwargs):
+        """Re-materialising the parameters (meta -> device storage) voids what earlier `load_state_dict` calls put there: the loaded-by-construction
+        record starts over, so a tower re-created after a load is judged by its values again."""
+        self._seen_in_load = set()
+        return super().to_empty(*args, **kwargs)
 
     def check_loaded(self):
         """Refuse to run on weights that were never loaded.  `from_pretrained(low_cpu_mem_usage=True)` matches checkpoint keys to

@@ -42,6 +42,8 @@ GEMM_PERSISTENT, GEMM_NO_MIX, GEMM_NO_FILL, GEMM_WEAVE, GEMM_FP8 = 8, 16, 32, 64
 STAGE_PERSISTENT_GEMM, STAGE_NO_MIX, STAGE_SELF_REDUCE, STAGE_FUSED_DECODE_ATTN, STAGE_DECODE_TAIL, STAGE_STC_UNFUSED = 1, 2, 4, 8, 16, 32
 STAGE_WEAVE = 256                     # lab: LDS-DMA issue woven into the MFMA phases of the 128x256 / 224x128 / 192x128 ping-pong GEMMs
 STAGE_NO_FILL_TILES = 128             # A/B of the fill-the-round GEMM tiles (csrc/k_gemm7.h)
+STAGE_NO_WEAVE4, GEMM_NO_WEAVE4 = 16384, 1024   # A/B: the 192-row tiles without the woven issue (their default since round 5)
+STAGE_WEAVE4, GEMM_WEAVE4 = 8192, 512 # the 256x256 / 192x256 ping-pong GEMMs issue their LDS-DMA from the matrix phases (k_gemm.h gemm4_body WEAVE4)
 STAGE_VIT_NO_PERSISTENT = 4096        # vl2_vit_forward without the persistent GEMM form (its default since round 5): A/B
 STAGE_NO_TICKET_OPS = 2048            # ops.gemm(norm_out=...) only: the appended launch instead of the in-kernel ticket (test / A/B control of the operator path)
 STAGE_ROW_TICKET, GEMM_NO_TICKET = 1024, 256  # stage calls: producer-side finalize (k_gemm.h gemm_rows_ticket) instead of the row_norm_finalize launches (lab: not faster)
@@ -86,11 +88,26 @@ def set_stage_flags(flags):
     _CTL["stage_flags"] = int(flags)
     _CTL["gemm_flags"] = (GEMM_PERSISTENT if flags & STAGE_PERSISTENT_GEMM else 0) | (GEMM_NO_MIX if flags & STAGE_NO_MIX else 0) | \
                          (GEMM_NO_FILL if flags & STAGE_NO_FILL_TILES else 0) | (GEMM_WEAVE if flags & STAGE_WEAVE else 0) | \
-                         (GEMM_NO_TICKET if flags & STAGE_NO_TICKET_OPS else 0)
+                         (GEMM_NO_TICKET if flags & STAGE_NO_TICKET_OPS else 0) | (GEMM_WEAVE4 if flags & STAGE_WEAVE4 else 0) | \
+                         (GEMM_NO_WEAVE4 if flags & STAGE_NO_WEAVE4 else 0)
 
 
 def stage_flags():
     return _CTL["stage_flags"]
+
+
+class tower_gemm_flags:
+    """The per-operator tower loops (tower.py `_hidden`) mirror what vl2_vit_forward does with its GEMMs: the persistent form (VL2_GEMM_PERSISTENT) is
+    the tower's default since round 5, unless STAGE_VIT_NO_PERSISTENT is set.  A context manager around those loops; restores the session's flags."""
+    def __enter__(self):
+        self._saved = _CTL["gemm_flags"]
+        if not (_CTL["stage_flags"] & STAGE_VIT_NO_PERSISTENT):
+            _CTL["gemm_flags"] |= GEMM_PERSISTENT
+        return self
+
+    def __exit__(self, *exc):
+        _CTL["gemm_flags"] = self._saved
+        return False
 
 
 def set_gemm_variant(v):

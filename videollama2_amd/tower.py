@@ -137,10 +137,14 @@ class HipCLIPVisionTower(nn.Module):
         if self._side is None or len(self._side) != ns:
             self._side = [torch.cuda.Stream(self._dev) for _ in range(ns)]
         bounds = [T * i // ns for i in range(ns + 1)]
-        for i, st in enumerate(self._side):
-            st.wait_stream(cur)
-            with torch.cuda.stream(st):
-                self._hidden(images[bounds[i]:bounds[i + 1]], out[bounds[i] * N1:bounds[i + 1] * N1])
+        self._multi_stream = True            # (the per-operator loops then keep off the persistent GEMM: its tile counters live in ONE shared workspace)
+        try:
+            for i, st in enumerate(self._side):
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    self._hidden(images[bounds[i]:bounds[i + 1]], out[bounds[i] * N1:bounds[i + 1] * N1])
+        finally:
+            self._multi_stream = False
         for st in self._side:
             cur.wait_stream(st)
         return out, T, N1
@@ -153,6 +157,13 @@ class HipCLIPVisionTower(nn.Module):
         images = images.to(self._dev)
         if ops.stage_enabled() and images.dtype in (torch.float32, torch.float16, torch.bfloat16, torch.uint8):
             return self._hidden_stage(images, T, u8, out)
+        if getattr(self, "_multi_stream", False):
+            return self._hidden_ops(images, T, H, u8, out)
+        with ops.tower_gemm_flags():                  # the same GEMM forms as the stage call takes (persistent q/k/v and fc1)
+            return self._hidden_ops(images, T, H, u8, out)
+
+    def _hidden_ops(self, images, T, H, u8, out):
+        v = self.cfg["vision"]
         w = self.w
         D, P = v["hidden_size"], v["patch_size"]
         G = H // P
@@ -234,6 +245,13 @@ class HipSiglipVisionTower(HipCLIPVisionTower):
         images = images.to(self._dev)
         if ops.stage_enabled() and images.dtype in (torch.float32, torch.float16, torch.bfloat16, torch.uint8):
             return self._hidden_stage(images, T, u8, out)
+        if getattr(self, "_multi_stream", False):
+            return self._hidden_ops(images, T, H, u8, out)
+        with ops.tower_gemm_flags():
+            return self._hidden_ops(images, T, H, u8, out)
+
+    def _hidden_ops(self, images, T, H, u8, out):
+        v = self.cfg["vision"]
         w = self.w
         D, P, nh = v["hidden_size"], v["patch_size"], v["num_attention_heads"]
         G = H // P
