@@ -587,7 +587,8 @@ extern "C" int32_t vl2_sample_token(const float* logits, int32_t V, float temper
                                     int32_t* hist, int32_t step, int32_t* state, float* dbg, void*) {
     if (!logits || !tok || !u || V <= 0 || !(temperature > 0.f) || top_k < 0 || !(top_p > 0.f)) return -1;
     SampleArgs a{logits, V, temperature, top_k, top_p, u, tok, hist, step, state, dbg};
-    emu::launch(dim3(1), dim3(1024), [=] { sample_token_kernel(a); });
+    if (V <= 32768) emu::launch(dim3(1), dim3(1024), [=] { sample_token_kernel<true>(a); });
+    else emu::launch(dim3(1), dim3(1024), [=] { sample_token_kernel<false>(a); });
     return 0;
 }
 extern "C" int32_t vl2_embed_rows(const int32_t* ids, const void* table, void* out, int32_t n, int32_t D, int32_t ldo, void*) {

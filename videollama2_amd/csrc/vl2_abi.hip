@@ -1146,7 +1146,12 @@ extern "C" int32_t vl2_sample_token(const float* logits, int32_t V, float temper
     if (!(temperature > 0.f) || top_k < 0 || !(top_p > 0.f)) return fail(VL2_E_BADARG, "vl2_sample_token: need temperature > 0, top_k >= 0, top_p > 0 (got %g, %d, %g)", (double)temperature, top_k, (double)top_p);
     if (!state && step < 0) return fail(VL2_E_BADARG, "vl2_sample_token: negative step");
     SampleArgs a{logits, V, temperature, top_k, top_p, u, tok, hist, step, state, dbg};
-    hipLaunchKernelGGL(sample_token_kernel, dim3(1), dim3(1024), 0, ST(stream), a);
+    if (V <= 32768) {                  // the scaled scores fit into LDS beside the kernel's 10 KB of static LDS
+        lds_attr<sample_token_kernel<true>>(32768 * 4);
+        hipLaunchKernelGGL(sample_token_kernel<true>, dim3(1), dim3(1024), (size_t)V * 4, ST(stream), a);
+    } else {
+        hipLaunchKernelGGL(sample_token_kernel<false>, dim3(1), dim3(1024), 0, ST(stream), a);
+    }
     return launched("vl2_sample_token");
 }
 // the decode step's argmax, which also clears `nzero` int32 words (the fused attention launches' ticket counters)
