@@ -80,10 +80,19 @@ __global__ __launch_bounds__(1024) void sample_token_kernel(SampleArgs p) {
             if (tid < 256) hist64[tid] = 0ull;
             __syncthreads();
             const int sh = lvl * 8;
+            // (a thread's elements mostly fall into the same bin at the upper levels -- the top byte of a key is sign + exponent -- so runs of equal
+            //  bins are summed in registers and flushed once: the LDS atomics on two or three hot bins were most of the kernel's time)
+            unsigned run_bin = 256u;
+            unsigned long long run = 0ull;
             for (int i = tid; i < V; i += 1024) {
                 const uint32_t k = sample_key(score(i));
-                if (lvl == 3 || (k >> (sh + 8)) == (prefix >> (sh + 8))) atomicAdd(&hist64[(k >> sh) & 255u], 1ull);
+                if (lvl == 3 || (k >> (sh + 8)) == (prefix >> (sh + 8))) {
+                    const unsigned bin = (k >> sh) & 255u;
+                    if (bin != run_bin) { if (run) atomicAdd(&hist64[run_bin], run); run_bin = bin; run = 0ull; }
+                    run += 1ull;
+                }
             }
+            if (run) atomicAdd(&hist64[run_bin], run);
             __syncthreads();
             if (tid == 0) {
                 unsigned long long acc = 0;
@@ -112,12 +121,18 @@ __global__ __launch_bounds__(1024) void sample_token_kernel(SampleArgs p) {
             if (tid < 256) hist64[tid] = 0ull;
             __syncthreads();
             const int sh = lvl * 8;
+            unsigned run_bin = 256u;
+            unsigned long long run = 0ull;
             for (int i = tid; i < V; i += 1024) {
                 const float s = score(i);
                 const uint32_t k = sample_key(s);
-                if (k >= key_lo && (lvl == 3 || (k >> (sh + 8)) == (prefix >> (sh + 8))))
-                    atomicAdd(&hist64[(k >> sh) & 255u], (unsigned long long)(__expf(s - mx) * SAMPLE_FIX));
+                if (k >= key_lo && (lvl == 3 || (k >> (sh + 8)) == (prefix >> (sh + 8)))) {
+                    const unsigned bin = (k >> sh) & 255u;
+                    if (bin != run_bin) { if (run) atomicAdd(&hist64[run_bin], run); run_bin = bin; run = 0ull; }
+                    run += (unsigned long long)(__expf(s - mx) * SAMPLE_FIX);
+                }
             }
+            if (run) atomicAdd(&hist64[run_bin], run);
             __syncthreads();
             if (tid == 0) {
                 if (lvl == 3) {
