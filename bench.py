@@ -581,8 +581,9 @@ def main():
         dom = max(by_shape.items(), key=lambda kv: kv[1][2]) if by_shape else None
         kernels = ("every vl2_gemm call of the step, whichever kernel the library picks per shape: gemm_mix_bf16_kernel (a row-split call = 256x256 ping-pong "
                    "tiles + 128x128 tail tiles in ONE launch: gate/up, STC 4096-wide convs), gemm4_bf16_kernel (256x256 / 192x256 ping-pong), "
-                   "gemm3_bf16_kernel (128x256 ping-pong), gemm_bf16_kernel (128x128), gemm_l8_bf16_kernel (one-round 128x128), gemm_s_bf16_kernel (64x64); "
-                   "gemm6_bf16_kernel (persistent) only with --stage-flags 1")
+                   "gemm3_bf16_kernel (128x256 ping-pong), gemm7_bf16_kernel (fill-the-round 192x128 / 224x128: the M = 1521 connector shapes), "
+                   "gemm6_bf16_kernel (persistent 256x256: the tower's q/k/v and fc1 since round 5), gemm_bf16_kernel (128x128), gemm_l8_bf16_kernel "
+                   "(one-round 128x128), gemm_s_bf16_kernel (64x64)")
         roof = dict(bound="mfma", kernel=kernels, achieved=round(ach, 2), peak=PEAK_MFMA_BF16_TFLOPS,
                     unit="TFLOP/s", frac=round(ach / PEAK_MFMA_BF16_TFLOPS, 4), traffic=traffic,
                     launches=ngemm, avg_launch_us=round(1e3 * gms / max(ngemm, 1), 2),

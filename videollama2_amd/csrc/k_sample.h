@@ -40,6 +40,42 @@ struct SampleArgs {
     float* dbg;            // optional [4]: {kept tokens, kept mass / total mass, threshold score, max score} of the call
 };
 
+// inclusive prefix sum of a 64-bit value over the lanes of a wave (six shuffle steps)
+__device__ __forceinline__ unsigned long long sample_wave_scan(unsigned long long v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long t = __shfl(v, lane >= d ? lane - d : lane);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+// The bin of a 256-bin histogram at which a running total crosses a threshold, found by ONE wave (lane L owns the bins of scan positions 4 L .. 4 L + 3;
+// a serial walk by one thread was ~100 LDS round trips per level and most of the kernel's time).  Scan order: ascending bins (DESC = false) or from bin
+// 255 downwards (DESC = true).  Crossing rule: DESC: the first position with acc + h >= thr (top-k: the rank is inside this bin); ascending: the first with
+// acc + h > thr (top-p: the cumulative mass exceeds the threshold).  No crossing: the last position.  Results (the bin, and acc in FRONT of it) -> *bin, *acc.
+template <bool DESC>
+__device__ __forceinline__ void sample_find_bin(const unsigned long long* hist, unsigned long long base, unsigned long long thr, int lane,
+                                                unsigned* bin, unsigned long long* acc_out, bool* found) {
+    unsigned long long h[4], mine = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int o = 4 * lane + j; h[j] = hist[DESC ? 255 - o : o]; mine += h[j]; }
+    const unsigned long long incl = base + sample_wave_scan(mine, lane), excl = incl - mine;
+    const bool cross = DESC ? (excl < thr && incl >= thr) : (excl <= thr && incl > thr);
+    const bool any = !__all(!cross);
+    *found = any ? cross : lane == 63;
+    if (*found) {
+        unsigned long long a = excl;
+        int j = 0;
+        for (; j < 3; ++j) {
+            if (DESC ? (a + h[j] >= thr) : (a + h[j] > thr)) break;
+            a += h[j];
+        }
+        const int o = 4 * lane + j;
+        *bin = (unsigned)(DESC ? 255 - o : o);
+        *acc_out = a;
+    }
+}
+
 // CACHE: the scaled scores live in dynamic LDS (V * 4 bytes, V <= 32768: the 32000-token vocabularies) after pass A, so the ten later passes read LDS
 // instead of re-reading the logits from L2 and re-dividing them (153 -> ~60 us per token at V = 32000); larger vocabularies stream from L2.
 template <bool CACHE>
@@ -52,7 +88,7 @@ __global__ __launch_bounds__(1024) void sample_token_kernel(SampleArgs p) {
     __shared__ uint32_t s_prefix;
     __shared__ unsigned long long s_base, s_target, s_thr;
     __shared__ int s_sel, s_tok, s_kept;
-    __shared__ unsigned long long s_m[1024];
+    __shared__ unsigned long long s_m[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int V = p.V;
     const float T = p.temperature;
@@ -94,15 +130,12 @@ __global__ __launch_bounds__(1024) void sample_token_kernel(SampleArgs p) {
             }
             if (run) atomicAdd(&hist64[run_bin], run);
             __syncthreads();
-            if (tid == 0) {
+            if (wave == 0) {
+                unsigned d = 0;
                 unsigned long long acc = 0;
-                int d = 255;
-                for (; d > 0; --d) {
-                    if (acc + hist64[d] >= need) break;
-                    acc += hist64[d];
-                }
-                s_prefix = prefix | ((uint32_t)d << sh);
-                s_base = need - acc;
+                bool found = false;
+                sample_find_bin<true>(hist64, 0ull, need, lane, &d, &acc, &found);
+                if (found) { s_prefix = prefix | ((uint32_t)d << sh); s_base = need - acc; }      // exactly one lane
             }
             __syncthreads();
             prefix = s_prefix;
@@ -134,23 +167,20 @@ __global__ __launch_bounds__(1024) void sample_token_kernel(SampleArgs p) {
             }
             if (run) atomicAdd(&hist64[run_bin], run);
             __syncthreads();
-            if (tid == 0) {
+            if (wave == 0) {
+                unsigned long long r = s_thr;
                 if (lvl == 3) {
-                    unsigned long long z = 0;
-                    for (int d = 0; d < 256; ++d) z += hist64[d];
-                    s_target = z;
+                    unsigned long long z = hist64[4 * lane] + hist64[4 * lane + 1] + hist64[4 * lane + 2] + hist64[4 * lane + 3];
+                    z = __shfl(sample_wave_scan(z, lane), 63);
                     // (1 - top_p) in fp32 as HF forms it, times Z in double: the largest integer mass that still counts as "<= threshold"
-                    s_thr = want_p ? (unsigned long long)((double)(1.0f - p.top_p) * (double)z) : 0ull;
+                    r = want_p ? (unsigned long long)((double)(1.0f - p.top_p) * (double)z) : 0ull;
+                    if (lane == 0) { s_target = z; s_thr = r; }
                 }
-                const unsigned long long r = s_thr;
-                unsigned long long acc = below;
-                int d = 0;
-                for (; d < 255; ++d) {
-                    if (acc + hist64[d] > r) break;                 // the first bin whose cumulative mass exceeds the threshold: its keys are (partly) kept
-                    acc += hist64[d];
-                }
-                s_prefix = prefix | ((uint32_t)d << sh);
-                s_base = acc;
+                unsigned d = 0;
+                unsigned long long acc = 0;
+                bool found = false;
+                sample_find_bin<false>(hist64, below, r, lane, &d, &acc, &found);     // the first bin whose cumulative mass exceeds the threshold: (partly) kept
+                if (found) { s_prefix = prefix | ((uint32_t)d << sh); s_base = acc; }
             }
             __syncthreads();
             if (lvl == 3) Z = s_target;
@@ -169,33 +199,37 @@ __global__ __launch_bounds__(1024) void sample_token_kernel(SampleArgs p) {
         const float s = score(i);
         if (sample_key(s) >= key_lo) { mine += (unsigned long long)(__expf(s - mx) * SAMPLE_FIX); ++cnt; }
     }
-    // the chunk that holds the target: the 1024 chunk masses through LDS, walked by thread 0 (a few microseconds; the kernel runs once per token)
-    s_m[tid] = mine;
     if (cnt) atomicAdd(&s_kept, cnt);
+    // (every wave scans its 64 chunk masses with shuffles, thread 0 walks the 16 wave totals: a serial walk over 1024 LDS words was ~50 us)
+    const unsigned long long incl_w = sample_wave_scan(mine, lane);
+    if (lane == 63) s_m[wave] = incl_w;
     __syncthreads();
     if (tid == 0) {
         unsigned long long tot = 0;
-        for (int t = 0; t < 1024; ++t) tot += s_m[t];
+        for (int w = 0; w < 16; ++w) tot += s_m[w];
         const int step = p.state ? p.state[1] : p.step;
         float u = p.u[step];
         u = u < 0.f ? 0.f : (u >= 1.f ? 0.99999994f : u);
         unsigned long long tgt = (unsigned long long)((double)u * (double)tot);
         if (tgt >= tot) tgt = tot - 1;
         unsigned long long acc = 0;
-        int t = 0;
-        for (; t < 1023; ++t) {
-            if (tgt < acc + s_m[t]) break;
-            acc += s_m[t];
+        int w = 0;
+        for (; w < 15; ++w) {
+            if (tgt < acc + s_m[w]) break;
+            acc += s_m[w];
         }
-        s_sel = t;                                                   // the owning chunk; its exclusive prefix in s_base
+        s_sel = w;                                                   // the owning wave; the exclusive prefix of its first chunk in s_base
         s_base = acc;
         s_target = tgt;
         if (p.dbg) { p.dbg[0] = (float)s_kept; p.dbg[1] = Z ? (float)((double)tot / (double)Z) : 1.f; p.dbg[3] = mx; }
     }
     __syncthreads();
-    if (tid == s_sel) {
+    const unsigned long long excl_t = s_base + incl_w - mine;
+    // the one chunk whose interval holds the target (a wave's last non-empty chunk if rounding left the target at its very end)
+    const bool own = wave == s_sel && mine > 0 && excl_t <= s_target && (s_target < excl_t + mine);
+    if (own) {
         const unsigned long long tgt = s_target;
-        unsigned long long acc = s_base;
+        unsigned long long acc = excl_t;
         int sel = -1, last = -1;
         for (int i = i0; i < i1; ++i) {
             const float s = score(i);
