@@ -64,7 +64,8 @@ int64_t vl2_workspace_bytes(void);
  * 224 / 192 = the fill-the-round 224x128 / 192x128 ping-pong kernel (csrc/k_gemm7.h; any N % 128 == 0, plain or gathered A, no SwiGLU; the
  * automatic choice takes it where its grid is one round of <= 256 workgroups and fills the chip better than the wider tiles:
  * the decoder's o / down projections at S = 1621, the STC convolutions on 1521 output positions).
- * Every variant produces the same bits.  profiles/r01_gemm_experiments.md, r03_experiments.md, r04_experiments.md. */
+ * 16 = the 256x256 ping-pong tile on v_mfma_f32_16x16x32_bf16 (csrc/k_gemm9.h, see VL2_GEMM_MFMA16): never the automatic choice.
+ * Every variant EXCEPT 16 produces the same bits.  profiles/r01_gemm_experiments.md, r03_experiments.md, r04_experiments.md. */
 #define VL2_GEMM_PERSISTENT 8  /* the automatic kernel choice may take the persistent form (variants 70 / 71; needs `tile_ctr` or `ws`).  Off by default:
                                  7-10 % faster per kernel on multi-round K = 1024 shapes, but in the power-limited pipeline it slows its successors
                                  and lost 1 ms per ViT pass on 3 of 11 boxes (profiles/r04_experiments.md) */
@@ -80,6 +81,11 @@ int64_t vl2_workspace_bytes(void);
 #define VL2_GEMM_NO_WEAVE4 1024 /* the 192x256 tiles (variant 12) WITHOUT the woven issue they take by default since round 5: A/B (ViT fc2 / out_proj, decoder q/k/v: -0.4 ... -3.7 %) */
 #define VL2_GEMM_NO_TICKET 256 /* `row_norm_out` is filled by a separate vl2_row_norm_finalize launch behind the GEMM (rounds 3-4) instead of by the GEMM's last
                                  column tile: A/B of the producer-side finalize (same bits) */
+#define VL2_GEMM_MFMA16  2048 /* opt-in: plain bf16-output calls without activation (incl. SWIGLU; N % 256 == 0, no gather / remap / stats_out) run on the 256x256 ping-pong
+                               * kernel built on v_mfma_f32_16x16x32_bf16 (csrc/k_gemm9.h; variant 16 = the same on demand).  The instruction sustains ~15 % more at this
+                               * part's power limit than the library's v_mfma_f32_32x32x16_bf16, but sums 32 products per accumulation step instead of 16: results are as
+                               * accurate but NOT bit-identical with every other variant, so a call site must use it for ALL its calls or none (a row's bits still do
+                               * not depend on M).  Ignored where the kernel is not built. */
 #define VL2_GEMM_WEAVE   64   /* lab: the 128x256 / 224x128 / 192x128 ping-pong kernels issue their LDS-DMA woven between the MFMAs of the matrix phases instead of
                                  from the load phases (same bits; faster back to back on warm operands, slower in the pipeline: profiles/r05_experiments.md) */
 /* stage-level descriptors (vl2_vit_desc / vl2_stc_desc / vl2_llm_desc) `flags`: experiment controls, all off by default */
@@ -91,6 +97,7 @@ int64_t vl2_workspace_bytes(void);
 #define VL2_STAGE_WEAVE          256   /* ... with VL2_GEMM_WEAVE */
 #define VL2_STAGE_WEAVE4        8192   /* ... with VL2_GEMM_WEAVE4 */
 #define VL2_STAGE_NO_WEAVE4    16384   /* ... with VL2_GEMM_NO_WEAVE4 */
+#define VL2_STAGE_MFMA16       32768   /* vl2_llm_prefill: the gate/up projection (the step's dominant GEMM) with VL2_GEMM_MFMA16, at every S */
 #define VL2_STAGE_ROW_TICKET    1024   /* ViT and LLM prefill: the statistics-producing GEMMs (out_proj / fc2, o / down) finalize their own output rows
                                          * (vl2_gemm_desc.row_norm_out: producer-side ticket, csrc/k_gemm.h gemm_rows_ticket) instead of a vl2_row_norm_finalize launch
                                          * behind each of them.  Same bits; measured round 5: neutral in the tower (-0.03 ms), SLOWER in the prefill (+0.12 ms: every

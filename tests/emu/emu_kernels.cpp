@@ -8,6 +8,7 @@ alignas(64) unsigned char vl2_smem[160 * 1024];
 #include "k_gemm6.h"
 #include "k_gemm7.h"
 #include "k_gemm8.h"
+#include "k_gemm9.h"
 #include "k_norm.h"
 #include "k_vit.h"
 #include "k_attn.h"
@@ -35,11 +36,26 @@ extern "C" int32_t vl2_fill_zero(void* p, int64_t bytes, void*) { if (!p || byte
 // per-call controls (vl2_gemm_desc.variant, VL2_GEMM_SPLITK, vl2_attn_fwd variant): set by the entry points below
 static int g_gemm_variant = 0;
 static bool g_no_weave4 = false;
+static int g_mfma16_mode = 0;       // variants 17 / 18: the lab orders of gemm9's LDS-DMA issue
+static bool g_mfma16 = false;       // variant 16 / VL2_GEMM_MFMA16: the 256 x 256 ping-pong tile on the 16 x 16 x 32 matrix instruction (k_gemm9.h)
 static bool g_weave4 = false;       // VL2_GEMM_WEAVE4: the 256-/192-row ping-pong bodies with the woven LDS-DMA issue
 static bool g_need_fin = false;     // a GEMM path without the producer-side finalize ran: append the row_norm_finalize launch (vl2_abi.hip GemmCtl.fin)
 static bool g_gemm6_dynamic = false;       // gemm6: tiles handed out through the counter block (variants 70 / 71 = 60 / 61 dynamic)
 template <int ACT, bool SW, bool F32, bool G>
 static void run_gemm(GemmArgs a) {
+    if constexpr (!G && !F32 && ACT == 0) {
+        if (g_mfma16) {
+            a.tiles_m = (a.M + 255) / 256; a.tiles_n = a.N / 256;
+            if (g_mfma16_mode == 1) emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(512), [=] { gemm9_bf16_kernel<SW, 1>(a); });
+            else if (g_mfma16_mode == 2) emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(512), [=] { gemm9_bf16_kernel<SW, 2>(a); });
+            else if (g_mfma16_mode == 3) emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(512), [=] { gemm9_bf16_kernel<SW, 3>(a); });
+            else if (g_mfma16_mode == 4) emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(512), [=] { gemm9_bf16_kernel<SW, 4>(a); });
+            else if (g_mfma16_mode == 5) emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(512), [=] { gemm9_bf16_kernel<SW, 5>(a); });
+            else if (g_mfma16_mode == 6) emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(512), [=] { gemm9_bf16_kernel<SW, 6>(a); });
+            else emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(512), [=] { gemm9_bf16_kernel<SW, 0>(a); });
+            return;
+        }
+    }
     if constexpr (!SW) {                                        // fill-the-round 224 x 128 / 192 x 128 tiles (k_gemm7.h), plain and gathered
         if (g_gemm_variant == 224 || g_gemm_variant == 192 || g_gemm_variant == 225 || g_gemm_variant == 193) {   // 225 / 193: LDS-DMA issue woven into the MFMA phases
             const bool weave = (g_gemm_variant & 1) != 0;
@@ -219,7 +235,14 @@ extern "C" int32_t vl2_gemm(const vl2_gemm_desc* d, void*) {
             g_need_fin = false;
         }
     } fin{d};
-    g_gemm_variant = (d->flags & VL2_GEMM_SPLITK) ? 16 : d->variant;     // 16 = the emulator's split-K form of the 128x128 kernel
+    const bool v16 = d->variant >= 16 && d->variant <= 22;
+    g_gemm_variant = (d->flags & VL2_GEMM_SPLITK) ? 16 : v16 ? 0 : d->variant;     // 16 = the emulator's split-K form of the 128x128 kernel
+    {   // the product's variant 16 / VL2_GEMM_MFMA16 (vl2_abi.hip vl2_gemm)
+        const bool ok16 = !d->a_idx && !(d->flags & 2) && d->out_grp <= 0 && d->res_row_mod <= 0 && act == 0 && !d->stats_out && N % 256 == 0;
+        if (v16 && !ok16) return -3;
+        g_mfma16 = ok16 && (v16 || (d->variant == 0 && (d->flags & VL2_GEMM_MFMA16)));
+        g_mfma16_mode = v16 ? d->variant - 16 : 0;
+    }
     const bool sw = d->flags & 1, f32 = d->flags & 2, g = a.a_idx != nullptr;
     if (d->flags & VL2_GEMM_FP8) {          // W8A8 on the (emulated) fp8 matrix pipe: rows of K bytes seen as K / 2 16-bit elements (vl2_abi.hip)
         if (N % 256 || K % 128 || !d->row_norm || !d->col_scale || g) return -2;

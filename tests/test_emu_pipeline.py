@@ -210,6 +210,49 @@ def test_emu_gemm_pingpong_variant(emu):
             ops.set_gemm_variant(0)
 
 
+def test_emu_gemm_mfma16_kernel(emu):
+    """csrc/k_gemm9.h: the 256 x 256 ping-pong tile on v_mfma_f32_16x16x32_bf16 (variant 16 / VL2_GEMM_MFMA16 / STAGE_MFMA16).  The ONE kernel whose
+    dot products associate differently from the family's ON THE GPU: held to the fp32 result at the family's tolerance, to the family's bits (emulator only),
+    and to ITSELF across M (a row's bits do not depend on how many rows the call has) and across the ways of asking for it."""
+    from videollama2_amd import ops
+    from videollama2_amd.weights import fold_norm, pack_gate_up
+    for M, K in ((300, 64), (257, 192), (520, 576)):                      # ragged M; K = 2 slabs (the ring never fills), 6, 18
+        N = 512
+        a, w, bias, res = bf(M, K), bf(N, K, scale=K ** -0.5), torch.randn(N), bf(M, N)
+        wg, wu = bf(256, K, scale=K ** -0.5, seed=3), bf(256, K, scale=K ** -0.5, seed=4)
+        g = 1 + 0.3 * torch.randn(K, generator=torch.Generator().manual_seed(5))
+        wgu, _, _ = fold_norm(pack_gate_up(wg, wu), g)
+        af = a.float()
+        rn = ops.row_norm_finalize(ops.row_stats(a), K, ops.NORM_RMS, 1e-6)
+        h = af * torch.rsqrt(af.pow(2).mean(-1, keepdim=True) + 1e-6) * g.bfloat16().float()
+        fam = (ops.gemm(a, w, bias=bias, res=res), ops.gemm(a, wgu, swiglu=True, norm=(ops.NORM_RMS, rn, 1e-6, None)))
+        try:
+            ops.set_gemm_variant(16)
+            y = ops.gemm(a, w, bias=bias, res=res)
+            y_sw = ops.gemm(a, wgu, swiglu=True, norm=(ops.NORM_RMS, rn, 1e-6, None))
+            assert rel(y, F.linear(af, w.float(), bias) + res.float()) < TOL_BF16_OUT, (M, K)
+            assert rel(y_sw, F.silu(h @ wg.float().T) * (h @ wu.float().T)) < TOL_BF16_OUT, (M, K)
+            # the emulated matrix instructions both sum their k in ascending order, so HERE the kernel must reproduce the family's bits exactly (an
+            # indexing check stronger than any tolerance); on the GPU the two instructions associate differently (tests/test_gpu_ops.py holds the bound)
+            assert torch.equal(y, fam[0]) and torch.equal(y_sw, fam[1]), (M, K)
+            for v in (17, 18, 19, 20, 21, 22):                              # lab forms (k_gemm9.h MODE 1 / 2 / 4 / 5 / 6: orders of the LDS-DMA issue; 3: register-staged slabs)
+                ops.set_gemm_variant(v)
+                assert torch.equal(ops.gemm(a, w, bias=bias, res=res), y) and torch.equal(ops.gemm(a, wgu, swiglu=True, norm=(ops.NORM_RMS, rn, 1e-6, None)), y_sw), (M, K, v)
+            ops.set_gemm_variant(16)
+            m1 = M - 130                                                    # fewer rows, other tile edge: the same bits row for row
+            assert torch.equal(ops.gemm(a[:m1], w, bias=bias, res=res[:m1]), y[:m1])
+            assert torch.equal(ops.gemm(a[:m1], wgu, swiglu=True, norm=(ops.NORM_RMS, rn[:m1], 1e-6, None)), y_sw[:m1])
+            with pytest.raises(RuntimeError):                               # variant 16 is a demand: not built for activations / fp32 outputs
+                ops.gemm(a, w, bias=bias, act=ops.ACT_QGELU)
+            ops.set_gemm_variant(0)
+            ops.set_stage_flags(ops.STAGE_MFMA16)                           # the session switch: SwiGLU GEMMs only
+            assert torch.equal(ops.gemm(a, wgu, swiglu=True, norm=(ops.NORM_RMS, rn, 1e-6, None)), y_sw)
+            assert torch.equal(ops.gemm(a, w, bias=bias, res=res), fam[0])
+        finally:
+            ops.set_gemm_variant(0)
+            ops.set_stage_flags(0)
+
+
 def test_emu_gemm_persistent_kernels_are_bit_identical(emu):
     """csrc/k_gemm6.h (persistent ping-pong GEMM; emulator knobs 60 = 256-row tiles, 61 = 192-row tiles, 62 = 192-row tiles with two
     accumulator sets and the previous tile's epilogue drained under the next tile's phases): three workgroups walk 6-15 tiles each across
@@ -876,6 +919,11 @@ def test_emu_stage_level_entry_points_equal_the_per_operator_path(emu, golden_sm
         ops.STAGE_ABI = True
         ops.set_stage_flags(ops.STAGE_ROW_TICKET)                  # producer-side finalize of the row statistics (k_gemm.h gemm_rows_ticket): same bits
         assert torch.equal(m.vision_tower(g["frames"]), a[0]) and torch.equal(m.decoder.prefill(g["inputs_embeds"]), a[2])
+        ops.set_stage_flags(ops.STAGE_MFMA16)                      # gate/up on the 16 x 16 x 32 matrix instruction (k_gemm9.h): other last bits than the default,
+        l16 = m.decoder.prefill(g["inputs_embeds"]).clone()        # but the SAME bits from the C++ layer loop and the per-operator loop
+        ops.STAGE_ABI = False
+        assert torch.equal(m.decoder.prefill(g["inputs_embeds"]), l16) and torch.equal(l16, a[2])   # (the emulated MFMAs sum k in order: here even the default's bits)
+        ops.STAGE_ABI = True
         ops.set_stage_flags(0)
         from videollama2_amd._lib import Vl2HipError
         d, _, ws = m.decoder._stage_desc()

@@ -667,6 +667,43 @@ def test_gemm_skinny_7b_shapes(ops):
     assert rel(got, ref) < TOL_BF16_OUT
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 512, 448), (1621, 28672, 4096), (2500, 1024, 14336)])
+def test_gemm_mfma16_kernel(ops, M, N, K):
+    """csrc/k_gemm9.h (variant 16 / VL2_GEMM_MFMA16 / STAGE_MFMA16): the 256 x 256 ping-pong tile on v_mfma_f32_16x16x32_bf16.  The one kernel that is NOT
+    bit-identical with the family (the instruction sums 32 products per accumulation step, the family's 16): held to the fp32 result at the
+    family's tolerance, to the family within two bf16 output roundings, deterministic, and a row's bits do not depend on M.  The decoder's
+    gate/up shape (SwiGLU + RMSNorm carried) and a residual-carrying projection."""
+    from videollama2_amd.weights import fold_norm, pack_gate_up
+    a, w, bias, res = bf(M, K), bf(N, K, scale=K ** -0.5), torch.randn(N), bf(M, N)
+    ad, wd, bd, rd = a.to(DEV), w.to(DEV), bias.to(DEV), res.to(DEV)
+    g = (1 + 0.3 * torch.randn(K, generator=torch.Generator().manual_seed(5))).bfloat16().float()
+    wg, wu = bf(N // 2, K, scale=K ** -0.5, seed=3), bf(N // 2, K, scale=K ** -0.5, seed=4)
+    wgu, _, _ = fold_norm(pack_gate_up(wg, wu), g, dev=DEV)
+    rn = ops.row_norm_finalize(ops.row_stats(ad), K, ops.NORM_RMS, 1e-6)
+    af = ad.float()
+    h = af * torch.rsqrt(af.pow(2).mean(-1, keepdim=True) + 1e-6) * g.to(DEV)
+    ref = F.linear(af, wd.float(), bd) + rd.float()
+    ref_sw = F.silu(h @ wg.to(DEV).float().T) * (h @ wu.to(DEV).float().T)
+    fam = (ops.gemm(ad, wd, bias=bd, res=rd), ops.gemm(ad, wgu, swiglu=True, norm=(ops.NORM_RMS, rn, 1e-6, None)))
+    try:
+        ops.set_gemm_variant(16)
+        y, y_sw = ops.gemm(ad, wd, bias=bd, res=rd), ops.gemm(ad, wgu, swiglu=True, norm=(ops.NORM_RMS, rn, 1e-6, None))
+        assert rel(y, ref) < TOL_BF16_OUT and rel(y_sw, ref_sw) < TOL_BF16_OUT, (rel(y, ref), rel(y_sw, ref_sw))
+        assert rel(y, fam[0]) < 2 * TOL_BF16_OUT and rel(y_sw, fam[1]) < 2 * TOL_BF16_OUT
+        assert rel(y, ref) < 1.1 * rel(fam[0], ref) + 1e-5 and rel(y_sw, ref_sw) < 1.1 * rel(fam[1], ref_sw) + 1e-5     # as accurate as the family
+        for _ in range(3):
+            assert torch.equal(ops.gemm(ad, wd, bias=bd, res=rd), y) and torch.equal(ops.gemm(ad, wgu, swiglu=True, norm=(ops.NORM_RMS, rn, 1e-6, None)), y_sw)
+        m1 = M - 130
+        assert torch.equal(ops.gemm(ad[:m1], wd, bias=bd, res=rd[:m1]), y[:m1])
+        assert torch.equal(ops.gemm(ad[:m1], wgu, swiglu=True, norm=(ops.NORM_RMS, rn[:m1], 1e-6, None)), y_sw[:m1])
+        ops.set_gemm_variant(0)
+        ops.set_stage_flags(ops.STAGE_MFMA16)                       # the session switch reaches SwiGLU calls only
+        assert torch.equal(ops.gemm(ad, wgu, swiglu=True, norm=(ops.NORM_RMS, rn, 1e-6, None)), y_sw) and torch.equal(ops.gemm(ad, wd, bias=bd, res=rd), fam[0])
+    finally:
+        ops.set_gemm_variant(0)
+        ops.set_stage_flags(0)
+
+
 def test_gemm_one_round_kernel_bit_identical(ops):
     """Grids of <= 256 tiles with K >= 4096 take the deep-ring 128x128 kernel automatically; same bits as the 2-stage kernel."""
     for M, N, K, kw in [(845, 4096, 4096, dict()), (945, 4096, 14336, dict(res=True)), (2308, 1024, 4096, dict(bias=True, res=True, act=ops.ACT_GELU))]:

@@ -55,7 +55,14 @@ def test_stage_calls_equal_per_operator_path_on_device(golden_small, golden_smal
         for _ in range(2):
             assert torch.equal(m.vision_tower(g["frames"].to(DEV)), a[0])
             assert torch.equal(dec.prefill(g["inputs_embeds"].to(DEV)), a[3])
+        # VL2_STAGE_MFMA16: gate/up on the 16 x 16 x 32 matrix instruction (k_gemm9.h) -- other last bits than the default's (an opt-in arithmetic), but the SAME
+        # bits from the C++ layer loop and from the per-operator loop, and logits within the bf16 noise of the default's
+        ops.set_stage_flags(ops.STAGE_MFMA16)
+        l16 = dec.prefill(g["inputs_embeds"].to(DEV)).clone()
+        ops.STAGE_ABI = False
+        assert torch.equal(dec.prefill(g["inputs_embeds"].to(DEV)), l16) and rel(l16, a[3]) < 5e-3
     finally:
+        ops.STAGE_ABI = True
         ops.set_stage_flags(0)
     # the graph decoder.generate uses replays the same entry point: tokens equal to eager generate
     ids = g["input_ids"][None].to(DEV)

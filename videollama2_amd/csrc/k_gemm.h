@@ -1041,7 +1041,8 @@ __device__ __forceinline__ void gemm4_body(const GemmArgs& p, int bid, int nwg) 
 #pragma unroll
         for (int i = 0; i < MI; ++i) VL2_PIN2(rowst[i][0], rowst[i][1]);
     }
-    wait_dma(nt > 2 ? 2 : nt > 1 ? 1 : 0);
+    // (woven form at nt = 2: its in-loop wait keeps ONE newer slab in flight, which would be slab 1 itself -- wait for both here)
+    wait_dma(nt > 2 ? 2 : (nt > 1 && !WEAVE4) ? 1 : 0);
     VL2_PHASE_BARRIER();
 
     if (grp == 1) VL2_PHASE_BARRIER();

@@ -1,0 +1,319 @@
+// gemm9: the 256 x 256 ping-pong GEMM of gemm4 on the OTHER bf16 matrix instruction, v_mfma_f32_16x16x32_bf16 (k_gemm.h gemm4_body is its twin on
+// v_mfma_f32_32x32x16_bf16).  Round 5, found last: an MFMA-only loop on random operands sustains 2.12-2.15 PF with the 16 x 16 x 32 shape where the
+// 32 x 32 x 16 shape sustains 1.79-1.88 (scripts/ubench/mfma_power16.hip) -- at the power limit this part runs at, the instruction with a quarter of the
+// accumulator registers per issue is worth 15 %; the vendor's GEMM kernels use it.
+//
+// A DIFFERENT ARITHMETIC in the last bits: the 16 x 16 x 32 instruction sums 32 products per accumulation step where the family's instruction sums 16, so a
+// dot product's association changes and this kernel is NOT bit-identical to the rest of the family (same fp32 accuracy: tests hold it to the fp32 oracle at the
+// family's tolerance, and to itself across M -- a row's bits do not depend on how many rows the call has).  Therefore OPT-IN (VL2_GEMM_MFMA16 on a
+// SwiGLU call = the decoder's gate/up projection, the step's dominant GEMM): the library's default keeps ONE association per dot product everywhere, which is
+// what sharded == unsharded and batched == sequential pin.  Moving the WHOLE family is the next round's first item.
+//
+// Same slabs (K in 32-deep slabs = ONE k-step of the instruction), the same 4-stage LDS-DMA ring, the same two wave groups in anti-phase, the same wave tile
+// (64 x 128 = 4 x 8 accumulator blocks of 16 x 16 = the same 128 accumulator registers).  What changes: fragment (i = row block of 16) = rows 16 i + (lane & 15),
+// 16-B chunk lane >> 4 of the slab row -- ONE ds_read_b128, base + 1 KiB per block -- and the LDS swizzle that makes THAT access pattern conflict-free
+// (`gemm9_lds_off`: chunk ^ H[(row >> 2) & 3], H = {0, 3, 2, 1}; checked against the ds_read_b128 lane groups of MI355X_MICROARCH.md: gemm4's swizzle is
+// 2-way conflicted under this pattern); accumulators: register r of block (i, j) = C[16 i + 4 (lane >> 4) + r][16 j + (lane & 15)].
+#pragma once
+#include <type_traits>
+#include "k_gemm.h"
+
+__device__ __forceinline__ int gemm9_lds_off(int row, int chunk) {
+    const int q = (row >> 2) & 3;
+    return (((row >> 2) << 4) + ((row & 3) << 2) + (chunk ^ ((4 - q) & 3))) << 4;
+}
+
+// MODE (lab; the same bits): 0 = the LDS-DMA of slab t+3 issued at the head of the load phase (gemm4's order); 1 = behind the load phase's fragment reads (the reads'
+// latency runs under the pieces' issue cost instead of behind it); 2 = woven into the matrix phase, one piece per eight MFMAs (gemm4's WEAVE4);
+// 4 / 5 / 6 = the four pieces SPLIT between the two phases: 2 / 3 / 1 of them woven into the matrix phase, the rest at the head of the load phase (if a piece costs
+// ~100 cycles in the load phase and ~50 beside MFMAs, the even split makes both phases ~600 cycles instead of 700 | 512);
+// 3 = NO LDS-DMA: the slabs come through REGISTERS (plain buffer loads two slabs ahead into two register sets, ds_write_b128 into the same LDS image one slab
+// ahead) -- the vendor kernels' path.  Why: an LDS-DMA piece blocks its wave's issue for 60-185 cycles (MI355X_MICROARCH.md), four pieces per load phase =
+// the load phase outlasts the partner's 512-cycle matrix phase (measured: 72 % of the matrix pipe's cycles at 1.81 GHz, the vendor kernel 83-88 % at 1.79 GHz,
+// profiles/r05_gemm_power_clock_ab.txt); a plain load issues in a few cycles and its ds_write_b128 in ~16.
+template <bool SWIGLU, int MODE = 0>
+__device__ __forceinline__ void gemm9_body(const GemmArgs& p, int bid, int nwg) {
+    constexpr int BM = 256, MI = 4, NJ = 8;                        // 16 x 16 accumulator blocks of a wave (64 rows x 128 columns)
+    extern __shared__ __attribute__((aligned(16))) unsigned char vl2_smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, w4 = wave & 3;
+    const int wrow = grp * 128 + (w4 >> 1) * 64, wcol = (w4 & 1) * 128;
+
+    const int t0 = xcd_remap(bid, nwg);
+    const int grp_sz = 4 * p.tiles_n;
+    const int first_m = (t0 / grp_sz) * 4;
+    const int gm = (p.tiles_m - first_m) < 4 ? (p.tiles_m - first_m) : 4;
+    const int tm = first_m + (t0 % grp_sz) % gm, tn = (t0 % grp_sz) / gm;
+    const int m0 = tm * BM, n0 = tn * GEMM4_BN;
+    f32x2 rst = {0.f, 1.f};
+
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x7fffffff, 0x00020000);
+    const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0x7fffffff, 0x00020000);
+    unsigned a_vo[2], w_vo[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {                                   // gemm4's piece map with this kernel's swizzle on the SOURCE chunk
+        const int aslot = ((grp * 8 + i * 4 + w4) << 6) + lane, wslot = grp * 512 + ((i * 4 + w4) << 6) + lane;
+        const int Ra = aslot >> 4, spa = aslot & 15, Rw = wslot >> 4, spw = wslot & 15;
+        const int rowa = 4 * Ra + (spa >> 2), chka = (spa & 3) ^ ((4 - (Ra & 3)) & 3);
+        const int roww = 4 * Rw + (spw >> 2), chkw = (spw & 3) ^ ((4 - (Rw & 3)) & 3);
+        int am = m0 + rowa;
+        am = am < p.M ? am : p.M - 1;
+        a_vo[i] = ((unsigned)am * (unsigned)p.lda + chka * 8) * 2;
+        w_vo[i] = ((unsigned)(n0 + roww) * (unsigned)p.ldw + chkw * 8) * 2;
+    }
+    auto issue_dma = [&](int t) {
+        const unsigned st = (unsigned)(t & 3) * GEMM4_STAGE, kb = (unsigned)t * (GEMM4_BK * 2);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(vl2_smem + st + ((grp * 8 + i * 4 + w4) << 10)), 16, a_vo[i], kb, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(vl2_smem + st + 16384 + ((grp * 8 + i * 4 + w4) << 10)), 16, w_vo[i], kb, 0, 0);
+    };
+    auto issue_piece = [&](int t, int tk, int i) {    // piece i (0, 1 = A; 2, 3 = W) of this wave's share of slab tk, into the ring slot of slab t
+        const unsigned st = (unsigned)(t & 3) * GEMM4_STAGE, kb = (unsigned)tk * (GEMM4_BK * 2);
+        if (i < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(vl2_smem + st + ((grp * 8 + i * 4 + w4) << 10)), 16, a_vo[i], kb, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(vl2_smem + st + 16384 + ((grp * 8 + (i - 2) * 4 + w4) << 10)), 16, w_vo[i - 2], kb, 0, 0);
+    };
+    auto wait_dma = [&](int slabs) {
+        if (slabs >= 2) VL2_WAIT_VMCNT(8);
+        else if (slabs == 1) VL2_WAIT_VMCNT(4);
+        else VL2_WAIT_VMCNT(0);
+    };
+
+    f32x4 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 fa[MI], fb[NJ];
+
+    const int nt = p.K / GEMM4_BK;
+    const unsigned a_rd = gemm9_lds_off(wrow + (lane & 15), lane >> 4);                 // block i / j is + 1024 B (16 rows)
+    const unsigned b_rd = 16384 + gemm9_lds_off(wcol + (lane & 15), lane >> 4);
+    unsigned long long c_start = 0;
+    if constexpr (MODE == 8) c_start = __builtin_readcyclecounter();      // MODE 8 (lab, variant 24 is taken: variant 25): MODE 0 with ONE stamp pair around the K loop
+    if constexpr (MODE == 7) {
+        // MODE 0 with s_memtime stamps around the parts of the two phases (lab, variant 23): per workgroup and wave, the sums over the K loop of
+        // [LDS-DMA issue | fragment reads issued and returned + the counted wait | barrier behind the load phase | 32 MFMAs issued | barrier behind the matrix phase]
+        // and the slab count, as six u64 at sk_ws[(workgroup * 8 + wave) * 6].  (The stamps wait for lgkmcnt(0) themselves: placed where nothing else is pending.)
+        auto now = [&]() { __builtin_amdgcn_sched_barrier(0); const unsigned long long c = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); return c; };
+        unsigned long long acc_t[5] = {0, 0, 0, 0, 0};
+        issue_dma(0);
+        if (nt > 1) issue_dma(1);
+        if (nt > 2) issue_dma(2);
+        rst = gemm_row_stats(p, m0, tid, BM);
+        VL2_PIN2(rst[0], rst[1]);
+        wait_dma(nt > 2 ? 2 : nt > 1 ? 1 : 0);
+        VL2_PHASE_BARRIER();
+        if (grp == 1) VL2_PHASE_BARRIER();
+        for (int t = 0; t < nt; ++t) {
+            const unsigned long long c0 = now();
+            if (t + 3 < nt) issue_dma(t + 3);
+            const unsigned long long c1 = now();
+            const unsigned st = (unsigned)(t & 3) * GEMM4_STAGE;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) fa[i] = *(const bf16x8*)(vl2_smem + st + a_rd + i * 1024);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) fb[j] = *(const bf16x8*)(vl2_smem + st + b_rd + j * 1024);
+            wait_dma(nt - 2 - t);
+            VL2_WAIT_LGKMCNT0();
+            const unsigned long long c2 = now();
+            VL2_PHASE_BARRIER();
+            const unsigned long long c3 = now();
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[i][j] = VL2_MFMA16(fa[i], fb[j], acc[i][j]);
+            const unsigned long long c4 = now();
+            VL2_PHASE_BARRIER();
+            const unsigned long long c5 = now();
+            acc_t[0] += c1 - c0; acc_t[1] += c2 - c1; acc_t[2] += c3 - c2; acc_t[3] += c4 - c3; acc_t[4] += c5 - c4;
+        }
+        if (lane == 0 && p.sk_ws) {
+            unsigned long long* o = (unsigned long long*)p.sk_ws + (size_t)(bid * 8 + wave) * 6;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) o[k] = acc_t[k];
+            o[5] = (unsigned long long)nt;
+        }
+    } else if constexpr (MODE >= 4) {
+        constexpr int NW = MODE == 4 ? 2 : MODE == 5 ? 3 : 1;        // pieces woven into the matrix phase (the last NW of the four)
+        // branch-free: always three slabs in the prologue and one per iteration -- past the end of K the LAST slab again, into a dead slot; so the counted wait
+        // is one number: behind the load phase's pieces, slab t+2 (4) and the load phase's share of slab t+3 (4 - NW) may be in flight
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) issue_piece(q, q < nt ? q : nt - 1, i);
+        rst = gemm_row_stats(p, m0, tid, BM);
+        VL2_PIN2(rst[0], rst[1]);
+        VL2_WAIT_VMCNT(8);
+        VL2_PHASE_BARRIER();
+        if (grp == 1) VL2_PHASE_BARRIER();
+        for (int t = 0; t < nt; ++t) {
+            const int tk = t + 3 < nt ? t + 3 : nt - 1;
+#pragma unroll
+            for (int i = 0; i < 4 - NW; ++i) issue_piece(t + 3, tk, i);
+            const unsigned st = (unsigned)(t & 3) * GEMM4_STAGE;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) fa[i] = *(const bf16x8*)(vl2_smem + st + a_rd + i * 1024);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) fb[j] = *(const bf16x8*)(vl2_smem + st + b_rd + j * 1024);
+            VL2_WAIT_VMCNT(8 - NW);
+            VL2_WAIT_LGKMCNT0();
+            VL2_PHASE_BARRIER();
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    acc[i][j] = VL2_MFMA16(fa[i], fb[j], acc[i][j]);
+                    constexpr int STEP = 32 / NW;
+                    const int idx = i * NJ + j;
+                    if (idx % STEP == STEP / 2) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        issue_piece(t + 3, tk, 4 - NW + idx / STEP);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            VL2_PHASE_BARRIER();
+        }
+        VL2_WAIT_VMCNT(0);
+    } else if constexpr (MODE == 3) {
+        // register-staged pipeline.  At LOAD(t): W(t+1) = this wave's four pieces of slab t+1 from register set (t+1) & 1 into ring slot (t+1) & 3 (the same
+        // lane-linear image the LDS-DMA writes: piece base + 16 lane, conflict-free), G(t+3) = the loads of slab t+3 into the set just written out, R(t) = the
+        // fragment reads of slab t; every wave wrote its pieces of slab t at ITS LOAD(t-1), one barrier or more before anyone's R(t).  hipcc counts vmcnt itself.
+        u32x4 ra[2][2], rw[2][2];
+        const unsigned wr_a = (unsigned)((grp * 8 + w4) << 10) + lane * 16, wr_w = 16384u + wr_a;        // piece i is + 4 KiB
+        auto G = [&](auto set, int t) {
+            constexpr int S = decltype(set)::value;
+            const unsigned kb = (unsigned)t * (GEMM4_BK * 2);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ra[S][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, a_vo[i], kb, 0));
+                rw[S][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, w_vo[i], kb, 0));
+            }
+        };
+        auto W = [&](auto set, int t) {
+            constexpr int S = decltype(set)::value;
+            const unsigned st = (unsigned)(t & 3) * GEMM4_STAGE;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                *(u32x4*)(vl2_smem + st + wr_a + i * 4096) = ra[S][i];
+                *(u32x4*)(vl2_smem + st + wr_w + i * 4096) = rw[S][i];
+            }
+        };
+        auto slab = [&](auto set1, int t, auto full) {             // set1 = the register set of slab t+1 (and t+3); full: t + 3 < nt is known (no branches)
+            if (decltype(full)::value || t + 1 < nt) W(set1, t + 1);
+            if (decltype(full)::value || t + 3 < nt) G(set1, t + 3);
+            const unsigned st = (unsigned)(t & 3) * GEMM4_STAGE;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) fa[i] = *(const bf16x8*)(vl2_smem + st + a_rd + i * 1024);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) fb[j] = *(const bf16x8*)(vl2_smem + st + b_rd + j * 1024);
+            VL2_WAIT_LGKMCNT0();
+            VL2_PHASE_BARRIER();
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[i][j] = VL2_MFMA16(fa[i], fb[j], acc[i][j]);
+            VL2_PHASE_BARRIER();
+        };
+        using S0 = std::integral_constant<int, 0>;
+        using S1 = std::integral_constant<int, 1>;
+        G(S0{}, 0);
+        if (nt > 1) G(S1{}, 1);
+        rst = gemm_row_stats(p, m0, tid, BM);
+        VL2_PIN2(rst[0], rst[1]);
+        W(S0{}, 0);
+        if (nt > 2) G(S0{}, 2);
+        VL2_WAIT_LGKMCNT0();
+        VL2_PHASE_BARRIER();
+        if (grp == 1) VL2_PHASE_BARRIER();
+        int t = 0;
+        for (; t + 4 < nt; t += 2) {                                // steady state without branches: hipcc's vmcnt for W(t+1) then leaves the loads of slab t+2 in flight
+            slab(S1{}, t, std::true_type{});                        // (with the tail's conditions inside the loop it merged the paths to vmcnt(0): one slab of latency cover)
+            slab(S0{}, t + 1, std::true_type{});
+        }
+        for (; t + 1 < nt; t += 2) {                                // the last three or four slabs (t stays even)
+            slab(S1{}, t, std::false_type{});
+            slab(S0{}, t + 1, std::false_type{});
+        }
+        if (t < nt) slab(S1{}, t, std::false_type{});
+    } else {
+    issue_dma(0);
+    if (nt > 1) issue_dma(1);
+    if (nt > 2) issue_dma(2);
+    rst = gemm_row_stats(p, m0, tid, BM);
+    VL2_PIN2(rst[0], rst[1]);
+    wait_dma(nt > 2 ? 2 : (nt > 1 && MODE != 2) ? 1 : 0);          // (woven form: its in-loop wait keeps ONE slab in flight, which at nt = 2 would be slab 1 itself)
+    VL2_PHASE_BARRIER();
+
+    if (grp == 1) VL2_PHASE_BARRIER();
+    for (int t = 0; t < nt; ++t) {
+        // ---------------- LOAD(t)
+        if ((MODE == 0 || MODE == 8) && t + 3 < nt) issue_dma(t + 3);
+        const unsigned st = (unsigned)(t & 3) * GEMM4_STAGE;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) fa[i] = *(const bf16x8*)(vl2_smem + st + a_rd + i * 1024);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) fb[j] = *(const bf16x8*)(vl2_smem + st + b_rd + j * 1024);
+        if constexpr (MODE == 1) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 3 < nt) issue_dma(t + 3);
+        }
+        if constexpr (MODE == 2) wait_dma(1); else wait_dma(nt - 2 - t);      // (woven: one newer slab in flight in every iteration, see gemm4_body)
+        VL2_WAIT_LGKMCNT0();
+        VL2_PHASE_BARRIER();
+        // ---------------- MFMA(t): 32 x v_mfma_f32_16x16x32_bf16 = the slab's one k-step
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                acc[i][j] = VL2_MFMA16(fa[i], fb[j], acc[i][j]);
+                if constexpr (MODE == 2) {
+                    const int idx = i * NJ + j;
+                    if (idx % 8 == 2) {                                      // behind MFMA 2, 10, 18, 26: one piece each (past the end of K: the last slab again, into the dead slot)
+                        __builtin_amdgcn_sched_barrier(0);
+                        issue_piece(t + 3, t + 3 < nt ? t + 3 : nt - 1, idx / 8);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+        VL2_PHASE_BARRIER();
+    }
+    if constexpr (MODE == 2) VL2_WAIT_VMCNT(0);
+    }
+    if constexpr (MODE == 8) {
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long c_end = __builtin_readcyclecounter();
+        if (lane == 0 && p.sk_ws) {
+            unsigned long long* o = (unsigned long long*)p.sk_ws + (size_t)(bid * 8 + wave) * 6;
+            o[0] = c_end - c_start; o[1] = o[2] = o[3] = o[4] = 0; o[5] = (unsigned long long)nt;
+        }
+    }
+    if (grp == 0) VL2_PHASE_BARRIER();
+
+    // ---- epilogue: 32 x 64 fp32 patches through the ring's memory, gemm_store_patch (bias / RMS row scale / SwiGLU / residual as the family)
+    float* ep = (float*)vl2_smem + wave * (32 * 68);
+    float* rowtab = (float*)vl2_smem + 8 * (32 * 68);
+    gemm_park_row_stats(p, rowtab, rst, tid, BM);
+    __syncthreads();
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh) {
+#pragma unroll
+            for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+                for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        ep[(ib * 16 + 4 * (lane >> 4) + r) * 68 + jb * 16 + (lane & 15)] = acc[mi * 2 + ib][nh * 4 + jb][r];
+            __builtin_amdgcn_wave_barrier();
+            gemm_store_patch<ACT_NONE, SWIGLU, false>(p, ep, m0 + wrow + mi * 32, n0 + wcol + nh * 64, lane, rowtab, wrow + mi * 32);
+            __builtin_amdgcn_wave_barrier();
+        }
+}
+template <bool SWIGLU, int MODE = 0>
+__global__ __launch_bounds__(512, 2) void gemm9_bf16_kernel(GemmArgs p) {
+    gemm9_body<SWIGLU, MODE>(p, blockIdx.x, gridDim.x);
+}

@@ -16,6 +16,7 @@
 #include "k_gemm6.h"
 #include "k_gemm7.h"
 #include "k_gemm8.h"
+#include "k_gemm9.h"
 #include "k_norm.h"
 #include "k_pack.h"
 #include "k_sample.h"
@@ -97,6 +98,7 @@ struct GemmCtl {
     bool no_fill = false;          // VL2_GEMM_NO_FILL
     bool weave = false;            // VL2_GEMM_WEAVE
     bool no_weave4 = false;        // VL2_GEMM_NO_WEAVE4: the 192-row tiles with the load-phase issue of rounds 3-4 (A/B)
+    bool mfma16 = false;           // VL2_GEMM_MFMA16 / variant 16: the 256 x 256 ping-pong kernel on v_mfma_f32_16x16x32_bf16 (k_gemm9.h; other bits)
     bool weave4 = false;           // VL2_GEMM_WEAVE4: the 256 x 256 / 192 x 256 ping-pong bodies issue their LDS-DMA from the matrix phases (k_gemm.h gemm4_body WEAVE4)
     bool* fin = nullptr;           // set to true by a launch path whose kernel has no producer-side finalize (gemm_rows_ticket): vl2_gemm then
                                    // appends the row_norm_finalize launch itself, so `row_norm_out` is filled whichever kernel ran
@@ -226,6 +228,43 @@ static void launch_gemm8(const GemmArgs& a0, hipStream_t s) {
     hipLaunchKernelGGL((gemm8_bf16_kernel<ACT, SW, F32, false>), dim3(a.tiles_m * a.tiles_n), dim3(256), GEMM8_LDS_BYTES, s, a);
 }
 
+// gemm9 (k_gemm9.h): the 256 x 256 ping-pong tile on the 16 x 16 x 32 matrix instruction -- opt-in, NOT the family's bits
+template <bool SW>
+static void launch_gemm9(const GemmArgs& a0, int mode, hipStream_t s) {
+    GemmArgs a = a0;
+    a.tiles_m = (a.M + 255) / 256;
+    a.tiles_n = a.N / GEMM4_BN;
+    const dim3 grid(a.tiles_m * a.tiles_n);
+    if (mode == 1) {          // lab (variant 17): the LDS-DMA issue behind the load phase's fragment reads
+        lds_attr<gemm9_bf16_kernel<SW, 1>>(GEMM4_LDS_BYTES);
+        hipLaunchKernelGGL((gemm9_bf16_kernel<SW, 1>), grid, dim3(512), GEMM4_LDS_BYTES, s, a);
+    } else if (mode == 2) {   // lab (variant 18): woven into the matrix phase
+        lds_attr<gemm9_bf16_kernel<SW, 2>>(GEMM4_LDS_BYTES);
+        hipLaunchKernelGGL((gemm9_bf16_kernel<SW, 2>), grid, dim3(512), GEMM4_LDS_BYTES, s, a);
+    } else if (mode == 7) {   // lab (variant 23): variant 16 with s_memtime stamps, sums into the workspace (scripts/gemm9_phase_stamps.py)
+        lds_attr<gemm9_bf16_kernel<SW, 7>>(GEMM4_LDS_BYTES);
+        hipLaunchKernelGGL((gemm9_bf16_kernel<SW, 7>), grid, dim3(512), GEMM4_LDS_BYTES, s, a);
+    } else if (mode == 8) {   // lab (variant 25): variant 16 with one stamp pair around the K loop
+        lds_attr<gemm9_bf16_kernel<SW, 8>>(GEMM4_LDS_BYTES);
+        hipLaunchKernelGGL((gemm9_bf16_kernel<SW, 8>), grid, dim3(512), GEMM4_LDS_BYTES, s, a);
+    } else if (mode == 4) {   // lab (variant 20): two pieces at the head of the load phase, two woven into the matrix phase
+        lds_attr<gemm9_bf16_kernel<SW, 4>>(GEMM4_LDS_BYTES);
+        hipLaunchKernelGGL((gemm9_bf16_kernel<SW, 4>), grid, dim3(512), GEMM4_LDS_BYTES, s, a);
+    } else if (mode == 5) {   // lab (variant 21): one / three
+        lds_attr<gemm9_bf16_kernel<SW, 5>>(GEMM4_LDS_BYTES);
+        hipLaunchKernelGGL((gemm9_bf16_kernel<SW, 5>), grid, dim3(512), GEMM4_LDS_BYTES, s, a);
+    } else if (mode == 6) {   // lab (variant 22): three / one
+        lds_attr<gemm9_bf16_kernel<SW, 6>>(GEMM4_LDS_BYTES);
+        hipLaunchKernelGGL((gemm9_bf16_kernel<SW, 6>), grid, dim3(512), GEMM4_LDS_BYTES, s, a);
+    } else if (mode == 3) {   // lab (variant 19): register-staged slabs (plain loads + ds_write_b128), no LDS-DMA
+        lds_attr<gemm9_bf16_kernel<SW, 3>>(GEMM4_LDS_BYTES);
+        hipLaunchKernelGGL((gemm9_bf16_kernel<SW, 3>), grid, dim3(512), GEMM4_LDS_BYTES, s, a);
+    } else {
+        lds_attr<gemm9_bf16_kernel<SW, 0>>(GEMM4_LDS_BYTES);
+        hipLaunchKernelGGL((gemm9_bf16_kernel<SW, 0>), grid, dim3(512), GEMM4_LDS_BYTES, s, a);
+    }
+}
+
 template <int ACT, bool SW, bool F32, int BM = GEMM4_BM>
 static void launch_gemm4(const GemmArgs& a0, hipStream_t s, bool weave4 = false) {
     GemmArgs a = a0;
@@ -352,6 +391,16 @@ static GemmArgs gemm_rows(const GemmArgs& a0, int m0, int rows, bool f32) {
 
 template <int ACT, bool SW, bool F32, bool G>
 static void launch_gemm(const GemmArgs& a0, const GemmCtl& c, hipStream_t s) {
+    if constexpr (!G && !F32 && ACT == ACT_NONE) {
+        if (c.mfma16 && (c.variant == 23 || c.variant == 25)) {                         // the stamps need room for 8 waves x 6 u64 per workgroup
+            GemmArgs a = a0;
+            const long wgs = (long)((a.M + 255) / 256) * (a.N / 256);
+            a.sk_ws = (c.ws && c.ws_bytes >= wgs * 8 * 6 * 8) ? (float*)c.ws : nullptr;
+            launch_gemm9<SW>(a, c.variant == 23 ? 7 : 8, s);
+            return;
+        }
+        if (c.mfma16) { launch_gemm9<SW>(a0, c.variant >= 17 && c.variant <= 23 ? c.variant - 16 : 0, s); return; }         // (vl2_gemm has checked that the call qualifies)
+    }
     if constexpr (!SW) {
         // fill-the-round tiles (k_gemm7.h): variants 224 / 192 on request (any shape with N % 128 == 0), or by the rule of choose_gemm7
         const int r1 = c.variant == 224 ? 3 : c.variant == 192 ? 2 : (c.variant == 0 && !c.no_fill) ? choose_gemm7(a0, G) : 0;
@@ -624,7 +673,7 @@ extern "C" int32_t vl2_gemm(const vl2_gemm_desc* d, void* stream) {
     }
     if (d->ws && (d->ws_bytes < SK_WS_BYTES || !ALIGNED16(d->ws))) return fail(VL2_E_BADARG, "vl2_gemm: workspace needs >= %lld bytes, 16-byte aligned", (long long)SK_WS_BYTES);
     const int v = d->variant;
-    if (!(v == 0 || v == 1 || v == 2 || v == 4 || v == 5 || v == 8 || v == 9 || v == 12 || v == 32 || v == 24 || v == 60 || v == 61 || v == 62 || v == 70 || v == 71 || v == 80 || v == 81 || v == 192 || v == 193 || v == 224 || v == 225 || v == 256)) return fail(VL2_E_BADARG, "vl2_gemm: unknown variant %d", v);
+    if (!(v == 0 || v == 1 || v == 2 || v == 4 || v == 5 || v == 8 || v == 9 || v == 12 || (v >= 16 && v <= 23) || v == 25 || v == 32 || v == 24 || v == 60 || v == 61 || v == 62 || v == 70 || v == 71 || v == 80 || v == 81 || v == 192 || v == 193 || v == 224 || v == 225 || v == 256)) return fail(VL2_E_BADARG, "vl2_gemm: unknown variant %d", v);
     GemmCtl ctl{d->ws, d->ws_bytes, v, (d->flags & VL2_GEMM_SPLITK) != 0};
     ctl.persist = (d->flags & VL2_GEMM_PERSISTENT) != 0;
     ctl.no_mix = (d->flags & VL2_GEMM_NO_MIX) != 0;
@@ -632,6 +681,11 @@ extern "C" int32_t vl2_gemm(const vl2_gemm_desc* d, void* stream) {
     ctl.weave = (d->flags & VL2_GEMM_WEAVE) != 0;
     ctl.weave4 = (d->flags & VL2_GEMM_WEAVE4) != 0;
     ctl.no_weave4 = (d->flags & VL2_GEMM_NO_WEAVE4) != 0;
+    {   // the 16 x 16 x 32 kernel: plain rows, bf16 output, no activation, no statistics out; the flag is a wish (ignored where the kernel is not built), variant 16 a demand
+        const bool ok16 = !g && !f32 && !remap && act == VL2_ACT_NONE && !d->stats_out && N % 256 == 0;
+        if (((v >= 16 && v <= 23) || v == 25) && !ok16) return fail(VL2_E_UNSUPP, "vl2_gemm: variant 16 (16x16x32 MFMA) is built for plain bf16 outputs without activation / gather / remap / stats_out, N %% 256 == 0");
+        ctl.mfma16 = ok16 && ((v >= 16 && v <= 23) || v == 25 || (v == 0 && (d->flags & VL2_GEMM_MFMA16)));     // 17 ... 22: lab forms (k_gemm9.h MODE 1 ... 6)
+    }
     bool need_fin = d->row_norm_out && (d->flags & VL2_GEMM_NO_TICKET);      // A/B: the separate launch as in rounds 3-4
     ctl.fin = &need_fin;
     GemmArgs a{};

@@ -44,6 +44,7 @@ STAGE_WEAVE = 256                     # lab: LDS-DMA issue woven into the MFMA p
 STAGE_NO_FILL_TILES = 128             # A/B of the fill-the-round GEMM tiles (csrc/k_gemm7.h)
 STAGE_NO_WEAVE4, GEMM_NO_WEAVE4 = 16384, 1024   # A/B: the 192-row tiles without the woven issue (their default since round 5)
 STAGE_WEAVE4, GEMM_WEAVE4 = 8192, 512 # the 256x256 / 192x256 ping-pong GEMMs issue their LDS-DMA from the matrix phases (k_gemm.h gemm4_body WEAVE4)
+STAGE_MFMA16, GEMM_MFMA16 = 32768, 2048  # opt-in: every SwiGLU (gate/up) GEMM of the session on the 16x16x32-MFMA kernel (csrc/k_gemm9.h): as accurate, OTHER last bits
 STAGE_VIT_NO_PERSISTENT = 4096        # vl2_vit_forward without the persistent GEMM form (its default since round 5): A/B
 STAGE_NO_TICKET_OPS = 2048            # ops.gemm(norm_out=...) only: the appended launch instead of the in-kernel ticket (test / A/B control of the operator path)
 STAGE_ROW_TICKET, GEMM_NO_TICKET = 1024, 256  # stage calls: producer-side finalize (k_gemm.h gemm_rows_ticket) instead of the row_norm_finalize launches (lab: not faster)
@@ -112,7 +113,8 @@ class tower_gemm_flags:
 
 def set_gemm_variant(v):
     """0 auto (per-shape choice), 1 128x128x64, 2 stream-K, 4 128x256x64 ping-pong, 8 256x256x32 ping-pong, 12 192x256, 32 64x64 small-M,
-    256 128x128 8-wave deep-ring one-round kernel, 224 / 192 the fill-the-round 224x128 / 192x128 ping-pong kernel (include/vl2hip.h)."""
+    256 128x128 8-wave deep-ring one-round kernel, 224 / 192 the fill-the-round 224x128 / 192x128 ping-pong kernel, 16 the 256x256 ping-pong
+    kernel on v_mfma_f32_16x16x32_bf16 (the one variant with other last bits) (include/vl2hip.h)."""
     _CTL["variant"] = int(v)
 
 
@@ -145,7 +147,8 @@ def gemm(a, w, bias=None, res=None, act=ACT_NONE, swiglu=False, out_f32=False, o
     grp, grp_pad, row_off = out_map or (0, 0, 0)
     rmod, roff = res_map or (0, 0)
     ws = _ws(a.device)
-    flags = (GEMM_SWIGLU if swiglu else 0) | (GEMM_OUT_F32 if out_f32 else 0) | (GEMM_SPLITK if (_CTL["splitk"] and ws is not None) else 0) | _CTL["gemm_flags"]
+    flags = (GEMM_SWIGLU if swiglu else 0) | (GEMM_OUT_F32 if out_f32 else 0) | (GEMM_SPLITK if (_CTL["splitk"] and ws is not None) else 0) | _CTL["gemm_flags"] | \
+            (GEMM_MFMA16 if (swiglu and _CTL["stage_flags"] & STAGE_MFMA16) else 0)
     kind, stats_in, eps, colsum = norm if norm is not None else (NORM_NONE, None, 0.0, None)
     row_norm = None
     if stats_in is not None and stats_in.dim() == 2:      # [rows, 2] = already reduced (row_norm_finalize)
