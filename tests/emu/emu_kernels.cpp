@@ -236,7 +236,7 @@ extern "C" int32_t vl2_gemm(const vl2_gemm_desc* d, void*) {
         }
     } fin{d};
     const bool v16 = d->variant >= 16 && d->variant <= 22;
-    g_gemm_variant = (d->flags & VL2_GEMM_SPLITK) ? 16 : v16 ? 0 : d->variant;     // 16 = the emulator's split-K form of the 128x128 kernel
+    g_gemm_variant = ((d->flags & VL2_GEMM_SPLITK) || d->variant == 116) ? 16 : v16 ? 0 : d->variant;     // 116: the emulator's own knob for the split-K form (tests)     // 16 = the emulator's split-K form of the 128x128 kernel
     {   // the product's variant 16 / VL2_GEMM_MFMA16 (vl2_abi.hip vl2_gemm)
         const bool ok16 = !d->a_idx && !(d->flags & 2) && d->out_grp <= 0 && d->res_row_mod <= 0 && act == 0 && !d->stats_out && N % 256 == 0;
         if (v16 && !ok16) return -3;

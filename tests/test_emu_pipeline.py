@@ -285,7 +285,7 @@ def test_emu_gemm_persistent_kernels_are_bit_identical(emu):
 
 
 def test_emu_gemm_splitk_plain_and_gathered(emu):
-    """Split-K form of the 128x128 kernel (emulator knob 16): partial tiles through the workspace, last arriver reduces in
+    """Split-K form of the 128x128 kernel (emulator knob 116): partial tiles through the workspace, last arriver reduces in
     split order and re-arms the tile counter (second launch reuses the counters without a host reset)."""
     from videollama2_amd import ops
     from videollama2_amd.connector import conv3d_k2s2p1_index
@@ -298,7 +298,7 @@ def test_emu_gemm_splitk_plain_and_gathered(emu):
     zero = torch.zeros(C, dtype=torch.bfloat16)
     refg = ops.gemm(pool, w3, bias=b3, act=ops.ACT_SILU, gather=(idx, zero, C))
     try:
-        ops.set_gemm_variant(16)
+        ops.set_gemm_variant(116)
         for _ in range(2):
             assert rel(ops.gemm(a, w, bias=bias, res=res, act=ops.ACT_SILU), ref.float()) < 2e-3
             assert rel(ops.gemm(a, w, out_f32=True), ref32) < 1e-5

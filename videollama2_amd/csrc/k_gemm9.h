@@ -9,6 +9,11 @@
 // SwiGLU call = the decoder's gate/up projection, the step's dominant GEMM): the library's default keeps ONE association per dot product everywhere, which is
 // what sharded == unsharded and batched == sequential pin.  Moving the WHOLE family is the next round's first item.
 //
+// MEASURED (round 5, profiles/r05_experiments.md section 11): against the same structure on 32 x 32 x 16 (variant 8), interleaved on one box -- 8192 x 4096 x 4096
+// 217 -> 201 us (1266 -> 1367 TF/s; vendor 176 us), 8192^3 840 -> 801 (vendor 677), at 1.81 instead of 1.60 GHz for the same 1.39 kW; K = 1024 shapes (not at the
+// power cap): equal; gate/up at S = 1621: 373 us against 341 for the default's mixed launch (6.3 tile rows: this kernel has no 128-row tail form) -> the stage
+// switch loses 0.6 ms of prefill, which is why it is a switch.  rel-L2 against fp32: 1.66e-3 on every shape, the family's figure.
+//
 // Same slabs (K in 32-deep slabs = ONE k-step of the instruction), the same 4-stage LDS-DMA ring, the same two wave groups in anti-phase, the same wave tile
 // (64 x 128 = 4 x 8 accumulator blocks of 16 x 16 = the same 128 accumulator registers).  What changes: fragment (i = row block of 16) = rows 16 i + (lane & 15),
 // 16-B chunk lane >> 4 of the slab row -- ONE ds_read_b128, base + 1 KiB per block -- and the LDS swizzle that makes THAT access pattern conflict-free
@@ -23,14 +28,13 @@ __device__ __forceinline__ int gemm9_lds_off(int row, int chunk) {
     return (((row >> 2) << 4) + ((row & 3) << 2) + (chunk ^ ((4 - q) & 3))) << 4;
 }
 
-// MODE (lab; the same bits): 0 = the LDS-DMA of slab t+3 issued at the head of the load phase (gemm4's order); 1 = behind the load phase's fragment reads (the reads'
-// latency runs under the pieces' issue cost instead of behind it); 2 = woven into the matrix phase, one piece per eight MFMAs (gemm4's WEAVE4);
-// 4 / 5 / 6 = the four pieces SPLIT between the two phases: 2 / 3 / 1 of them woven into the matrix phase, the rest at the head of the load phase (if a piece costs
-// ~100 cycles in the load phase and ~50 beside MFMAs, the even split makes both phases ~600 cycles instead of 700 | 512);
-// 3 = NO LDS-DMA: the slabs come through REGISTERS (plain buffer loads two slabs ahead into two register sets, ds_write_b128 into the same LDS image one slab
-// ahead) -- the vendor kernels' path.  Why: an LDS-DMA piece blocks its wave's issue for 60-185 cycles (MI355X_MICROARCH.md), four pieces per load phase =
-// the load phase outlasts the partner's 512-cycle matrix phase (measured: 72 % of the matrix pipe's cycles at 1.81 GHz, the vendor kernel 83-88 % at 1.79 GHz,
-// profiles/r05_gemm_power_clock_ab.txt); a plain load issues in a few cycles and its ds_write_b128 in ~16.
+// MODE: 0 = the shipped form (variant 16).  Lab forms, all the same bits, all measured on the device (profiles/r05_gemm_power_clock_ab.txt; 8192 x 4096 x 4096, MODE 0
+// = 201.5 us): 1 (variant 17) the LDS-DMA of slab t+3 behind the load phase's fragment reads instead of ahead of them: 212 us; 2 (18) woven into the matrix phase, one
+// piece per eight MFMAs (gemm4's WEAVE4): 201.3; 4 / 5 / 6 (20 / 21 / 22) the four pieces split 2 + 2 / 1 + 3 / 3 + 1 between load and matrix phase: 204.5-205.0 (and
+// -3 ... -9 % on 8192^3); 3 (19) NO LDS-DMA: the slabs through REGISTERS (plain buffer loads two slabs ahead into two register sets, ds_write_b128 into the same LDS
+// image one slab ahead -- the vendor kernels' path; 222 VGPRs, no spills, hipcc's own counted vmcnt(7 / 5 / 4)): 224 us.  7 / 8 (23 / 25) MODE 0 with s_memtime stamps
+// (scripts/gemm9_phase_stamps.py): per wave and slab, LDS-DMA issue 252 cycles, fragment reads 250, the 32 MFMAs' issue 506, the two barriers ~50 + ~120; the undisturbed
+// K loop 1225 cycles per slab against the matrix pipe's 1024.  So: the placement of the memory instructions is not what holds this structure.
 template <bool SWIGLU, int MODE = 0>
 __device__ __forceinline__ void gemm9_body(const GemmArgs& p, int bid, int nwg) {
     constexpr int BM = 256, MI = 4, NJ = 8;                        // 16 x 16 accumulator blocks of a wave (64 rows x 128 columns)
