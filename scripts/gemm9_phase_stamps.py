@@ -61,10 +61,18 @@ def main():
         ops.set_gemm_variant(0)
         t2 = ws[: wgs * 8 * 6 * 8].view(torch.int64).view(wgs, 8, 6).double().cpu()
         loop_cyc = t2[..., 0].mean().item()
+        setup_cyc, epi_cyc = t2[..., 1].mean().item(), t2[..., 2].mean().item()
+        # the LAST launch's stamps: per CU slot the workgroups' [entry, end] intervals; s_memtime is one counter per XCD at best, so only spans are compared:
+        # a workgroup's life = setup + loop + epilogue; kernel span on the device = max(end) - min(entry) over workgroups of an XCD is not comparable across XCDs
+        life = (t2[..., 4] - t2[..., 3]).mean().item()
         us25 = e0.elapsed_time(e1) * 1e3 / 50
         rounds = wgs / 256.0
         row.update(loop_cycles_per_slab=round(loop_cyc / (K // 32), 1), us_per_call_loop=round(us25, 1), k_loop_cycles=round(loop_cyc), wg_rounds=rounds,
                    effective_clock_MHz_lower_bound=round(rounds * loop_cyc / us25, 1))
+        row.update(setup_cycles=round(setup_cyc), epilogue_cycles=round(epi_cyc), workgroup_life_cycles=round(life),
+                   effective_clock_MHz_from_lives=round(rounds * life / us25, 1))
+        print(f"    a workgroup's life: setup {setup_cyc:.0f} + ring fill and K loop {loop_cyc:.0f} + epilogue {epi_cyc:.0f} = {life:.0f} cycles; {rounds:.2f} rounds x life / call time = "
+              f"{row['effective_clock_MHz_from_lives']} MHz (what is missing to the sysfs clock = dispatch gaps and the tail of the last round)", flush=True)
         print(f"    undisturbed loop: {row['loop_cycles_per_slab']} cycles per slab (ideal 1024 = {1024 / row['loop_cycles_per_slab']:.1%} of the matrix pipe), {us25:.1f} us per call back to back, "
               f"{rounds:.2f} rounds x {loop_cyc:.0f} loop cycles / call time = {row['effective_clock_MHz_lower_bound']} MHz (lower bound of the effective clock: prologue / epilogue not counted)", flush=True)
         out[f"{M}x{N}x{K}"] = row

@@ -23,7 +23,7 @@ def main():
     ap.add_argument("out")
     ap.add_argument("--seconds", type=float, default=2.0)
     ap.add_argument("--reps", type=int, default=2)
-    ap.add_argument("--forms", default="", help="comma list of v8,v16,v17,v18,v19,v9,vendor (default: all)")
+    ap.add_argument("--forms", default="", help="comma list of v8,v16,v17,...,v22,v26,v9,vendor (default: all)")
     args = ap.parse_args()
     from videollama2_amd import ops
     dev = "cuda"
@@ -52,12 +52,12 @@ def main():
                 ops.gemm(a, w, out=out)
                 ops.set_gemm_variant(0)
             return f
-        forms = [("v8 32x32x16", lib(8)), ("v16 16x16x32", lib(16)), ("v17 16x16x32 dma-behind-reads", lib(17)), ("v18 16x16x32 woven", lib(18)), ("v19 16x16x32 register-staged", lib(19)), ("v20 16x16x32 dma 2+2", lib(20)), ("v21 16x16x32 dma 1+3", lib(21)), ("v22 16x16x32 dma 3+1", lib(22)), ("v9 4-wave", lib(9)),
+        forms = [("v8 32x32x16", lib(8)), ("v16 16x16x32", lib(16)), ("v17 16x16x32 dma-behind-reads", lib(17)), ("v18 16x16x32 woven", lib(18)), ("v19 16x16x32 register-staged", lib(19)), ("v20 16x16x32 dma 2+2", lib(20)), ("v21 16x16x32 dma 1+3", lib(21)), ("v22 16x16x32 dma 3+1", lib(22)), ("v26 16x16x32 64-deep phases", lib(26)), ("v9 4-wave", lib(9)),
                  ("vendor", lambda: torch.matmul(a, w.T, out=out))]
         forms = [f for f in forms if not args.forms or f[0].split()[0] in args.forms.split(",")]
         lib(16)()
         ref16 = out.clone()
-        for v in (17, 18, 19, 20, 21, 22):
+        for v in (17, 18, 19, 20, 21, 22, 26):
             lib(v)()
             print(f"{M}x{N}x{K}: variant {v} bits equal to variant 16: {torch.equal(out, ref16)}", flush=True)
         del ref16

@@ -49,6 +49,7 @@ static void run_gemm(GemmArgs a) {
             if (g_mfma16_mode == 1) emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(512), [=] { gemm9_bf16_kernel<SW, 1>(a); });
             else if (g_mfma16_mode == 2) emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(512), [=] { gemm9_bf16_kernel<SW, 2>(a); });
             else if (g_mfma16_mode == 3) emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(512), [=] { gemm9_bf16_kernel<SW, 3>(a); });
+            else if (g_mfma16_mode == 9) emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(512), [=] { gemm9_bf16_kernel<SW, 9>(a); });
             else if (g_mfma16_mode == 4) emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(512), [=] { gemm9_bf16_kernel<SW, 4>(a); });
             else if (g_mfma16_mode == 5) emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(512), [=] { gemm9_bf16_kernel<SW, 5>(a); });
             else if (g_mfma16_mode == 6) emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(512), [=] { gemm9_bf16_kernel<SW, 6>(a); });
@@ -235,13 +236,13 @@ extern "C" int32_t vl2_gemm(const vl2_gemm_desc* d, void*) {
             g_need_fin = false;
         }
     } fin{d};
-    const bool v16 = d->variant >= 16 && d->variant <= 22;
+    const bool v16 = (d->variant >= 16 && d->variant <= 22) || d->variant == 26;
     g_gemm_variant = ((d->flags & VL2_GEMM_SPLITK) || d->variant == 116) ? 16 : v16 ? 0 : d->variant;     // 116: the emulator's own knob for the split-K form (tests)     // 16 = the emulator's split-K form of the 128x128 kernel
     {   // the product's variant 16 / VL2_GEMM_MFMA16 (vl2_abi.hip vl2_gemm)
         const bool ok16 = !d->a_idx && !(d->flags & 2) && d->out_grp <= 0 && d->res_row_mod <= 0 && act == 0 && !d->stats_out && N % 256 == 0;
         if (v16 && !ok16) return -3;
         g_mfma16 = ok16 && (v16 || (d->variant == 0 && (d->flags & VL2_GEMM_MFMA16)));
-        g_mfma16_mode = v16 ? d->variant - 16 : 0;
+        g_mfma16_mode = d->variant == 26 ? 9 : v16 ? d->variant - 16 : 0;
     }
     const bool sw = d->flags & 1, f32 = d->flags & 2, g = a.a_idx != nullptr;
     if (d->flags & VL2_GEMM_FP8) {          // W8A8 on the (emulated) fp8 matrix pipe: rows of K bytes seen as K / 2 16-bit elements (vl2_abi.hip)

@@ -235,7 +235,7 @@ def test_emu_gemm_mfma16_kernel(emu):
             # the emulated matrix instructions both sum their k in ascending order, so HERE the kernel must reproduce the family's bits exactly (an
             # indexing check stronger than any tolerance); on the GPU the two instructions associate differently (tests/test_gpu_ops.py holds the bound)
             assert torch.equal(y, fam[0]) and torch.equal(y_sw, fam[1]), (M, K)
-            for v in (17, 18, 19, 20, 21, 22):                              # lab forms (k_gemm9.h MODE 1 / 2 / 4 / 5 / 6: orders of the LDS-DMA issue; 3: register-staged slabs)
+            for v in (17, 18, 19, 20, 21, 22, 26):                          # lab forms (k_gemm9.h MODE 1 / 2 / 4 / 5 / 6: orders of the LDS-DMA issue; 3: register-staged slabs; 9: 64-deep phases)
                 ops.set_gemm_variant(v)
                 assert torch.equal(ops.gemm(a, w, bias=bias, res=res), y) and torch.equal(ops.gemm(a, wgu, swiglu=True, norm=(ops.NORM_RMS, rn, 1e-6, None)), y_sw), (M, K, v)
             ops.set_gemm_variant(16)

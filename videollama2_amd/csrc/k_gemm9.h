@@ -35,10 +35,13 @@ __device__ __forceinline__ int gemm9_lds_off(int row, int chunk) {
 // image one slab ahead -- the vendor kernels' path; 222 VGPRs, no spills, hipcc's own counted vmcnt(7 / 5 / 4)): 224 us.  7 / 8 (23 / 25) MODE 0 with s_memtime stamps
 // (scripts/gemm9_phase_stamps.py): per wave and slab, LDS-DMA issue 252 cycles, fragment reads 250, the 32 MFMAs' issue 506, the two barriers ~50 + ~120; the undisturbed
 // K loop 1225 cycles per slab against the matrix pipe's 1024.  So: the placement of the memory instructions is not what holds this structure.
+// 9 (variant 26): 64-deep phases on a 5-stage ring in the full 160 KiB of LDS (half the barriers per FLOP; see the block below): +1.2 ... +2.7 % (8192^3 811 -> 793 us).
 template <bool SWIGLU, int MODE = 0>
 __device__ __forceinline__ void gemm9_body(const GemmArgs& p, int bid, int nwg) {
     constexpr int BM = 256, MI = 4, NJ = 8;                        // 16 x 16 accumulator blocks of a wave (64 rows x 128 columns)
     extern __shared__ __attribute__((aligned(16))) unsigned char vl2_smem[];
+    unsigned long long c_k0 = 0, c_loop0 = 0, c_loop1 = 0;           // MODE 8 stamps: kernel entry | ring fill starts | K loop done (the fourth: epilogue done)
+    if constexpr (MODE == 8) c_k0 = __builtin_readcyclecounter();
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2, w4 = wave & 3;
@@ -96,8 +99,71 @@ __device__ __forceinline__ void gemm9_body(const GemmArgs& p, int bid, int nwg) 
     const int nt = p.K / GEMM4_BK;
     const unsigned a_rd = gemm9_lds_off(wrow + (lane & 15), lane >> 4);                 // block i / j is + 1024 B (16 rows)
     const unsigned b_rd = 16384 + gemm9_lds_off(wcol + (lane & 15), lane >> 4);
-    unsigned long long c_start = 0;
-    if constexpr (MODE == 8) c_start = __builtin_readcyclecounter();      // MODE 8 (lab, variant 24 is taken: variant 25): MODE 0 with ONE stamp pair around the K loop
+    if constexpr (MODE == 9) {
+        // 64-deep PHASES on a 5-stage ring (the whole 160 KiB): a load phase reads the fragments of TWO slabs (24 ds_read_b128 into 96 registers), a matrix phase
+        // issues 64 MFMAs -- half the barriers per FLOP (the stamps of MODE 7: the two-barrier hand-over costs ~100 of every ~612 cycles).  Group 0 issues the WHOLE
+        // slab 2T+3 in its LOAD(T) (eight pieces per wave), group 1 the whole slab 2T+4 in its LOAD(T); each wave sees its own pieces land (vmcnt(0)) at the end of
+        // the matrix phase that follows, one barrier or more before anyone reads them: slab 2T+3 is read at LOAD(T+1), two phases after its issue; 2T+4 at LOAD(T+2).
+        // Ring slot of slab s: s mod 5 -- the slot of pair T-1, whose last reader (group 1's LOAD(T-1)) is a barrier behind.
+        const int np = nt >> 1;                                     // K % 64 == 0 (vl2_gemm): whole pairs
+        bf16x8 fa2[2][MI], fb2[2][NJ];
+        unsigned a_vo4[4], w_vo4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                               // this wave's eight pieces of a WHOLE slab: pieces w4 + 4 i of the 16 (A) + 16 (W)
+            const int slot = ((i * 4 + w4) << 6) + lane;
+            const int R = slot >> 4, sp = slot & 15;
+            const int row = 4 * R + (sp >> 2), chk = (sp & 3) ^ ((4 - (R & 3)) & 3);
+            int am = m0 + row;
+            am = am < p.M ? am : p.M - 1;
+            a_vo4[i] = ((unsigned)am * (unsigned)p.lda + chk * 8) * 2;
+            w_vo4[i] = ((unsigned)(n0 + row) * (unsigned)p.ldw + chk * 8) * 2;
+        }
+        auto issue_slab = [&](int slab, int slot5) {
+            const unsigned st = (unsigned)slot5 * GEMM4_STAGE, kb = (unsigned)slab * (GEMM4_BK * 2);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(vl2_smem + st + ((i * 4 + w4) << 10)), 16, a_vo4[i], kb, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(vl2_smem + st + 16384 + ((i * 4 + w4) << 10)), 16, w_vo4[i], kb, 0, 0);
+        };
+        auto mod5 = [](int x) { return x >= 5 ? x - 5 : x; };
+        if (grp == 0) issue_slab(0, 0);
+        else { issue_slab(1, 1); if (nt > 2) issue_slab(2, 2); }
+        rst = gemm_row_stats(p, m0, tid, BM);
+        VL2_PIN2(rst[0], rst[1]);
+        VL2_WAIT_VMCNT(0);
+        VL2_PHASE_BARRIER();
+        if (grp == 1) VL2_PHASE_BARRIER();
+        int sa = 0;                                                 // ring slot of slab 2T
+        for (int T = 0; T < np; ++T) {
+            // ---------------- LOAD(T)
+            const int mine = 2 * T + 3 + grp;
+            if (mine < nt) issue_slab(mine, mod5(sa + 3 + grp));
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const unsigned st = (unsigned)mod5(sa + h) * GEMM4_STAGE;
+#pragma unroll
+                for (int i = 0; i < MI; ++i) fa2[h][i] = *(const bf16x8*)(vl2_smem + st + a_rd + i * 1024);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) fb2[h][j] = *(const bf16x8*)(vl2_smem + st + b_rd + j * 1024);
+            }
+            VL2_WAIT_LGKMCNT0();
+            VL2_PHASE_BARRIER();
+            // ---------------- MFMA(T): 64 MFMAs, k ascending (slab 2T, then 2T+1): the same sums as the 32-deep phases
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) acc[i][j] = VL2_MFMA16(fa2[h][i], fb2[h][j], acc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
+            VL2_WAIT_VMCNT(0);                                      // this wave's pieces of the slab it issued in LOAD(T) have landed
+            VL2_PHASE_BARRIER();
+            sa = mod5(sa + 2);
+        }
+    } else {
+    if constexpr (MODE == 8) { __builtin_amdgcn_sched_barrier(0); c_loop0 = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }   // MODE 8 (lab, variant 25): MODE 0 between stamps
     if constexpr (MODE == 7) {
         // MODE 0 with s_memtime stamps around the parts of the two phases (lab, variant 23): per workgroup and wave, the sums over the K loop of
         // [LDS-DMA issue | fragment reads issued and returned + the counted wait | barrier behind the load phase | 32 MFMAs issued | barrier behind the matrix phase]
@@ -286,13 +352,7 @@ __device__ __forceinline__ void gemm9_body(const GemmArgs& p, int bid, int nwg) 
     }
     if constexpr (MODE == 2) VL2_WAIT_VMCNT(0);
     }
-    if constexpr (MODE == 8) {
-        __builtin_amdgcn_sched_barrier(0);
-        const unsigned long long c_end = __builtin_readcyclecounter();
-        if (lane == 0 && p.sk_ws) {
-            unsigned long long* o = (unsigned long long*)p.sk_ws + (size_t)(bid * 8 + wave) * 6;
-            o[0] = c_end - c_start; o[1] = o[2] = o[3] = o[4] = 0; o[5] = (unsigned long long)nt;
-        }
+    if constexpr (MODE == 8) { __builtin_amdgcn_sched_barrier(0); c_loop1 = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
     }
     if (grp == 0) VL2_PHASE_BARRIER();
 
@@ -316,6 +376,14 @@ __device__ __forceinline__ void gemm9_body(const GemmArgs& p, int bid, int nwg) 
             gemm_store_patch<ACT_NONE, SWIGLU, false>(p, ep, m0 + wrow + mi * 32, n0 + wcol + nh * 64, lane, rowtab, wrow + mi * 32);
             __builtin_amdgcn_wave_barrier();
         }
+    if constexpr (MODE == 8) {          // [ring fill + K loop | setup before it | epilogue (stores issued, not drained) | entry stamp | 0 | slabs]
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long c_end = __builtin_readcyclecounter();
+        if (lane == 0 && p.sk_ws) {
+            unsigned long long* o = (unsigned long long*)p.sk_ws + (size_t)(bid * 8 + wave) * 6;
+            o[0] = c_loop1 - c_loop0; o[1] = c_loop0 - c_k0; o[2] = c_end - c_loop1; o[3] = c_k0; o[4] = c_end; o[5] = (unsigned long long)nt;
+        }
+    }
 }
 template <bool SWIGLU, int MODE = 0>
 __global__ __launch_bounds__(512, 2) void gemm9_bf16_kernel(GemmArgs p) {

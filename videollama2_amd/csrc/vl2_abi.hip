@@ -244,6 +244,9 @@ static void launch_gemm9(const GemmArgs& a0, int mode, hipStream_t s) {
     } else if (mode == 7) {   // lab (variant 23): variant 16 with s_memtime stamps, sums into the workspace (scripts/gemm9_phase_stamps.py)
         lds_attr<gemm9_bf16_kernel<SW, 7>>(GEMM4_LDS_BYTES);
         hipLaunchKernelGGL((gemm9_bf16_kernel<SW, 7>), grid, dim3(512), GEMM4_LDS_BYTES, s, a);
+    } else if (mode == 9) {   // lab (variant 26): 64-deep phases, 5-stage ring = the whole 160 KiB of LDS
+        lds_attr<gemm9_bf16_kernel<SW, 9>>(5 * GEMM4_STAGE);
+        hipLaunchKernelGGL((gemm9_bf16_kernel<SW, 9>), grid, dim3(512), 5 * GEMM4_STAGE, s, a);
     } else if (mode == 8) {   // lab (variant 25): variant 16 with one stamp pair around the K loop
         lds_attr<gemm9_bf16_kernel<SW, 8>>(GEMM4_LDS_BYTES);
         hipLaunchKernelGGL((gemm9_bf16_kernel<SW, 8>), grid, dim3(512), GEMM4_LDS_BYTES, s, a);
@@ -399,7 +402,7 @@ static void launch_gemm(const GemmArgs& a0, const GemmCtl& c, hipStream_t s) {
             launch_gemm9<SW>(a, c.variant == 23 ? 7 : 8, s);
             return;
         }
-        if (c.mfma16) { launch_gemm9<SW>(a0, c.variant >= 17 && c.variant <= 23 ? c.variant - 16 : 0, s); return; }         // (vl2_gemm has checked that the call qualifies)
+        if (c.mfma16) { launch_gemm9<SW>(a0, c.variant >= 17 && c.variant <= 23 ? c.variant - 16 : c.variant == 26 ? 9 : 0, s); return; }         // (vl2_gemm has checked that the call qualifies)
     }
     if constexpr (!SW) {
         // fill-the-round tiles (k_gemm7.h): variants 224 / 192 on request (any shape with N % 128 == 0), or by the rule of choose_gemm7
@@ -673,7 +676,7 @@ extern "C" int32_t vl2_gemm(const vl2_gemm_desc* d, void* stream) {
     }
     if (d->ws && (d->ws_bytes < SK_WS_BYTES || !ALIGNED16(d->ws))) return fail(VL2_E_BADARG, "vl2_gemm: workspace needs >= %lld bytes, 16-byte aligned", (long long)SK_WS_BYTES);
     const int v = d->variant;
-    if (!(v == 0 || v == 1 || v == 2 || v == 4 || v == 5 || v == 8 || v == 9 || v == 12 || (v >= 16 && v <= 23) || v == 25 || v == 32 || v == 24 || v == 60 || v == 61 || v == 62 || v == 70 || v == 71 || v == 80 || v == 81 || v == 192 || v == 193 || v == 224 || v == 225 || v == 256)) return fail(VL2_E_BADARG, "vl2_gemm: unknown variant %d", v);
+    if (!(v == 0 || v == 1 || v == 2 || v == 4 || v == 5 || v == 8 || v == 9 || v == 12 || (v >= 16 && v <= 23) || v == 25 || v == 26 || v == 32 || v == 24 || v == 60 || v == 61 || v == 62 || v == 70 || v == 71 || v == 80 || v == 81 || v == 192 || v == 193 || v == 224 || v == 225 || v == 256)) return fail(VL2_E_BADARG, "vl2_gemm: unknown variant %d", v);
     GemmCtl ctl{d->ws, d->ws_bytes, v, (d->flags & VL2_GEMM_SPLITK) != 0};
     ctl.persist = (d->flags & VL2_GEMM_PERSISTENT) != 0;
     ctl.no_mix = (d->flags & VL2_GEMM_NO_MIX) != 0;
@@ -683,8 +686,8 @@ extern "C" int32_t vl2_gemm(const vl2_gemm_desc* d, void* stream) {
     ctl.no_weave4 = (d->flags & VL2_GEMM_NO_WEAVE4) != 0;
     {   // the 16 x 16 x 32 kernel: plain rows, bf16 output, no activation, no statistics out; the flag is a wish (ignored where the kernel is not built), variant 16 a demand
         const bool ok16 = !g && !f32 && !remap && act == VL2_ACT_NONE && !d->stats_out && N % 256 == 0;
-        if (((v >= 16 && v <= 23) || v == 25) && !ok16) return fail(VL2_E_UNSUPP, "vl2_gemm: variant 16 (16x16x32 MFMA) is built for plain bf16 outputs without activation / gather / remap / stats_out, N %% 256 == 0");
-        ctl.mfma16 = ok16 && ((v >= 16 && v <= 23) || v == 25 || (v == 0 && (d->flags & VL2_GEMM_MFMA16)));     // 17 ... 22: lab forms (k_gemm9.h MODE 1 ... 6)
+        if (((v >= 16 && v <= 23) || v == 25 || v == 26) && !ok16) return fail(VL2_E_UNSUPP, "vl2_gemm: variant 16 (16x16x32 MFMA) is built for plain bf16 outputs without activation / gather / remap / stats_out, N %% 256 == 0");
+        ctl.mfma16 = ok16 && ((v >= 16 && v <= 23) || v == 25 || v == 26 || (v == 0 && (d->flags & VL2_GEMM_MFMA16)));     // 17 ... 22: lab forms (k_gemm9.h MODE 1 ... 6)
     }
     bool need_fin = d->row_norm_out && (d->flags & VL2_GEMM_NO_TICKET);      // A/B: the separate launch as in rounds 3-4
     ctl.fin = &need_fin;
