@@ -51,64 +51,29 @@ int64_t vl2_workspace_bytes(void);
 #define VL2_GEMM_OUT_F32 2  /* C is fp32 (validation / logits) */
 #define VL2_GEMM_SPLITK  4  /* small grids may split K through the workspace (`ws`): trades "a row's bits do not depend on M"
                                for latency on few-tile shapes (per-rank shapes of the frame-sharded encoder); off by default */
-/* kernel variants (vl2_gemm_desc.variant; 0 = per-shape choice): 1 = 128x128x64 two-barrier kernel, 2 = its stream-K form
- * (needs `ws`), 4 = 128x256x64 ping-pong, 8 = 256x256x32 ping-pong, 12 = the same on 192x256 tiles (4, 8, 12: N%256==0; 12: bf16
- * output), 32 = 64x64 small-M kernel,
- * 256 = 128x128 8-wave deep-ring one-round kernel; 60 / 61 = the PERSISTENT 256x256 / 192x256 ping-pong kernel with a static tile walk, 70 / 71 = with tiles handed out through
- * `tile_ctr` (what the automatic choice uses; one workgroup per CU
- * walks its tiles, csrc/k_gemm6.h: bf16 output without residual / statistics / gather, norm through `row_norm`, K >= 1024; a call that
- * does not qualify gets the automatic choice), 62 = 61 with two accumulator sets (the previous tile's epilogue drained under the next
- * tile's phases; measured slower than 61, kept for A/B), 24 = the automatic choice without the persistent form (A/B),
- * 5 = variant 4 with the woven LDS-DMA issue (VL2_GEMM_WEAVE), 225 / 193 = 224 / 192 with it (lab),
- * 9 = lab: the 256x256 tile on FOUR waves (one per SIMD, 128x128 wave tiles, csrc/k_gemm8.h; measured within 2 % of variant 8, never the automatic choice),
- * 224 / 192 = the fill-the-round 224x128 / 192x128 ping-pong kernel (csrc/k_gemm7.h; any N % 128 == 0, plain or gathered A, no SwiGLU; the
- * automatic choice takes it where its grid is one round of <= 256 workgroups and fills the chip better than the wider tiles:
- * the decoder's o / down projections at S = 1621, the STC convolutions on 1521 output positions).
- * 16 = the 256x256 ping-pong tile on v_mfma_f32_16x16x32_bf16 (csrc/k_gemm9.h, see VL2_GEMM_MFMA16): never the automatic choice.
- * Every variant EXCEPT 16 produces the same bits.  profiles/r01_gemm_experiments.md, r03_experiments.md, r04_experiments.md. */
-#define VL2_GEMM_PERSISTENT 8  /* the automatic kernel choice may take the persistent form (variants 70 / 71; needs `tile_ctr` or `ws`).  Off by default:
-                                 7-10 % faster per kernel on multi-round K = 1024 shapes, but in the power-limited pipeline it slows its successors
-                                 and lost 1 ms per ViT pass on 3 of 11 boxes (profiles/r04_experiments.md) */
-#define VL2_GEMM_NO_MIX  16   /* a row-split call stays two launches instead of ONE mixed launch (A/B of gemm_mix_bf16_kernel) */
-#define VL2_GEMM_NO_FILL 32   /* the automatic choice does not take the fill-the-round kernel (variants 224 / 192): A/B of csrc/k_gemm7.h */
+#define VL2_GEMM_PERSISTENT 8  /* the automatic kernel choice may take the persistent form (one workgroup per CU walks its tiles through `tile_ctr`,
+                                  csrc/k_gemm6.h: bf16 output without residual / statistics / gather, K >= 1024, more than one round of 256-row tiles).
+                                  vl2_vit_forward sets it for the tower's GEMMs (q/k/v, fc1: -0.15 ... -0.27 ms per 16-frame pass on 7 of 7 boxes,
+                                  profiles/r05_experiments.md section 5); elsewhere off (neutral or slower in the power-limited pipeline) */
 #define VL2_GEMM_FP8     128  /* W8A8 on the fp8 matrix pipe (v_mfma_f32_32x32x64_f8f6f4, twice the 16-bit MFMA rate; SURVEY 8f row 5 / BASELINE.json configs[4]
                                  "fp8 MFMA on CDNA4"): A [M, lda] and W [N, ldw] hold OCP e4m3fn BYTES (K = elements = bytes, K % 128 == 0, N % 256 == 0),
                                  `row_norm` [M][2] = (0, row multiplier) as vl2_quant_act_fp8 writes it (activation scale x RMS rstd), `col_scale` [N] = the
                                  weight rows' scales (vl2_pack_quant_fp8).  C = epilogue(rowmul_m * colscale_n * sum_k A8 W8): bias / SiLU / SwiGLU / residual /
                                  fp32 output as the 16-bit form.  An OPTIONAL arithmetic (both operands rounded to e4m3fn), never the default */
-#define VL2_GEMM_WEAVE4  512  /* the 256x256 / 192x256 ping-pong kernels (and the big-tile part of the mixed launch) issue the LDS-DMA of slab t+3 from their MATRIX
-                                 phases, one piece behind every fourth MFMA, instead of from the load phases (csrc/k_gemm.h gemm4_body WEAVE4; same bits) */
-#define VL2_GEMM_NO_WEAVE4 1024 /* the 192x256 tiles (variant 12) WITHOUT the woven issue they take by default since round 5: A/B (ViT fc2 / out_proj, decoder q/k/v: -0.4 ... -3.7 %) */
-#define VL2_GEMM_NO_TICKET 256 /* `row_norm_out` is filled by a separate vl2_row_norm_finalize launch behind the GEMM (rounds 3-4) instead of by the GEMM's last
-                                 column tile: A/B of the producer-side finalize (same bits) */
 #define VL2_GEMM_MFMA16  2048 /* opt-in: plain bf16-output calls without activation (incl. SWIGLU; N % 256 == 0, no gather / remap / stats_out) run on the 256x256 ping-pong
                                * kernel built on v_mfma_f32_16x16x32_bf16 (csrc/k_gemm9.h; variant 16 = the same on demand).  The instruction sustains ~15 % more at this
                                * part's power limit than the library's v_mfma_f32_32x32x16_bf16, but sums 32 products per accumulation step instead of 16: results are as
                                * accurate but NOT bit-identical with every other variant, so a call site must use it for ALL its calls or none (a row's bits still do
                                * not depend on M).  Ignored where the kernel is not built. */
-#define VL2_GEMM_WEAVE   64   /* lab: the 128x256 / 224x128 / 192x128 ping-pong kernels issue their LDS-DMA woven between the MFMAs of the matrix phases instead of
-                                 from the load phases (same bits; faster back to back on warm operands, slower in the pipeline: profiles/r05_experiments.md) */
-/* stage-level descriptors (vl2_vit_desc / vl2_stc_desc / vl2_llm_desc) `flags`: experiment controls, all off by default */
-#define VL2_STAGE_PERSISTENT_GEMM  1   /* every GEMM of the stage with VL2_GEMM_PERSISTENT */
-#define VL2_STAGE_VIT_NO_PERSISTENT 4096 /* vl2_vit_forward only: its GEMMs WITHOUT VL2_GEMM_PERSISTENT (the tower's default since round 5: -0.15 ... -0.27 ms per 16-frame pass
-                                          * on 7 of 7 boxes, profiles/r05_experiments.md section 5); A/B switch */
-#define VL2_STAGE_NO_MIX           2   /* ... with VL2_GEMM_NO_MIX */
-#define VL2_STAGE_NO_FILL_TILES  128   /* ... with VL2_GEMM_NO_FILL */
-#define VL2_STAGE_WEAVE          256   /* ... with VL2_GEMM_WEAVE */
-#define VL2_STAGE_WEAVE4        8192   /* ... with VL2_GEMM_WEAVE4 */
-#define VL2_STAGE_NO_WEAVE4    16384   /* ... with VL2_GEMM_NO_WEAVE4 */
+/* kernel variants (vl2_gemm_desc.variant; 0 = per-shape choice; every variant EXCEPT 16 produces the same bits): 1 = 128x128x64 two-barrier kernel,
+ * 4 = 128x256x64 ping-pong, 8 = 256x256x32 ping-pong, 12 = the same on 192x256 tiles (4, 8, 12: N%256==0; 12: bf16 output), 32 = 64x64 small-M kernel,
+ * 256 = 128x128 8-wave deep-ring one-round kernel, 224 / 192 = the fill-the-round 224x128 / 192x128 ping-pong kernel (csrc/k_gemm7.h; N % 128 == 0,
+ * plain or gathered A, no SwiGLU), 60 / 61 = the persistent 256x256 / 192x256 kernel with a static tile walk, 70 / 71 = with tiles handed out through
+ * `tile_ctr` (what VL2_GEMM_PERSISTENT selects), 24 = the automatic choice without the persistent form, 16 = the 256x256 tile on
+ * v_mfma_f32_16x16x32_bf16 (see VL2_GEMM_MFMA16).  A call that does not qualify for a forced variant gets the automatic choice. */
+/* stage-level descriptors (vl2_vit_desc / vl2_stc_desc / vl2_llm_desc) `flags` */
+#define VL2_STAGE_PERSISTENT_GEMM  1   /* every GEMM of the stage with VL2_GEMM_PERSISTENT (vl2_vit_forward: the default, see VL2_STAGE_VIT_NO_PERSISTENT) */
 #define VL2_STAGE_MFMA16       32768   /* vl2_llm_prefill: the gate/up projection (the step's dominant GEMM) with VL2_GEMM_MFMA16, at every S */
-#define VL2_STAGE_ROW_TICKET    1024   /* ViT and LLM prefill: the statistics-producing GEMMs (out_proj / fc2, o / down) finalize their own output rows
-                                         * (vl2_gemm_desc.row_norm_out: producer-side ticket, csrc/k_gemm.h gemm_rows_ticket) instead of a vl2_row_norm_finalize launch
-                                         * behind each of them.  Same bits; measured round 5: neutral in the tower (-0.03 ms), SLOWER in the prefill (+0.12 ms: every
-                                         * tile drains its stores and pays an agent-scope atomic round trip), profiles/r05_experiments.md -- off by default */
-#define VL2_STAGE_SELF_REDUCE      4   /* ViT and LLM prefill: the norm-carrying GEMMs reduce the row statistics themselves (no row_norm_finalize launches;
-                                         * same bits, measured slower: LLM prefill 24.4 -> 26.0 ms, profiles/r04_experiments.md section 1) */
-#define VL2_STAGE_FUSED_DECODE_ATTN 8  /* decode step: attention + combine as one launch (vl2_attn_decode_fused; measured slower) */
-#define VL2_STAGE_STC_UNFUSED      32   /* connector: the SE block as the five launches of rounds 1-3 (dwconv, chan_mean, 2 x small_linear, se_scale) instead of
-                                         * vl2_dwconv3x3_ln_silu_mean + small_linear + vl2_se_excite_scale */
-#define VL2_STAGE_DECODE_TAIL      16   /* decode step: o_proj / gate-up / down as ONE vl2_decode_tail launch instead of three vl2_gemv_bf16 launches
-                                          (same bits; measured slower: 98.5 vs 66.7 us per layer, profiles/r04_experiments.md) */
 #define VL2_STAGE_PREFILL_FP8     512   /* vl2_llm_prefill: the four projections of every layer as VL2_GEMM_FP8 calls on the fp8 weight copies (layers_w8), their
                                          * inputs quantised per row by vl2_quant_act_fp8 (which also computes the RMS rstd: no statistics launches).  Attention,
                                          * RoPE, the KV cache and lm_head stay 16-bit.  OPTIONAL arithmetic (W8A8), never the default, never the headline */
@@ -117,6 +82,33 @@ int64_t vl2_workspace_bytes(void);
                                          * (weights rounded to e4m3fn): OPTIONAL, never the default, never the headline number */
 #define VL2_GEMV_RMS_PLAIN 32  /* vl2_gemv_bf16 `flags`: RMS-normalise x with NO weight vector (the norm weight is folded into W; `norm_w` is ignored):
                                  the same bits as a vector of ones, without every workgroup reading 4 K bytes of ones */
+#ifdef VL2_EXPERIMENTAL
+/* ---- A/B SWITCHES AND LAB FORMS (not permanent ABI; a host sees them only with -DVL2_EXPERIMENTAL).  Every one of them selects another schedule of the
+ * SAME arithmetic (same bits) that was measured against the default and did not win; the numbers are in profiles/r0*_experiments.md.  "lab" = compiled only
+ * into libvl2hip_lab.so (-DVL2_LAB, scripts/build_lab_lib.sh): the product library ignores the flag or refuses the variant (VL2_E_UNSUPP). */
+#define VL2_GEMM_NO_MIX  16   /* a row-split call stays two launches instead of ONE mixed launch (gemm_mix_bf16_kernel) */
+#define VL2_GEMM_NO_FILL 32   /* the automatic choice does not take the fill-the-round kernel (variants 224 / 192) */
+#define VL2_GEMM_WEAVE   64   /* lab: the 128x256 / 224x128 / 192x128 ping-pong kernels issue their LDS-DMA woven between the MFMAs of the matrix phases */
+#define VL2_GEMM_NO_TICKET 256 /* `row_norm_out` is filled by a separate vl2_row_norm_finalize launch behind the GEMM instead of by the GEMM's last column tile */
+#define VL2_GEMM_WEAVE4  512  /* lab: the 256x256 ping-pong kernel (and the big tiles of the mixed launch) with the woven issue the 192x256 tiles take by default */
+#define VL2_GEMM_NO_WEAVE4 1024 /* lab: the 192x256 tiles WITHOUT the woven issue */
+/* lab variants: 2 = stream-K form of variant 1 (needs `ws`; other summation order), 5 = variant 4 with the woven issue, 225 / 193 = 224 / 192 with it,
+ * 9 = the 256x256 tile on FOUR waves (csrc/k_gemm8.h), 62 = 61 with two accumulator sets, 17 ... 22, 26 = issue orders of variant 16, 23 / 25 = variant 16
+ * with s_memtime stamps (scripts/gemm9_phase_stamps.py). */
+#define VL2_STAGE_VIT_NO_PERSISTENT 4096 /* vl2_vit_forward only: its GEMMs WITHOUT VL2_GEMM_PERSISTENT */
+#define VL2_STAGE_NO_MIX           2   /* every GEMM of the stage with VL2_GEMM_NO_MIX */
+#define VL2_STAGE_NO_FILL_TILES  128   /* ... with VL2_GEMM_NO_FILL */
+#define VL2_STAGE_WEAVE          256   /* ... with VL2_GEMM_WEAVE (lab) */
+#define VL2_STAGE_WEAVE4        8192   /* ... with VL2_GEMM_WEAVE4 (lab) */
+#define VL2_STAGE_NO_WEAVE4    16384   /* ... with VL2_GEMM_NO_WEAVE4 (lab) */
+#define VL2_STAGE_ROW_TICKET    1024   /* ViT and LLM prefill: the statistics-producing GEMMs (out_proj / fc2, o / down) finalize their own output rows
+                                         * (vl2_gemm_desc.row_norm_out: producer-side ticket) instead of a vl2_row_norm_finalize launch behind each of them */
+#define VL2_STAGE_SELF_REDUCE      4   /* ViT and LLM prefill: the norm-carrying GEMMs reduce the row statistics themselves (no row_norm_finalize launches) */
+#define VL2_STAGE_FUSED_DECODE_ATTN 8  /* lab: decode step: attention + combine as one launch (vl2_attn_decode_fused) */
+#define VL2_STAGE_STC_UNFUSED      32   /* connector: the SE block as the five launches of rounds 1-3 (dwconv, chan_mean, 2 x small_linear, se_scale) instead of
+                                         * vl2_dwconv3x3_ln_silu_mean + small_linear + vl2_se_excite_scale */
+#define VL2_STAGE_DECODE_TAIL      16   /* lab: decode step: o_proj / gate-up / down as ONE vl2_decode_tail launch instead of three vl2_gemv_bf16 launches */
+#endif /* VL2_EXPERIMENTAL (flags) */
 #define VL2_NORM_NONE 0
 #define VL2_NORM_RMS  1     /* HF:modeling_mistral.py MistralRMSNorm in front of q/k/v and gate/up */
 #define VL2_NORM_LN   2     /* HF:modeling_clip.py layer_norm1 / layer_norm2 in front of q/k/v and fc1 */
@@ -273,9 +265,8 @@ int32_t vl2_gemv_batched_bf16(const void* W, const void* x, const float* norm_w,
  *   pos_dev != NULL: the position is read from device memory (*pos_dev) so a captured hipGraph replays as it moves; the
  *   launch then covers positions < ctx_cap.  partial: fp32 workspace >= nh*ceil(cap/64)*130 floats (cap = ctx_cap or pos+1). */
 #ifdef VL2_EXPERIMENTAL
-/* ---- EXPERIMENTAL SURFACE (not permanent ABI).  The two entry points below are exported for the A/B tests and the lab scripts that
- * measured them SLOWER than the launches they replace; a host sees their declarations only with -DVL2_EXPERIMENTAL, nothing in the product calls
- * them by default, and they may disappear with any ABI version.  (Their stage flags: VL2_STAGE_FUSED_DECODE_ATTN, VL2_STAGE_DECODE_TAIL.) */
+/* ---- LAB ENTRY POINTS (not permanent ABI): exported by libvl2hip_lab.so only (-DVL2_LAB, scripts/build_lab_lib.sh), for the A/B tests and the lab
+ * scripts that measured them SLOWER than the launches they replace.  (Their stage flags: VL2_STAGE_FUSED_DECODE_ATTN, VL2_STAGE_DECODE_TAIL.) */
 /* The same attention + combine in ONE launch (the workgroup that finishes a kv head's last slice combines its q heads): position from
  * device memory only, partial sized for smax (nh*ceil(smax/64)*130 floats), cnt = nkv int32 ticket counters that must be ZERO when the
  * launch starts (the caller clears them; NOT with a hipMemsetAsync node of a few bytes inside a captured hipGraph -- that did not replay

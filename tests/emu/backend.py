@@ -24,6 +24,7 @@ def emulated_backend():
         fn = getattr(lib, name)
         fn.restype = ctypes.c_int32
         fn.argtypes = args
+    _lib.bind_lab(lib)                 # the emulator exports the lab entry points too (vl2_attn_decode_fused, vl2_decode_tail)
     saved = (_lib._lib, ops._chk, ops._stream)
     _lib._lib = lib
 

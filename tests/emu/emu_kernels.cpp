@@ -472,6 +472,12 @@ extern "C" int32_t vl2_gemv_bf16(const void* W, const void* x, const float* norm
     const bool sw = flags & 1, f32 = flags & 2;
     const int n_out = sw ? N / 2 : N;
     dim3 g((n_out + 7) / 8), blk(256);
+    if (!sw && (a.norm_w || a.rms_plain) && K <= 4096) {          // vl2_abi.hip launch_gemv: the x-first form for norm-carrying single-pass rows
+        dim3 g4((n_out + 3) / 4);
+        if (f32) emu::launch(g4, blk, [=] { gemv_xfirst_bf16_kernel<false, true, 2>(a); });
+        else emu::launch(g4, blk, [=] { gemv_xfirst_bf16_kernel<false, false, 2>(a); });
+        return 0;
+    }
     if (sw) emu::launch(g, blk, [=] { gemv_bf16_kernel<true, false, 2>(a); });
     else if (f32) emu::launch(g, blk, [=] { gemv_bf16_kernel<false, true, 2>(a); });
     else emu::launch(g, blk, [=] { gemv_bf16_kernel<false, false, 2>(a); });

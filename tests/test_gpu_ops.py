@@ -84,13 +84,13 @@ def test_gemm_pingpong_variant_is_bit_identical(ops, M, N, K):
     try:
         ops.set_gemm_variant(1)
         ref = ops.gemm(ad, wd, bias=bd, res=rd, act=ops.ACT_QGELU)
-        for v in (4, 5, 8, 9, 12, 0):                                # 5 = the 128x256 kernel with its LDS-DMA issue woven into the MFMA phases (lab); 9 = gemm8 (four waves)
+        for v in (4, 8, 12, 0):                                      # (the lab forms 5 / 9: tests/test_gpu_lab.py)
             ops.set_gemm_variant(v)
             for _ in range(3):
                 assert torch.equal(ops.gemm(ad, wd, bias=bd, res=rd, act=ops.ACT_QGELU), ref)
         ops.set_gemm_variant(1)
         ref = ops.gemm(ad, wd, bias=bd, act=ops.ACT_QGELU)           # no residual: the register-resident C^T epilogue of 4 / 8 / 12
-        for v in (4, 8, 9, 12, 0):
+        for v in (4, 8, 12, 0):
             ops.set_gemm_variant(v)
             assert torch.equal(ops.gemm(ad, wd, bias=bd, act=ops.ACT_QGELU), ref)
     finally:
@@ -117,7 +117,7 @@ def test_gemm_fill_round_kernel_is_bit_identical(ops, M, N, K):
     try:
         ops.set_gemm_variant(1)
         ref = run()
-        for v in (224, 192, 225, 193, 0):
+        for v in (224, 192, 0):                                       # (225 / 193 = the woven issue: lab, tests/test_gpu_lab.py)
             ops.set_gemm_variant(v)
             for _ in range(3):
                 assert all(torch.equal(x, y) for x, y in zip(run(), ref)), (M, N, K, v)
@@ -173,24 +173,6 @@ def test_gemm_round_split_is_bit_identical(ops, M, N, K):
         for _ in range(2):
             got = (ops.gemm(a, w), ops.gemm(a, w, bias=bias, act=ops.ACT_GELU), ops.gemm(a, w, res=res, stats_out=st[1]))
             assert all(torch.equal(x, y) for x, y in zip(got, ref)) and torch.equal(st[0], st[1])
-    finally:
-        ops.set_gemm_variant(0)
-
-
-def test_gemm_stream_k_variant(ops):
-    """Stream-K form (tuning knob 2): partial tiles cross workgroups through the caller-owned workspace with an
-    agent-scope release/acquire hand-off; repeated launches screen for stale reads.  fp32 sums in a different order."""
-    M, N, K = 1621, 4096, 4096
-    a, w, res = bf(M, K), bf(N, K, scale=K ** -0.5), bf(M, N)
-    ad, wd, rd = a.to(DEV), w.to(DEV), res.to(DEV)
-    ref = ops.gemm(ad, wd, res=rd).float()
-    ops.attach_workspace(DEV)
-    try:
-        ops.set_gemm_variant(2)
-        for _ in range(5):
-            out = ops.gemm(ad, wd, res=rd).float()
-            assert (out - ref).abs().max().item() <= 0.04 * ref.abs().max().item()
-            assert rel(out, ref) < 2e-3
     finally:
         ops.set_gemm_variant(0)
 
@@ -522,32 +504,6 @@ def test_attn_decode_fused_rope_append(ops, pos):
         vf = torch.cat([vc[:, :pos], vn[:, None]], 1).float().repeat_interleave(nh // nkv, 0)
         a = torch.softmax(torch.einsum("hd,hkd->hk", qr, kf) * HD ** -0.5, -1)
         assert rel(out, torch.einsum("hk,hkd->hd", a, vf).reshape(-1)) < TOL_BF16_OUT
-
-
-@pytest.mark.parametrize("nh,nkv,smax,pos", [(32, 8, 2048, 300), (32, 8, 2048, 1650), (28, 4, 512, 300), (32, 8, 2048, 63), (32, 8, 2048, 64),
-                                             (32, 8, 512, 511), (64, 8, 1024, 700)])
-def test_attn_decode_fused_combine_equals_two_kernels(ops, nh, nkv, smax, pos):
-    """vl2_attn_decode_fused (the kv head's last-finishing slice combines its q heads inside the attention launch; what
-    vl2_llm_decode_step enqueues) must give the bits of vl2_attn_decode (attention + combine kernels): same output, same appended
-    cache rows, every ticket counter at the number of live slices -- Mistral (group 4), Qwen2-7B (group 7 = two head blocks per kv
-    head), 72B (group 8), slice boundaries and the last cache row, repeated launches."""
-    HD = 128
-    qkv, kc, vc = bf((nh + 2 * nkv) * HD, seed=pos), bf(nkv, smax, HD, seed=2), bf(nkv, smax, HD, seed=3)
-    inv = 1.0 / (1e6 ** (torch.arange(0, HD, 2).float() / HD))
-    fr = torch.arange(smax).float()[:, None] * inv[None]
-    cos_t, sin_t = fr.cos().contiguous().to(DEV), fr.sin().contiguous().to(DEV)
-    nsp, group = (smax + 63) // 64, nh // nkv
-    pos_dev = torch.tensor([pos], dtype=torch.int32, device=DEV)
-    for rep in range(3):
-        k1, v1, k2, v2 = kc.to(DEV), vc.to(DEV), kc.to(DEV), vc.to(DEV)
-        p1, p2 = torch.full((nh * nsp * 130,), 7.0, device=DEV), torch.full((nh * nsp * 130,), -3.0, device=DEV)   # stale garbage
-        o1, o2 = torch.zeros(nh * HD, dtype=torch.bfloat16, device=DEV), torch.ones(nh * HD, dtype=torch.bfloat16, device=DEV)
-        ops.attn_decode(qkv.to(DEV), k1, v1, cos_t, sin_t, p1, o1, nh, nkv, pos, HD ** -0.5, pos_dev=pos_dev, ctx_cap=smax)
-        cnt = torch.zeros(nkv, dtype=torch.int32, device=DEV)
-        ops.attn_decode_fused(qkv.to(DEV), k2, v2, cos_t, sin_t, p2, o2, nh, nkv, pos_dev, HD ** -0.5, cnt)
-        assert torch.equal(o1, o2), (rep, int((o1 != o2).sum()))
-        assert torch.equal(k1, k2) and torch.equal(v1, v2)
-        assert cnt.tolist() == [((pos + 64) // 64) * ((group + 3) // 4)] * nkv
 
 
 def test_argmax_embed(ops):

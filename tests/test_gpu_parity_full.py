@@ -1,6 +1,6 @@
 """Parity on BASELINE.json configs[1] ITSELF (VideoLLaMA2-7B widths and depths, 16 frames, S = 1621), on MI355X.
 
-For every stage three numbers are produced in the same test and written to gpurun_out/r05_parity.json (copied to
+For every stage three numbers are produced in the same test and written to gpurun_out/r06_parity.json (copied to
 profiles/ by the round's GPU script):
     ours   = rel-L2( HIP path            , fp32 oracle )      the oracle runs in fp32 on the HOST cores of the GPU box
     floor  = rel-L2( reference-bf16 path , fp32 oracle )      the same restatement run in bf16 with torch-ROCm ops on the GPU --
@@ -47,7 +47,7 @@ def _flush():
         return
     out = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out, exist_ok=True)
-    with open(os.path.join(out, "r05_parity.json"), "w") as f:
+    with open(os.path.join(out, "r06_parity.json"), "w") as f:
         json.dump(dict(config="BASELINE.json configs[1]: VideoLLaMA2-7B widths, bf16, MI355X; fp32 oracle on the host cores, "
                               "reference-bf16 floor = the same restatement in bf16 on torch-ROCm", host_cores=os.cpu_count(),
                        rows=RECORD), f, indent=1)
@@ -236,7 +236,7 @@ def test_configs1_full_depth_end_to_end():
     above, every stage consumes the previous stage's OWN output, so the numbers are end-to-end errors.  Decode is compared
     teacher-forced on the oracle's tokens (8 steps) and the free-running product `generate` must reproduce those tokens wherever
     the fp32 top-2 margin exceeds twice the logit error."""
-    run_end_to_end(O.config_videollama2_7b(16), 16, 32, 2048, min_decidable=3, fp8_decode=True)
+    run_end_to_end(O.config_videollama2_7b(16), 16, 32, 2048, min_decidable=16, fp8_decode=True)
 
 
 @pytest.mark.gpu
@@ -245,7 +245,7 @@ def test_configs1_full_depth_end_to_end_fp16_build():
     instruction and pack/unpack switch at compile time, csrc/dev_common.h).  fp16 is what the reference's mm_infer runs in
     (/root/reference/videollama2/__init__.py:60 `.half()`), and its 10-bit mantissa puts the floor ~4-8 x below bf16's: the floor
     chain here is torch-ROCm in float16, the bar stays ours <= max(2 x floor, 4e-3) and the prefill logits must be inside 3e-3."""
-    run_end_to_end(O.config_videollama2_7b(16), 16, 32, 2048, min_decidable=3, tag="fp16 ", elem="fp16")
+    run_end_to_end(O.config_videollama2_7b(16), 16, 32, 2048, min_decidable=24, tag="fp16 ", elem="fp16")
     row = [r for r in RECORD if r["stage"].startswith("fp16 e2e prefill logits")][-1]
     assert row["ours_rel_l2"] <= 3e-3, row
 
@@ -256,7 +256,7 @@ def test_full_depth_end_to_end_other_frame_counts(T):
     """the same full-depth chain at the frame counts of BASELINE.json configs[0] (8 frames, S = 945) and configs[2]
     (32 frames, S = 2973, here on one GPU): other GEMM tile choices (one-round grids at T = 8, the fill-the-round tiles do not apply),
     other attention lengths, the Conv3d border frames at other positions.  Weights = the cached seeded set of the T = 16 case."""
-    run_end_to_end(O.config_videollama2_7b(T), T, 8, 4096, tag=f"T={T} ")
+    run_end_to_end(O.config_videollama2_7b(T), T, 8, 4096, min_decidable=4, tag=f"T={T} ")
 
 
 def plant_outliers(sd, cfg, seed=7, n_ch=6, llm_layers=None, llm_mult=40.0):
@@ -316,7 +316,26 @@ def test_outlier_channels_twelve_tower_eight_decoder_layers(elem):
     cfg = O.config_videollama2_7b(4)
     cfg["vision"]["num_hidden_layers"] = 13                        # hidden_states[-2] = the output of layer 12
     cfg["llm"]["num_hidden_layers"] = 8
-    run_end_to_end(cfg, 4, 31, 1024, min_decidable=3 if elem == "bf16" else 16, mutate=plant_outliers_stationary, tag=f"outliers 12+8 {elem} ", elem=elem)
+    run_end_to_end(cfg, 4, 31, 1024, min_decidable=8 if elem == "bf16" else 16, mutate=plant_outliers_stationary, tag=f"outliers 12+8 {elem} ", elem=elem)
+
+
+N_LOUD_ROWS, LOUD_GAIN = 32, 8.0
+
+
+def loud_vocab_rows(sd, seed=11):
+    """VERDICT r05 item 7 / SURVEY 7.3-6: seeded-normal lm_head rows make every step a near-tie of 32000 look-alike logits (top-2 margin ~0.2 sigma
+    against a bf16 logit error of ~0.06 sigma: a third of the steps decidable, none at T = 32), so "same token as the oracle" tests little.  Real
+    checkpoints are not like that: a few dozen frequent tokens carry logits far above the rest.  The end-to-end fixtures therefore give 32 seeded
+    vocabulary rows 8 x the norm (a power of two: exact in bf16 and fp16) -- the top-2 margin becomes the gap between the two largest of 32
+    N(0, (8 sigma)^2) draws (~2.8 sigma) while the logit error of those rows grows 8 x with them (~0.3 sigma): most steps become decidable, in both
+    element types, and the free-running product stream can be held to the oracle's for many tokens.  Same mutation for the fp32 oracle, the 16-bit
+    floor chain and the product (it happens before any of them sees the weights)."""
+    w = sd["lm_head.weight"]
+    rows = torch.randperm(w.shape[0], generator=torch.Generator().manual_seed(seed))[:N_LOUD_ROWS]
+    w = w.clone()
+    w[rows] = w[rows] * LOUD_GAIN
+    sd["lm_head.weight"] = w
+    return rows.tolist()
 
 
 def run_end_to_end(cfg, T, n_dec, max_seq_len, min_decidable=0, mutate=None, tag="", elem="bf16", fp8_decode=False):
@@ -347,6 +366,7 @@ def _run_end_to_end(cfg, T, n_dec, max_seq_len, min_decidable, mutate, tag, half
         if mutate is None and all(torch.equal(v.bfloat16().float(), v) for v in list(sd.values())[:8]):
             _CACHE[sd_key] = {k: v.bfloat16() for k, v in sd.items()}
     planted = mutate(sd, cfg) if mutate is not None else None
+    loud = loud_vocab_rows(sd)
     t_sd = time.perf_counter() - t0
     u8 = torch.randint(0, 256, (T, side, side, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(15))
     frames = O.normalise_frames_u8(u8.numpy()).bfloat16().float()            # what `.to(bfloat16)` of process_video's output holds
@@ -453,8 +473,11 @@ def _run_end_to_end(cfg, T, n_dec, max_seq_len, min_decidable, mutate, tag, half
     got = out[0].tolist()
     upto = n_dec + 1 if first_tie is None else first_tie
     assert got[:upto] == toks[:upto], (got, toks, first_tie)
+    free_equal = next((i for i, (a_, b_) in enumerate(zip(got, toks)) if a_ != b_), min(len(got), len(toks)))
     RECORD.append(dict(stage=f"{tag}e2e greedy tokens: product generate() vs fp32 oracle", ours=got, oracle=toks, teacher_forced_top1_agree=agree, steps=n_dec + 1,
-                       first_unresolvable_tie=first_tie, decidable_steps=decidable, decidable_steps_agreeing=decided_ok))
+                       first_unresolvable_tie=first_tie, decidable_steps=decidable, decidable_steps_agreeing=decided_ok,
+                       free_running_tokens_equal_to_oracle=free_equal, loud_vocab_rows=N_LOUD_ROWS, loud_gain=LOUD_GAIN,
+                       oracle_tokens_in_loud_rows=sum(t in set(loud) for t in toks)))
     if fp8_decode:
         # OPTIONAL arithmetic (decoder.enable_fp8_decode): the same teacher-forced decode steps on the e4m3fn copies of the
         # decoder weights, from the same (16-bit) prefill.  Reported against the fp32 oracle (whose weights are NOT quantised: this is the

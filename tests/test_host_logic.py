@@ -18,10 +18,20 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     from videollama2_amd import _lib
     lib = ctypes.CDLL(_lib.LIB_PATH)
     header = open(os.path.join(ROOT, "include", "vl2hip.h")).read()
-    declared = set(re.findall(r"\b(vl2_[a-z0-9_]+)\s*\(", header))
+    # the lab entry points (libvl2hip_lab.so only) are declared inside #ifdef VL2_EXPERIMENTAL blocks: the product exports exactly the rest
+    product_part = re.sub(r"#ifdef VL2_EXPERIMENTAL.*?#endif /\* VL2_EXPERIMENTAL[^\n]*", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(vl2_[a-z0-9_]+)\s*\(", product_part))
+    lab_declared = set(re.findall(r"\b(vl2_[a-z0-9_]+)\s*\(", header)) - declared
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    assert lab_declared == set(_lib.LAB_SIGNATURES), lab_declared ^ set(_lib.LAB_SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), name
+    for name in lab_declared:
+        assert not hasattr(lib, name), f"{name}: a lab entry point exported by the product library"
+    import subprocess
+    nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = {l.split()[-1] for l in nm.splitlines() if " T " in l and l.split()[-1].startswith("vl2_")}
+    assert exported == declared, exported ^ declared                  # `nm -D` = the documented export set
     assert _lib.load().vl2_version() == 6
     assert _lib.load().vl2_elem_name() == b"bf16"
     f16 = ctypes.CDLL(_lib.LIB_PATHS["fp16"])               # the fp16 build: same export table, other element type

@@ -69,7 +69,6 @@ SIGNATURES = {
     "vl2_gemm": [ctypes.POINTER(GemmDesc), _vp],
     "vl2_row_stats": [_vp, _vp, _i32, _i32, _i32, _vp],
     "vl2_fill_zero": [_vp, _i64, _vp],
-    "vl2_decode_tail": [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp],
     "vl2_row_norm_finalize": [_vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp],
     "vl2_vit_forward": [ctypes.POINTER(VitDesc), _vp, _i32, _vp, _i32, _vp, _vp, _i64, _vp],
     "vl2_stc_forward": [ctypes.POINTER(StcDesc), _vp, _i32, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _i64, _vp],
@@ -101,11 +100,16 @@ SIGNATURES = {
     "vl2_gemm_skinny_bf16": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp],
     "vl2_gemv_batched_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp],
     "vl2_attn_decode": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _f32, _vp],
-    "vl2_attn_decode_fused": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _f32, _vp, _vp],
     "vl2_attn_decode_batched": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _i64, _i32, _i32, _i32, _vp, _i32, _f32, _vp],
     "vl2_argmax": [_vp, _i32, _vp, _vp, _i32, _vp, _vp],
     "vl2_sample_token": [_vp, _i32, _f32, _i32, _f32, _vp, _vp, _vp, _i32, _vp, _vp, _vp],
     "vl2_embed_rows": [_vp, _vp, _vp, _i32, _i32, _i32, _vp],
+}
+# entry points of the LAB build only (libvl2hip_lab.so = the same sources with -DVL2_LAB, scripts/build_lab_lib.sh: the experiments that were
+# measured and lost stay buildable and testable without riding in the product library); also exported by the CPU emulator (tests/emu)
+LAB_SIGNATURES = {
+    "vl2_decode_tail": [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp],
+    "vl2_attn_decode_fused": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _f32, _vp, _vp],
 }
 EXPORTS = ["vl2_version", "vl2_elem_name", "vl2_last_error_string", "vl2_workspace_bytes", "vl2_vit_workspace_bytes", "vl2_stc_workspace_bytes", "vl2_llm_workspace_bytes", "vl2_dwconv_mean_workspace_bytes"] + list(SIGNATURES)
 
@@ -116,6 +120,33 @@ _lib = None
 _ELEM = "bf16"
 _LIBS = {}
 LIB_PATHS = {"bf16": LIB_PATH, "fp16": os.path.join(_HERE, "libvl2hip_f16.so")}
+LAB_LIB_PATH = os.path.join(_HERE, "libvl2hip_lab.so")       # bf16 elements
+_LAB = False
+
+
+def lab_built():
+    return os.path.exists(LAB_LIB_PATH)
+
+
+def lab():
+    return _LAB
+
+
+def set_lab(on):
+    """Route every kernel call that follows through the LAB build (bf16 only; scripts, A/B runs and the lab tests).  The product never
+    calls this."""
+    global _LAB, _lib
+    on = bool(on)
+    if on == _LAB:
+        return
+    if on and _ELEM != "bf16":
+        raise ValueError("the lab library is built on bf16 elements")
+    if on and not lab_built():
+        raise Vl2HipError(f"{LAB_LIB_PATH} not found: build it with scripts/build_lab_lib.sh")
+    if _lib is not None:
+        _LIBS["lab" if _LAB else _ELEM] = _lib
+    _LAB = on
+    _lib = _LIBS.get("lab" if on else _ELEM)
 
 
 def elem():
@@ -142,6 +173,8 @@ def set_elem(name):
         raise ValueError(f"unknown element type {name!r} (bf16 | fp16)")
     if name == _ELEM:
         return
+    if _LAB:
+        raise ValueError("switch the lab library off (_lib.set_lab(False)) before changing the element type")
     if _lib is not None:
         _LIBS[_ELEM] = _lib
     _ELEM = name
@@ -157,7 +190,7 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    path = LIB_PATHS[_ELEM] if _ELEM != "bf16" else LIB_PATH
+    path = LAB_LIB_PATH if _LAB else (LIB_PATHS[_ELEM] if _ELEM != "bf16" else LIB_PATH)
     if not os.path.exists(path):
         raise Vl2HipError(f"{path} not found: build it with `python -m videollama2_amd.csrc.build` "
                           "(hipcc --offload-arch=gfx950); the HIP path has no fallback")
@@ -180,6 +213,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = _i32
         fn.argtypes = args
+    bind_lab(lib)
     if lib.vl2_version() != 6:
         raise Vl2HipError("libvl2hip.so ABI version mismatch")
     lib.vl2_elem_name.restype = ctypes.c_char_p
@@ -187,13 +221,29 @@ def load():
     if lib.vl2_elem_name().decode() != _ELEM:
         raise Vl2HipError(f"{path} computes in {lib.vl2_elem_name().decode()}, not {_ELEM}: rebuild it (python -m videollama2_amd.csrc.build)")
     _lib = lib
-    _LIBS[_ELEM] = lib
+    _LIBS["lab" if _LAB else _ELEM] = lib
     return lib
+
+
+def bind_lab(lib):
+    """ctypes signatures of the lab entry points a library exports (the lab build, the emulator); returns their names."""
+    have = []
+    for name, args in LAB_SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            continue
+        fn.restype = _i32
+        fn.argtypes = args
+        have.append(name)
+    return have
 
 
 def call(name, *args):
     """Call an entry point; non-zero return codes become Vl2HipError with the library's message."""
     lib = load()
+    if name in LAB_SIGNATURES and not hasattr(lib, name):
+        raise Vl2HipError(f"{name} is a lab entry point: built into libvl2hip_lab.so only (scripts/build_lab_lib.sh, then _lib.set_lab(True))")
     rc = getattr(lib, name)(*args)
     if rc != 0:
         msg = lib.vl2_last_error_string().decode(errors="replace")

@@ -21,6 +21,11 @@ __device__ __forceinline__ float dot2_bf16(uint32_t a, uint32_t b, float c) {
 }
 #endif
 
+// rotate-half RoPE of one (x[d], x[d + 64]) pair, the contraction pinned (shared by the decode kernels, which must agree to the bit)
+__device__ __forceinline__ void rope_pair(float x1, float x2, float c, float sn, float& o1, float& o2) {
+    o1 = __builtin_fmaf(x1, c, -(x2 * sn));       // q*cos + rotate_half(q)*sin, first half:  -x2
+    o2 = __builtin_fmaf(x2, c, x1 * sn);          //                              second half: +x1
+}
 // qkv [S, (nh+2*nkv)*HD] -> q_out [S, nh*HD] (roped), kcache/vcache [nkv][smax][HD] rows pos0+s.
 // cos/sin: fp32 [maxpos][HD/2].  One thread per (token, head, 8-dim chunk of the first half).  HD = 128.
 __global__ __launch_bounds__(256) void rope_kv_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ q_out,
@@ -169,6 +174,108 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvArgs p) {
     }
 }
 
+// gemv_bf16_kernel with the activation vector requested BEFORE the weight row: a wave's loads return in order, so x queued behind the row's
+// eight 16-B weight loads per lane cannot be normalised and staged before they have landed -- requested first, the RMSNorm prologue (two
+// barriers, an LDS round trip) runs while the weights are still in flight.  Same arithmetic in the same order: the same bits.  Measured
+// (scripts/ubench/decode_lab.hip, profiles/r06_experiments.md): q/k/v rows 11.6 -> 10.8 us per layer; no gain without a norm (o_proj) and
+// -0.3 us on the SwiGLU pair (94 VGPRs), so the launcher takes it for norm-carrying single-pass rows only (q/k/v, lm_head).
+// XV = 16-B vectors of x per thread (K <= XV * 2048).  grid = ceil(N_out / 4), block 256, dynamic LDS = K * 2 bytes.
+template <bool SWIGLU, bool OUT_F32, int XV>
+__global__ __launch_bounds__(256) void gemv_xfirst_bf16_kernel(GemvArgs p) {
+#pragma clang fp reassociate(off)                  // see gemv_bf16_kernel: the norm arithmetic is pinned to one order
+    extern __shared__ __attribute__((aligned(16))) unsigned char vl2_smem[];
+    __shared__ float red[8];
+    bf16_t* xs = (bf16_t*)vl2_smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_out = SWIGLU ? p.N / 2 : p.N;
+    const int nvec = p.K >> 3;
+    // x first, then the first pass of the row's weights: both in flight before anything is waited for
+    u32x4 xr[XV];
+#pragma unroll
+    for (int i = 0; i < XV; ++i) {
+        const int k = tid * 8 + i * 2048;
+        if (k < p.K) xr[i] = *(const u32x4*)(p.x + k);
+    }
+    u32x4 wv[8], uv[8];
+    auto issue_row = [&](int j, int v0) {
+        const int row0 = SWIGLU ? (j >> 5) * 64 + (j & 31) : j;
+        const bf16_t* w0p = p.W + (size_t)row0 * p.ldw;
+        const bf16_t* w1p = w0p + (size_t)32 * p.ldw;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int v = v0 + i * 64 + lane;
+            if (v < nvec) {
+                wv[i] = __builtin_nontemporal_load((const u32x4*)(w0p + (size_t)v * 8));
+                if (SWIGLU) uv[i] = __builtin_nontemporal_load((const u32x4*)(w1p + (size_t)v * 8));
+            }
+        }
+    };
+    const int j = blockIdx.x * 4 + wave;
+    if (j < n_out) issue_row(j, 0);
+    float rstd = 1.f;
+    const bool norm = p.norm_w != nullptr || p.rms_plain;
+    if (norm) {
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < XV; ++i) {
+            if (tid * 8 + i * 2048 < p.K) {
+                float v[8];
+                unpack8(xr[i], v);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) ss = __builtin_fmaf(v[q], v[q], ss);
+            }
+        }
+        ss = wave_sum(ss);
+        if (lane == 0) red[wave] = ss;
+        __syncthreads();
+        rstd = rsqrtf(((red[0] + red[1]) + (red[2] + red[3])) / (float)p.K + p.eps);
+    }
+#pragma unroll
+    for (int i = 0; i < XV; ++i) {
+        const int k = tid * 8 + i * 2048;
+        if (k < p.K) {
+            u32x4 raw = xr[i];
+            if (norm) {
+                float v[8];
+                unpack8(raw, v);
+                f32x4 w0 = {1.f, 1.f, 1.f, 1.f}, w1 = w0;
+                if (p.norm_w) { w0 = *(const f32x4*)(p.norm_w + k); w1 = *(const f32x4*)(p.norm_w + k + 4); }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = (v[q] * rstd) * (q < 4 ? w0[q] : w1[q - 4]);
+                raw = pack8(v);
+            }
+            *(u32x4*)(xs + k) = raw;
+        }
+    }
+    __syncthreads();
+    if (j >= n_out) return;
+    float a0 = 0.f, a1 = 0.f;
+    for (int v0 = 0; v0 < nvec; v0 += 64 * 8) {
+        if (v0) issue_row(j, v0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int v = v0 + i * 64 + lane;
+            if (v < nvec) {
+                const u32x4 xv = *(const u32x4*)(xs + (size_t)v * 8);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    a0 = dot2_bf16(wv[i][q], xv[q], a0);
+                    if (SWIGLU) a1 = dot2_bf16(uv[i][q], xv[q], a1);
+                }
+            }
+        }
+    }
+    a0 = wave_sum(a0);
+    if (SWIGLU) a1 = wave_sum(a1);
+    if (lane == 0) {
+        float o = SWIGLU ? silu_f(a0) * a1 : a0;
+        if (!SWIGLU && p.bias) o += p.bias[j];
+        if (p.res) o += bf2f(p.res[j]);
+        if (OUT_F32) ((float*)p.y)[j] = o;
+        else ((bf16_t*)p.y)[j] = f2bf(o);
+    }
+}
+
 // Multi-row form for BATCHED decode: y[b][:] = W x[b][:] for MB = 2..4 sequences in one pass over W.
 // Decode is bound by streaming the weights; with MB tokens (one per sequence) sharing the stream, the weights are read once
 // for MB outputs.  Same structure as gemv_bf16_kernel (one output row per wave, the row's 8 loads issued before x is
@@ -291,7 +398,7 @@ __device__ __forceinline__ float attn_ld(const float* p) {
     if (ACQ) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return *p;
 }
-template <bool ACQ, int TPH = 128>
+template <bool ACQ, int TPH = 128, bool WT = false>
 __device__ __forceinline__ void attn_combine_head(const float* __restrict__ src, int nsplit, int d, float* wgt, float* red,
                                                   bf16_t* outp, bool store) {
     // TPH threads work on one head (d = 0 .. TPH-1; the first 64 of them are one wave and turn the (m_i, l_i) pairs into weights);
@@ -312,12 +419,17 @@ __device__ __forceinline__ void attn_combine_head(const float* __restrict__ src,
             for (int i = 0; i < COMBINE_EARLY; ++i) ev[i] = i < nsplit ? attn_ld<ACQ>(src + i * 130 + 2 + d) : 0.f;
         }
     }
+    // ... and so are slice d's (m, l) (early: nsplit <= 32 <= TPH): the passes below then need no further memory round trip
+    float pm = -1e30f, pl = 0.f;
+    if (early && d < nsplit) { pm = attn_ld<ACQ>(src + d * 130); pl = attn_ld<ACQ>(src + d * 130 + 1); }
     if (d < 64) {                                             // one wave: global max M, then L = sum_i l_i 2^(m_i - M)
         float M = -1e30f;
-        for (int i0 = 0; i0 < nsplit; i0 += 64) M = fmaxf(M, (i0 + d < nsplit) ? attn_ld<ACQ>(src + (i0 + d) * 130) : -1e30f);
+        if (early) M = fmaxf(M, pm);
+        else for (int i0 = 0; i0 < nsplit; i0 += 64) M = fmaxf(M, (i0 + d < nsplit) ? attn_ld<ACQ>(src + (i0 + d) * 130) : -1e30f);
         M = wave_max(M);
         float L = 0.f;
-        for (int i0 = 0; i0 < nsplit; i0 += 64)
+        if (early) { if (d < nsplit) L = __builtin_fmaf(pl, exp2f(pm - M), L); }
+        else for (int i0 = 0; i0 < nsplit; i0 += 64)
             if (i0 + d < nsplit) L = __builtin_fmaf(attn_ld<ACQ>(src + (i0 + d) * 130 + 1), exp2f(attn_ld<ACQ>(src + (i0 + d) * 130) - M), L);
         L = wave_sum(L);
         if (d == 0) { red[0] = M; red[1] = 1.0f / L; }
@@ -330,7 +442,8 @@ __device__ __forceinline__ void attn_combine_head(const float* __restrict__ src,
     for (int c0 = 0; c0 < nsplit; c0 += COMBINE_CHUNK) {
         const int nc = nsplit - c0 < COMBINE_CHUNK ? nsplit - c0 : COMBINE_CHUNK;
         if (c0 > 0) __syncthreads();                          // the previous chunk's weights have been consumed
-        for (int i = d; i < nc; i += TPH) wgt[i] = exp2f(attn_ld<ACQ>(src + (c0 + i) * 130) - M);
+        if (early) { if (d < nc) wgt[d] = exp2f(pm - M); }
+        else for (int i = d; i < nc; i += TPH) wgt[i] = exp2f(attn_ld<ACQ>(src + (c0 + i) * 130) - M);
         __syncthreads();
         if constexpr (EARLY) {
             if (early) {                                      // nc == nsplit, c0 == 0
@@ -356,9 +469,94 @@ __device__ __forceinline__ void attn_combine_head(const float* __restrict__ src,
     }
     if (store) {
 #pragma unroll
-        for (int c = 0; c < 128 / TPH; ++c) outp[d + c * TPH] = f2bf(o[c] * red[1]);
+        for (int c = 0; c < 128 / TPH; ++c) {
+            const bf16_t r = f2bf(o[c] * red[1]);
+            if (WT) __hip_atomic_store(outp + d + c * TPH, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write-through: read by other workgroups of this launch
+            else outp[d + c * TPH] = r;
+        }
     }
 }
+// ---- one 64-key slice of the decode attention, shared by attn_decode_kernel and attn_oproj_kernel (k_decode2.h): four waves (`tid` = 0..255
+// inside the group of four) hold 16 keys each (kreg = the lane's K row, vv = the wave's V rows, `valid` = the lane's key is inside the
+// context), the roped q heads of the block are in qs.  Scores, slice softmax (exp2 domain), P V and the {m, l, o[128]} partial of each of
+// the `ng` heads -> pdst + h * hstride (only when `store`).  WT = write-through (sc1) partial stores (read by other workgroups of the same
+// launch).  Contains three workgroup barriers: every thread of the workgroup calls it the same number of times.  The sums are explicit
+// FMAs in a fixed order: the function is inlined into several kernels and -ffast-math would otherwise be free to contract them differently
+// in each (seen on hardware: last-bit differences in the partials between two kernels sharing this code).
+struct AttnSliceSmem {
+    __attribute__((aligned(16))) float qs[4][128];
+    __attribute__((aligned(16))) float pk[64][4];       // p[key][head]
+    float wred[2][4][4];                                 // [max|sum][wave][head]
+    __attribute__((aligned(16))) float oacc[4][4][128];  // [wave][head][d]
+};
+template <bool WT>
+__device__ __forceinline__ void attn_slice_compute(AttnSliceSmem& sm, int tid, const u32x4 (&kreg)[16], const uint32_t (&vv)[16], bool valid, int ng,
+                                                   float scale_log2e, float* pdst, size_t hstride, bool store) {
+#pragma clang fp reassociate(off)
+    constexpr int HD = 128;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int kl = lane & 15, hh = lane >> 4;
+    const int hq = hh < ng ? hh : ng - 1;
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        float kv[8];
+        unpack8(kreg[c], kv);
+        const f32x4 q0 = *(const f32x4*)&sm.qs[hq][c * 8], q1 = *(const f32x4*)&sm.qs[hq][c * 8 + 4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __builtin_fmaf(kv[4 + j], q1[j], __builtin_fmaf(kv[j], q0[j], acc));
+    }
+    const float s = valid ? acc * scale_log2e : -1e30f;
+    float mx = s;
+#pragma unroll
+    for (int msk = 8; msk >= 1; msk >>= 1) mx = fmaxf(mx, __shfl_xor(mx, msk));     // over the 16 keys of (wave, head)
+    if (kl == 0) sm.wred[0][wave][hh] = mx;
+    __syncthreads();
+    const float m = fmaxf(fmaxf(sm.wred[0][0][hh], sm.wred[0][1][hh]), fmaxf(sm.wred[0][2][hh], sm.wred[0][3][hh]));
+    const float pv = valid ? exp2f(s - m) : 0.f;
+    float sum = pv;
+#pragma unroll
+    for (int msk = 8; msk >= 1; msk >>= 1) sum += __shfl_xor(sum, msk);
+    if (kl == 0) sm.wred[1][wave][hh] = sum;
+    sm.pk[wave * 16 + kl][hh] = pv;
+    __syncthreads();
+
+    float o[4][2];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) o[h][0] = o[h][1] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const f32x4 p4 = *(const f32x4*)sm.pk[wave * 16 + i];
+        const float v0 = e_lo(vv[i]), v1 = e_hi(vv[i]);
+#pragma unroll
+        for (int h = 0; h < 4; ++h) { o[h][0] = __builtin_fmaf(p4[h], v0, o[h][0]); o[h][1] = __builtin_fmaf(p4[h], v1, o[h][1]); }
+    }
+#pragma unroll
+    for (int h = 0; h < 4; ++h) { sm.oacc[wave][h][lane * 2] = o[h][0]; sm.oacc[wave][h][lane * 2 + 1] = o[h][1]; }
+    __syncthreads();
+    // a thread stores a PAIR of floats (8-byte aligned: slices are 130 floats apart): half as many stores, and a write-through store is one
+    // fabric write whatever its width
+    auto put2 = [](float* p, float v0, float v1) {
+        if (WT) {
+            const f32x2 v = {v0, v1};
+            __hip_atomic_store((uint64_t*)p, __builtin_bit_cast(uint64_t, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // write-through (sc1)
+        } else {
+            *(f32x2*)p = f32x2{v0, v1};
+        }
+    };
+    if (store) {
+        for (int t = tid; t < ng * (HD / 2); t += 256) {
+            const int h = t / (HD / 2), d = (t % (HD / 2)) * 2;
+            float* dst = pdst + (size_t)h * hstride;
+            put2(dst + 2 + d, ((sm.oacc[0][h][d] + sm.oacc[1][h][d]) + sm.oacc[2][h][d]) + sm.oacc[3][h][d],
+                 ((sm.oacc[0][h][d + 1] + sm.oacc[1][h][d + 1]) + sm.oacc[2][h][d + 1]) + sm.oacc[3][h][d + 1]);
+            if (d == 0)
+                put2(dst, fmaxf(fmaxf(sm.wred[0][0][h], sm.wred[0][1][h]), fmaxf(sm.wred[0][2][h], sm.wred[0][3][h])),
+                     ((sm.wred[1][0][h] + sm.wred[1][1][h]) + sm.wred[1][2][h]) + sm.wred[1][3][h]);
+        }
+    }
+}
+
 // ---- decode attention (flash-decoding) fused with RoPE and the KV-cache append of the new token.
 // qkv [(nh+2*nkv)*128] = the un-roped fused projection of the ONE new token at position pos (pos = *pos_dev when pos_dev
 // is non-null, so a captured hipGraph replays with a moving position).  grid = (nsplit_cap, nkv, ceil(group/4)), 256
@@ -387,12 +585,10 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
     // batched decode: blockIdx.y = kv head + nkv * sequence; sequence b uses qkv + b*qkv_bs, caches + b*cache_bs,
     // partial + b*partial_bs and position pos_dev[b] (single sequence: strides 0, b = 0)
     constexpr int HD = 128, HALF = 64;
-    __shared__ __attribute__((aligned(16))) float qs[4][HD];
-    __shared__ __attribute__((aligned(16))) float pk[64][4];       // p[key][head]
-    __shared__ float wred[2][4][4];                                 // [max|sum][wave][head]
-    __shared__ __attribute__((aligned(16))) float oacc[4][4][HD];   // [wave][head][d]
+    __shared__ AttnSliceSmem sm;
+    auto& qs = sm.qs;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int kl = lane & 15, hh = lane >> 4;
+    const int kl = lane & 15;
     const int split = blockIdx.x, hk = (int)blockIdx.y % nkv, bseq = (int)blockIdx.y / nkv, nsplit = gridDim.x;
     const int h0 = blockIdx.z * 4;                                  // first q head (within the group) of this block
     const int ng = group - h0 < 4 ? group - h0 : 4;                 // q heads of this block
@@ -416,17 +612,19 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
     for (int t = tid; t < ng * HALF; t += 256) {
         const int h = t / HALF, d = t % HALF;
         const bf16_t* qh = qkv + (size_t)(hk * group + h0 + h) * HD;
-        const float x1 = bf2f(qh[d]), x2 = bf2f(qh[d + HALF]), c = cp[d], sn = sp[d];
-        qs[h][d] = bf2f(f2bf(x1 * c - x2 * sn));
-        qs[h][d + HALF] = bf2f(f2bf(x2 * c + x1 * sn));
+        float o1, o2;
+        rope_pair(bf2f(qh[d]), bf2f(qh[d + HALF]), cp[d], sp[d], o1, o2);
+        qs[h][d] = bf2f(f2bf(o1));                      // rounded through bf16 like the prefill's roped q
+        qs[h][d + HALF] = bf2f(f2bf(o2));
     }
     // the slice that owns the new position appends roped k_new and v_new to the cache before anyone reads row `pos`
     if (pos >= k0 && pos < k0 + 64 && tid < HALF) {
         const bf16_t* kn = qkv + (size_t)(nh + hk) * HD;
         const bf16_t* vn = qkv + (size_t)(nh + nkv + hk) * HD;
-        const float x1 = bf2f(kn[tid]), x2 = bf2f(kn[tid + HALF]), c = cp[tid], sn = sp[tid];
-        Kb[(size_t)pos * HD + tid] = f2bf(x1 * c - x2 * sn);
-        Kb[(size_t)pos * HD + tid + HALF] = f2bf(x2 * c + x1 * sn);
+        float o1, o2;
+        rope_pair(bf2f(kn[tid]), bf2f(kn[tid + HALF]), cp[tid], sp[tid], o1, o2);
+        Kb[(size_t)pos * HD + tid] = f2bf(o1);
+        Kb[(size_t)pos * HD + tid + HALF] = f2bf(o2);
         Vb[(size_t)pos * HD + tid] = vn[tid];
         Vb[(size_t)pos * HD + tid + HALF] = vn[tid + HALF];
     }
@@ -447,57 +645,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
 #pragma unroll
     for (int c = 0; c < 16; ++c) kreg[c] = *(const u32x4*)(kr + c * 8);
 
-    const int hq = hh < ng ? hh : ng - 1;
-    float acc = 0.f;
-#pragma unroll
-    for (int c = 0; c < 16; ++c) {
-        float kv[8];
-        unpack8(kreg[c], kv);
-        const f32x4 q0 = *(const f32x4*)&qs[hq][c * 8], q1 = *(const f32x4*)&qs[hq][c * 8 + 4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc += kv[j] * q0[j] + kv[4 + j] * q1[j];
-    }
-    const float s = valid ? acc * scale_log2e : -1e30f;
-    float mx = s;
-#pragma unroll
-    for (int msk = 8; msk >= 1; msk >>= 1) mx = fmaxf(mx, __shfl_xor(mx, msk));     // over the 16 keys of (wave, head)
-    if (kl == 0) wred[0][wave][hh] = mx;
-    __syncthreads();
-    const float m = fmaxf(fmaxf(wred[0][0][hh], wred[0][1][hh]), fmaxf(wred[0][2][hh], wred[0][3][hh]));
-    const float pv = valid ? exp2f(s - m) : 0.f;
-    float sm = pv;
-#pragma unroll
-    for (int msk = 8; msk >= 1; msk >>= 1) sm += __shfl_xor(sm, msk);
-    if (kl == 0) wred[1][wave][hh] = sm;
-    pk[wave * 16 + kl][hh] = pv;
-    __syncthreads();
-
-    float o[4][2];
-#pragma unroll
-    for (int h = 0; h < 4; ++h) o[h][0] = o[h][1] = 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const f32x4 p4 = *(const f32x4*)pk[wave * 16 + i];
-        const float v0 = e_lo(vv[i]), v1 = e_hi(vv[i]);
-#pragma unroll
-        for (int h = 0; h < 4; ++h) { o[h][0] += p4[h] * v0; o[h][1] += p4[h] * v1; }
-    }
-#pragma unroll
-    for (int h = 0; h < 4; ++h) { oacc[wave][h][lane * 2] = o[h][0]; oacc[wave][h][lane * 2 + 1] = o[h][1]; }
-    __syncthreads();
-    auto put = [](float* p, float v) {
-        if (FUSED) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // write-through (sc1)
-        else *p = v;
-    };
-    for (int t = tid; t < ng * HD; t += 256) {
-        const int h = t / HD, d = t % HD;
-        float* dst = partial + ((size_t)(hk * group + h0 + h) * nsplit + split) * 130;
-        put(dst + 2 + d, oacc[0][h][d] + oacc[1][h][d] + oacc[2][h][d] + oacc[3][h][d]);
-        if (d == 0) {
-            put(dst, fmaxf(fmaxf(wred[0][0][h], wred[0][1][h]), fmaxf(wred[0][2][h], wred[0][3][h])));
-            put(dst + 1, wred[1][0][h] + wred[1][1][h] + wred[1][2][h] + wred[1][3][h]);
-        }
-    }
+    attn_slice_compute<FUSED>(sm, tid, kreg, vv, valid, ng, scale_log2e,
+                              partial + ((size_t)(hk * group + h0) * nsplit + split) * 130, (size_t)nsplit * 130, true);
     if constexpr (FUSED) {
         __shared__ float wgtf[4][COMBINE_CHUNK];
         __shared__ float redf[4][2];

@@ -10,13 +10,22 @@
 #include "k_attn.h"
 #include "k_attn2.h"
 #include "k_decode.h"
-#include "k_decode_tail.h"
 #include "k_fp8.h"
 #include "k_gemm.h"
 #include "k_gemm6.h"
 #include "k_gemm7.h"
-#include "k_gemm8.h"
 #include "k_gemm9.h"
+// libvl2hip.so = the default path + the documented options.  The experiments that were measured and lost (the four-wave 256x256 tile, the
+// issue-order / stamped forms of the 16x16x32 kernel, the woven LDS-DMA issue outside the 192-row tiles, the two-accumulator persistent
+// form, stream-K, the decode tail engine, attention + elected combine in one launch) are compiled only with -DVL2_LAB into
+// libvl2hip_lab.so (scripts/build_lab_lib.sh); in the product build a request for one of them is refused with VL2_E_UNSUPP.
+#ifdef VL2_LAB
+#include "k_decode_tail.h"
+#include "k_gemm8.h"
+static constexpr bool kLab = true;
+#else
+static constexpr bool kLab = false;
+#endif
 #include "k_norm.h"
 #include "k_pack.h"
 #include "k_sample.h"
@@ -211,6 +220,7 @@ static bool want_small_m(const GemmArgs& a, const GemmCtl& c) {
 // produce the same bits (hash-checked per shape), so the choice is invisible to every caller.
 static bool want_tr_epilogue(const GemmArgs& a) { return a.res == nullptr; }
 
+#ifdef VL2_LAB
 // gemm8 (k_gemm8.h): the 256 x 256 tile on four waves, one per SIMD, 128 x 128 wave tiles
 template <int ACT, bool SW, bool F32>
 static void launch_gemm8(const GemmArgs& a0, hipStream_t s) {
@@ -227,6 +237,7 @@ static void launch_gemm8(const GemmArgs& a0, hipStream_t s) {
     lds_attr<gemm8_bf16_kernel<ACT, SW, F32, false>>(GEMM8_LDS_BYTES);
     hipLaunchKernelGGL((gemm8_bf16_kernel<ACT, SW, F32, false>), dim3(a.tiles_m * a.tiles_n), dim3(256), GEMM8_LDS_BYTES, s, a);
 }
+#endif
 
 // gemm9 (k_gemm9.h): the 256 x 256 ping-pong tile on the 16 x 16 x 32 matrix instruction -- opt-in, NOT the family's bits
 template <bool SW>
@@ -235,6 +246,7 @@ static void launch_gemm9(const GemmArgs& a0, int mode, hipStream_t s) {
     a.tiles_m = (a.M + 255) / 256;
     a.tiles_n = a.N / GEMM4_BN;
     const dim3 grid(a.tiles_m * a.tiles_n);
+    if constexpr (kLab) {
     if (mode == 1) {          // lab (variant 17): the LDS-DMA issue behind the load phase's fragment reads
         lds_attr<gemm9_bf16_kernel<SW, 1>>(GEMM4_LDS_BYTES);
         hipLaunchKernelGGL((gemm9_bf16_kernel<SW, 1>), grid, dim3(512), GEMM4_LDS_BYTES, s, a);
@@ -262,10 +274,11 @@ static void launch_gemm9(const GemmArgs& a0, int mode, hipStream_t s) {
     } else if (mode == 3) {   // lab (variant 19): register-staged slabs (plain loads + ds_write_b128), no LDS-DMA
         lds_attr<gemm9_bf16_kernel<SW, 3>>(GEMM4_LDS_BYTES);
         hipLaunchKernelGGL((gemm9_bf16_kernel<SW, 3>), grid, dim3(512), GEMM4_LDS_BYTES, s, a);
-    } else {
-        lds_attr<gemm9_bf16_kernel<SW, 0>>(GEMM4_LDS_BYTES);
-        hipLaunchKernelGGL((gemm9_bf16_kernel<SW, 0>), grid, dim3(512), GEMM4_LDS_BYTES, s, a);
     }
+    if (mode != 0) return;
+    }
+    lds_attr<gemm9_bf16_kernel<SW, 0>>(GEMM4_LDS_BYTES);
+    hipLaunchKernelGGL((gemm9_bf16_kernel<SW, 0>), grid, dim3(512), GEMM4_LDS_BYTES, s, a);
 }
 
 template <int ACT, bool SW, bool F32, int BM = GEMM4_BM>
@@ -274,25 +287,37 @@ static void launch_gemm4(const GemmArgs& a0, hipStream_t s, bool weave4 = false)
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = a.N / GEMM4_BN;
     const dim3 grid(a.tiles_m * a.tiles_n);
+    // the product builds ONE issue order per tile height: woven (WEAVE4) on the 192-row tiles, load-phase on the 256-row tiles; the other
+    // order of each is a lab form (VL2_GEMM_NO_WEAVE4 / VL2_GEMM_WEAVE4)
+    constexpr bool kWoven = BM == 192 && !F32, kPlain = !kWoven;
+    if constexpr (!kLab) weave4 = kWoven;
     if constexpr (!F32) {
         if (want_tr_epilogue(a)) {
-            if (weave4) {
-                lds_attr<gemm4_bf16_kernel<ACT, SW, false, true, -1, BM, true>>(GEMM4_LDS_BYTES);
-                hipLaunchKernelGGL((gemm4_bf16_kernel<ACT, SW, false, true, -1, BM, true>), grid, dim3(512), GEMM4_LDS_BYTES, s, a);
-            } else {
+            if constexpr (kLab || kWoven) {
+                if (weave4) {
+                    lds_attr<gemm4_bf16_kernel<ACT, SW, false, true, -1, BM, true>>(GEMM4_LDS_BYTES);
+                    hipLaunchKernelGGL((gemm4_bf16_kernel<ACT, SW, false, true, -1, BM, true>), grid, dim3(512), GEMM4_LDS_BYTES, s, a);
+                    return;
+                }
+            }
+            if constexpr (kLab || kPlain) {
                 lds_attr<gemm4_bf16_kernel<ACT, SW, false, true, -1, BM>>(GEMM4_LDS_BYTES);
                 hipLaunchKernelGGL((gemm4_bf16_kernel<ACT, SW, false, true, -1, BM>), grid, dim3(512), GEMM4_LDS_BYTES, s, a);
             }
             return;
         }
-        if (weave4) {
-            lds_attr<gemm4_bf16_kernel<ACT, SW, false, false, -1, BM, true>>(GEMM4_LDS_BYTES);
-            hipLaunchKernelGGL((gemm4_bf16_kernel<ACT, SW, false, false, -1, BM, true>), grid, dim3(512), GEMM4_LDS_BYTES, s, a);
-            return;
+        if constexpr (kLab || kWoven) {
+            if (weave4) {
+                lds_attr<gemm4_bf16_kernel<ACT, SW, false, false, -1, BM, true>>(GEMM4_LDS_BYTES);
+                hipLaunchKernelGGL((gemm4_bf16_kernel<ACT, SW, false, false, -1, BM, true>), grid, dim3(512), GEMM4_LDS_BYTES, s, a);
+                return;
+            }
         }
     }
-    lds_attr<gemm4_bf16_kernel<ACT, SW, F32, false, -1, BM>>(GEMM4_LDS_BYTES);
-    hipLaunchKernelGGL((gemm4_bf16_kernel<ACT, SW, F32, false, -1, BM>), grid, dim3(512), GEMM4_LDS_BYTES, s, a);
+    if constexpr (kLab || kPlain) {
+        lds_attr<gemm4_bf16_kernel<ACT, SW, F32, false, -1, BM>>(GEMM4_LDS_BYTES);
+        hipLaunchKernelGGL((gemm4_bf16_kernel<ACT, SW, F32, false, -1, BM>), grid, dim3(512), GEMM4_LDS_BYTES, s, a);
+    }
 }
 
 // ---- persistent ping-pong GEMM (k_gemm6.h): ONE workgroup per CU walks its tiles, the LDS ring runs across tile boundaries, the stores
@@ -344,7 +369,7 @@ static void launch_gemm6(const GemmArgs& a0, int kern, hipStream_t s) {
     } else if (kern == 61) {
         lds_attr<gemm6_bf16_kernel<ACT, SW, 192, false>>(GEMM6_LDS_BYTES);
         hipLaunchKernelGGL((gemm6_bf16_kernel<ACT, SW, 192, false>), dim3(g), dim3(512), GEMM6_LDS_BYTES, s, a);
-    } else {
+    } else if constexpr (kLab) {                                       // 62: two accumulator sets (measured slower than 61)
         lds_attr<gemm6_bf16_kernel<ACT, SW, 192, true>>(GEMM6_LDS_BYTES);
         hipLaunchKernelGGL((gemm6_bf16_kernel<ACT, SW, 192, true>), dim3(g), dim3(512), GEMM6_LDS_BYTES, s, a);
     }
@@ -409,9 +434,13 @@ static void launch_gemm(const GemmArgs& a0, const GemmCtl& c, hipStream_t s) {
         const int r1 = c.variant == 224 ? 3 : c.variant == 192 ? 2 : (c.variant == 0 && !c.no_fill) ? choose_gemm7(a0, G) : 0;
         // (225 / 193 = 224 / 192 with the LDS-DMA issue woven into the MFMA phases, as VL2_GEMM_WEAVE selects it: lab form, see gemm3 below)
         const int r1v = c.variant == 225 ? 3 : c.variant == 193 ? 2 : r1;
-        const bool weave7 = c.weave || c.variant == 225 || c.variant == 193;
-        if (r1v == 3) { if (weave7) launch_gemm7<ACT, F32, G, 3, true>(a0, s); else launch_gemm7<ACT, F32, G, 3, false>(a0, s); return; }
-        if (r1v == 2) { if (weave7) launch_gemm7<ACT, F32, G, 2, true>(a0, s); else launch_gemm7<ACT, F32, G, 2, false>(a0, s); return; }
+        const bool weave7 = kLab && (c.weave || c.variant == 225 || c.variant == 193);
+        if constexpr (kLab) {
+            if (weave7 && r1v == 3) { launch_gemm7<ACT, F32, G, 3, true>(a0, s); return; }
+            if (weave7 && r1v == 2) { launch_gemm7<ACT, F32, G, 2, true>(a0, s); return; }
+        }
+        if (r1v == 3) { launch_gemm7<ACT, F32, G, 3, false>(a0, s); return; }
+        if (r1v == 2) { launch_gemm7<ACT, F32, G, 2, false>(a0, s); return; }
     }
     if constexpr (!G && !F32) {
         // persistent form: on request (variants 60 / 61; 62 = 192-row tiles with two accumulator sets, measured slower, kept for the lab) or
@@ -446,17 +475,21 @@ static void launch_gemm(const GemmArgs& a0, const GemmCtl& c, hipStream_t s) {
             if (!no_mix && t_tail > 128 && t_tail <= 512) {
                 big.tiles_m = M1 / GEMM4_BM; big.tiles_n = a0.N / GEMM4_BN;
                 const dim3 gmix((unsigned)(t_big + t_tail));
-                if (want_tr_epilogue(big)) {
+                if constexpr (kLab) {                 // the big tiles with the woven LDS-DMA issue (VL2_GEMM_WEAVE4)
                     if (c.weave4) {
-                        lds_attr<gemm_mix_bf16_kernel<ACT, SW, true, true>>(GEMM4_LDS_BYTES);
-                        hipLaunchKernelGGL((gemm_mix_bf16_kernel<ACT, SW, true, true>), gmix, dim3(512), GEMM4_LDS_BYTES, s, big, tail, (int)t_big);
-                    } else {
-                        lds_attr<gemm_mix_bf16_kernel<ACT, SW, true>>(GEMM4_LDS_BYTES);
-                        hipLaunchKernelGGL((gemm_mix_bf16_kernel<ACT, SW, true>), gmix, dim3(512), GEMM4_LDS_BYTES, s, big, tail, (int)t_big);
+                        if (want_tr_epilogue(big)) {
+                            lds_attr<gemm_mix_bf16_kernel<ACT, SW, true, true>>(GEMM4_LDS_BYTES);
+                            hipLaunchKernelGGL((gemm_mix_bf16_kernel<ACT, SW, true, true>), gmix, dim3(512), GEMM4_LDS_BYTES, s, big, tail, (int)t_big);
+                        } else {
+                            lds_attr<gemm_mix_bf16_kernel<ACT, SW, false, true>>(GEMM4_LDS_BYTES);
+                            hipLaunchKernelGGL((gemm_mix_bf16_kernel<ACT, SW, false, true>), gmix, dim3(512), GEMM4_LDS_BYTES, s, big, tail, (int)t_big);
+                        }
+                        return;
                     }
-                } else if (c.weave4) {
-                    lds_attr<gemm_mix_bf16_kernel<ACT, SW, false, true>>(GEMM4_LDS_BYTES);
-                    hipLaunchKernelGGL((gemm_mix_bf16_kernel<ACT, SW, false, true>), gmix, dim3(512), GEMM4_LDS_BYTES, s, big, tail, (int)t_big);
+                }
+                if (want_tr_epilogue(big)) {
+                    lds_attr<gemm_mix_bf16_kernel<ACT, SW, true>>(GEMM4_LDS_BYTES);
+                    hipLaunchKernelGGL((gemm_mix_bf16_kernel<ACT, SW, true>), gmix, dim3(512), GEMM4_LDS_BYTES, s, big, tail, (int)t_big);
                 } else {
                     lds_attr<gemm_mix_bf16_kernel<ACT, SW, false>>(GEMM4_LDS_BYTES);
                     hipLaunchKernelGGL((gemm_mix_bf16_kernel<ACT, SW, false>), gmix, dim3(512), GEMM4_LDS_BYTES, s, big, tail, (int)t_big);
@@ -503,36 +536,42 @@ static void launch_gemm(const GemmArgs& a0, const GemmCtl& c, hipStream_t s) {
             // -2...-9 % back to back with the operands warm in the Infinity Cache, but +4...+12 % IN THE PIPELINE (down 206 -> 218 us, o 66 -> 69,
             // Conv3d on the 192-row tiles 425 -> 476): the woven pieces have 1.5 phases of flight instead of 3, which cold weights do not forgive.
             // So it is a lab switch: variant 5 or VL2_GEMM_WEAVE.
-            const bool weave = kern == 5 || c.weave;
+            const bool weave = kLab && (kern == 5 || c.weave);
             GemmArgs a = a0;
             a.tiles_m = (a.M + GEMM3_BM - 1) / GEMM3_BM;
             a.tiles_n = a.N / GEMM3_BN;
             const dim3 grid(a.tiles_m * a.tiles_n);
-            if constexpr (!F32) {
-                if (want_tr_epilogue(a)) {
-                    if (weave) {
-                        lds_attr<gemm3_bf16_kernel<ACT, SW, false, true, -1, true>>(GEMM3_LDS_BYTES);
-                        hipLaunchKernelGGL((gemm3_bf16_kernel<ACT, SW, false, true, -1, true>), grid, dim3(512), GEMM3_LDS_BYTES, s, a);
-                    } else {
-                        lds_attr<gemm3_bf16_kernel<ACT, SW, false, true>>(GEMM3_LDS_BYTES);
-                        hipLaunchKernelGGL((gemm3_bf16_kernel<ACT, SW, false, true>), grid, dim3(512), GEMM3_LDS_BYTES, s, a);
+            if constexpr (kLab) {
+                if (weave) {
+                    if constexpr (!F32) {
+                        if (want_tr_epilogue(a)) {
+                            lds_attr<gemm3_bf16_kernel<ACT, SW, false, true, -1, true>>(GEMM3_LDS_BYTES);
+                            hipLaunchKernelGGL((gemm3_bf16_kernel<ACT, SW, false, true, -1, true>), grid, dim3(512), GEMM3_LDS_BYTES, s, a);
+                            return;
+                        }
                     }
+                    lds_attr<gemm3_bf16_kernel<ACT, SW, F32, false, -1, true>>(GEMM3_LDS_BYTES);
+                    hipLaunchKernelGGL((gemm3_bf16_kernel<ACT, SW, F32, false, -1, true>), grid, dim3(512), GEMM3_LDS_BYTES, s, a);
                     return;
                 }
             }
-            if (weave) {
-                lds_attr<gemm3_bf16_kernel<ACT, SW, F32, false, -1, true>>(GEMM3_LDS_BYTES);
-                hipLaunchKernelGGL((gemm3_bf16_kernel<ACT, SW, F32, false, -1, true>), grid, dim3(512), GEMM3_LDS_BYTES, s, a);
-            } else {
-                lds_attr<gemm3_bf16_kernel<ACT, SW, F32>>(GEMM3_LDS_BYTES);
-                hipLaunchKernelGGL((gemm3_bf16_kernel<ACT, SW, F32>), grid, dim3(512), GEMM3_LDS_BYTES, s, a);
+            if constexpr (!F32) {
+                if (want_tr_epilogue(a)) {
+                    lds_attr<gemm3_bf16_kernel<ACT, SW, false, true>>(GEMM3_LDS_BYTES);
+                    hipLaunchKernelGGL((gemm3_bf16_kernel<ACT, SW, false, true>), grid, dim3(512), GEMM3_LDS_BYTES, s, a);
+                    return;
+                }
             }
+            lds_attr<gemm3_bf16_kernel<ACT, SW, F32>>(GEMM3_LDS_BYTES);
+            hipLaunchKernelGGL((gemm3_bf16_kernel<ACT, SW, F32>), grid, dim3(512), GEMM3_LDS_BYTES, s, a);
             return;
         }
+#ifdef VL2_LAB
         if (kern == 9 && a0.N % GEMM4_BN == 0) {                              // lab / forced: the four-wave 256 x 256 kernel (k_gemm8.h)
             launch_gemm8<ACT, SW, F32>(a0, s);
             return;
         }
+#endif
         if ((kern == 8 || (F32 && kern == 12)) && a0.N % GEMM4_BN == 0) {     // (the 192-row form is built for bf16 outputs only)
             launch_gemm4<ACT, SW, F32>(a0, s, c.weave4);
             return;
@@ -547,7 +586,7 @@ static void launch_gemm(const GemmArgs& a0, const GemmCtl& c, hipStream_t s) {
             }
         }
     }
-    if constexpr (!G) {
+    if constexpr (!G && kLab) {
         if (want_stream_k(a0, c)) {
             lds_attr<gemm_sk_bf16_kernel<ACT, SW, F32>>(GEMM_LDS_BYTES);
             GemmArgs a = a0;
@@ -677,6 +716,8 @@ extern "C" int32_t vl2_gemm(const vl2_gemm_desc* d, void* stream) {
     if (d->ws && (d->ws_bytes < SK_WS_BYTES || !ALIGNED16(d->ws))) return fail(VL2_E_BADARG, "vl2_gemm: workspace needs >= %lld bytes, 16-byte aligned", (long long)SK_WS_BYTES);
     const int v = d->variant;
     if (!(v == 0 || v == 1 || v == 2 || v == 4 || v == 5 || v == 8 || v == 9 || v == 12 || (v >= 16 && v <= 23) || v == 25 || v == 26 || v == 32 || v == 24 || v == 60 || v == 61 || v == 62 || v == 70 || v == 71 || v == 80 || v == 81 || v == 192 || v == 193 || v == 224 || v == 225 || v == 256)) return fail(VL2_E_BADARG, "vl2_gemm: unknown variant %d", v);
+    if (!kLab && (v == 2 || v == 5 || v == 9 || (v >= 17 && v <= 23) || v == 25 || v == 26 || v == 62 || v == 193 || v == 225))
+        return fail(VL2_E_UNSUPP, "vl2_gemm: variant %d is a lab form: built into libvl2hip_lab.so only (scripts/build_lab_lib.sh)", v);
     GemmCtl ctl{d->ws, d->ws_bytes, v, (d->flags & VL2_GEMM_SPLITK) != 0};
     ctl.persist = (d->flags & VL2_GEMM_PERSISTENT) != 0;
     ctl.no_mix = (d->flags & VL2_GEMM_NO_MIX) != 0;
@@ -1052,6 +1093,13 @@ extern "C" int32_t vl2_rope_kv(const void* qkv, void* q_out, void* kcache, void*
 template <bool SW, bool F32>
 static void launch_gemv(const GemvArgs& a, int n_out, hipStream_t s) {
     // one output row per wave: measured on MI355X 3.09 / 3.30 / 3.97 ms per 7B decode token at 1 / 2 / 4 rows per wave
+    // norm-carrying single-pass rows (q/k/v, lm_head): x requested before the weight row (k_decode.h gemv_xfirst_bf16_kernel, same bits)
+    if constexpr (!SW) {
+        if ((a.norm_w || a.rms_plain) && a.K <= 4096) {
+            hipLaunchKernelGGL((gemv_xfirst_bf16_kernel<false, F32, 2>), dim3((n_out + 3) / 4), dim3(256), (size_t)a.K * 2, s, a);
+            return;
+        }
+    }
     hipLaunchKernelGGL((gemv_bf16_kernel<SW, F32, 1>), dim3((n_out + 3) / 4), dim3(256), (size_t)a.K * 2, s, a);
 }
 extern "C" int32_t vl2_gemv_bf16(const void* W, const void* x, const float* norm_w, const void* res, const float* bias, void* y,
@@ -1152,6 +1200,7 @@ extern "C" int32_t vl2_attn_decode(const void* qkv, void* kcache, void* vcache, 
     hipLaunchKernelGGL(attn_decode_combine_kernel, dim3(nh), dim3(128), 0, ST(stream), partial, (bf16_t*)out, nsplit, pos, pos_dev, 0L, 0L);
     return launched("vl2_attn_decode");
 }
+#ifdef VL2_LAB
 // attention + combine of ONE decode token in one launch (k_decode.h attn_decode_kernel<true>): `cnt` = nkv int32 ticket counters,
 // zero when the launch starts (vl2_llm_decode_step clears the counters of all layers in its argmax launch).  Same bits as
 // vl2_attn_decode.  Measured 2.4 us per layer SLOWER than the two launches (profiles/r03_experiments.md section 5), so the stage-level
@@ -1171,6 +1220,7 @@ extern "C" int32_t vl2_attn_decode_fused(const void* qkv, void* kcache, void* vc
         return fail(VL2_E_BADARG, "vl2_attn_decode_fused: bad args");
     return attn_decode_fused(qkv, kcache, vcache, cos_t, sin_t, partial, out, nh, nkv, smax, pos_dev, scale, cnt, stream);
 }
+#endif
 extern "C" int32_t vl2_attn_decode_batched(const void* qkv, void* kcache, void* vcache, const float* cos_t, const float* sin_t,
                                            float* partial, void* out, int32_t B, int64_t qkv_bs, int64_t cache_bs, int64_t out_bs,
                                            int32_t nh, int32_t nkv, int32_t smax, const int32_t* pos_dev, int32_t ctx_cap, float scale,
@@ -1218,6 +1268,7 @@ static int32_t argmax_and_clear(const float* logits, int32_t V, int32_t* tok, in
                        (const bf16_t*)embed, (bf16_t*)x0, D);
     return launched("vl2_llm_decode_step: argmax");
 }
+#ifdef VL2_LAB
 extern "C" int32_t vl2_decode_tail(const void* Wo, const void* Wgu, const void* Wd, int32_t ldwo, int32_t ldwgu, int32_t ldwd, const void* o,
                                    const void* x0, void* x1, void* act, void* xout, int32_t D, int32_t QD, int32_t I, float eps, int32_t* bar,
                                    void* stream) {
@@ -1234,6 +1285,7 @@ extern "C" int32_t vl2_decode_tail(const void* Wo, const void* Wgu, const void* 
     hipLaunchKernelGGL((decode_tail_kernel<7>), dim3(g), dim3(1024), (size_t)kmax * 2, ST(stream), a);
     return launched("vl2_decode_tail");
 }
+#endif
 extern "C" int32_t vl2_embed_rows(const int32_t* ids, const void* table, void* out, int32_t n, int32_t D, int32_t ldo, void* stream) {
     if (!ids || !table || !out || n <= 0 || D % 8 || ldo % 8) return fail(VL2_E_BADARG, "vl2_embed_rows: bad args");
     hipLaunchKernelGGL(embed_rows_kernel, dim3(n), dim3(128), 0, ST(stream), ids, (const bf16_t*)table, (bf16_t*)out, D, ldo);

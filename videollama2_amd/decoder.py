@@ -74,12 +74,24 @@ class HipMistralDecoder(nn.Module):
         if self.tp > 1:
             raise NotImplementedError("fp8 decode weights: single-rank decoders only")
         if on and getattr(self, "w8", None) is None:
-            self.w8 = dict(layers=[{k: ops.quant_fp8(lw[k]) for k in ("wqkv", "wo", "wgu", "wd")} for lw in self.w["layers"]],
-                           lm_head=ops.quant_fp8(self.w["lm_head"]))
-            self._stage = None                                    # the descriptor is rebuilt with the fp8 pointers
+            self._make_w8()
         self.decode_fp8 = bool(on)
-        self.graph = None                                         # a captured step holds the other projections
+        self._invalidate_graphs()                                 # a captured step (greedy or sampled) holds the other projections
         return self
+
+    def _make_w8(self):
+        """The fp8 copies of the packed projections (shared by the decode and the prefill switch).  The stage descriptor is rebuilt with
+        the fp8 pointers -- and with it the decode workspace, so every captured graph (which points into the old workspace) goes too."""
+        self.w8 = dict(layers=[{k: ops.quant_fp8(lw[k]) for k in ("wqkv", "wo", "wgu", "wd")} for lw in self.w["layers"]],
+                       lm_head=ops.quant_fp8(self.w["lm_head"]))
+        self._stage = None
+        self._invalidate_graphs()
+
+    def _invalidate_graphs(self):
+        """Drop every captured decode graph: the greedy one and the sampled one (keyed by the sampler only) both bake in the weight
+        pointers / arithmetic (`decode_fp8`) and the stage workspace of the moment they were captured."""
+        self.graph = None
+        self._graph_sample = (None, None)
 
     @torch.no_grad()
     def enable_fp8_prefill(self, on=True):
@@ -91,9 +103,7 @@ class HipMistralDecoder(nn.Module):
         if self.tp > 1:
             raise NotImplementedError("fp8 prefill: single-rank decoders only")
         if on and getattr(self, "w8", None) is None:
-            self.w8 = dict(layers=[{k: ops.quant_fp8(lw[k]) for k in ("wqkv", "wo", "wgu", "wd")} for lw in self.w["layers"]],
-                           lm_head=ops.quant_fp8(self.w["lm_head"]))
-            self._stage = None
+            self._make_w8()
         self.prefill_fp8 = bool(on)
         return self
 
@@ -351,6 +361,9 @@ class HipMistralDecoder(nn.Module):
         M: fuller GEMM grids), RoPE / cache fill / causal attention per sequence on its own cache.  Every kernel here is
         row-independent, so the result is bit-identical to prefilling the prompts one by one.
         xs: list of [S_b, D]; caches: list of (k per layer, v per layer); logits_out: [B, V] fp32 (last position of each)."""
+        if getattr(self, "prefill_fp8", False):
+            raise NotImplementedError("fp8 prefill (enable_fp8_prefill) covers the single-sequence prefill; the batched prefill runs the 16-bit "
+                                      "projections: call enable_fp8_prefill(False) first")
         lens = [x.shape[0] for x in xs]
         if max(lens) > self.max_seq_len:
             raise ValueError(f"sequence length {max(lens)} exceeds the KV cache ({self.max_seq_len})")
