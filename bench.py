@@ -565,7 +565,7 @@ def main():
         # HBM-side bytes per launch come from a separate rocprofv3 --pmc run (scripts/gpu_traffic.sh; PMC cannot be
         # collected inside this process); only quoted for the workload it was collected on (T=16, 241 GEMM launches).
         traffic, tsrc = None, None
-        for tname in ("r05_gemm_traffic.json", "r04_gemm_traffic.json", "r03_gemm_traffic.json", "r02_gemm_traffic.json"):     # PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs) of this round's kernels first
+        for tname in ("r06_gemm_traffic.json", "r05_gemm_traffic.json", "r04_gemm_traffic.json", "r03_gemm_traffic.json", "r02_gemm_traffic.json"):     # PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs) of this round's kernels first
             tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", tname)
             if os.path.exists(tpath):
                 tj = json.load(open(tpath))
@@ -579,8 +579,9 @@ def main():
                 e = by_shape.setdefault(pr[4], [0, 0.0, 0.0])
                 e[0] += 1; e[1] += pr[1] / 1e9; e[2] += pr[2].elapsed_time(pr[3])
         dom = max(by_shape.items(), key=lambda kv: kv[1][2]) if by_shape else None
-        kernels = ("every vl2_gemm call of the step, whichever kernel the library picks per shape: gemm_mix_bf16_kernel (a row-split call = 256x256 ping-pong "
-                   "tiles + 128x128 tail tiles in ONE launch: gate/up, STC 4096-wide convs), gemm4_bf16_kernel (256x256 / 192x256 ping-pong), "
+        kernels = ("every vl2_gemm call of the step, whichever kernel the library picks per shape: gemm_mix16_bf16_kernel (gate/up + SwiGLU since round 6: "
+                   "256x256 ping-pong tiles + 128x128 tail tiles on v_mfma_f32_16x16x32 in ONE launch), gemm_mix_bf16_kernel (the same mixed launch on "
+                   "v_mfma_f32_32x32x16: STC 4096-wide convs), gemm4_bf16_kernel (256x256 / 192x256 ping-pong), "
                    "gemm3_bf16_kernel (128x256 ping-pong), gemm7_bf16_kernel (fill-the-round 192x128 / 224x128: the M = 1521 connector shapes), "
                    "gemm6_bf16_kernel (persistent 256x256: the tower's q/k/v and fc1 since round 5), gemm_bf16_kernel (128x128), gemm_l8_bf16_kernel "
                    "(one-round 128x128), gemm_s_bf16_kernel (64x64)")
@@ -593,7 +594,7 @@ def main():
                           for k, v in sorted(by_shape.items(), key=lambda kv: -kv[1][2])]
         if dom is not None:
             (dM, dN, dK), (dn, dgf, dms) = dom
-            roof["dominant"] = dict(gemm=f"M={dM} N={dN} K={dK}" + (f" (gate/up + SwiGLU: gemm_mix_bf16_kernel = 256x256 ping-pong tiles on the first {dM // 256 * 256} rows + "
+            roof["dominant"] = dict(gemm=f"M={dM} N={dN} K={dK}" + (f" (gate/up + SwiGLU: gemm_mix16_bf16_kernel = 256x256 ping-pong tiles (v_mfma_f32_16x16x32, 64-deep phases) on the first {dM // 256 * 256} rows + "
                                                                      f"128x128 tiles on the last {dM - dM // 256 * 256}, one launch)"
                                                                      if (dN, dK) == (2 * cfg["llm"]["intermediate_size"], cfg["llm"]["hidden_size"]) and dM % 256 else ""),
                                     launches=dn, avg_launch_us=round(1e3 * dms / dn, 2), gflop_per_launch=round(dgf / dn, 1),

@@ -69,11 +69,15 @@ int64_t vl2_workspace_bytes(void);
  * 4 = 128x256x64 ping-pong, 8 = 256x256x32 ping-pong, 12 = the same on 192x256 tiles (4, 8, 12: N%256==0; 12: bf16 output), 32 = 64x64 small-M kernel,
  * 256 = 128x128 8-wave deep-ring one-round kernel, 224 / 192 = the fill-the-round 224x128 / 192x128 ping-pong kernel (csrc/k_gemm7.h; N % 128 == 0,
  * plain or gathered A, no SwiGLU), 60 / 61 = the persistent 256x256 / 192x256 kernel with a static tile walk, 70 / 71 = with tiles handed out through
- * `tile_ctr` (what VL2_GEMM_PERSISTENT selects), 24 = the automatic choice without the persistent form, 16 = the 256x256 tile on
- * v_mfma_f32_16x16x32_bf16 (see VL2_GEMM_MFMA16).  A call that does not qualify for a forced variant gets the automatic choice. */
+ * `tile_ctr` (what VL2_GEMM_PERSISTENT selects), 24 = the automatic choice without the persistent form, 16 / 26 = the 256x256 tile on
+ * v_mfma_f32_16x16x32_bf16 with 32- / 64-deep phases (see VL2_GEMM_MFMA16; a row-split call = ONE mixed launch with 128x128 tail tiles of the same instruction).  A call that does not qualify for a forced variant gets the automatic choice. */
 /* stage-level descriptors (vl2_vit_desc / vl2_stc_desc / vl2_llm_desc) `flags` */
 #define VL2_STAGE_PERSISTENT_GEMM  1   /* every GEMM of the stage with VL2_GEMM_PERSISTENT (vl2_vit_forward: the default, see VL2_STAGE_VIT_NO_PERSISTENT) */
-#define VL2_STAGE_MFMA16       32768   /* vl2_llm_prefill: the gate/up projection (the step's dominant GEMM) with VL2_GEMM_MFMA16, at every S */
+#define VL2_STAGE_MFMA16       32768   /* (rounds 5: opt-in; since round 6 the default of vl2_llm_prefill -- accepted and ignored) */
+#define VL2_STAGE_NO_MFMA16    65536   /* vl2_llm_prefill: the gate/up projection (the step's dominant GEMM) WITHOUT VL2_GEMM_MFMA16.  Default since round 6: gate/up runs
+                                         * on v_mfma_f32_16x16x32_bf16 at every S -- ONE launch of 256 x 256 tiles + 128 x 128 tail tiles (csrc/k_gemm9.h gemm_mix16_bf16_kernel):
+                                         * 354 -> 333 us at S = 1621, prefill -0.6 ms (profiles/r06_experiments.md).  The call site keeps one arithmetic for all its rows and
+                                         * all M (what batched == sequential pins); its dot products associate in steps of 32 products where the rest of the family's take 16. */
 #define VL2_STAGE_PREFILL_FP8     512   /* vl2_llm_prefill: the four projections of every layer as VL2_GEMM_FP8 calls on the fp8 weight copies (layers_w8), their
                                          * inputs quantised per row by vl2_quant_act_fp8 (which also computes the RMS rstd: no statistics launches).  Attention,
                                          * RoPE, the KV cache and lm_head stay 16-bit.  OPTIONAL arithmetic (W8A8), never the default, never the headline */
@@ -93,7 +97,8 @@ int64_t vl2_workspace_bytes(void);
 #define VL2_GEMM_WEAVE4  512  /* lab: the 256x256 ping-pong kernel (and the big tiles of the mixed launch) with the woven issue the 192x256 tiles take by default */
 #define VL2_GEMM_NO_WEAVE4 1024 /* lab: the 192x256 tiles WITHOUT the woven issue */
 /* lab variants: 2 = stream-K form of variant 1 (needs `ws`; other summation order), 5 = variant 4 with the woven issue, 225 / 193 = 224 / 192 with it,
- * 9 = the 256x256 tile on FOUR waves (csrc/k_gemm8.h), 62 = 61 with two accumulator sets, 17 ... 22, 26 = issue orders of variant 16, 23 / 25 = variant 16
+ * 10 = the 256-wide ping-pong kernel on 160-row tiles (round 6: fills the one-round grids of the tower's N = 1024 GEMMs better and is not faster -- the part is power-limited),
+ * 9 = the 256x256 tile on FOUR waves (csrc/k_gemm8.h), 62 = 61 with two accumulator sets, 17 ... 22 = issue orders of variant 16, 23 / 25 = variant 16
  * with s_memtime stamps (scripts/gemm9_phase_stamps.py). */
 #define VL2_STAGE_VIT_NO_PERSISTENT 4096 /* vl2_vit_forward only: its GEMMs WITHOUT VL2_GEMM_PERSISTENT */
 #define VL2_STAGE_NO_MIX           2   /* every GEMM of the stage with VL2_GEMM_NO_MIX */

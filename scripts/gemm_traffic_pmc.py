@@ -23,10 +23,14 @@ def run(M, N, K, kw):
     res = rnd(M, ncol) if kw.get("res") else None
     c = torch.empty(M, ncol, dtype=torch.bfloat16, device=dev)
     ops.attach_workspace(dev)
-    # round 5: the tower's q/k/v and fc1 take the persistent form by default (vl2_vit_forward): the same per-call flag here
-    ops.set_stage_flags(ops.STAGE_PERSISTENT_GEMM if (M == 9232 and K == 1024 and N >= 3072) else 0)
+    # the kernels of the DEFAULT path (round 6): the tower's q/k/v and fc1 take the persistent form (vl2_vit_forward: VL2_GEMM_PERSISTENT + a tile
+    # counter block -- round 5's driver set the flag without the counters and so counted the non-persistent kernels), the decoder's gate/up runs
+    # on the 16 x 16 x 32 instruction (vl2_llm_prefill: VL2_GEMM_MFMA16, the mixed launch of k_gemm9.h)
+    persistent = M == 9232 and K == 1024 and N >= 3072
+    ops.set_stage_flags(ops.STAGE_PERSISTENT_GEMM if persistent else 0)
+    ctr = torch.zeros(16, dtype=torch.int32, device=dev) if persistent else None
     for _ in range(2):      # launch 1 = warm-up (L2/MALL state), launch 2 = the one post-processing reads
-        ops.gemm(a, w, bias=bias, res=res, act=kw.get("act", 0), swiglu=bool(kw.get("swiglu")), out=c)
+        ops.gemm(a, w, bias=bias, res=res, act=kw.get("act", 0), swiglu=bool(kw.get("swiglu")), out=c, mfma16=bool(kw.get("swiglu")), tile_ctr=ctr)
         SEP.fill_(1.0)      # separator kernel: a vl2_gemm call may be two kernels back to back (row split), the post-processor groups by it
     torch.cuda.synchronize()
     ops.set_stage_flags(0)

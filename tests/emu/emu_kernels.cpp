@@ -37,6 +37,7 @@ extern "C" int32_t vl2_fill_zero(void* p, int64_t bytes, void*) { if (!p || byte
 static int g_gemm_variant = 0;
 static bool g_no_weave4 = false;
 static int g_mfma16_mode = 0;       // variants 17 / 18: the lab orders of gemm9's LDS-DMA issue
+static int g_mfma16_tile = 0;       // 256 / 224 / 192 with VL2_GEMM_MFMA16: the one-round 128 x 128 / fill-the-round tiles of the 16 x 16 x 32 set (k_gemm9.h, k_gemm7.h)
 static bool g_mfma16 = false;       // variant 16 / VL2_GEMM_MFMA16: the 256 x 256 ping-pong tile on the 16 x 16 x 32 matrix instruction (k_gemm9.h)
 static bool g_weave4 = false;       // VL2_GEMM_WEAVE4: the 256-/192-row ping-pong bodies with the woven LDS-DMA issue
 static bool g_need_fin = false;     // a GEMM path without the producer-side finalize ran: append the row_norm_finalize launch (vl2_abi.hip GemmCtl.fin)
@@ -44,6 +45,35 @@ static bool g_gemm6_dynamic = false;       // gemm6: tiles handed out through th
 template <int ACT, bool SW, bool F32, bool G>
 static void run_gemm(GemmArgs a) {
     if constexpr (!G && !F32 && ACT == 0) {
+        if constexpr (!SW) {
+            if (g_mfma16 && (g_mfma16_tile == 256 || (g_mfma16_tile == 0 && g_mfma16_mode == 0 && (long)a.tiles_m * a.tiles_n <= 4))) {     // (vl2_abi.hip: <= 256 tiles; the emulator's shapes are small)
+                emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(512), [=] { gemm_l8_16_bf16_kernel<false>(a); });
+                return;
+            }
+            if (g_mfma16 && (g_mfma16_tile == 224 || g_mfma16_tile == 192)) {
+                const int bm = g_mfma16_tile;
+                a.tiles_m = (a.M + bm - 1) / bm; a.tiles_n = a.N / 128;
+                if (bm == 224) emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(512), [=] { gemm7_16_bf16_kernel<3>(a); });
+                else emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(512), [=] { gemm7_16_bf16_kernel<2>(a); });
+                return;
+            }
+        }
+        if (g_mfma16 && g_mfma16_mode == 0 && a.M > 256 && a.M % 256 != 0 && a.N % 256 == 0) {
+            // vl2_abi.hip launch_gemm: a row-split call on the 16 x 16 x 32 instruction is ONE mixed launch (k_gemm9.h gemm_mix16_bf16_kernel)
+            const int M1 = (a.M / 256) * 256;
+            GemmArgs big = a, tail = a;
+            big.M = M1; big.tiles_m = M1 / 256; big.tiles_n = a.N / 256;
+            tail.M = a.M - M1; tail.A = a.A + (size_t)M1 * a.lda; tail.C = (void*)((bf16_t*)a.C + (size_t)M1 * a.ldc);
+            if (a.res) tail.res = a.res + (size_t)M1 * a.ldres;
+            if (a.stats_out) tail.stats_out = a.stats_out + (size_t)M1 * a.stats_out_np * 2;
+            if (a.stats_in) tail.stats_in = a.stats_in + (size_t)M1 * a.stats_in_np * 2;
+            if (a.row_norm) tail.row_norm = a.row_norm + (size_t)M1 * 2;
+            if (a.row_norm_out) { tail.row_norm_out = a.row_norm_out + (size_t)M1 * 2; tail.row_ticket = a.row_ticket + M1 / 64; }
+            tail.tiles_m = (tail.M + 127) / 128; tail.tiles_n = a.N / 128;
+            const int n_big = big.tiles_m * big.tiles_n, n_all = n_big + tail.tiles_m * tail.tiles_n;
+            emu::launch(dim3(n_all), dim3(512), [=] { gemm_mix16_bf16_kernel<SW>(big, tail, n_big); });
+            return;
+        }
         if (g_mfma16) {
             a.tiles_m = (a.M + 255) / 256; a.tiles_n = a.N / 256;
             if (g_mfma16_mode == 1) emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(512), [=] { gemm9_bf16_kernel<SW, 1>(a); });
@@ -151,6 +181,13 @@ static void run_gemm(GemmArgs a) {
             if (tile_ctr[0] || tile_ctr[1]) fprintf(stderr, "EMU: gemm6 tile counters not re-armed (%u, %u)\n", tile_ctr[0], tile_ctr[1]);
             return;
         }
+        if constexpr (!SW) {
+            if (g_gemm_variant == 10 && a.N % 256 == 0) {        // gemm4 on 160 x 256 tiles (the 192-row tile without group 1's third row block)
+                a.tiles_m = (a.M + 159) / 160; a.tiles_n = a.N / 256;
+                emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(512), [=] { gemm4_bf16_kernel<ACT, SW, false, false, -1, 160>(a); });
+                return;
+            }
+        }
         if (g_gemm_variant == 12 && a.N % 256 == 0) {            // gemm4 on 192 x 256 tiles
             a.tiles_m = (a.M + 191) / 192; a.tiles_n = a.N / 256;
             if (!g_no_weave4) {                                 // the 192-row tiles' default since round 5 (vl2_abi.hip)
@@ -239,9 +276,11 @@ extern "C" int32_t vl2_gemm(const vl2_gemm_desc* d, void*) {
     const bool v16 = (d->variant >= 16 && d->variant <= 22) || d->variant == 26;
     g_gemm_variant = ((d->flags & VL2_GEMM_SPLITK) || d->variant == 116) ? 16 : v16 ? 0 : d->variant;     // 116: the emulator's own knob for the split-K form (tests)     // 16 = the emulator's split-K form of the 128x128 kernel
     {   // the product's variant 16 / VL2_GEMM_MFMA16 (vl2_abi.hip vl2_gemm)
-        const bool ok16 = !d->a_idx && !(d->flags & 2) && d->out_grp <= 0 && d->res_row_mod <= 0 && act == 0 && !d->stats_out && N % 256 == 0;
+        const bool ok16 = !d->a_idx && !(d->flags & 2) && d->out_grp <= 0 && d->res_row_mod <= 0 && act == 0 && !(d->stats_out && (d->flags & 1)) && N % 256 == 0;
         if (v16 && !ok16) return -3;
-        g_mfma16 = ok16 && (v16 || (d->variant == 0 && (d->flags & VL2_GEMM_MFMA16)));
+        const bool set16 = (d->variant == 256 || d->variant == 224 || d->variant == 192) && !(d->flags & 1);      // that tile of the 16 x 16 x 32 set on demand
+        g_mfma16 = ok16 && (v16 || ((d->variant == 0 || set16) && (d->flags & VL2_GEMM_MFMA16)));
+        g_mfma16_tile = g_mfma16 && set16 ? d->variant : 0;
         g_mfma16_mode = d->variant == 26 ? 9 : v16 ? d->variant - 16 : 0;
     }
     const bool sw = d->flags & 1, f32 = d->flags & 2, g = a.a_idx != nullptr;

@@ -108,12 +108,12 @@ def test_emu_norm_carrying_gemms(emu):
     y2 = ops.gemm(x2, wl, bias=tl, norm=(ops.NORM_LN, st2, eps, sl))
     assert rel(y2, ref2) < TOL_BF16_OUT
     try:
-        for v in (1, 4, 5, 8, 12, 32, 256):
+        for v in (1, 4, 5, 8, 10, 12, 32, 256):                             # 10 = the 160-row tile (round 6): the 192-row tile without group 1's third row block
             ops.set_gemm_variant(v)
             stv = torch.zeros_like(st)
             assert torch.equal(ops.gemm(a, w, bias=bias, res=res, stats_out=stv), x) and torch.equal(stv, st), v
             assert torch.equal(ops.gemm(x2, wl, bias=tl, norm=(ops.NORM_LN, st2, eps, sl)), y2), v
-            if v != 32:                                                    # the 64x64 small-M kernel has no SwiGLU form
+            if v != 32:                                                    # the 64x64 small-M kernel has no SwiGLU form (10: falls back to the automatic choice)
                 assert torch.equal(ops.gemm(x, wgu, swiglu=True, norm=(ops.NORM_RMS, st, eps, None)), y_sw), v
     finally:
         ops.set_gemm_variant(0)
@@ -134,7 +134,7 @@ def test_emu_gemm_producer_side_finalize_equals_the_launch(emu):
             st_ref = torch.zeros(M, N // 64, 2)
             y_ref = ops.gemm(a, w, bias=bias, res=res, stats_out=st_ref)
             rn_ref = ops.row_norm_finalize(st_ref, N, kind, eps)
-            for v, use_res in ((1, True), (4, True), (4, False), (8, True), (8, False), (12, True), (12, False), (224, True), (192, True), (256, True),
+            for v, use_res in ((1, True), (4, True), (4, False), (8, True), (8, False), (12, True), (12, False), (10, True), (10, False), (224, True), (192, True), (256, True),
                                (24, True), (24, False), (32, True), (0, True)):
                 ops.set_gemm_variant(v)
                 st, rn, tick = torch.zeros(M, N // 64, 2), torch.full((M, 2), -7.0), torch.zeros(M // 64 + 2, dtype=torch.int32)
@@ -238,6 +238,16 @@ def test_emu_gemm_mfma16_kernel(emu):
             for v in (17, 18, 19, 20, 21, 22, 26):                          # lab forms (k_gemm9.h MODE 1 / 2 / 4 / 5 / 6: orders of the LDS-DMA issue; 3: register-staged slabs; 9: 64-deep phases)
                 ops.set_gemm_variant(v)
                 assert torch.equal(ops.gemm(a, w, bias=bias, res=res), y) and torch.equal(ops.gemm(a, wgu, swiglu=True, norm=(ops.NORM_RMS, rn, 1e-6, None)), y_sw), (M, K, v)
+            # round 6: the other tiles of the 16 x 16 x 32 set (the decoder's o / down projections: residual + row statistics [+ producer-side finalize]): the
+            # one-round 128 x 128 body (k_gemm9.h gemm_l8_16_body) and the fill-the-round tiles (k_gemm7.h gemm7_loop16), by the flag (auto) and on demand
+            st_f, rn_f, tick = torch.zeros(M, N // 64, 2), torch.zeros(M, 2), torch.zeros(M // 64 + 2, dtype=torch.int32)
+            ops.set_gemm_variant(1)
+            y_f = ops.gemm(a, w, bias=bias, res=res, stats_out=st_f, norm_out=(ops.NORM_RMS, 1e-6, rn_f, tick))
+            for v in (0, 256, 224, 192, 16, 26):
+                ops.set_gemm_variant(v)
+                st_v, rn_v = torch.zeros(M, N // 64, 2), torch.full((M, 2), -3.0)
+                y_v = ops.gemm(a, w, bias=bias, res=res, stats_out=st_v, norm_out=(ops.NORM_RMS, 1e-6, rn_v, tick), mfma16=True)
+                assert torch.equal(y_v, y_f) and torch.equal(st_v, st_f) and torch.equal(rn_v, rn_f) and int(tick.abs().sum()) == 0, (M, K, v)
             ops.set_gemm_variant(16)
             m1 = M - 130                                                    # fewer rows, other tile edge: the same bits row for row
             assert torch.equal(ops.gemm(a[:m1], w, bias=bias, res=res[:m1]), y[:m1])
@@ -919,7 +929,7 @@ def test_emu_stage_level_entry_points_equal_the_per_operator_path(emu, golden_sm
         ops.STAGE_ABI = True
         ops.set_stage_flags(ops.STAGE_ROW_TICKET)                  # producer-side finalize of the row statistics (k_gemm.h gemm_rows_ticket): same bits
         assert torch.equal(m.vision_tower(g["frames"]), a[0]) and torch.equal(m.decoder.prefill(g["inputs_embeds"]), a[2])
-        ops.set_stage_flags(ops.STAGE_MFMA16)                      # gate/up on the 16 x 16 x 32 matrix instruction (k_gemm9.h): other last bits than the default,
+        ops.set_stage_flags(ops.STAGE_NO_MFMA16)                   # gate/up WITHOUT the default's 16 x 16 x 32 matrix instruction (k_gemm9.h): other last bits on the GPU,
         l16 = m.decoder.prefill(g["inputs_embeds"]).clone()        # but the SAME bits from the C++ layer loop and the per-operator loop
         ops.STAGE_ABI = False
         assert torch.equal(m.decoder.prefill(g["inputs_embeds"]), l16) and torch.equal(l16, a[2])   # (the emulated MFMAs sum k in order: here even the default's bits)

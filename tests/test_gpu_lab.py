@@ -8,7 +8,7 @@ from tests.util import rel
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
-LAB_VARIANTS = (2, 5, 9, 17, 18, 19, 20, 21, 22, 23, 25, 26, 62, 193, 225)
+LAB_VARIANTS = (2, 5, 9, 10, 17, 18, 19, 20, 21, 22, 23, 25, 62, 193, 225)
 
 
 def bf(*shape, scale=1.0, seed=0):
@@ -59,7 +59,7 @@ def test_lab_gemm_variants_are_bit_identical(ops, M, N, K):
     ops.set_gemm_variant(1)
     ref = (ops.gemm(a, w, bias=bias, res=res, act=ops.ACT_QGELU), ops.gemm(a, w, bias=bias, act=ops.ACT_QGELU), ops.gemm(a, w))
     run = lambda: (ops.gemm(a, w, bias=bias, res=res, act=ops.ACT_QGELU), ops.gemm(a, w, bias=bias, act=ops.ACT_QGELU), ops.gemm(a, w))
-    for v in (5, 9, 193, 225, 62):
+    for v in (5, 9, 10, 193, 225, 62):                          # 10 = the 160-row tile of round 6 (the 192-row tile without group 1's third row block)
         ops.set_gemm_variant(v)
         for _ in range(2):
             assert all(torch.equal(x, y) for x, y in zip(run(), ref)), (M, N, K, v)
@@ -68,6 +68,26 @@ def test_lab_gemm_variants_are_bit_identical(ops, M, N, K):
         ops.set_stage_flags(fl)
         assert all(torch.equal(x, y) for x, y in zip(run(), ref)), (M, N, K, v, fl)
         ops.set_stage_flags(0)
+
+
+@pytest.mark.parametrize("M,N,K", [(1621, 4096, 4096), (700, 512, 1024), (300, 1024, 14336)])
+def test_lab_mfma16_set_is_one_arithmetic(ops, M, N, K):
+    """Every tile of the 16 x 16 x 32 set -- the 256 x 256 ping-pong tile (variants 16 / 26 = 32- / 64-deep phases; a row-split call = the mixed launch), the
+    one-round 128 x 128 body (256 + VL2_GEMM_MFMA16) and the fill-the-round tiles (224 / 192 + the flag: k_gemm7.h gemm7_loop16, lab) -- accumulates a dot
+    product as the same sequence of 32-product steps: the same bits ON THE GPU, with residual + row statistics + the producer-side finalize."""
+    a, w, bias, res = bf(M, K).to(DEV), bf(N, K, scale=K ** -0.5).to(DEV), torch.randn(N).to(DEV), bf(M, N).to(DEV)
+    ref = None
+    for v in (16, 26, 256, 224, 192, 0):
+        ops.set_gemm_variant(v)
+        st, rn, tick = torch.zeros(M, N // 64, 2, device=DEV), torch.zeros(M, 2, device=DEV), torch.zeros(M // 64 + 2, dtype=torch.int32, device=DEV)
+        y = ops.gemm(a, w, bias=bias, res=res, stats_out=st, norm_out=(ops.NORM_RMS, 1e-6, rn, tick), mfma16=True)
+        y2 = ops.gemm(a, w, mfma16=True)
+        if ref is None:
+            ref = (y, st, rn, y2)
+            assert rel(y, a.float() @ w.float().T + bias + res.float()) < 1e-2
+        else:
+            assert torch.equal(y, ref[0]) and torch.equal(st, ref[1]) and torch.equal(rn, ref[2]) and torch.equal(y2, ref[3]), (M, N, K, v)
+        assert int(tick.abs().sum().item()) == 0, v
 
 
 def test_lab_gemm9_issue_orders_equal_variant_16(ops):

@@ -84,7 +84,7 @@ def test_gemm_pingpong_variant_is_bit_identical(ops, M, N, K):
     try:
         ops.set_gemm_variant(1)
         ref = ops.gemm(ad, wd, bias=bd, res=rd, act=ops.ACT_QGELU)
-        for v in (4, 8, 12, 0):                                      # (the lab forms 5 / 9: tests/test_gpu_lab.py)
+        for v in (4, 8, 12, 0):                                      # (the lab forms 5 / 9 / 10: tests/test_gpu_lab.py)
             ops.set_gemm_variant(v)
             for _ in range(3):
                 assert torch.equal(ops.gemm(ad, wd, bias=bd, res=rd, act=ops.ACT_QGELU), ref)

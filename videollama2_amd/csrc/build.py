@@ -49,13 +49,16 @@ def _run(targets, verbose=False):
         cmd = [hipcc, *FLAGS, *extra, SRC, "-o", out]
         if verbose:
             cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-        procs.append((out, extra, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
-    for out, extra, pr in procs:
+        if os.path.exists(out + ".srchash"):
+            os.remove(out + ".srchash")             # a build that dies leaves no hash behind
+        h = _src_hash(extra)                        # of the sources as they are when the compiler starts: an edit during the build leaves a mismatch
+        procs.append((out, h, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
+    for out, h, pr in procs:
         so, se = pr.communicate()
         if pr.returncode != 0:
             sys.stderr.write(so + se)
             raise RuntimeError(f"hipcc failed building {os.path.basename(out)}")
-        open(out + ".srchash", "w").write(_src_hash(extra) + "\n")
+        open(out + ".srchash", "w").write(h + "\n")
         if verbose:
             print(se)
 

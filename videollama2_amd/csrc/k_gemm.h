@@ -936,8 +936,9 @@ template <int ACT, bool SWIGLU, bool OUT_F32, bool TR = false, int EF = -1, int 
 __device__ __forceinline__ void gemm4_body(const GemmArgs& p, int bid, int nwg) {
     static_assert(!(TR && OUT_F32), "gemm_store_tr writes bf16");
     static_assert(!(FP8 && TR), "the fp8 form stores through gemm_store_patch");
-    static_assert(BM == 256 || BM == 192, "gemm4: 256- or 192-row tiles");
-    constexpr int GR = BM / 2;                                     // rows of a wave group
+    static_assert(BM == 256 || BM == 192 || BM == 160, "gemm4: 256-, 192- or 160-row tiles");
+    static_assert(BM != 160 || (!TR && !FP8 && !WEAVE4), "gemm4: the 160-row tile is built with the LDS epilogue and the load-phase issue");
+    constexpr int GR = BM == 256 ? 128 : 96;                       // rows of wave group 0 (= the row offset of group 1)
     constexpr int MI = BM == 256 ? 2 : 3, NJ = BM == 256 ? 4 : 2;  // 32 x 32 accumulator blocks of a wave
     extern __shared__ __attribute__((aligned(16))) unsigned char vl2_smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -946,6 +947,12 @@ __device__ __forceinline__ void gemm4_body(const GemmArgs& p, int bid, int nwg) 
     const int wrow = BM == 256 ? grp * 128 + (w4 >> 1) * 64 : grp * 96;     // first row / column of the wave tile inside the block tile
     const int wcol = BM == 256 ? (w4 & 1) * 128 : w4 * 64;
 
+    // BM = 160 (round 6): the 192-row tile WITHOUT the third row block of group 1 -- group 0 owns rows [0, 96) (3 x 2 blocks per wave), group 1 rows
+    //   [96, 160) (2 x 2 blocks per wave: its third block is never loaded, multiplied or stored).  For GEMMs whose 192-row grid is one badly filled
+    //   round: ViT out_proj / fc2 at 16 frames are 49 x 4 = 196 tiles of 192 rows on 256 CUs (77 %), 58 x 4 = 232 tiles of 160 rows (91 %), and a
+    //   one-round grid takes one tile time whatever its fill.  The two groups' matrix phases are 12 and 8 MFMAs per slab (a SIMD carries one wave
+    //   of each: 20 per slab instead of 24).  Same slabs, same k order -> same bits per element.
+    const bool blk2 = !(BM == 160 && grp == 1);                    // this wave has its third row block (wave-uniform)
     const int t0 = xcd_remap(bid, nwg);
     const int grp_sz = 4 * p.tiles_n;                              // 4 tile-rows (1024 rows of A) per raster group
     const int first_m = (t0 / grp_sz) * 4;
@@ -961,7 +968,7 @@ __device__ __forceinline__ void gemm4_body(const GemmArgs& p, int bid, int nwg) 
     const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x7fffffff, 0x00020000);
     const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0x7fffffff, 0x00020000);
     constexpr int APG = GR / 16;                                   // A pieces (16 rows each) of a group: 8 or 6
-    const bool two_a = BM == 256 || w4 < 2;                        // this wave's second A piece exists (wave-uniform)
+    const bool two_a = BM == 256 || (w4 < 2 && blk2);              // this wave's second A piece exists (wave-uniform; 160 rows: group 1 has four pieces)
     unsigned a_vo[2], w_vo[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -1054,7 +1061,8 @@ __device__ __forceinline__ void gemm4_body(const GemmArgs& p, int bid, int nwg) 
         for (int ks = 0; ks < 2; ++ks) {
             const unsigned ab = a_rd[ks] + st, bb = b_rd[ks] + st;
 #pragma unroll
-            for (int i = 0; i < MI; ++i) fa[ks][i] = *(const bf16x8*)(vl2_smem + ab + i * 2048);
+            for (int i = 0; i < MI; ++i)
+                if (i < 2 || blk2) fa[ks][i] = *(const bf16x8*)(vl2_smem + ab + i * 2048);
 #pragma unroll
             for (int j = 0; j < NJ; ++j) fb[ks][j] = *(const bf16x8*)(vl2_smem + bb + j * 2048);
         }
@@ -1077,6 +1085,7 @@ __device__ __forceinline__ void gemm4_body(const GemmArgs& p, int bid, int nwg) 
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) {
+                        if (BM == 160 && i == 2 && !blk2) continue;
                         acc[i][j] = TR ? VL2_MFMA32(fb[ks][j], fa[ks][i], acc[i][j])
                                        : VL2_MFMA32(fa[ks][i], fb[ks][j], acc[i][j]);
                         if constexpr (WEAVE4) {
@@ -1109,6 +1118,7 @@ __device__ __forceinline__ void gemm4_body(const GemmArgs& p, int bid, int nwg) 
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int nh = 0; nh < NJ / 2; ++nh) {
+            if (BM == 160 && mi == 2 && !blk2) continue;           // (rows 160 .. 191 of the 192-row layout belong to the next tile)
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni)
 #pragma unroll

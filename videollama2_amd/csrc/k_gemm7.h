@@ -127,6 +127,44 @@ __device__ __forceinline__ void gemm7_store_rows(const GemmArgs& p, const float*
 // wave that streams MFMAs has idle issue slots: a piece costs ~60 cycles there against 100-185 in a load phase that also carries 16
 // ds_read_b128 -- MI355X_MICROARCH.md "LDS-DMA piece issue cost"), and the load phase keeps the fragment reads only.  The pieces then have
 // one phase of flight (retired by vmcnt(0) at the end of the wave's next load phase) instead of two.
+// The same loop on v_mfma_f32_16x16x32_bf16 (round 6, the o / down projections of the decoder prefill: VL2_GEMM_MFMA16): a K-tile is two k-steps of the
+// instruction; group 0's wave tile 64 x 64 = 4 x 4 blocks of 16 x 16 (4 + 4 fragment reads per 16 MFMAs), group 1's strip 32 R1 x 32 = 2 R1 x 2 blocks
+// (2 R1 + 2 reads per 4 R1 MFMAs) -- the same number of fragment reads per K-tile as the 32 x 32 x 16 form, twice the MFMA count.  Fragment (block of 16
+// rows) = rows 16 b + (lane & 15), 16-B chunk 4 kk + (lane >> 4): gemm9_body's k index function, k ascending, so a dot product is the same sequence of
+// 32-product accumulation steps in every kernel of the 16 x 16 x 32 set (a row's bits do not depend on which of them computes it).
+// a_rd / b_rd: [2 kk + parity] = LDS offset of block `parity`'s fragment at k-step kk; block b is + (b >> 1) * 4096 B from the entry of its parity (the
+// image's swizzle repeats every 32 rows: gemm_lds_off xors the slot with (row >> 1) & 15).
+template <int R1, bool G0, class Dma>
+__device__ __forceinline__ void gemm7_loop16(unsigned char* smem, f32x4 (&acc)[16], const unsigned (&a_rd)[4], const unsigned (&b_rd)[4], int nt, int npw,
+                                             Dma&& issue_dma) {
+    constexpr int STAGE = Gemm7Geo<R1>::STAGE, NPW = Gemm7Geo<R1>::NPW;
+    constexpr int NA_ = G0 ? 4 : 2 * R1, NB_ = G0 ? 4 : 2;          // 16-row blocks of A / W in the wave tile
+    bf16x8 fa[2][NA_], fb[2][NB_];
+    for (int t = 0; t < nt; ++t) {
+        const bool more = t + 2 < nt;
+        if (more) issue_dma(t + 2, 0, NPW);
+        const unsigned st = (unsigned)(t % 3) * STAGE;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+            for (int i = 0; i < NA_; ++i) fa[kk][i] = *(const bf16x8*)(smem + a_rd[2 * kk + (i & 1)] + st + (i >> 1) * 4096);
+#pragma unroll
+            for (int j = 0; j < NB_; ++j) fb[kk][j] = *(const bf16x8*)(smem + b_rd[2 * kk + (j & 1)] + st + (j >> 1) * 4096);
+        }
+        if (more) { if (npw == 6) VL2_WAIT_VMCNT(6); else VL2_WAIT_VMCNT(5); }
+        else VL2_WAIT_VMCNT(0);
+        VL2_WAIT_LGKMCNT0();
+        VL2_PHASE_BARRIER();
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < NA_; ++i)
+#pragma unroll
+                for (int j = 0; j < NB_; ++j) acc[i * NB_ + j] = VL2_MFMA16(fa[kk][i], fb[kk][j], acc[i * NB_ + j]);
+        VL2_PHASE_BARRIER();
+    }
+}
+
 template <int R1, bool G0, bool WEAVE, class Dma>
 __device__ __forceinline__ void gemm7_loop(unsigned char* smem, f32x16 (&acc)[4], const unsigned (&a_rd)[4], const unsigned (&b_rd)[4], int nt, int npw,
                                            Dma&& issue_dma) {
@@ -182,9 +220,10 @@ __device__ __forceinline__ void gemm7_loop(unsigned char* smem, f32x16 (&acc)[4]
 
 // (a __device__ body: the host pass of hipcc drops a __global__ template whose own body holds device-only inline asm -- VL2_PIN2 -- without
 //  a diagnostic, and the launch then fails to link)
-template <int ACT, bool OUT_F32, bool GATHER, int R1, bool WEAVE = false>
+template <int ACT, bool OUT_F32, bool GATHER, int R1, bool WEAVE = false, bool M16 = false>
 __device__ __forceinline__ void gemm7_body(const GemmArgs& p) {
     static_assert(R1 == 2 || R1 == 3, "gemm7: 192- or 224-row tiles");
+    static_assert(!(M16 && (WEAVE || GATHER)), "gemm7: the 16 x 16 x 32 form is built plain (no gather, load-phase issue)");
     using Geo = Gemm7Geo<R1>;
     constexpr int BM = Geo::BM, NA = Geo::NA, NPIECE = Geo::NPIECE, STAGE = Geo::STAGE, NPW = Geo::NPW;
     extern __shared__ __attribute__((aligned(16))) unsigned char vl2_smem[];
@@ -256,18 +295,23 @@ __device__ __forceinline__ void gemm7_body(const GemmArgs& p) {
     };
 
     f32x16 acc[4];
+    f32x4 acc16[16];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc16[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nt = p.K / GEMM_BK;
-    const int frow = lane & 31, fchk = lane >> 5;
+    const int frow = M16 ? (lane & 15) : (lane & 31), fchk = M16 ? (lane >> 4) : (lane >> 5);
     unsigned a_rd[4], b_rd[4];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        a_rd[ks] = gemm_lds_off((grp == 0 ? (w4 >> 1) * 64 : 128) + frow, ks * 2 + fchk);
-        b_rd[ks] = BM * 128 + gemm_lds_off((grp == 0 ? (w4 & 1) * 64 : w4 * 32) + frow, ks * 2 + fchk);
+    for (int ks = 0; ks < 4; ++ks) {                                 // (16 x 16 x 32: entry 2 kk + parity = k-step kk, 16-row block `parity` of the wave tile)
+        const int chunk = M16 ? (ks >> 1) * 4 + fchk : ks * 2 + fchk;
+        const int r16 = M16 ? (ks & 1) * 16 : 0;
+        a_rd[ks] = gemm_lds_off((grp == 0 ? (w4 >> 1) * 64 : 128) + r16 + frow, chunk);
+        b_rd[ks] = BM * 128 + gemm_lds_off((grp == 0 ? (w4 & 1) * 64 : w4 * 32) + r16 + frow, chunk);
     }
     issue_dma(0, 0, NPW);
     if (nt > 1) issue_dma(1, 0, NPW);
@@ -278,7 +322,15 @@ __device__ __forceinline__ void gemm7_body(const GemmArgs& p) {
     else VL2_WAIT_VMCNT(0);
     VL2_PHASE_BARRIER();
 
-    if (grp == 0) {
+    if constexpr (M16) {
+        if (grp == 0) {
+            gemm7_loop16<R1, true>(vl2_smem, acc16, a_rd, b_rd, nt, npw, issue_dma);
+            VL2_PHASE_BARRIER();
+        } else {
+            VL2_PHASE_BARRIER();
+            gemm7_loop16<R1, false>(vl2_smem, acc16, a_rd, b_rd, nt, npw, issue_dma);
+        }
+    } else if (grp == 0) {
         gemm7_loop<R1, true, WEAVE>(vl2_smem, acc, a_rd, b_rd, nt, npw, issue_dma);
         VL2_PHASE_BARRIER();
     } else {
@@ -289,7 +341,26 @@ __device__ __forceinline__ void gemm7_body(const GemmArgs& p) {
     // ---- epilogue: every wave's blocks -> the fp32 image (the ring is dead: all operands were in registers before the last barrier)
     float* img = (float*)vl2_smem;
     float* rowtab = img + BM * GEMM7_IMG_LD;
-    {
+    if constexpr (M16) {                        // register r of block (i, j) = C[16 i + 4 (lane >> 4) + r][16 j + (lane & 15)]
+        const int er = 4 * (lane >> 4), ec = lane & 15;
+        if (grp == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        img[((w4 >> 1) * 64 + i * 16 + er + r) * GEMM7_IMG_LD + (w4 & 1) * 64 + j * 16 + ec] = acc16[i * 4 + j][r];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2 * R1; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        img[(128 + i * 16 + er + r) * GEMM7_IMG_LD + w4 * 32 + j * 16 + ec] = acc16[i * 2 + j][r];
+        }
+    } else {
         const int er = 4 * (lane >> 5), ec = lane & 31;
         if (grp == 0) {
 #pragma unroll
@@ -315,4 +386,9 @@ __device__ __forceinline__ void gemm7_body(const GemmArgs& p) {
 template <int ACT, bool OUT_F32, bool GATHER, int R1, bool WEAVE = false>
 __global__ __launch_bounds__(512, 2) void gemm7_bf16_kernel(GemmArgs p) {
     gemm7_body<ACT, OUT_F32, GATHER, R1, WEAVE>(p);
+}
+// the same tile on v_mfma_f32_16x16x32_bf16 (bf16 output, no activation: the decoder's o / down projections under VL2_GEMM_MFMA16)
+template <int R1>
+__global__ __launch_bounds__(512, 2) void gemm7_16_bf16_kernel(GemmArgs p) {
+    gemm7_body<ACT_NONE, false, false, R1, false, true>(p);
 }

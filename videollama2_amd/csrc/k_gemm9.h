@@ -376,6 +376,7 @@ __device__ __forceinline__ void gemm9_body(const GemmArgs& p, int bid, int nwg) 
             gemm_store_patch<ACT_NONE, SWIGLU, false>(p, ep, m0 + wrow + mi * 32, n0 + wcol + nh * 64, lane, rowtab, wrow + mi * 32);
             __builtin_amdgcn_wave_barrier();
         }
+    if constexpr (!SWIGLU && MODE == 0) gemm_rows_ticket<512>(p, tm, m0, BM, tid);       // producer-side finalize of the row statistics (o / down); (MODE 9 owns all 160 KiB of LDS: no room for the ticket's word)
     if constexpr (MODE == 8) {          // [ring fill + K loop | setup before it | epilogue (stores issued, not drained) | entry stamp | 0 | slabs]
         __builtin_amdgcn_sched_barrier(0);
         const unsigned long long c_end = __builtin_readcyclecounter();
@@ -388,4 +389,116 @@ __device__ __forceinline__ void gemm9_body(const GemmArgs& p, int bid, int nwg) 
 template <bool SWIGLU, int MODE = 0>
 __global__ __launch_bounds__(512, 2) void gemm9_bf16_kernel(GemmArgs p) {
     gemm9_body<SWIGLU, MODE>(p, blockIdx.x, gridDim.x);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The 128 x 128 one-round tile (k_gemm.h gemm_l8_body: eight waves, wave tile 32 x 64, 4-stage 128 KiB LDS-DMA ring, one barrier per 64-deep
+// K-tile) on v_mfma_f32_16x16x32_bf16: the TAIL tiles of a row-split call whose leading rows run on gemm9_body (gemm_mix16_bf16_kernel below).
+// Same LDS image and ring as gemm_l8_body; a K-tile is two k-steps of the instruction (k ascending), fragment (block of 16 rows) = rows
+// 16 b + (lane & 15), 16-B chunk 4 kk + (lane >> 4) -- the k index function of gemm9_body, so every dot product is the SAME sequence of
+// 32-product accumulation steps: a row has gemm9's bits whichever of the two bodies computes it.  Accumulators: 2 x 4 blocks of 16 x 16
+// (register r of block (i, j) = C[16 i + 4 (lane >> 4) + r][16 j + (lane & 15)]), through the family's LDS patch epilogue.
+template <bool SWIGLU>
+__device__ __forceinline__ void gemm_l8_16_body(const GemmArgs& p, int bid, int nwg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char vl2_smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;                    // wm 0..3 (32 rows each), wn 0..1 (64 columns each)
+    const int t = xcd_remap(bid, nwg);
+    const int tm = t % p.tiles_m, tn = t / p.tiles_m;            // consecutive workgroups share a W panel
+    const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
+    const int nt = p.K / GEMM_BK;
+    const f32x2 rst = gemm_row_stats(p, m0, tid, GEMM_BM);
+
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x7fffffff, 0x00020000);
+    const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0x7fffffff, 0x00020000);
+    unsigned a_vo[2], w_vo;                                     // 2 A pieces + 2 W pieces per wave (piece i = +64 rows): gemm_l8_body's piece map
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int slot = ((i * 8 + wave) << 6) + lane;
+        const int R = slot >> 4, sx = (slot & 15) ^ (R & 15);
+        int am = m0 + 2 * R + (sx >> 3);
+        am = am < p.M ? am : p.M - 1;
+        a_vo[i] = ((unsigned)am * (unsigned)p.lda + (sx & 7) * 8) * 2;
+        if (i == 0) w_vo = ((unsigned)(n0 + 2 * R + (sx >> 3)) * (unsigned)p.ldw + (sx & 7) * 8) * 2;
+    }
+    const unsigned w_step = 128u * (unsigned)p.ldw;
+    const int frow = lane & 15, fchk = lane >> 4;
+    unsigned a_rd[2][2], b_rd[2][4];                            // [k-step][block]
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a_rd[kk][i] = gemm_lds_off(wm * 32 + i * 16 + frow, kk * 4 + fchk);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b_rd[kk][j] = 16384 + gemm_lds_off(wn * 64 + j * 16 + frow, kk * 4 + fchk);
+    }
+    auto stage = [&](int kt) {
+        const unsigned lds_buf = (unsigned)(kt & (GEMML_STAGES - 1)) * GEMML_STAGE_BYTES, kb = (unsigned)kt * (GEMM_BK * 2);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(vl2_smem + lds_buf + ((i * 8 + wave) << 10)),
+                                                     16, a_vo[i], kb, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(vl2_smem + lds_buf + 16384 + ((i * 8 + wave) << 10)),
+                                                     16, w_vo, kb + i * w_step, 0, 0);
+    };
+#pragma unroll
+    for (int s = 0; s < GEMML_STAGES - 1; ++s)
+        if (s < nt) stage(s);
+    for (int kt = 0; kt < nt; ++kt) {
+        const int newer = nt - 1 - kt < GEMML_STAGES - 2 ? nt - 1 - kt : GEMML_STAGES - 2;
+        if (newer >= 2) VL2_WAIT_VMCNT(8); else if (newer == 1) VL2_WAIT_VMCNT(4); else VL2_WAIT_VMCNT(0);
+        VL2_PHASE_BARRIER();                                        // everyone's pieces of tile kt landed; buffer (kt-1)&3 is free
+        if (kt + GEMML_STAGES - 1 < nt) stage(kt + GEMML_STAGES - 1);
+        const unsigned lds_buf = (unsigned)(kt & (GEMML_STAGES - 1)) * GEMML_STAGE_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 fa[2], fb[4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = *(const bf16x8*)(vl2_smem + lds_buf + a_rd[kk][i]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[j] = *(const bf16x8*)(vl2_smem + lds_buf + b_rd[kk][j]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = VL2_MFMA16(fa[i], fb[j], acc[i][j]);
+        }
+    }
+    VL2_WAIT_LGKMCNT0();
+    VL2_PHASE_BARRIER();
+
+    float* ep = (float*)vl2_smem + wave * (32 * 68);
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                ep[(ib * 16 + 4 * (lane >> 4) + r) * 68 + jb * 16 + (lane & 15)] = acc[ib][jb][r];
+    float* rowtab = (float*)vl2_smem + 8 * (32 * 68);
+    gemm_park_row_stats(p, rowtab, rst, tid, GEMM_BM);
+    __syncthreads();
+    gemm_store_patch<ACT_NONE, SWIGLU, false>(p, ep, m0 + wm * 32, n0 + wn * 64, lane, rowtab, wm * 32);
+    if constexpr (!SWIGLU) gemm_rows_ticket<512>(p, tm, m0, GEMM_BM, tid);
+}
+template <bool SWIGLU>
+__global__ __launch_bounds__(512, 1) void gemm_l8_16_bf16_kernel(GemmArgs p) {
+    gemm_l8_16_body<SWIGLU>(p, blockIdx.x, gridDim.x);
+}
+
+// ONE launch for a row-split call on the 16 x 16 x 32 instruction (the twin of k_gemm.h gemm_mix_bf16_kernel): workgroups [0, n_big) run gemm9_body on
+// the leading whole 256-row tiles (`pb`), workgroups [n_big, grid) the 128 x 128 body above on the tail rows (`ps`).  Round 5 measured gemm9 alone on
+// gate/up at S = 1621 at 373 us against 341 for the default's mixed launch -- seven 256-row tiles for 6.3 tile rows of work; this form keeps the mix.
+// MODE = the big tiles' form: 0 = 32-deep phases on the 4-stage ring (128 KiB of LDS), 9 = 64-deep phases on the 5-stage ring (160 KiB; K % 64 == 0).
+template <bool SWIGLU, int MODE = 0>
+__global__ __launch_bounds__(512, 2) void gemm_mix16_bf16_kernel(GemmArgs pb, GemmArgs ps, int n_big) {
+    if ((int)blockIdx.x < n_big) gemm9_body<SWIGLU, MODE>(pb, blockIdx.x, n_big);
+    else gemm_l8_16_body<SWIGLU>(ps, (int)blockIdx.x - n_big, (int)gridDim.x - n_big);
 }

@@ -146,6 +146,12 @@ static int choose_gemm_kernel(const GemmArgs& a, double* eff = nullptr) {
     const double m192 = (double)a.M / (((a.M + 191) / 192) * 192.0);
     const double e5 = fill((double)((a.M + 191) / 192) * (a.N / 256) / 256.0) * m192 * 1.13;
     if (a.K >= 512 && e5 > eb * 1.02) { best = 12; eb = e5; }
+    // ... and on 160-row tiles (variant 10, round 6: the 192-row tile without group 1's third row block): ONE-round grids only, where a finer tile
+    // shortens the single round -- ViT out_proj / fc2 at 16 frames: 196 tiles of 192 rows (77 % of the CUs) -> 232 tiles of 160 rows (91 %).  Rate 1.08:
+    // a SIMD issues 20 MFMAs per slab behind the same load phases (24 on 192 rows).
+    // MEASURED AND NOT TAKEN (profiles/r06_tile160_bench.txt, interleaved on one box): fc2 9232 x 1024 x 4096 79.2 us on 192 rows, 82.7 on 160; out_proj 30.4 vs
+    // 30.9; 18464 rows: 163.5 vs 166.5.  A one-round grid at 77 % of the CUs is NOT 77 % of the chip: the part runs at its power limit, and 196 workgroups at a
+    // higher clock do what 232 do at a lower one -- filling the round buys nothing where watts, not CUs, are the budget.  The tile stays a lab form (variant 10).
     if (eff) *eff = best == 1 ? e1 : eb;
     return best;
 }
@@ -246,6 +252,11 @@ static void launch_gemm9(const GemmArgs& a0, int mode, hipStream_t s) {
     a.tiles_m = (a.M + 255) / 256;
     a.tiles_n = a.N / GEMM4_BN;
     const dim3 grid(a.tiles_m * a.tiles_n);
+    if (mode == 9) {          // variant 26: 64-deep phases, 5-stage ring = the whole 160 KiB of LDS
+        lds_attr<gemm9_bf16_kernel<SW, 9>>(5 * GEMM4_STAGE);
+        hipLaunchKernelGGL((gemm9_bf16_kernel<SW, 9>), grid, dim3(512), 5 * GEMM4_STAGE, s, a);
+        return;
+    }
     if constexpr (kLab) {
     if (mode == 1) {          // lab (variant 17): the LDS-DMA issue behind the load phase's fragment reads
         lds_attr<gemm9_bf16_kernel<SW, 1>>(GEMM4_LDS_BYTES);
@@ -256,9 +267,6 @@ static void launch_gemm9(const GemmArgs& a0, int mode, hipStream_t s) {
     } else if (mode == 7) {   // lab (variant 23): variant 16 with s_memtime stamps, sums into the workspace (scripts/gemm9_phase_stamps.py)
         lds_attr<gemm9_bf16_kernel<SW, 7>>(GEMM4_LDS_BYTES);
         hipLaunchKernelGGL((gemm9_bf16_kernel<SW, 7>), grid, dim3(512), GEMM4_LDS_BYTES, s, a);
-    } else if (mode == 9) {   // lab (variant 26): 64-deep phases, 5-stage ring = the whole 160 KiB of LDS
-        lds_attr<gemm9_bf16_kernel<SW, 9>>(5 * GEMM4_STAGE);
-        hipLaunchKernelGGL((gemm9_bf16_kernel<SW, 9>), grid, dim3(512), 5 * GEMM4_STAGE, s, a);
     } else if (mode == 8) {   // lab (variant 25): variant 16 with one stamp pair around the K loop
         lds_attr<gemm9_bf16_kernel<SW, 8>>(GEMM4_LDS_BYTES);
         hipLaunchKernelGGL((gemm9_bf16_kernel<SW, 8>), grid, dim3(512), GEMM4_LDS_BYTES, s, a);
@@ -291,6 +299,10 @@ static void launch_gemm4(const GemmArgs& a0, hipStream_t s, bool weave4 = false)
     // order of each is a lab form (VL2_GEMM_NO_WEAVE4 / VL2_GEMM_WEAVE4)
     constexpr bool kWoven = BM == 192 && !F32, kPlain = !kWoven;
     if constexpr (!kLab) weave4 = kWoven;
+    if constexpr (BM == 160) {                       // one form: LDS epilogue, load-phase issue
+        lds_attr<gemm4_bf16_kernel<ACT, SW, F32, false, -1, 160>>(GEMM4_LDS_BYTES);
+        hipLaunchKernelGGL((gemm4_bf16_kernel<ACT, SW, F32, false, -1, 160>), grid, dim3(512), GEMM4_LDS_BYTES, s, a);
+    } else {
     if constexpr (!F32) {
         if (want_tr_epilogue(a)) {
             if constexpr (kLab || kWoven) {
@@ -317,6 +329,7 @@ static void launch_gemm4(const GemmArgs& a0, hipStream_t s, bool weave4 = false)
     if constexpr (kLab || kPlain) {
         lds_attr<gemm4_bf16_kernel<ACT, SW, F32, false, -1, BM>>(GEMM4_LDS_BYTES);
         hipLaunchKernelGGL((gemm4_bf16_kernel<ACT, SW, F32, false, -1, BM>), grid, dim3(512), GEMM4_LDS_BYTES, s, a);
+    }
     }
 }
 
@@ -427,7 +440,64 @@ static void launch_gemm(const GemmArgs& a0, const GemmCtl& c, hipStream_t s) {
             launch_gemm9<SW>(a, c.variant == 23 ? 7 : 8, s);
             return;
         }
-        if (c.mfma16) { launch_gemm9<SW>(a0, c.variant >= 17 && c.variant <= 23 ? c.variant - 16 : c.variant == 26 ? 9 : 0, s); return; }         // (vl2_gemm has checked that the call qualifies)
+        if (c.mfma16) {                                                                                                                         // (vl2_gemm has checked that the call qualifies)
+            // a row-split call keeps its ONE mixed launch (k_gemm9.h gemm_mix16_bf16_kernel): whole 256-row tiles on gemm9_body, the tail rows on the
+            // 128 x 128 body of the same instruction -- the same bits row by row, so the split stays invisible (as in the 32 x 32 x 16 family)
+            if (c.variant == 0 || c.variant == 16 || c.variant == 26) {
+                GemmCtl c0 = c;
+                c0.variant = 0;
+                if (const int M1 = m_split_rows(a0, c0); M1 > 0 && !c.no_mix) {
+                    GemmArgs big = gemm_rows(a0, 0, M1, false), tail = gemm_rows(a0, M1, a0.M - M1, false);
+                    const long t_big = (long)(M1 / GEMM4_BM) * (a0.N / GEMM4_BN), t_tail = (long)tail.tiles_m * tail.tiles_n;
+                    if (t_tail > 128 && t_tail <= 512) {
+                        big.tiles_m = M1 / GEMM4_BM; big.tiles_n = a0.N / GEMM4_BN;
+                        const dim3 gmix((unsigned)(t_big + t_tail));
+                        // the big tiles with 64-deep phases on the 5-stage ring (the whole 160 KiB of LDS): the flag's form and variant 26 (gate/up at
+                        // S = 945 / 1621 / 2973: 195.9 / 334.8 / 609.5 -> 192.4 / 332.2 / 596.9 us, profiles/r06_mix16_bench_64deep.txt); 16 = the 32-deep form
+                        if (c.variant != 16) {
+                            lds_attr<gemm_mix16_bf16_kernel<SW, 9>>(5 * GEMM4_STAGE);
+                            hipLaunchKernelGGL((gemm_mix16_bf16_kernel<SW, 9>), gmix, dim3(512), 5 * GEMM4_STAGE, s, big, tail, (int)t_big);
+                        } else {
+                            lds_attr<gemm_mix16_bf16_kernel<SW>>(GEMM4_LDS_BYTES);
+                            hipLaunchKernelGGL((gemm_mix16_bf16_kernel<SW>), gmix, dim3(512), GEMM4_LDS_BYTES, s, big, tail, (int)t_big);
+                        }
+                        return;
+                    }
+                }
+            }
+            if constexpr (!SW) {
+                // the other two tiles of the 16 x 16 x 32 set (round 6: the decoder's o / down projections): at most one 128 x 128 tile per CU -> the one-round
+                // 128 x 128 body; a one-round grid of fill-the-round tiles where the family's rule picks them -> gemm7 on this instruction; else the 256 x 256 tile
+                if (c.variant == 0 || c.variant == 256 || c.variant == 224 || c.variant == 192) {       // (256 / 224 / 192 with the flag: that tile of the set on demand)
+                    if (c.variant == 256 || (c.variant == 0 && (long)a0.tiles_m * a0.tiles_n <= 256)) {
+                        lds_attr<gemm_l8_16_bf16_kernel<false>>(GEMML_LDS_BYTES);
+                        hipLaunchKernelGGL((gemm_l8_16_bf16_kernel<false>), dim3(a0.tiles_m * a0.tiles_n), dim3(512), GEMML_LDS_BYTES, s, a0);
+                        return;
+                    }
+                    // (lab: the fill-the-round tiles on this instruction, k_gemm7.h gemm7_loop16 -- bit-identical with the rest of the set, measured at parity
+                    //  with their 32 x 32 x 16 twins on the one-round grids they exist for: no call site uses them)
+                    if (const int r1 = !kLab ? 0 : c.variant == 224 ? 3 : c.variant == 192 ? 2 : c.no_fill ? 0 : choose_gemm7(a0, false); r1 != 0) {
+                        GemmArgs a = a0;
+                        const int bm = 128 + 32 * r1;
+                        a.tiles_m = (a.M + bm - 1) / bm;
+                        a.tiles_n = a.N / GEMM7_BN;
+#ifdef VL2_LAB
+                        if (r1 == 3) {
+                            lds_attr<gemm7_16_bf16_kernel<3>>(Gemm7Geo<3>::LDS_BYTES);
+                            hipLaunchKernelGGL((gemm7_16_bf16_kernel<3>), dim3(a.tiles_m * a.tiles_n), dim3(512), Gemm7Geo<3>::LDS_BYTES, s, a);
+                        } else {
+                            lds_attr<gemm7_16_bf16_kernel<2>>(Gemm7Geo<2>::LDS_BYTES);
+                            hipLaunchKernelGGL((gemm7_16_bf16_kernel<2>), dim3(a.tiles_m * a.tiles_n), dim3(512), Gemm7Geo<2>::LDS_BYTES, s, a);
+                        }
+                        return;
+#endif
+                    }
+                }
+            }
+            if (c.variant != 0 && c.variant != 16 && a0.row_norm_out && c.fin) *c.fin = true;      // only the shipped form (MODE 0) finalizes its rows itself
+            launch_gemm9<SW>(a0, c.variant >= 17 && c.variant <= 23 ? c.variant - 16 : c.variant == 26 ? 9 : 0, s);
+            return;
+        }
     }
     if constexpr (!SW) {
         // fill-the-round tiles (k_gemm7.h): variants 224 / 192 on request (any shape with N % 128 == 0), or by the rule of choose_gemm7
@@ -576,6 +646,12 @@ static void launch_gemm(const GemmArgs& a0, const GemmCtl& c, hipStream_t s) {
             launch_gemm4<ACT, SW, F32>(a0, s, c.weave4);
             return;
         }
+        if constexpr (!F32 && !SW && kLab) {
+            if (kern == 10 && a0.N % GEMM4_BN == 0) {                          // lab: 160-row tiles (measured: not faster than the 192-row tiles)
+                launch_gemm4<ACT, SW, false, 160>(a0, s);
+                return;
+            }
+        }
         if constexpr (!F32) {
             if (kern == 12 && a0.N % GEMM4_BN == 0) {
                 // 192-row tiles take the woven LDS-DMA issue by default (round 5, scripts/weave4_bench.py, interleaved on one box, same bits): their load
@@ -715,8 +791,8 @@ extern "C" int32_t vl2_gemm(const vl2_gemm_desc* d, void* stream) {
     }
     if (d->ws && (d->ws_bytes < SK_WS_BYTES || !ALIGNED16(d->ws))) return fail(VL2_E_BADARG, "vl2_gemm: workspace needs >= %lld bytes, 16-byte aligned", (long long)SK_WS_BYTES);
     const int v = d->variant;
-    if (!(v == 0 || v == 1 || v == 2 || v == 4 || v == 5 || v == 8 || v == 9 || v == 12 || (v >= 16 && v <= 23) || v == 25 || v == 26 || v == 32 || v == 24 || v == 60 || v == 61 || v == 62 || v == 70 || v == 71 || v == 80 || v == 81 || v == 192 || v == 193 || v == 224 || v == 225 || v == 256)) return fail(VL2_E_BADARG, "vl2_gemm: unknown variant %d", v);
-    if (!kLab && (v == 2 || v == 5 || v == 9 || (v >= 17 && v <= 23) || v == 25 || v == 26 || v == 62 || v == 193 || v == 225))
+    if (!(v == 0 || v == 1 || v == 2 || v == 4 || v == 5 || v == 8 || v == 9 || v == 10 || v == 12 || (v >= 16 && v <= 23) || v == 25 || v == 26 || v == 32 || v == 24 || v == 60 || v == 61 || v == 62 || v == 70 || v == 71 || v == 80 || v == 81 || v == 192 || v == 193 || v == 224 || v == 225 || v == 256)) return fail(VL2_E_BADARG, "vl2_gemm: unknown variant %d", v);
+    if (!kLab && (v == 2 || v == 5 || v == 9 || v == 10 || (v >= 17 && v <= 23) || v == 25 || v == 62 || v == 193 || v == 225))
         return fail(VL2_E_UNSUPP, "vl2_gemm: variant %d is a lab form: built into libvl2hip_lab.so only (scripts/build_lab_lib.sh)", v);
     GemmCtl ctl{d->ws, d->ws_bytes, v, (d->flags & VL2_GEMM_SPLITK) != 0};
     ctl.persist = (d->flags & VL2_GEMM_PERSISTENT) != 0;
@@ -726,9 +802,10 @@ extern "C" int32_t vl2_gemm(const vl2_gemm_desc* d, void* stream) {
     ctl.weave4 = (d->flags & VL2_GEMM_WEAVE4) != 0;
     ctl.no_weave4 = (d->flags & VL2_GEMM_NO_WEAVE4) != 0;
     {   // the 16 x 16 x 32 kernel: plain rows, bf16 output, no activation, no statistics out; the flag is a wish (ignored where the kernel is not built), variant 16 a demand
-        const bool ok16 = !g && !f32 && !remap && act == VL2_ACT_NONE && !d->stats_out && N % 256 == 0;
+        const bool ok16 = !g && !f32 && !remap && act == VL2_ACT_NONE && N % 256 == 0 && !(d->stats_out && (d->flags & VL2_GEMM_SWIGLU));
         if (((v >= 16 && v <= 23) || v == 25 || v == 26) && !ok16) return fail(VL2_E_UNSUPP, "vl2_gemm: variant 16 (16x16x32 MFMA) is built for plain bf16 outputs without activation / gather / remap / stats_out, N %% 256 == 0");
-        ctl.mfma16 = ok16 && ((v >= 16 && v <= 23) || v == 25 || v == 26 || (v == 0 && (d->flags & VL2_GEMM_MFMA16)));     // 17 ... 22: lab forms (k_gemm9.h MODE 1 ... 6)
+        ctl.mfma16 = ok16 && ((v >= 16 && v <= 23) || v == 25 || v == 26 ||
+                              ((v == 0 || ((v == 256 || v == 224 || v == 192) && !(d->flags & VL2_GEMM_SWIGLU))) && (d->flags & VL2_GEMM_MFMA16)));     // 17 ... 22: lab forms (k_gemm9.h MODE 1 ... 6)
     }
     bool need_fin = d->row_norm_out && (d->flags & VL2_GEMM_NO_TICKET);      // A/B: the separate launch as in rounds 3-4
     ctl.fin = &need_fin;

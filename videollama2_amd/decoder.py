@@ -194,7 +194,7 @@ class HipMistralDecoder(nn.Module):
             ops.attn_fwd(q, kcache[li], vcache[li], o, (0, hd, nh * hd), (0, smax * hd, hd), (0, smax * hd, hd),
                          (0, hd, nh * hd), 1, nh, S, S, nh // nkv, hd ** -0.5, True, 0, hd)
             x = self._row_parallel(o, lw["wo"], x, rs, rn)
-            a = ops.gemm(x, lw["wgu"], swiglu=True, norm=(ops.NORM_RMS, rn, self.eps, None))
+            a = ops.gemm(x, lw["wgu"], swiglu=True, norm=(ops.NORM_RMS, rn, self.eps, None), mfma16=True)
             x = self._row_parallel(a, lw["wd"], x, rs, rn)
         self.pos = S
         self.last_hidden = x
@@ -384,7 +384,7 @@ class HipMistralDecoder(nn.Module):
                 ops.attn_fwd(q[s0:s1], kc[li], vc[li], o[s0:s1], (0, hd, nh * hd), (0, smax * hd, hd), (0, smax * hd, hd),
                              (0, hd, nh * hd), 1, nh, S, S, nh // nkv, hd ** -0.5, True, 0, hd)
             X = self._row_parallel(o, lw["wo"], X, rs, rn)
-            a = ops.gemm(X, lw["wgu"], swiglu=True, norm=(ops.NORM_RMS, rn, self.eps, None))
+            a = ops.gemm(X, lw["wgu"], swiglu=True, norm=(ops.NORM_RMS, rn, self.eps, None), mfma16=True)
             X = self._row_parallel(a, lw["wd"], X, rs, rn)
         for b in range(len(xs)):
             ops.gemv(self.w["lm_head"], X[offs[b + 1] - 1], norm_w=self.w["norm_w"], eps=self.eps, out_f32=True, out=logits_out[b])

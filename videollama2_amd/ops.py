@@ -44,6 +44,7 @@ STAGE_WEAVE = 256                     # lab: LDS-DMA issue woven into the MFMA p
 STAGE_NO_FILL_TILES = 128             # A/B of the fill-the-round GEMM tiles (csrc/k_gemm7.h)
 STAGE_NO_WEAVE4, GEMM_NO_WEAVE4 = 16384, 1024   # A/B: the 192-row tiles without the woven issue (their default since round 5)
 STAGE_WEAVE4, GEMM_WEAVE4 = 8192, 512 # the 256x256 / 192x256 ping-pong GEMMs issue their LDS-DMA from the matrix phases (k_gemm.h gemm4_body WEAVE4)
+STAGE_NO_MFMA16 = 65536               # the decoder prefill's gate/up WITHOUT the 16x16x32-MFMA kernels (its default since round 6: decoder.prefill passes mfma16=True)
 STAGE_MFMA16, GEMM_MFMA16 = 32768, 2048  # opt-in: every SwiGLU (gate/up) GEMM of the session on the 16x16x32-MFMA kernel (csrc/k_gemm9.h): as accurate, OTHER last bits
 STAGE_VIT_NO_PERSISTENT = 4096        # vl2_vit_forward without the persistent GEMM form (its default since round 5): A/B
 STAGE_NO_TICKET_OPS = 2048            # ops.gemm(norm_out=...) only: the appended launch instead of the in-kernel ticket (test / A/B control of the operator path)
@@ -119,7 +120,7 @@ def set_gemm_variant(v):
 
 
 def gemm(a, w, bias=None, res=None, act=ACT_NONE, swiglu=False, out_f32=False, out=None, M=None,
-         gather=None, out_map=None, res_map=None, flop_k=None, stats_out=None, norm=None, norm_out=None):
+         gather=None, out_map=None, res_map=None, flop_k=None, stats_out=None, norm=None, norm_out=None, mfma16=False, tile_ctr=None):
     """C = epilogue(a @ w.T).  a [M,K] bf16 (or row pool when `gather`), w [N,K] bf16, bias fp32 [N], res bf16 rows.
     gather = (a_idx int32 [nseg, M], zero_row (unused), seg_k).  out_map = (grp, grp_pad, row_off),
     res_map = (row_mod, row_off) -- see include/vl2hip.h.
@@ -148,7 +149,7 @@ def gemm(a, w, bias=None, res=None, act=ACT_NONE, swiglu=False, out_f32=False, o
     rmod, roff = res_map or (0, 0)
     ws = _ws(a.device)
     flags = (GEMM_SWIGLU if swiglu else 0) | (GEMM_OUT_F32 if out_f32 else 0) | (GEMM_SPLITK if (_CTL["splitk"] and ws is not None) else 0) | _CTL["gemm_flags"] | \
-            (GEMM_MFMA16 if (swiglu and _CTL["stage_flags"] & STAGE_MFMA16) else 0)
+            (GEMM_MFMA16 if ((mfma16 and not _CTL["stage_flags"] & STAGE_NO_MFMA16) or (swiglu and _CTL["stage_flags"] & STAGE_MFMA16)) else 0)
     kind, stats_in, eps, colsum = norm if norm is not None else (NORM_NONE, None, 0.0, None)
     row_norm = None
     if stats_in is not None and stats_in.dim() == 2:      # [rows, 2] = already reduced (row_norm_finalize)
@@ -171,6 +172,8 @@ def gemm(a, w, bias=None, res=None, act=ACT_NONE, swiglu=False, out_f32=False, o
         if stats_out is None or rn_out.shape[0] < M or tick.numel() < M // 64 + 2 or tick.dtype not in (torch.int32, torch.uint32):
             raise ValueError("gemm: norm_out needs stats_out, row_norm_out [>= M, 2] and >= M/64 + 2 zeroed 32-bit tickets")
         d.row_norm_out, d.row_ticket, d.norm_out, d.norm_out_eps = _p(rn_out), _p(tick), ko, float(eo)
+    if tile_ctr is not None:        # >= 16 bytes, zeroed once: the tile queue of the persistent form (GEMM_PERSISTENT; the kernels re-arm it) -- what the stage calls pass
+        d.tile_ctr = _p(tile_ctr)
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
