@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define VL2_ABI_VERSION 6
+#define VL2_ABI_VERSION 7   /* 7 (round 6): the lab entry points left the product library; VL2_STAGE_NO_MFMA16; gate/up of vl2_llm_prefill on the 16x16x32 kernels by default */
 #define VL2_E_BADARG  (-1)   /* null pointer / non-positive size */
 #define VL2_E_SHAPE   (-2)   /* shape not supported by the gfx950 kernels (alignment / multiple-of constraints) */
 #define VL2_E_UNSUPP  (-3)   /* option combination not built */

@@ -75,6 +75,7 @@ static void run_gemm(GemmArgs a) {
             return;
         }
         if (g_mfma16) {
+            if (g_mfma16_mode != 0 && a.row_norm_out) g_need_fin = true;       // only the shipped form (MODE 0) finalizes its rows itself (vl2_abi.hip launch_gemm)
             a.tiles_m = (a.M + 255) / 256; a.tiles_n = a.N / 256;
             if (g_mfma16_mode == 1) emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(512), [=] { gemm9_bf16_kernel<SW, 1>(a); });
             else if (g_mfma16_mode == 2) emu::launch(dim3(a.tiles_m * a.tiles_n), dim3(512), [=] { gemm9_bf16_kernel<SW, 2>(a); });

@@ -32,7 +32,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
     exported = {l.split()[-1] for l in nm.splitlines() if " T " in l and l.split()[-1].startswith("vl2_")}
     assert exported == declared, exported ^ declared                  # `nm -D` = the documented export set
-    assert _lib.load().vl2_version() == 6
+    assert _lib.load().vl2_version() == 7
     assert _lib.load().vl2_elem_name() == b"bf16"
     f16 = ctypes.CDLL(_lib.LIB_PATHS["fp16"])               # the fp16 build: same export table, other element type
     for name in declared:

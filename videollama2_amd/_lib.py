@@ -214,7 +214,7 @@ def load():
         fn.restype = _i32
         fn.argtypes = args
     bind_lab(lib)
-    if lib.vl2_version() != 6:
+    if lib.vl2_version() != 7:
         raise Vl2HipError("libvl2hip.so ABI version mismatch")
     lib.vl2_elem_name.restype = ctypes.c_char_p
     lib.vl2_elem_name.argtypes = []

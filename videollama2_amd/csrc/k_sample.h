@@ -9,6 +9,11 @@
 // consumes its Philox stream in an implementation-defined way), so the contract is: the KEPT SET and the renormalised probabilities are the
 // warpers', and the token is the inverse CDF of those probabilities, in token-index order, at the uniform number `u` the host hands over
 // (oracle/sampling_oracle.py restates exactly this and is pinned to the live HF warpers).
+// ONE documented deviation: top-p is a KEY threshold here -- every token whose score EQUALS the boundary score is kept -- while HF's
+// TopPLogitsWarper cuts INSIDE a group of exactly tied scores (its sort orders the tie arbitrarily and removes the part whose cumulative probability is
+// still <= 1 - top_p).  With exactly tied logits at the boundary (possible after temperature scaling of low-precision logits) the kept set is a superset
+// of HF's by members of that one tie group, each of the boundary probability; HF's own choice among them is an artefact of its sort's tie order, not a
+// defined semantics, so the oracle masks the boundary group (`boundary_tokens`) when it compares kept sets.
 //
 // No sort: floats are compared through their order-preserving 32-bit keys, and both thresholds are found by radix descent over the key bits,
 // 8 bits per pass -- counts for top-k, probability MASS for top-p.  Mass is summed in 2^-40 fixed point (64-bit integer LDS atomics): integer

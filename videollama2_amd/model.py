@@ -233,7 +233,17 @@ class VideoLLaMA2Hip(nn.Module):
         if kwargs.get("do_sample", False):
             # HF GenerationMixin.generate -> _get_logits_processor: temperature (default 1.0), top_k (generation_config default 50), top_p (default
             # 1.0) as warpers in that order, then one multinomial draw per step (videollama2/__init__.py:93-106 passes temperature and top_p)
-            temperature, top_k, top_p = kwargs.get("temperature", 1.0), kwargs.get("top_k", 50), kwargs.get("top_p", 1.0)
+            # An unspecified value comes from the checkpoint's generation_config when the model carries one (`self.generation_config`, set by the loader
+            # from generation_config.json like HF's from_pretrained does), else from HF's GenerationConfig defaults.  Warpers this path does not build are
+            # refused instead of silently skipped (a checkpoint that sets them would be sampled from another kept set than the reference's).
+            gc = getattr(self, "generation_config", None)
+            gcv = lambda k, dflt: getattr(gc, k, None) if (gc is not None and getattr(gc, k, None) is not None) else dflt
+            for k, neutral in (("repetition_penalty", 1.0), ("min_p", None), ("typical_p", 1.0), ("epsilon_cutoff", 0.0), ("eta_cutoff", 0.0),
+                               ("no_repeat_ngram_size", 0), ("num_beams", 1)):
+                val = kwargs.get(k, gcv(k, neutral))
+                if val is not None and val != neutral:
+                    raise NotImplementedError(f"HIP path: do_sample with {k}={val} is not built (temperature / top_k / top_p are)")
+            temperature, top_k, top_p = kwargs.get("temperature", gcv("temperature", 1.0)), kwargs.get("top_k", gcv("top_k", 50)), kwargs.get("top_p", gcv("top_p", 1.0))
             temperature = 1.0 if temperature is None else float(temperature)
             top_k, top_p = (0 if top_k is None else int(top_k)), (1.0 if top_p is None else float(top_p))
             if not temperature > 0.0:
