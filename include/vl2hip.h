@@ -419,7 +419,7 @@ typedef struct vl2_llm_desc {
     const vl2_llm_layer_w8* layers_w8;                            /* host array [n_layers] or NULL; read only with VL2_STAGE_DECODE_FP8 / VL2_STAGE_PREFILL_FP8 */
     const void* lm_head_w8; const float* lm_head_scale;          /* fp8 copy of lm_head (final norm weight NOT folded: norm_w is applied) */
 } vl2_llm_desc;
-int64_t vl2_llm_workspace_bytes(const vl2_llm_desc* w, int32_t S);
+int64_t vl2_llm_workspace_bytes(const vl2_llm_desc* w, int32_t S);   /* for `w->flags` as set: the fp8 activation image is part of it only with VL2_STAGE_PREFILL_FP8 */
 /* Prefill: inputs_embeds x [S, D] bf16 -> K/V cache rows 0..S-1 of every layer, fp32 logits of the LAST position [vocab]. */
 int32_t vl2_llm_prefill(const vl2_llm_desc* w, const void* x, int32_t S, float* logits_last, void* ws, int64_t ws_bytes, void* stream);
 /* One greedy decode step, hipGraph-replayable (everything that moves lives on the device): tok = argmax(logits) (also written

@@ -30,15 +30,12 @@ def main():
         for _ in range(rounds):
             ours.append(timeit(lambda: ops.gemm(a, w, out=out), iters=30))
             vend.append(timeit(lambda: F.linear(a, w), iters=30))
-            ops.set_gemm_variant(9)                                   # gemm8 (k_gemm8.h): the 256 x 256 tile on four waves, forced
-            try:
-                g8.append(timeit(lambda: ops.gemm(a, w, out=out), iters=30))
-            finally:
-                ops.set_gemm_variant(0)
+            # round 6: the same call on the 16 x 16 x 32 set (VL2_GEMM_MFMA16: gemm9 / the mixed launch / the one-round 128 x 128 body by the set's rule)
+            g8.append(timeit(lambda: ops.gemm(a, w, out=out, mfma16=True), iters=30) if N % 256 == 0 else float("nan"))
         fl = 2.0 * M * N * K
         rel = (out.float() - F.linear(a, w).float()).norm() / out.float().norm()
         print(f"{name:20s} {M}x{N}x{K}: ours {min(ours):7.1f} us ({fl / min(ours) / 1e6:5.0f} TF/s)   vendor {min(vend):7.1f} us ({fl / min(vend) / 1e6:5.0f} TF/s)   "
-              f"ours/vendor {min(ours) / min(vend):.2f}   gemm8 {min(g8):7.1f} us ({fl / min(g8) / 1e6:5.0f} TF/s)   rel diff {rel:.1e}", flush=True)
+              f"ours/vendor {min(ours) / min(vend):.2f}   16x16x32 set {min(g8):7.1f} us ({fl / min(g8) / 1e6:5.0f} TF/s)   rel diff {rel:.1e}", flush=True)
         if not name.startswith("sq"):
             tot["ours"] += min(ours); tot["vendor"] += min(vend)
     print(f"sum over the step's shapes (one launch each): ours {tot['ours']:.0f} us, vendor {tot['vendor']:.0f} us")

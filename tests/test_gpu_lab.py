@@ -70,7 +70,7 @@ def test_lab_gemm_variants_are_bit_identical(ops, M, N, K):
         ops.set_stage_flags(0)
 
 
-@pytest.mark.parametrize("M,N,K", [(1621, 4096, 4096), (700, 512, 1024), (300, 1024, 14336)])
+@pytest.mark.parametrize("M,N,K", [(1621, 4096, 4096), (700, 512, 1024), (300, 1024, 14336), (1621, 28672, 1024)])      # (the last: a row-split call = the mixed launch, without SwiGLU)
 def test_lab_mfma16_set_is_one_arithmetic(ops, M, N, K):
     """Every tile of the 16 x 16 x 32 set -- the 256 x 256 ping-pong tile (variants 16 / 26 = 32- / 64-deep phases; a row-split call = the mixed launch), the
     one-round 128 x 128 body (256 + VL2_GEMM_MFMA16) and the fill-the-round tiles (224 / 192 + the flag: k_gemm7.h gemm7_loop16, lab) -- accumulates a dot

@@ -454,13 +454,16 @@ static void launch_gemm(const GemmArgs& a0, const GemmCtl& c, hipStream_t s) {
                         const dim3 gmix((unsigned)(t_big + t_tail));
                         // the big tiles with 64-deep phases on the 5-stage ring (the whole 160 KiB of LDS): the flag's form and variant 26 (gate/up at
                         // S = 945 / 1621 / 2973: 195.9 / 334.8 / 609.5 -> 192.4 / 332.2 / 596.9 us, profiles/r06_mix16_bench_64deep.txt); 16 = the 32-deep form
-                        if (c.variant != 16) {
-                            lds_attr<gemm_mix16_bf16_kernel<SW, 9>>(5 * GEMM4_STAGE);
-                            hipLaunchKernelGGL((gemm_mix16_bf16_kernel<SW, 9>), gmix, dim3(512), 5 * GEMM4_STAGE, s, big, tail, (int)t_big);
-                        } else {
-                            lds_attr<gemm_mix16_bf16_kernel<SW>>(GEMM4_LDS_BYTES);
-                            hipLaunchKernelGGL((gemm_mix16_bf16_kernel<SW>), gmix, dim3(512), GEMM4_LDS_BYTES, s, big, tail, (int)t_big);
+                        // (SwiGLU calls only: without SwiGLU the tail body ends in gemm_rows_ticket, whose LDS word does not fit beside the 160-KiB ring)
+                        if constexpr (SW) {
+                            if (c.variant != 16) {
+                                lds_attr<gemm_mix16_bf16_kernel<SW, 9>>(5 * GEMM4_STAGE);
+                                hipLaunchKernelGGL((gemm_mix16_bf16_kernel<SW, 9>), gmix, dim3(512), 5 * GEMM4_STAGE, s, big, tail, (int)t_big);
+                                return;
+                            }
                         }
+                        lds_attr<gemm_mix16_bf16_kernel<SW>>(GEMM4_LDS_BYTES);
+                        hipLaunchKernelGGL((gemm_mix16_bf16_kernel<SW>), gmix, dim3(512), GEMM4_LDS_BYTES, s, big, tail, (int)t_big);
                         return;
                     }
                 }

@@ -607,8 +607,8 @@ def _llm_ws(desc, S, device):
 
 
 def llm_prefill(desc, x, logits_out, fp8=False):
+    desc.flags = _CTL["stage_flags"] | (STAGE_PREFILL_FP8 if fp8 else 0)      # (before the size query: the fp8 activation image is carved only with the flag)
     ws, n = _llm_ws(desc, x.shape[0], x.device)
-    desc.flags = _CTL["stage_flags"] | (STAGE_PREFILL_FP8 if fp8 else 0)
     _lib.call("vl2_llm_prefill", ctypes.byref(desc), _p(x), x.shape[0], _p(logits_out), _p(ws), n, _stream())
     return logits_out
 
