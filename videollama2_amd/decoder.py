@@ -513,17 +513,26 @@ class HipMistralDecoder(nn.Module):
         return g
 
     @torch.no_grad()
-    def generate_batch(self, inputs_embeds_list, max_new_tokens=2048, eos_token_id=None, return_logits=False, use_graph=None):
+    def generate_batch(self, inputs_embeds_list, max_new_tokens=2048, eos_token_id=None, return_logits=False, use_graph=None, sampler=None):
         """Greedy decode of several requests at once (not in the reference, whose eval loops run batch 1 and whose worker
         serialises requests; its padded-batch `prepare_inputs_labels_for_multimodal`, arch.py:227-261, is the nearest thing):
         every request is prefilled on its own (its M is already large), then ALL of them decode together, one token per
         request per step.  Prompts may have different lengths (per-sequence positions, no padding).  Returns a list of
         LongTensor [n_new_b] (each ends at its EOS / max_new_tokens); with return_logits also the per-step fp32 logits
         [steps, B, V].  A row of a batched step is bit-identical to the single-sequence step while nb < GEMM_BATCH.
-        use_graph (default: on a GPU without tensor parallelism) replays one captured hipGraph per step."""
+        use_graph (default: on a GPU without tensor parallelism) replays one captured hipGraph per step.
+        sampler = (temperature, top_k, top_p[, generator]): HF `_sample` with do_sample=True for every request -- one ops.sample_token launch per request
+        and step in place of its argmax (request b draws from its own row u[b, step] of uniform numbers, generated request by request from the
+        generator, so request 0's stream is the one a single-sequence `generate` with the same seed would use); the steps run eagerly."""
         nb = len(inputs_embeds_list)
         if use_graph is None:
             use_graph = self._dev.type == "cuda" and self.tp == 1
+        if sampler is not None:
+            use_graph = False
+            T_, tk_, tp_ = float(sampler[0]), int(sampler[1]), float(sampler[2])
+            gen = sampler[3] if len(sampler) > 3 else None
+            n_u = min(max_new_tokens, self.max_seq_len) + 1
+            u_rows = torch.stack([torch.rand((n_u,), device=self._dev, generator=gen) for _ in range(nb)]).contiguous()
         eos = set()
         if eos_token_id is not None:
             eos = set(eos_token_id) if isinstance(eos_token_id, (list, tuple, set)) else {int(eos_token_id)}
@@ -559,6 +568,9 @@ class HipMistralDecoder(nn.Module):
             last = step + 1 == max_new_tokens
             if graph is not None and not last:
                 graph.replay()                                               # argmax(step) + forward of the new tokens
+            elif sampler is not None:
+                for b in range(nb):
+                    ops.sample_token(bb["logits"][b], bb["tok"][b:b + 1], u_rows[b], T_, tk_, tp_, step=step)
             else:
                 for b in range(nb):
                     ops.argmax(bb["logits"][b], bb["tok"][b:b + 1])

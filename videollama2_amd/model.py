@@ -264,9 +264,9 @@ class VideoLLaMA2Hip(nn.Module):
                                          use_graph=kwargs.get("use_graph", self._dev.type == "cuda" and self.decoder.tp == 1))
         # batch > 1 (right-padded, arch.py:227-261): the sequences decode together, each on its own cache / position; finished rows
         # are filled with pad_token_id like HF's generate does
-        if kwargs.get("stopping_criteria") is not None or kwargs.get("streamer") is not None or kwargs.get("return_logits") or sampler is not None:
-            raise NotImplementedError("HIP path: stopping_criteria / streamer / return_logits / do_sample are built for batch 1")
-        outs = self.decoder.generate_batch([emb[bi, :lens[bi]] for bi in range(emb.shape[0])], max_new_tokens=max_new, eos_token_id=eos)
+        if kwargs.get("stopping_criteria") is not None or kwargs.get("streamer") is not None or kwargs.get("return_logits"):
+            raise NotImplementedError("HIP path: stopping_criteria / streamer / return_logits are built for batch 1")
+        outs = self.decoder.generate_batch([emb[bi, :lens[bi]] for bi in range(emb.shape[0])], max_new_tokens=max_new, eos_token_id=eos, sampler=sampler)
         pad = kwargs.get("pad_token_id", None)
         pad = 0 if pad is None else int(pad)
         width = max(o.numel() for o in outs)
