@@ -1176,7 +1176,12 @@ def test_emu_parity_full_end_to_end_dry_run(emu):
     saved = PF.DEV
     PF.DEV = "cpu"
     try:
-        PF.run_end_to_end(O.config_small(4), 4, 3, 256)
+        PF.FORCE_HF_FLOOR = True                                   # (exercise the HF-module floor pass of the full-depth GPU cases once on the CPU)
+        try:
+            PF.run_end_to_end(O.config_small(4), 4, 3, 256)
+        finally:
+            PF.FORCE_HF_FLOOR = False
+        assert any("hf_modules_floor_rel_l2" in r for r in PF.RECORD), "the HF-module floor pass did not run"
         assert any(r.get("stage", "").startswith("e2e greedy tokens") for r in PF.RECORD)
         # second run of the same case: the seeded weights come back from the 16-bit copy (what the fp16-build test of the GPU suite does),
         # the fp32 truth from its cache, and the optional fp8-weights decode rows are appended
