@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""A/B of the two attention structures (vl2_attn_fwd variant 1/2 = k_attn.h register-staged, 3 = k_attn2.h LDS-DMA ring +
-transpose reads) at the workload's shapes, interleaved rounds in one process (guide rule 24), random data (rule 25).
+"""A/B of the attention structures (vl2_attn_fwd variant 1/2 = k_attn.h register-staged, 3 = k_attn2.h LDS-DMA ring +
+transpose reads, 4 = the same with two key streams per query block) at the workload's shapes, interleaved rounds in one process (guide rule 24), random data (rule 25).
 Prints one JSON line per shape.  Usage: python scripts/attn_bench2.py"""
 import json
 import os
@@ -30,7 +30,7 @@ def main():
         qkv = rnd(B * N, 3 * H * D)
         o = torch.empty(B * N, H * D, dtype=torch.bfloat16, device="cuda")
         st = (N * 3 * H * D, D, 3 * H * D)
-        best = ab(lambda: ops.attn_fwd(qkv, qkv[:, H * D:], qkv[:, 2 * H * D:], o, st, st, st, (N * H * D, D, H * D), B, H, N, N, 1, D ** -0.5, False, 0, D), (1, 3))
+        best = ab(lambda: ops.attn_fwd(qkv, qkv[:, H * D:], qkv[:, 2 * H * D:], o, st, st, st, (N * H * D, D, H * D), B, H, N, N, 1, D ** -0.5, False, 0, D), (0, 3, 4))
         fl = 4.0 * B * H * N * N * D
         print(json.dumps(dict(shape=f"vit T={B} 16x577x64", **{f"v{v}": dict(us=round(u, 1), tflops=round(fl / u / 1e6, 1)) for v, u in best.items()})), flush=True)
     D, smax = 128, 4096
@@ -38,10 +38,26 @@ def main():
         q, kc, vc = rnd(S, nh * D), rnd(nkv, smax, D), rnd(nkv, smax, D)
         o = torch.empty(S, nh * D, dtype=torch.bfloat16, device="cuda")
         best = ab(lambda: ops.attn_fwd(q, kc, vc, o, (0, D, nh * D), (0, smax * D, D), (0, smax * D, D), (0, D, nh * D), 1, nh, S, S, nh // nkv,
-                                       D ** -0.5, True, 0, D), (1, 2, 3))
+                                       D ** -0.5, True, 0, D), (1, 2, 3, 4))
         fl = 4.0 * nh * (S * (S + 1) / 2) * D
         print(json.dumps(dict(shape=f"causal {name} S={S} heads={nh}/{nkv}", **{f"v{v}": dict(us=round(u, 1), tflops=round(fl / u / 1e6, 1)) for v, u in best.items()})), flush=True)
 
 
+def extra():
+    """Shapes around the chooser's rule for variant 4 (two key streams): short prompts, a chunk of new rows against a long cache, a batch."""
+    D, smax, nh, nkv = 128, 4096, 32, 8
+    for name, nq, nk, off, B in (("S=256", 256, 256, 0, 1), ("S=512", 512, 512, 0, 1), ("S=1152", 1152, 1152, 0, 1), ("S=1280", 1280, 1280, 0, 1), ("S=1408", 1408, 1408, 0, 1),
+                                 ("chunk 128 @ 1621", 128, 1621, 1493, 1), ("chunk 512 @ 1621", 512, 1621, 1109, 1), ("chunk 512 @ 4096", 512, 4096, 3584, 1),
+                                 ("batch 2 x S=945", 945, 945, 0, 2), ("batch 4 x S=945", 945, 945, 0, 4)):
+        q, kc, vc = rnd(B, nq, nh * D), rnd(B, nkv, smax, D), rnd(B, nkv, smax, D)
+        o = torch.empty(B, nq, nh * D, dtype=torch.bfloat16, device="cuda")
+        best = ab(lambda: ops.attn_fwd(q, kc, vc, o, (nq * nh * D, D, nh * D), (nkv * smax * D, smax * D, D), (nkv * smax * D, smax * D, D), (nq * nh * D, D, nh * D),
+                                       B, nh, nq, nk, nh // nkv, D ** -0.5, True, off, D), (3, 4))
+        print(json.dumps(dict(shape=f"causal {name} heads={nh}/{nkv}", wgs=B * nh * ((nq + 127) // 128), **{f"v{v}": dict(us=round(u, 1)) for v, u in best.items()})), flush=True)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "extra":
+        extra()
+        sys.exit(0)
     main()

@@ -398,7 +398,19 @@ extern "C" int32_t vl2_attn_fwd(const void* q, const void* k, const void* v, voi
     dim3 g((nq + 127) / 128, H, B), blk(256);
     if (causal) g = dim3(((nq + 127) / 128) * H * B, 1, 1);
     const bool cls_peel = variant == 0 && D == 64 && !causal && nq == nk && nk > 64 && (nk - 1) % 64 == 0 && group == 1;   // as the product launcher
-    if (variant == 0 && (D == 64 || D == 128)) variant = 3;   // auto, as the product launcher
+    if (variant == 0 && D == 128 && causal && (long)((nq + 127) / 128) * H <= 352) variant = 4;   // auto, as the product launcher
+    if (variant == 0 && (D == 64 || D == 128)) variant = 3;
+    if (variant == 4) {                                     // two key streams per query block (NS = 2), as the product launcher
+        const bool peel4 = D == 64 && !causal && nq == nk && nk > 64 && (nk - 1) % 64 == 0 && group == 1;
+        const dim3 b2(512);
+        if (peel4) emu::launch(dim3((nq - 1 + 127) / 128 + ((((nq - 1) & 127) == 0 || ((nq - 1) & 127) > 96) ? 1 : 0), H, B), b2, [=] { attn2_fwd_kernel<64, false, true, 2>(a); });
+        else if (D == 64 && !causal) emu::launch(g, b2, [=] { attn2_fwd_kernel<64, false, false, 2>(a); });
+        else if (D == 64 && causal) emu::launch(g, b2, [=] { attn2_fwd_kernel<64, true, false, 2>(a); });
+        else if (D == 128 && !causal) emu::launch(g, b2, [=] { attn2_fwd_kernel<128, false, false, 2>(a); });
+        else if (D == 128 && causal) emu::launch(g, b2, [=] { attn2_fwd_kernel<128, true, false, 2>(a); });
+        else return -2;
+        return 0;
+    }
     if (variant == 3) {                                     // second structure (k_attn2.h): LDS-DMA ring + transpose reads
         if (cls_peel) emu::launch(dim3((nq - 1 + 127) / 128 + ((((nq - 1) & 127) == 0 || ((nq - 1) & 127) > 96) ? 1 : 0), H, B), blk, [=] { attn2_fwd_kernel<64, false, true>(a); });
         else if (D == 64 && !causal) emu::launch(g, blk, [=] { attn2_fwd_kernel<64, false>(a); });

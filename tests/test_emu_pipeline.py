@@ -543,12 +543,16 @@ def test_emu_attention_second_structure(emu):
 
     def both(fn, shape):
         outs = []
-        for var in (1, 3):
+        for var in (1, 3, 4):
             ops.set_attn_kv_groups(var)
             o = torch.zeros(shape, dtype=torch.bfloat16)
             fn(o)
             outs.append(o)
-        return outs
+        # variant 4 = variant 3 with two key streams per query block (even / odd tiles, merged in fp32 through LDS): same tolerance
+        # against torch is checked by the callers through o3; here: it agrees with the one-stream form to the rounding of P (each stream rounds exp2(s - its own running maximum) to 16 bits)
+        assert rel(outs[2], outs[1]) < 3e-3, rel(outs[2], outs[1])
+        both.last4 = outs[2]
+        return outs[:2]
 
     try:
         for B, H, N, D in ((2, 2, 150, 64), (1, 1, 64, 64), (1, 3, 577, 64), (1, 2, 130, 128)):
@@ -558,7 +562,7 @@ def test_emu_attention_second_structure(emu):
                                                  D ** -0.5, False, 0, D), (B * N, H * D))
             q, k, v = [t.view(B, N, H, D).transpose(1, 2).float() for t in qkv.view(B * N, 3, H * D).unbind(1)]
             ref = (torch.softmax(q @ k.transpose(-1, -2) * D ** -0.5, -1) @ v).transpose(1, 2).reshape(B * N, H * D)
-            assert rel(o3, ref) < TOL_BF16_OUT and rel(o3, o1) < 3e-3, (B, H, N, D)
+            assert rel(both.last4, ref) < TOL_BF16_OUT and rel(o3, ref) < TOL_BF16_OUT and rel(o3, o1) < 3e-3, (B, H, N, D)
         nh, nkv, D, smax = 4, 2, 128, 384
         for S in (60, 130, 200, 330):
             q, kc, vc = bf(S, nh * D, seed=S), bf(nkv, smax, D, seed=S + 1), bf(nkv, smax, D, seed=S + 2)
@@ -568,10 +572,10 @@ def test_emu_attention_second_structure(emu):
             kf, vf = kc[:, :S].float().repeat_interleave(2, 0), vc[:, :S].float().repeat_interleave(2, 0)
             sc = (qf @ kf.transpose(1, 2) * D ** -0.5).masked_fill(torch.triu(torch.ones(S, S, dtype=torch.bool), 1), float("-inf"))
             ref = (torch.softmax(sc, -1) @ vf).transpose(0, 1).reshape(S, nh * D)
-            assert rel(o3, ref) < TOL_BF16_OUT and rel(o3, o1) < 3e-3, S
+            assert rel(both.last4, ref) < TOL_BF16_OUT and rel(o3, ref) < TOL_BF16_OUT and rel(o3, o1) < 3e-3, S
             if S == 200:                                              # 40 new rows against 200 keys (chunked prefill form)
                 _, o2 = both(lambda o: ops.attn_fwd(q[160:].contiguous(), kc, vc, o, *args, 40, S, nh // nkv, D ** -0.5, True, 160, D), (40, nh * D))
-                assert rel(o2, ref[160:]) < TOL_BF16_OUT
+                assert rel(o2, ref[160:]) < TOL_BF16_OUT and rel(both.last4, ref[160:]) < TOL_BF16_OUT
         # causal D = 64 (not used by the models, built for completeness) and the rescale branch (guide rule 26)
         N, D = 300, 64
         qkv = bf(N, 3 * D, seed=7)
@@ -581,10 +585,10 @@ def test_emu_attention_second_structure(emu):
         _, o3 = both(lambda o: ops.attn_fwd(qkv, qkv[:, D:], qkv[:, 2 * D:], o, st, st, st, (N * D, D, D), 1, 1, N, N, 1, D ** -0.5, False, 0, D), (N, D))
         q, k, v = [t.float() for t in qkv.view(N, 3, D).unbind(1)]
         ref = torch.softmax(q @ k.T * D ** -0.5, -1) @ v
-        assert rel(o3, ref) < TOL_BF16_OUT and rel(o3[17], ref[17]) < 1e-2
+        assert rel(both.last4, ref) < TOL_BF16_OUT and rel(o3, ref) < TOL_BF16_OUT and rel(o3[17], ref[17]) < 1e-2
         _, o3 = both(lambda o: ops.attn_fwd(qkv, qkv[:, D:], qkv[:, 2 * D:], o, st, st, st, (N * D, D, D), 1, 1, N, N, 1, D ** -0.5, True, 0, D), (N, D))
         sc = (q @ k.T * D ** -0.5).masked_fill(torch.triu(torch.ones(N, N, dtype=torch.bool), 1), float("-inf"))
-        assert rel(o3, torch.softmax(sc, -1) @ v) < TOL_BF16_OUT
+        assert rel(o3, torch.softmax(sc, -1) @ v) < TOL_BF16_OUT and rel(both.last4, torch.softmax(sc, -1) @ v) < TOL_BF16_OUT
     finally:
         ops.set_attn_kv_groups(0)
 

@@ -776,6 +776,65 @@ def test_attn_second_structure_causal_gqa(ops, S, nh, nkv):
     assert rel(o, ref) < TOL_BF16_OUT
 
 
+@pytest.mark.parametrize("S,nh,nkv,off", [(945, 32, 8, 0), (1621, 32, 8, 0), (200, 4, 2, 0), (64, 2, 1, 0), (65, 2, 1, 0), (129, 4, 2, 0), (1345, 8, 2, 0), (300, 8, 2, 700)])
+def test_attn_two_key_streams_causal_gqa(ops, S, nh, nkv, off):
+    """k_attn2.h NS = 2 (variant 4; automatic for causal head_dim 128 while a sequence has <= 352 (query block, head) pairs): even / odd key tiles on two
+    groups of four waves, merged through LDS.  1, 2, 3 tiles (the odd stream empty / shorter), a chunk of new rows against a longer cache, the workload's
+    shapes; against torch, against the one-stream form (P is rounded relative to each stream's own running maximum: two 16-bit roundings apart at most),
+    deterministic over repeated launches, and the automatic choice is a function of the SEQUENCE: a prompt's bits are the same alone and in a batch of 3."""
+    D, smax, nk = 128, 4096, S + off
+    q, kc, vc = bf(S, nh * D), bf(nkv, smax, D), bf(nkv, smax, D, seed=1)
+    qd, kd, vd = q.to(DEV), kc.to(DEV), vc.to(DEV)
+    outs = {}
+    try:
+        for var in (3, 4, 0):
+            ops.set_attn_kv_groups(var)
+            outs[var] = []
+            for _ in range(3):
+                o = torch.zeros(S, nh * D, dtype=torch.bfloat16, device=DEV)
+                ops.attn_fwd(qd, kd, vd, o, (0, D, nh * D), (0, smax * D, D), (0, smax * D, D), (0, D, nh * D), 1, nh, S, nk, nh // nkv, D ** -0.5, True, off, D)
+                outs[var].append(o)
+        ops.set_attn_kv_groups(0)
+        B = 3
+        qb = torch.stack([qd, torch.zeros_like(qd), qd]).contiguous()
+        kb, vb = torch.stack([kd, kd, kd]).contiguous(), torch.stack([vd, vd, vd]).contiguous()
+        ob = torch.zeros(B, S, nh * D, dtype=torch.bfloat16, device=DEV)
+        ops.attn_fwd(qb, kb, vb, ob, (S * nh * D, D, nh * D), (nkv * smax * D, smax * D, D), (nkv * smax * D, smax * D, D), (S * nh * D, D, nh * D),
+                     B, nh, S, nk, nh // nkv, D ** -0.5, True, off, D)
+    finally:
+        ops.set_attn_kv_groups(0)
+    qf = q.view(S, nh, D).transpose(0, 1).float()
+    kf = kc[:, :nk].float().repeat_interleave(nh // nkv, 0)
+    vf = vc[:, :nk].float().repeat_interleave(nh // nkv, 0)
+    vis = torch.arange(nk)[None, :] <= torch.arange(S)[:, None] + off
+    ref = (torch.softmax((qf @ kf.transpose(1, 2) * D ** -0.5).masked_fill(~vis, float("-inf")), -1) @ vf).transpose(0, 1).reshape(S, nh * D)
+    assert rel(outs[4][0], ref) < TOL_BF16_OUT and rel(outs[4][0], outs[3][0]) < 3e-3
+    assert all(torch.equal(o, outs[4][0]) for o in outs[4][1:])
+    auto_is_two = ((S + 127) // 128) * nh <= 352
+    assert torch.equal(outs[0][0], outs[4 if auto_is_two else 3][0])
+    assert torch.equal(ob[0], outs[0][0]) and torch.equal(ob[2], outs[0][0])
+
+
+def test_attn_two_key_streams_noncausal(ops):
+    """The other instances of the two-stream form (not chosen automatically): ViT shape with the class-token peel, ragged head_dim 64, head_dim 128."""
+    for B, H, N, D in ((2, 16, 577, 64), (2, 2, 150, 64), (1, 4, 130, 128)):
+        qkv = bf(B * N, 3 * H * D, seed=N)
+        g = qkv.to(DEV)
+        st = (N * 3 * H * D, D, 3 * H * D)
+        outs = {}
+        try:
+            for var in (3, 4):
+                ops.set_attn_kv_groups(var)
+                outs[var] = torch.zeros(B * N, H * D, dtype=torch.bfloat16, device=DEV)
+                for _ in range(3):
+                    ops.attn_fwd(g, g[:, H * D:], g[:, 2 * H * D:], outs[var], st, st, st, (N * H * D, D, H * D), B, H, N, N, 1, D ** -0.5, False, 0, D)
+        finally:
+            ops.set_attn_kv_groups(0)
+        q, k, v = [t.view(B, N, H, D).transpose(1, 2).float() for t in qkv.view(B * N, 3, H * D).unbind(1)]
+        ref = (torch.softmax(q @ k.transpose(-1, -2) * D ** -0.5, -1) @ v).transpose(1, 2).reshape(B * N, H * D)
+        assert rel(outs[4], ref) < TOL_BF16_OUT and rel(outs[4], outs[3]) < 3e-3, (B, H, N, D)
+
+
 def test_attn_class_token_peel_matches_plain_tiling(ops):
     """k_attn2.h CLS = true (automatic for the CLIP tower's 577 = 1 + 576 tokens): class key as the initial softmax state, class query in a
     dead wave of the last query block, nine key tiles -- against the plain tiling (variant 3) and torch at the workload's shape."""

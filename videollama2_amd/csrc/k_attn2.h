@@ -60,22 +60,40 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, unsigned ch
 // 64-key tiles instead of ten, the tenth holding ONE key) and never need a mask; its QUERY is the only live row of a wave that holds no
 // patch row (the patch queries fill whole 32-row waves: 576 = 18 x 32; unpeeled, that wave ran all ten tiles for row 576 alone).
 // HF:modeling_clip.py:272 computes the same softmax.
-template <int D, bool CAUSAL, bool CLS = false>
-__global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(AttnArgs p) {
+//
+// NS = 2 (round 6; 512 threads): TWO KEY STREAMS per query block.  Waves 0-3 walk the even 64-key tiles, waves 4-7 the odd ones, of the
+// SAME 128 query rows, each stream with its own two-stage ring (dynamic LDS: 4 stages) and its own online-softmax state; after the
+// last tile the odd stream hands (m, l, O^T) over through LDS and the even stream merges the two states (the flash-decoding combine,
+// in fp32, inside the workgroup) and stores.  Why: the kernel's time is the longest DEPENDENT chain of tiles of one wave (causal
+// S = 1621: 26 tiles of the last query block at ~2.9 k cycles each, the co-resident workgroup long gone; ViT: "10 us fixed" of the
+// affine law in profiles/r03_experiments.md 5b) and two waves of one SIMD do not slow each other much below their sum -- so the chain
+// is cut in two and both halves run on the same SIMDs.  A wave also skips a tile that the causal mask hides from all of its rows
+// (every P of it is 0: same bits as computing it).
+template <int D, bool CAUSAL, bool CLS = false, int NS = 1>
+__global__ __launch_bounds__(256 * NS, (NS == 2 && D == 64) ? 4 : 2) void attn2_fwd_kernel(AttnArgs p) {
     static_assert(D == 64 || D == 128, "attn2: head_dim 64 or 128");
     static_assert(!(CLS && CAUSAL), "the class-token peel is for full attention");
+    static_assert(NS == 1 || NS == 2, "attn2: one or two key streams");
     constexpr int NKS = D / 16;                // k-steps of the QK^T MFMA chain
     constexpr int NDB = D / 32;                // 32-row d blocks of O^T
     constexpr int K_BYTES = 64 * D * 2, STAGE = 2 * K_BYTES;
     constexpr int PPW = K_BYTES / 1024 / 4;    // 1-KiB LDS-DMA pieces per wave, per operand and tile (D = 128: 4, D = 64: 2)
     constexpr int QUAD = (D / 16) * 128;       // bytes of one key quad in the V image
-    __shared__ __attribute__((aligned(16))) unsigned char lds_mem[2 * STAGE];
-    unsigned char* const lds = lds_mem;        // the lambdas below capture this pointer, not the __shared__ array itself (casting
-                                               // the array to an LDS address space inside a lambda of a kernel TEMPLATE makes the host
-                                               // pass of hipcc drop the kernel's stub without a diagnostic)
-
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int st = NS == 2 ? wave_all >> 2 : 0;             // key stream of this wave: global tiles st, st + NS, ...
+    const int wave = NS == 2 ? wave_all & 3 : wave_all;     // its 32-row group of the query block / its share of the stream's DMA
+    unsigned char* lds_all;
+    if constexpr (NS == 1) {
+        __shared__ __attribute__((aligned(16))) unsigned char lds_mem[2 * STAGE];
+        lds_all = lds_mem;
+    } else {
+        extern __shared__ __attribute__((aligned(16))) unsigned char vl2_smem[];      // NS * 2 * STAGE bytes
+        lds_all = vl2_smem;
+    }
+    unsigned char* const lds = lds_all + st * (2 * STAGE);   // the lambdas below capture this pointer, not the __shared__ array itself
+                                               // (casting the array to an LDS address space inside a lambda of a kernel TEMPLATE makes
+                                               // the host pass of hipcc drop the kernel's stub without a diagnostic)
     const int hi = lane >> 5, l31 = lane & 31;
     // grid mapping as in k_attn.h (causal: longest q blocks first, then ascending, so a CU pairs a long block with a short one)
     int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
@@ -133,7 +151,8 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(AttnArgs p) {
     const int k_bytes = ((p.nk - 1) * p.k_rs + D) * 2, v_bytes = ((p.nk - 1) * p.v_rs + D) * 2;   // valid bytes behind K / V
     // rows past nk lie outside NUM_RECORDS and arrive as zeros (their scores are masked, their P is 0).
     // (descriptors declared with their type, not `auto`: see lds_dma16)
-    auto dma_tile = [&](int t, unsigned so) {
+    auto dma_tile = [&](int ts, unsigned so) {
+        const int t = NS * ts + st;                             // global tile of this stream's ts-th
         const int kskip = (KROW0 + t * 64) * p.k_rs * 2, vskip = (KROW0 + t * 64) * p.v_rs * 2;
         const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)K + kskip), 0, k_bytes > kskip ? k_bytes - kskip : 0, 0x00020000);
         const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)V + vskip), 0, v_bytes > vskip ? v_bytes - vskip : 0, 0x00020000);
@@ -159,7 +178,8 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(AttnArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) oT[i][r] = 0.f;
     float m = -1e30f, l = 0.f;      // m: running max in the exp2 domain (first tile always rescales: mt - m is huge)
-    if constexpr (CLS) {
+    if (CLS && (NS == 1 || st == 0)) {
+        // (two key streams: the even stream starts from the class key, the odd one from the empty state)
         // the class token's key (row 0) as the initial state: s = q . K[0] (this lane holds half of its query's dims, the partner lane the
         // other half), p = exp2(s c - m) = 1 with m = s c, O^T = 1 * V[0]
         float part = 0.f;
@@ -187,8 +207,9 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(AttnArgs p) {
             }
     }
 
-    auto compute_tile = [&](int t, unsigned so) {
-        const int kv0 = t * 64;
+    auto compute_tile = [&](int ts, unsigned so) {
+        const int kv0 = (NS * ts + st) * 64;
+        if (CAUSAL && NS == 2 && kv0 > q0 + wave * 32 + 31 + p.causal_off) return;     // hidden from all 32 rows of this wave: every P is 0
         // S^T = K . Q^T
         f32x16 sT[2];
         const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -269,17 +290,44 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(AttnArgs p) {
     // a wave whose 32 query rows all lie past nq (the last query block of a 577-row ViT frame: rows 65..127 of it) still moves its
     // share of every K/V tile and meets every barrier, but skips the arithmetic: its issue slots go to the waves it shares a SIMD with
     const bool live = cls_w || q0 + wave * 32 < p.nq;
-    dma_tile(0, 0);
-    for (int t = 0; t < ntiles; t += 2) {
+    const int nt_s = (ntiles - st + NS - 1) / NS;           // tiles of this stream; every wave meets the barriers of all `nsteps`
+    const int nsteps = (ntiles + NS - 1) / NS;
+    if (NS == 1 || nt_s > 0) dma_tile(0, 0);
+    for (int t = 0; t < nsteps; t += 2) {
         VL2_WAIT_VMCNT(0);
         VL2_ATTN2_BARRIER();
-        if (t + 1 < ntiles) dma_tile(t + 1, STAGE);
-        if (live) compute_tile(t, 0);
-        if (t + 1 >= ntiles) break;
+        if (t + 1 < nt_s) dma_tile(t + 1, STAGE);
+        if (live && (NS == 1 || t < nt_s)) compute_tile(t, 0);
+        if (t + 1 >= nsteps) break;
         VL2_WAIT_VMCNT(0);
         VL2_ATTN2_BARRIER();
-        if (t + 2 < ntiles) dma_tile(t + 2, 0);
-        if (live) compute_tile(t + 1, STAGE);
+        if (t + 2 < nt_s) dma_tile(t + 2, 0);
+        if (live && (NS == 1 || t + 1 < nt_s)) compute_tile(t + 1, STAGE);
+    }
+
+    if constexpr (NS == 2) {
+        // merge of the two streams' online-softmax states: [4 row groups][NDB * 16 + 2 values][64 lanes] fp32 over the tile images
+        constexpr int NR = NDB * 16 + 2;
+        float* const xch = (float*)lds_all + (wave * NR) * 64 + lane;
+        __syncthreads();                                     // every wave is done reading its last tile
+        if (st == 1) {
+#pragma unroll
+            for (int db = 0; db < NDB; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) xch[(db * 16 + r) * 64] = oT[db][r];
+            xch[(NDB * 16) * 64] = m;
+            xch[(NDB * 16 + 1) * 64] = l;
+        }
+        __syncthreads();
+        if (st == 1) return;
+        const float m1 = xch[(NDB * 16) * 64], l1 = xch[(NDB * 16 + 1) * 64];
+        const float mn = fmaxf(m, m1);
+        const float a0 = __builtin_amdgcn_exp2f(m - mn), a1 = __builtin_amdgcn_exp2f(m1 - mn);     // an empty stream: m1 = -1e30, l1 = 0, O = 0
+        l = __builtin_fmaf(l, a0, l1 * a1);
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oT[db][r] = __builtin_fmaf(oT[db][r], a0, xch[(db * 16 + r) * 64] * a1);
     }
 
     if (qrow < p.nq) {

@@ -994,13 +994,22 @@ extern "C" int32_t vl2_attn_fwd(const void* q, const void* k, const void* v, voi
         !ALIGNED16(k) || !ALIGNED16(v) || ((uintptr_t)o & 7))
         return fail(VL2_E_SHAPE, "vl2_attn_fwd: strides must keep 16-byte row alignment");
     if (causal && causal_off < 0) return fail(VL2_E_SHAPE, "vl2_attn_fwd: causal_off must be >= 0");
-    if (variant < 0 || variant > 3) return fail(VL2_E_BADARG, "vl2_attn_fwd: unknown variant %d", variant);
+    if (variant < 0 || variant > 4) return fail(VL2_E_BADARG, "vl2_attn_fwd: unknown variant %d", variant);
     // auto: the LDS-DMA / transpose-read structure wherever it is built (measured on MI355X, profiles/r02_attn_ab_*.jsonl:
     // causal D=128 S=945 / 1621 / 2973: 23.3 / 38.1 / 97.7 us vs 26.3 / 43.8 / 106.1 us; ViT D=64 T=8 / 16 / 32: 25.4 / 43.0 / 78.5 vs
     // 26.9 / 43.8 / 78.1 us); head_dim 96 (SigLIP's padded 72) stays on the register-staged kernel
     // full attention over [class token | 64 n patch tokens] (the CLIP tower: 577 = 1 + 576): the class token is peeled off the tiling
     // (k_attn2.h CLS = true: nine key tiles instead of ten, no dead query rows) -- automatic choice only, variant 3 keeps the plain tiling
     const bool cls_peel = variant == 0 && D == 64 && !causal && nq == nk && nk > 64 && (nk - 1) % 64 == 0 && group == 1;
+    const bool cls_peel4 = variant == 4 && D == 64 && !causal && nq == nk && nk > 64 && (nk - 1) % 64 == 0 && group == 1;
+    // causal head_dim 128 (the decoders' prefill): two key streams per query block (k_attn2.h NS = 2) while a SEQUENCE has at most 352 (query block, head)
+    // pairs -- the longest query block's chain of dependent tiles is the launch's makespan there, and two streams halve it.  Decided per sequence (B is left
+    // out) so that a prompt gets the same bits prefilled alone or in a batch.  Measured (profiles/r06_attn_ns2_ab*.jsonl, one / two streams, us): S = 512
+    // 15.7 / 14.8, 945 23.5 / 21.2, 1152 28.7 / 25.2, 1408 33.1 / 30.6, 1452 x 28 heads 32.9 / 30.5, a 512-row chunk against 4096 keys 78.7 / 66.5;
+    // beyond: S = 1621 (416 pairs) 37.4 / 41.1, 2973 92.2 / 102.5 -- one 128-KiB workgroup per CU balances worse than two of 64 KiB once the CUs hold
+    // more than ~1.4 of them.  (The price of the per-sequence rule: a batch of short prompts, 2 x S = 945: 27.3 / 35.6.)  The ViT form stays on one stream
+    // (T = 16: 40.8 / 42.8).
+    if (variant == 0 && D == 128 && causal && (long)((nq + 127) / 128) * H <= 352) variant = 4;
     if (variant == 0 && (D == 64 || D == 128)) variant = 3;
     // K / V tiles are fetched through raw buffer resources whose byte offsets and NUM_RECORDS are 32-bit
     if (((int64_t)(nk - 1) * k_rs + D) * 2 >= (int64_t)1 << 31 || ((int64_t)(nk - 1) * v_rs + D) * 2 >= (int64_t)1 << 31)
@@ -1010,6 +1019,19 @@ extern "C" int32_t vl2_attn_fwd(const void* q, const void* k, const void* v, voi
     dim3 g((nq + 127) / 128, H, B), b(256);
     if (causal) g = dim3(((nq + 127) / 128) * H * B, 1, 1);
     hipStream_t s = ST(stream);
+    if (variant == 4) {                                   // k_attn2.h with two key streams per query block (NS = 2): 512 threads, four LDS stages
+        if (D != 64 && D != 128) return fail(VL2_E_SHAPE, "vl2_attn_fwd: variant 4 is built for head_dim 64 and 128 (got %d)", D);
+        const dim3 b2(512);
+        const int lds_bytes = 4 * (2 * 64 * D * 2);
+#define VL2_ATTN_NS2(KERN, GRID) do { lds_attr<KERN>(lds_bytes); hipLaunchKernelGGL(KERN, GRID, b2, lds_bytes, s, a); } while (0)
+        if (cls_peel4) VL2_ATTN_NS2((attn2_fwd_kernel<64, false, true, 2>), dim3((nq - 1 + 127) / 128 + ((((nq - 1) & 127) == 0 || ((nq - 1) & 127) > 96) ? 1 : 0), H, B));
+        else if (D == 64 && !causal) VL2_ATTN_NS2((attn2_fwd_kernel<64, false, false, 2>), g);
+        else if (D == 64 && causal) VL2_ATTN_NS2((attn2_fwd_kernel<64, true, false, 2>), g);
+        else if (D == 128 && !causal) VL2_ATTN_NS2((attn2_fwd_kernel<128, false, false, 2>), g);
+        else VL2_ATTN_NS2((attn2_fwd_kernel<128, true, false, 2>), g);
+#undef VL2_ATTN_NS2
+        return launched("vl2_attn_fwd");
+    }
     if (variant == 3) {                                   // second structure (k_attn2.h): LDS-DMA ring + transpose reads
         if (cls_peel) hipLaunchKernelGGL((attn2_fwd_kernel<64, false, true>), dim3((nq - 1 + 127) / 128 + ((((nq - 1) & 127) == 0 || ((nq - 1) & 127) > 96) ? 1 : 0), H, B), b, 0, s, a);
         else if (D == 64 && !causal) hipLaunchKernelGGL((attn2_fwd_kernel<64, false>), g, b, 0, s, a);

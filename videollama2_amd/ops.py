@@ -78,8 +78,8 @@ def set_splitk(on):
 
 
 def set_attn_kv_groups(n):
-    """Causal D=128 attention (vl2_attn_fwd `variant`): 0 = auto, 1 = one group of 4 waves per workgroup, 2 = two groups that
-    split the KV tiles and merge through LDS."""
+    """Attention structure (vl2_attn_fwd `variant`, include/vl2hip.h): 0 = auto, 1 = register-staged with one group of 4 waves per workgroup,
+    2 = two groups that split the KV tiles and merge through LDS, 3 = LDS-DMA ring + transpose reads, 4 = 3 with two key streams."""
     _CTL["attn_variant"] = int(n)
 
 
