@@ -114,3 +114,75 @@ def gemm_w8a8(qa, tab, qw, sw, bias=None, res=None, act=None, swiglu=False):
     if res is not None:
         y = y + res.float().cpu()
     return y
+
+
+# ---- the W8A8 prefill as ONE chain (videollama2_amd/decoder.py prefill under enable_fp8_prefill; csrc/vl2_stage.inc VL2_STAGE_PREFILL_FP8) ----------
+def _quant_rows_anywhere(w):
+    """`quant_rows` on the device the tensor lives on (host cores or torch-ROCm; the conversion to torch.float8_e4m3fn is the same OFP8 rounding on
+    both -- tests/test_gpu_parity_full.py checks the two against each other before it trusts the device)."""
+    wf = w.detach().float()
+    e = row_scale_exponent(wf.abs().amax(dim=1))
+    return (wf * torch.exp2(-e.float())[:, None]).to(torch.float8_e4m3fn), torch.exp2(e.float())
+
+
+def _w8a8(x, qw, sw, store, rms_eps=None):
+    """One projection: the activation rows as `store` holds them -> e4m3fn codes with a power-of-two row scale (quant_act_rows; the RMS factor is
+    the rstd of the RAW row), exact products, fp32 sum, x row scale x weight row scale.  Returns fp32 [M, N]."""
+    xs = x.to(store)
+    qa, sa = _quant_rows_anywhere(xs)
+    if rms_eps is not None:
+        xf = xs.float()
+        sa = sa * torch.rsqrt((xf * xf).mean(dim=1) + rms_eps)
+    return (qa.float() @ qw.float().T) * sa[:, None] * sw[None, :]
+
+
+def quantise_decoder_for_prefill(sd, cfg, elem=torch.bfloat16, device="cpu", n_layers=None):
+    """The four projections of every layer as the fp8 prefill streams them: W' = the packed matrix in the 16-bit element type (q/k/v and gate/up with
+    the RMSNorm gain folded in and rounded, videollama2_amd/weights.py fold_norm:39-40), then one power-of-two scale per output row and e4m3fn codes."""
+    n_layers = cfg["llm"]["num_hidden_layers"] if n_layers is None else n_layers
+    out = []
+    r = lambda w: w.to(device=device, dtype=elem).float()
+    for i in range(n_layers):
+        p = f"model.layers.{i}."
+        g1, g2 = r(sd[p + "input_layernorm.weight"]), r(sd[p + "post_attention_layernorm.weight"])
+        fold = lambda names, g: (torch.cat([r(sd[p + n + ".weight"]) for n in names], 0) * g[None, :]).to(elem)
+        out.append(dict(qkv=_quant_rows_anywhere(fold(("self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj"), g1)),
+                        o=_quant_rows_anywhere(r(sd[p + "self_attn.o_proj.weight"])),
+                        gate=_quant_rows_anywhere(fold(("mlp.gate_proj",), g2)), up=_quant_rows_anywhere(fold(("mlp.up_proj",), g2)),
+                        down=_quant_rows_anywhere(r(sd[p + "mlp.down_proj.weight"]))))
+    return out
+
+
+def mistral_prefill_w8a8(sd, cfg, x, q8, elem=torch.bfloat16, chain=torch.float32):
+    """Last-position logits of the prefill with W8A8 projections, as the product defines it: the quantisers read the activation in the 16-bit element
+    type `elem` at the four places the product stores it (the residual stream before q/k/v and before gate/up, the attention output, the SwiGLU
+    output); RoPE, the causal softmax attention (HF:modeling_mistral.py:96-117), the residual adds, the final norm and lm_head are the 16-bit path's.
+    chain = torch.float32: the TRUTH of that definition (every other value kept in fp32); chain = elem: the same definition with every stored tensor
+    rounded to the element type -- the floor a 16-bit implementation of it sits on.  q8 = quantise_decoder_for_prefill(...) on x's device."""
+    import torch.nn.functional as F
+    from oracle import vl2_oracle as O
+    l = cfg["llm"]
+    nh, nkv, hd, eps = l["num_attention_heads"], l["num_key_value_heads"], l["head_dim"], l["rms_norm_eps"]
+    S, dev = x.shape[0], x.device
+    cos, sin = O.rope_cos_sin(cfg, torch.arange(S), chain)
+    cos, sin = cos.to(dev), sin.to(dev)
+    x = x.to(chain)
+    for w in q8:
+        qkv = _w8a8(x, *w["qkv"], store=elem, rms_eps=eps).to(chain)
+        q, k, v = qkv.split([nh * hd, nkv * hd, nkv * hd], dim=1)
+        q, k, v = q.view(S, nh, hd).transpose(0, 1), k.view(S, nkv, hd).transpose(0, 1), v.view(S, nkv, hd).transpose(0, 1)
+        q, k = q * cos + O.rotate_half(q) * sin, k * cos + O.rotate_half(k) * sin
+        rep = nh // nkv
+        kk = k[:, None].expand(nkv, rep, S, hd).reshape(nh, S, hd)
+        vv = v[:, None].expand(nkv, rep, S, hd).reshape(nh, S, hd)
+        a = torch.matmul(q, kk.transpose(1, 2)) * (hd ** -0.5)
+        a = a.masked_fill(torch.triu(torch.ones(S, S, dtype=torch.bool, device=dev), 1)[None], torch.finfo(a.dtype).min)
+        a = F.softmax(a, dim=-1, dtype=torch.float32).to(chain)
+        o = torch.matmul(a, vv).transpose(0, 1).reshape(S, nh * hd)
+        x = (x.float() + _w8a8(o, *w["o"], store=elem)).to(chain)
+        g, u = _w8a8(x, *w["gate"], store=elem, rms_eps=eps), _w8a8(x, *w["up"], store=elem, rms_eps=eps)
+        act = (F.silu(g) * u).to(chain)
+        x = (x.float() + _w8a8(act, *w["down"], store=elem)).to(chain)
+    r = lambda t: t.to(device=dev, dtype=elem).to(chain)
+    h = O.rmsnorm(x[-1:], r(sd["model.norm.weight"]), eps)
+    return F.linear(h, r(sd["lm_head.weight"]))[0].float()

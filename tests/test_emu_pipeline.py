@@ -1197,6 +1197,8 @@ def test_emu_parity_full_end_to_end_dry_run(emu):
         assert any(r["stage"].startswith("fp8-weights decode:") for r in again)
         # massive-activation channels + shifted stream (ONE planted channel: the small config's streams are 64-256 wide, six channels
         # would be a tenth of it; the GPU test plants six in 1024 / 4096)
+        PF.run_fp8_prefill_row(O.config_small(4), 70, 128)           # the W8A8 prefill against the truth of its own definition (oracle/fp8_oracle.py)
+        assert any(r.get("stage", "").startswith("fp8 (W8A8) prefill logits") for r in PF.RECORD)
         PF.run_end_to_end(O.config_small(4), 4, 2, 256, mutate=lambda sd, cfg: PF.plant_outliers(sd, cfg, n_ch=1), tag="outliers ")
         assert any(r.get("stage", "").startswith("outliers e2e greedy tokens") for r in PF.RECORD)
     finally:

@@ -306,6 +306,57 @@ def test_configs1_full_depth_end_to_end():
 
 
 @pytest.mark.gpu
+def test_fp8_prefill_full_depth_kernel_error_row():
+    """OPTIONAL arithmetic (decoder.enable_fp8_prefill): the W8A8 prefill at configs[1]'s depth and length (32 layers, S = 1621) against the
+    fp32 TRUTH OF ITS OWN DEFINITION -- oracle/fp8_oracle.py mistral_prefill_w8a8: the same e4m3fn codes of the same folded weights, the activations quantised
+    at the product's four places from their 16-bit values, everything else in fp32 -- so the row holds the KERNELS' error (the fp8 MFMA's sums, the 16-bit
+    stores between the operators), not the format's.  Floor = the same definition with every stored tensor in bf16 on torch-ROCm; usual bar, ours <= max(2 x
+    floor, 4e-3).  Both are large next to a 16-bit chain's: a code of the NEXT quantiser flips wherever a 16-bit rounding moves an activation across an e4m3fn
+    boundary (a 6 % step), for the floor chain as for the kernels.  The format's own error (against the unquantised fp32 oracle) is recorded beside it, no bar."""
+    run_fp8_prefill_row(O.config_videollama2_7b(16), 1621, 2048)
+
+
+def run_fp8_prefill_row(cfg, S, max_seq_len):
+    from oracle import fp8_oracle as F8
+    from videollama2_amd.decoder import HipMistralDecoder
+    D, I = cfg["llm"]["hidden_size"], cfg["llm"]["intermediate_size"]
+    keep = lambda n: n.startswith(("model.layers.", "model.norm", "model.embed_tokens", "lm_head"))
+    sd_key = ("e2e_weights", json.dumps({k: v for k, v in cfg.items() if k != "num_frames"}, sort_keys=True, default=str))
+    torch.set_num_threads(min(os.cpu_count() or 8, 32))
+    t0 = time.perf_counter()
+    sd16 = ({k: v for k, v in _CACHE[sd_key].items() if keep(k)} if sd_key in _CACHE else
+            {k: v.bfloat16() for k, v in O.seeded_state_dict(cfg, 31, only=keep).items()})
+    t_sd = time.perf_counter() - t0
+    x = (torch.randn(S, D, generator=torch.Generator().manual_seed(12)) * 0.5).bfloat16()
+    # the device's float8 conversion against the host's (the oracle's definition): same codes, before the device is trusted with the quantisers
+    probe = torch.cat([sd16["model.layers.0.mlp.down_proj.weight"][:64].float(), x[:64, :].float().repeat(1, (I + D - 1) // D)[:, :I] * 3.0])
+    qh, sh = F8.quant_rows(probe)
+    qd, sdv = F8._quant_rows_anywhere(probe.to(DEV))
+    assert torch.equal(qd.view(torch.uint8).cpu(), qh) and torch.equal(sdv.cpu(), sh)
+    with torch.no_grad():
+        sdd = {k: v.to(DEV) for k, v in sd16.items()}
+        q8 = F8.quantise_decoder_for_prefill(sdd, cfg, elem=torch.bfloat16, device=DEV)
+        t0 = time.perf_counter()
+        truth = F8.mistral_prefill_w8a8(sdd, cfg, x.to(DEV), q8, chain=torch.float32).cpu()
+        floor = F8.mistral_prefill_w8a8(sdd, cfg, x.to(DEV), q8, chain=torch.bfloat16).cpu()
+        t_or = time.perf_counter() - t0
+        unq = O.mistral_forward({k: v.float() for k, v in sdd.items()}, cfg, x.to(DEV).float())[0][0].cpu()      # the unquantised fp32 chain (format error's reference), on the device
+        del q8
+    dec = HipMistralDecoder(cfg, {k: v.float() for k, v in sd16.items()}, DEV, max_seq_len=max_seq_len)
+    l16 = dec.prefill(x.to(DEV)).clone().cpu()
+    dec.enable_fp8_prefill()
+    ours = dec.prefill(x.to(DEV)).clone().cpu()
+    dec.enable_fp8_prefill(False)
+    ok, margin, dmax = token_tie_ok(ours, truth)
+    _note(f"fp8 (W8A8) prefill logits, {cfg['llm']['num_hidden_layers']} layers, S={S}, vs the fp32 truth of the W8A8 definition (kernel error; OPTIONAL arithmetic)", rel(ours, truth), rel(floor, truth),
+          dict(format_error_vs_unquantised_fp32_oracle=float(rel(ours, unq)), w8a8_truth_vs_unquantised_fp32_oracle=float(rel(truth, unq)),
+               sixteen_bit_prefill_vs_unquantised_fp32_oracle=float(rel(l16, unq)), top1_equals_w8a8_truth=int(ours.argmax()) == int(truth.argmax()),
+               top1_equals_unquantised_oracle=int(ours.argmax()) == int(unq.argmax()), fp32_top2_margin=margin, max_abs_dlogit=dmax,
+               weights_s=round(t_sd, 1), oracle_chains_on_device_s=round(t_or, 1)))
+    assert int(ours.argmax()) == int(truth.argmax()) or ok
+
+
+@pytest.mark.gpu
 def test_configs1_full_depth_end_to_end_fp16_build():
     """The same case through the fp16 build of the library (libvl2hip_f16.so, -DVL2_ELEM_F16: every kernel's element type, MFMA
     instruction and pack/unpack switch at compile time, csrc/dev_common.h).  fp16 is what the reference's mm_infer runs in
