@@ -57,6 +57,7 @@ struct GemmArgs {
     unsigned* row_ticket;    // one zeroed word per row tile of THIS launch (index = the kernel's tile row), re-armed by the last arriver
     int norm_out;            // 1 RMSNorm (mean = 0), 2 LayerNorm
     float norm_out_eps;
+    int tile_group;          // k_gemm9.h: depth of the row-tile group that shares a W panel on an XCD; 0 = the kernel's own (4)
 };
 
 // ---- norm-carrying GEMMs ------------------------------------------------------------------------------------------------

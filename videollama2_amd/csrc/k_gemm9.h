@@ -48,9 +48,10 @@ __device__ __forceinline__ void gemm9_body(const GemmArgs& p, int bid, int nwg) 
     const int wrow = grp * 128 + (w4 >> 1) * 64, wcol = (w4 & 1) * 128;
 
     const int t0 = xcd_remap(bid, nwg);
-    const int grp_sz = 4 * p.tiles_n;
-    const int first_m = (t0 / grp_sz) * 4;
-    const int gm = (p.tiles_m - first_m) < 4 ? (p.tiles_m - first_m) : 4;
+    const int GD = p.tile_group > 0 ? p.tile_group : 4;              // row tiles that walk one W panel together on an XCD (lab variants 27-29: 8 / 2 / 6)
+    const int grp_sz = GD * p.tiles_n;
+    const int first_m = (t0 / grp_sz) * GD;
+    const int gm = (p.tiles_m - first_m) < GD ? (p.tiles_m - first_m) : GD;
     const int tm = first_m + (t0 % grp_sz) % gm, tn = (t0 % grp_sz) / gm;
     const int m0 = tm * BM, n0 = tn * GEMM4_BN;
     f32x2 rst = {0.f, 1.f};

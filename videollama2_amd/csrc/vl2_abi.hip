@@ -443,11 +443,12 @@ static void launch_gemm(const GemmArgs& a0, const GemmCtl& c, hipStream_t s) {
         if (c.mfma16) {                                                                                                                         // (vl2_gemm has checked that the call qualifies)
             // a row-split call keeps its ONE mixed launch (k_gemm9.h gemm_mix16_bf16_kernel): whole 256-row tiles on gemm9_body, the tail rows on the
             // 128 x 128 body of the same instruction -- the same bits row by row, so the split stays invisible (as in the 32 x 32 x 16 family)
-            if (c.variant == 0 || c.variant == 16 || c.variant == 26) {
+            if (c.variant == 0 || c.variant == 16 || c.variant == 26 || (kLab && c.variant >= 27 && c.variant <= 29)) {
                 GemmCtl c0 = c;
                 c0.variant = 0;
                 if (const int M1 = m_split_rows(a0, c0); M1 > 0 && !c.no_mix) {
                     GemmArgs big = gemm_rows(a0, 0, M1, false), tail = gemm_rows(a0, M1, a0.M - M1, false);
+                    if (kLab && c.variant >= 27) big.tile_group = c.variant == 27 ? 8 : c.variant == 28 ? 2 : 6;      // lab: variant 26 with another group depth
                     const long t_big = (long)(M1 / GEMM4_BM) * (a0.N / GEMM4_BN), t_tail = (long)tail.tiles_m * tail.tiles_n;
                     if (t_tail > 128 && t_tail <= 512) {
                         big.tiles_m = M1 / GEMM4_BM; big.tiles_n = a0.N / GEMM4_BN;
@@ -794,8 +795,8 @@ extern "C" int32_t vl2_gemm(const vl2_gemm_desc* d, void* stream) {
     }
     if (d->ws && (d->ws_bytes < SK_WS_BYTES || !ALIGNED16(d->ws))) return fail(VL2_E_BADARG, "vl2_gemm: workspace needs >= %lld bytes, 16-byte aligned", (long long)SK_WS_BYTES);
     const int v = d->variant;
-    if (!(v == 0 || v == 1 || v == 2 || v == 4 || v == 5 || v == 8 || v == 9 || v == 10 || v == 12 || (v >= 16 && v <= 23) || v == 25 || v == 26 || v == 32 || v == 24 || v == 60 || v == 61 || v == 62 || v == 70 || v == 71 || v == 80 || v == 81 || v == 192 || v == 193 || v == 224 || v == 225 || v == 256)) return fail(VL2_E_BADARG, "vl2_gemm: unknown variant %d", v);
-    if (!kLab && (v == 2 || v == 5 || v == 9 || v == 10 || (v >= 17 && v <= 23) || v == 25 || v == 62 || v == 193 || v == 225))
+    if (!(v == 0 || v == 1 || v == 2 || v == 4 || v == 5 || v == 8 || v == 9 || v == 10 || v == 12 || (v >= 16 && v <= 23) || v == 25 || (v >= 26 && v <= 29) || v == 32 || v == 24 || v == 60 || v == 61 || v == 62 || v == 70 || v == 71 || v == 80 || v == 81 || v == 192 || v == 193 || v == 224 || v == 225 || v == 256)) return fail(VL2_E_BADARG, "vl2_gemm: unknown variant %d", v);
+    if (!kLab && (v == 2 || v == 5 || v == 9 || v == 10 || (v >= 17 && v <= 23) || v == 25 || (v >= 27 && v <= 29) || v == 62 || v == 193 || v == 225))
         return fail(VL2_E_UNSUPP, "vl2_gemm: variant %d is a lab form: built into libvl2hip_lab.so only (scripts/build_lab_lib.sh)", v);
     GemmCtl ctl{d->ws, d->ws_bytes, v, (d->flags & VL2_GEMM_SPLITK) != 0};
     ctl.persist = (d->flags & VL2_GEMM_PERSISTENT) != 0;
@@ -806,8 +807,8 @@ extern "C" int32_t vl2_gemm(const vl2_gemm_desc* d, void* stream) {
     ctl.no_weave4 = (d->flags & VL2_GEMM_NO_WEAVE4) != 0;
     {   // the 16 x 16 x 32 kernel: plain rows, bf16 output, no activation, no statistics out; the flag is a wish (ignored where the kernel is not built), variant 16 a demand
         const bool ok16 = !g && !f32 && !remap && act == VL2_ACT_NONE && N % 256 == 0 && !(d->stats_out && (d->flags & VL2_GEMM_SWIGLU));
-        if (((v >= 16 && v <= 23) || v == 25 || v == 26) && !ok16) return fail(VL2_E_UNSUPP, "vl2_gemm: variant 16 (16x16x32 MFMA) is built for plain bf16 outputs without activation / gather / remap / stats_out, N %% 256 == 0");
-        ctl.mfma16 = ok16 && ((v >= 16 && v <= 23) || v == 25 || v == 26 ||
+        if (((v >= 16 && v <= 23) || (v >= 25 && v <= 29)) && !ok16) return fail(VL2_E_UNSUPP, "vl2_gemm: variant 16 (16x16x32 MFMA) is built for plain bf16 outputs without activation / gather / remap / stats_out, N %% 256 == 0");
+        ctl.mfma16 = ok16 && ((v >= 16 && v <= 23) || (v >= 25 && v <= 29) ||
                               ((v == 0 || ((v == 256 || v == 224 || v == 192) && !(d->flags & VL2_GEMM_SWIGLU))) && (d->flags & VL2_GEMM_MFMA16)));     // 17 ... 22: lab forms (k_gemm9.h MODE 1 ... 6)
     }
     bool need_fin = d->row_norm_out && (d->flags & VL2_GEMM_NO_TICKET);      // A/B: the separate launch as in rounds 3-4
