@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """gate/up + SwiGLU on the default mixed 16 x 16 x 32 launch with other depths of the row-tile group that walks one W panel together on an XCD (k_gemm9.h
-gemm9_body: 4 shipped = variant 26; lab variants 27 / 28 / 29 = 8 / 2 / 6), one binary (libvl2hip_lab.so), alternating.  Usage: python scripts/gemm9_group_ab.py [rounds]"""
+gemm9_body: 4 shipped = variant 26; lab variants 27 / 29 = 8 / 6; 28 = depth 4 with the empty waves of the tail tiles computing, i.e. without the dead-wave skip), one binary (libvl2hip_lab.so), alternating.  Usage: python scripts/gemm9_group_ab.py [rounds]"""
 import os
 import sys
 
@@ -38,7 +38,7 @@ def main():
                     res[v].append(e0.elapsed_time(e1) * 1e3 / 20)
         ops.set_gemm_variant(0)
         fl = 2.0 * M * N * K
-        for v, depth in zip(vs, (4, 8, 2, 6)):
+        for v, depth in zip(vs, (4, 8, '4, no dead-wave skip', 6)):
             t = sorted(res[v])[len(res[v]) // 2]
             print(f"gate/up M={M}: group depth {depth} (variant {v}) median {t:7.1f} us  {fl / t * 1e-6:7.1f} TF/s   all {[round(x, 1) for x in res[v]]}   same bits {bool(torch.equal(outs[v], outs[26]))}")
 

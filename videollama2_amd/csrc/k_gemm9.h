@@ -410,6 +410,10 @@ __device__ __forceinline__ void gemm_l8_16_body(const GemmArgs& p, int bid, int 
     const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
     const int nt = p.K / GEMM_BK;
     const f32x2 rst = gemm_row_stats(p, m0, tid, GEMM_BM);
+    // a wave whose 32 rows all lie past M (the ragged last row tile: 85 live rows of gate/up's tail at S = 1621 leave wave row 3 empty) moves its share of
+    // every slab and meets every barrier but issues no fragment read and no MFMA: nothing of it is stored, and on a part that runs these launches at its
+    // power limit the matrix work it skips is clock for the others
+    const bool live = m0 + wm * 32 < p.M || p.tile_group < 0;      // (tile_group < 0: lab variant 28, the skip switched off for A/B runs)
 
     f32x4 acc[2][4];
 #pragma unroll
@@ -459,6 +463,7 @@ __device__ __forceinline__ void gemm_l8_16_body(const GemmArgs& p, int bid, int 
         VL2_PHASE_BARRIER();                                        // everyone's pieces of tile kt landed; buffer (kt-1)&3 is free
         if (kt + GEMML_STAGES - 1 < nt) stage(kt + GEMML_STAGES - 1);
         const unsigned lds_buf = (unsigned)(kt & (GEMML_STAGES - 1)) * GEMML_STAGE_BYTES;
+        if (!live) continue;                                        // (see `live` above: loads and barriers only)
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             bf16x8 fa[2], fb[4];

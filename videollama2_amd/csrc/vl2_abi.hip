@@ -448,7 +448,8 @@ static void launch_gemm(const GemmArgs& a0, const GemmCtl& c, hipStream_t s) {
                 c0.variant = 0;
                 if (const int M1 = m_split_rows(a0, c0); M1 > 0 && !c.no_mix) {
                     GemmArgs big = gemm_rows(a0, 0, M1, false), tail = gemm_rows(a0, M1, a0.M - M1, false);
-                    if (kLab && c.variant >= 27) big.tile_group = c.variant == 27 ? 8 : c.variant == 28 ? 2 : 6;      // lab: variant 26 with another group depth
+                    if (kLab && c.variant >= 27) big.tile_group = c.variant == 27 ? 8 : c.variant == 28 ? 0 : 6;      // lab: variant 26 with another group depth
+                    if (kLab && c.variant == 28) tail.tile_group = -1;                                                // lab: variant 26 with the tail's empty waves computing (as before round 6's skip)
                     const long t_big = (long)(M1 / GEMM4_BM) * (a0.N / GEMM4_BN), t_tail = (long)tail.tiles_m * tail.tiles_n;
                     if (t_tail > 128 && t_tail <= 512) {
                         big.tiles_m = M1 / GEMM4_BM; big.tiles_n = a0.N / GEMM4_BN;
