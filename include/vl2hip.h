@@ -202,7 +202,8 @@ int32_t vl2_fill_cls(void* x, const void* cls_pos, int32_t T, int32_t D, int32_t
  * register-staged kernel for head_dim 96); 1 = register-staged K/V (k_attn.h), one
  * group of 4 waves per workgroup; 2 = the same with two groups that split the KV tiles and merge through LDS (causal D=128 only);
  * 3 = K/V by LDS-DMA into a two-stage ring, V through the transpose read (k_attn2.h); 4 = 3 with two key streams per query block
- * (even / odd 64-key tiles on two groups of 4 waves, states merged in fp32 through LDS; 512 threads, four LDS stages).
+ * (even / odd 64-key tiles on two groups of 4 waves, states merged in fp32 through LDS; 512 threads, four LDS stages); 5 = (libvl2hip_lab.so only) 3 for
+ * causal head_dim 128 without the return from tiles the mask hides from a whole wave, for A/B runs.
  * Fused attention forward, softmax in fp32.  D = 64 or 128.  Element strides: *_bs batch, *_hs head, *_rs row.
  * kv head of q head h = h / group.  causal: key j visible to q row i iff j <= i + causal_off.
  * Replaces flash-attn (videollama2/model/encoder.py:24) / HF eager_attention_forward for CLIP, and HF Mistral

@@ -56,7 +56,29 @@ def extra():
         print(json.dumps(dict(shape=f"causal {name} heads={nh}/{nkv}", wgs=B * nh * ((nq + 127) // 128), **{f"v{v}": dict(us=round(u, 1)) for v, u in best.items()})), flush=True)
 
 
+def skip_ab():
+    """One-stream causal kernel with / without the skip of tiles the mask hides from a whole wave (lab variant 5 = without), libvl2hip_lab.so."""
+    from videollama2_amd import _lib
+    _lib.set_lab(True)
+    D, smax = 128, 4096
+    for name, S, nh, nkv in (("T16 7B", 1621, 32, 8), ("T32 7B", 2973, 32, 8), ("T16 72B", 1621, 64, 8), ("S=1792", 1792, 32, 8)):
+        q, kc, vc = rnd(S, nh * D), rnd(nkv, smax, D), rnd(nkv, smax, D)
+        outs = {}
+        for v in (3, 5):
+            ops.set_attn_kv_groups(v)
+            outs[v] = torch.zeros(S, nh * D, dtype=torch.bfloat16, device="cuda")
+            ops.attn_fwd(q, kc, vc, outs[v], (0, D, nh * D), (0, smax * D, D), (0, smax * D, D), (0, D, nh * D), 1, nh, S, S, nh // nkv, D ** -0.5, True, 0, D)
+        o = outs[3]
+        best = ab(lambda: ops.attn_fwd(q, kc, vc, o, (0, D, nh * D), (0, smax * D, D), (0, smax * D, D), (0, D, nh * D), 1, nh, S, S, nh // nkv,
+                                       D ** -0.5, True, 0, D), (3, 5), rounds=6)
+        print(json.dumps(dict(shape=f"causal {name} S={S} heads={nh}/{nkv}", skip_us=round(best[3], 1), no_skip_us=round(best[5], 1),
+                              same_bits=bool(torch.equal(outs[3], outs[5])))), flush=True)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "skip":
+        skip_ab()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "extra":
         extra()
         sys.exit(0)

@@ -69,7 +69,8 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, unsigned ch
 // affine law in profiles/r03_experiments.md 5b) and two waves of one SIMD do not slow each other much below their sum -- so the chain
 // is cut in two and both halves run on the same SIMDs.  A wave also skips a tile that the causal mask hides from all of its rows
 // (every P of it is 0: same bits as computing it).
-template <int D, bool CAUSAL, bool CLS = false, int NS = 1>
+// SKIP = false (lab, variant 5): the one-stream causal kernel as it was before that skip, for A/B runs.
+template <int D, bool CAUSAL, bool CLS = false, int NS = 1, bool SKIP = true>
 __global__ __launch_bounds__(256 * NS, (NS == 2 && D == 64) ? 4 : 2) void attn2_fwd_kernel(AttnArgs p) {
     static_assert(D == 64 || D == 128, "attn2: head_dim 64 or 128");
     static_assert(!(CLS && CAUSAL), "the class-token peel is for full attention");
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(256 * NS, (NS == 2 && D == 64) ? 4 : 2) void attn2_
 
     auto compute_tile = [&](int ts, unsigned so) {
         const int kv0 = (NS * ts + st) * 64;
-        if (CAUSAL && NS == 2 && kv0 > q0 + wave * 32 + 31 + p.causal_off) return;     // hidden from all 32 rows of this wave: every P is 0
+        if (CAUSAL && SKIP && kv0 > q0 + wave * 32 + 31 + p.causal_off) return;        // hidden from all 32 rows of this wave: every P is 0 (same bits as computing it)
         // S^T = K . Q^T
         f32x16 sT[2];
         const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};

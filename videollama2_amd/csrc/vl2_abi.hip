@@ -996,7 +996,8 @@ extern "C" int32_t vl2_attn_fwd(const void* q, const void* k, const void* v, voi
         !ALIGNED16(k) || !ALIGNED16(v) || ((uintptr_t)o & 7))
         return fail(VL2_E_SHAPE, "vl2_attn_fwd: strides must keep 16-byte row alignment");
     if (causal && causal_off < 0) return fail(VL2_E_SHAPE, "vl2_attn_fwd: causal_off must be >= 0");
-    if (variant < 0 || variant > 4) return fail(VL2_E_BADARG, "vl2_attn_fwd: unknown variant %d", variant);
+    if (variant < 0 || variant > 5) return fail(VL2_E_BADARG, "vl2_attn_fwd: unknown variant %d", variant);
+    if (variant == 5 && (!kLab || D != 128 || !causal)) return fail(VL2_E_UNSUPP, "vl2_attn_fwd: variant 5 (variant 3 without the hidden-tile skip) is a lab form of the causal head_dim 128 kernel: libvl2hip_lab.so only");
     // auto: the LDS-DMA / transpose-read structure wherever it is built (measured on MI355X, profiles/r02_attn_ab_*.jsonl:
     // causal D=128 S=945 / 1621 / 2973: 23.3 / 38.1 / 97.7 us vs 26.3 / 43.8 / 106.1 us; ViT D=64 T=8 / 16 / 32: 25.4 / 43.0 / 78.5 vs
     // 26.9 / 43.8 / 78.1 us); head_dim 96 (SigLIP's padded 72) stays on the register-staged kernel
@@ -1034,6 +1035,12 @@ extern "C" int32_t vl2_attn_fwd(const void* q, const void* k, const void* v, voi
 #undef VL2_ATTN_NS2
         return launched("vl2_attn_fwd");
     }
+#ifdef VL2_LAB
+    if (variant == 5) {
+        hipLaunchKernelGGL((attn2_fwd_kernel<128, true, false, 1, false>), g, b, 0, s, a);
+        return launched("vl2_attn_fwd");
+    }
+#endif
     if (variant == 3) {                                   // second structure (k_attn2.h): LDS-DMA ring + transpose reads
         if (cls_peel) hipLaunchKernelGGL((attn2_fwd_kernel<64, false, true>), dim3((nq - 1 + 127) / 128 + ((((nq - 1) & 127) == 0 || ((nq - 1) & 127) > 96) ? 1 : 0), H, B), b, 0, s, a);
         else if (D == 64 && !causal) hipLaunchKernelGGL((attn2_fwd_kernel<64, false>), g, b, 0, s, a);
