@@ -8,7 +8,7 @@ from tests.util import rel
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
-LAB_VARIANTS = (2, 5, 9, 10, 17, 18, 19, 20, 21, 22, 23, 25, 62, 193, 225)
+LAB_VARIANTS = (2, 5, 9, 10, 17, 18, 19, 20, 21, 22, 23, 25, 27, 28, 29, 62, 193, 225)
 
 
 def bf(*shape, scale=1.0, seed=0):
@@ -99,6 +99,38 @@ def test_lab_gemm9_issue_orders_equal_variant_16(ops):
     for v in (17, 18, 19, 20, 21, 22, 26):
         ops.set_gemm_variant(v)
         assert torch.equal(ops.gemm(a, w), ref), v
+
+
+def test_lab_gate_up_group_depth_and_tail_switch_equal_the_shipped_launch(ops):
+    """Round 6: the mixed 16 x 16 x 32 launch of gate/up with other depths of the row-tile group that shares a W panel on an XCD (27 / 29 = 8 / 6) and with the
+    empty waves of the ragged tail tiles computing (28: the launch as it was before the skip) -> the shipped launch's bits (variant 26), ragged and whole M."""
+    from videollama2_amd.weights import pack_gate_up
+    for M in (1621, 945, 1536 + 128):
+        a = bf(M, 4096).to(DEV)
+        wgu = pack_gate_up(bf(2048, 4096, scale=1 / 64, seed=3), bf(2048, 4096, scale=1 / 64, seed=4)).to(DEV)
+        rn = ops.row_norm_finalize(ops.row_stats(a), 4096, ops.NORM_RMS, 1e-6)
+        ops.set_gemm_variant(26)
+        ref = ops.gemm(a, wgu, swiglu=True, norm=(ops.NORM_RMS, rn, 1e-6, None))
+        for v in (27, 28, 29):
+            ops.set_gemm_variant(v)
+            assert torch.equal(ops.gemm(a, wgu, swiglu=True, norm=(ops.NORM_RMS, rn, 1e-6, None)), ref), (M, v)
+    ops.set_gemm_variant(0)
+
+
+def test_lab_causal_attention_without_the_hidden_tile_skip(ops):
+    """vl2_attn_fwd variant 5 (lab): the one-stream causal kernel computing the tiles the mask hides from a whole wave -> variant 3's bits (every P of such a tile is 0)."""
+    D, smax = 128, 2048
+    for S, nh, nkv, off in ((1621, 32, 8, 0), (200, 4, 2, 0), (300, 8, 2, 700)):
+        q, kc, vc = bf(S, nh * D).to(DEV), bf(nkv, smax, D).to(DEV), bf(nkv, smax, D, seed=1).to(DEV)
+        outs = {}
+        try:
+            for v in (3, 5):
+                ops.set_attn_kv_groups(v)
+                outs[v] = torch.zeros(S, nh * D, dtype=torch.bfloat16, device=DEV)
+                ops.attn_fwd(q, kc, vc, outs[v], (0, D, nh * D), (0, smax * D, D), (0, smax * D, D), (0, D, nh * D), 1, nh, S, S + off, nh // nkv, D ** -0.5, True, off, D)
+        finally:
+            ops.set_attn_kv_groups(0)
+        assert torch.equal(outs[3], outs[5]), (S, nh, nkv, off)
 
 
 def test_lab_gemm_stream_k_variant(ops):
