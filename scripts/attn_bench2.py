@@ -75,7 +75,28 @@ def skip_ab():
                               same_bits=bool(torch.equal(outs[3], outs[5])))), flush=True)
 
 
+def vit_order_ab():
+    """The tower's class-token kernel with the query block as the slowest grid index (default since round 6) against the old order (lab variant 5)."""
+    from videollama2_amd import _lib
+    _lib.set_lab(True)
+    for B in (16, 8, 32, 4):
+        H, N, D = 16, 577, 64
+        qkv = rnd(B * N, 3 * H * D)
+        st = (N * 3 * H * D, D, 3 * H * D)
+        outs = {}
+        for v in (0, 5):
+            ops.set_attn_kv_groups(v)
+            outs[v] = torch.zeros(B * N, H * D, dtype=torch.bfloat16, device="cuda")
+            ops.attn_fwd(qkv, qkv[:, H * D:], qkv[:, 2 * H * D:], outs[v], st, st, st, (N * H * D, D, H * D), B, H, N, N, 1, D ** -0.5, False, 0, D)
+        o = outs[0]
+        best = ab(lambda: ops.attn_fwd(qkv, qkv[:, H * D:], qkv[:, 2 * H * D:], o, st, st, st, (N * H * D, D, H * D), B, H, N, N, 1, D ** -0.5, False, 0, D), (0, 5), rounds=6)
+        print(json.dumps(dict(shape=f"vit T={B} 16x577x64", block_slowest_us=round(best[0], 1), old_order_us=round(best[5], 1), same_bits=bool(torch.equal(outs[0], outs[5])))), flush=True)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "vit_order":
+        vit_order_ab()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "skip":
         skip_ab()
         sys.exit(0)

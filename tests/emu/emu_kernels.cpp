@@ -412,7 +412,7 @@ extern "C" int32_t vl2_attn_fwd(const void* q, const void* k, const void* v, voi
         return 0;
     }
     if (variant == 3) {                                     // second structure (k_attn2.h): LDS-DMA ring + transpose reads
-        if (cls_peel) emu::launch(dim3((nq - 1 + 127) / 128 + ((((nq - 1) & 127) == 0 || ((nq - 1) & 127) > 96) ? 1 : 0), H, B), blk, [=] { attn2_fwd_kernel<64, false, true>(a); });
+        if (cls_peel) emu::launch(dim3(H, B, (nq - 1 + 127) / 128 + ((((nq - 1) & 127) == 0 || ((nq - 1) & 127) > 96) ? 1 : 0)), blk, [=] { attn2_fwd_kernel<64, false, true>(a); });
         else if (D == 64 && !causal) emu::launch(g, blk, [=] { attn2_fwd_kernel<64, false>(a); });
         else if (D == 64 && causal) emu::launch(g, blk, [=] { attn2_fwd_kernel<64, true>(a); });
         else if (D == 128 && !causal) emu::launch(g, blk, [=] { attn2_fwd_kernel<128, false>(a); });

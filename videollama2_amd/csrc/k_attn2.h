@@ -69,7 +69,7 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, unsigned ch
 // affine law in profiles/r03_experiments.md 5b) and two waves of one SIMD do not slow each other much below their sum -- so the chain
 // is cut in two and both halves run on the same SIMDs.  A wave also skips a tile that the causal mask hides from all of its rows
 // (every P of it is 0: same bits as computing it).
-// SKIP = false (lab, variant 5): the one-stream causal kernel as it was before that skip, for A/B runs.
+// SKIP = false (lab, variant 5): the one-stream kernels as they were before round 6's scheduling changes (that skip; the tower's grid order), for A/B runs.
 template <int D, bool CAUSAL, bool CLS = false, int NS = 1, bool SKIP = true>
 __global__ __launch_bounds__(256 * NS, (NS == 2 && D == 64) ? 4 : 2) void attn2_fwd_kernel(AttnArgs p) {
     static_assert(D == 64 || D == 128, "attn2: head_dim 64 or 128");
@@ -98,6 +98,9 @@ __global__ __launch_bounds__(256 * NS, (NS == 2 && D == 64) ? 4 : 2) void attn2_
     const int hi = lane >> 5, l31 = lane & 31;
     // grid mapping as in k_attn.h (causal: longest q blocks first, then ascending, so a CU pairs a long block with a short one)
     int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    // CLS (the tower): the query block is the SLOWEST grid index -- the ragged last block of every (head, frame) (64 patch rows + the class query: two and a bit
+    // live waves of four) is dispatched last, so the launch's partially filled last round of workgroups is made of its cheapest ones
+    if constexpr (CLS && SKIP && NS == 1) { qb = blockIdx.z; h = blockIdx.x; b = blockIdx.y; }
     if (CAUSAL) {
         const int G = p.heads * p.batch, nqb = (p.nq + 127) >> 7;
         const int g = (int)blockIdx.x % G, r = (int)blockIdx.x / G;

@@ -997,7 +997,9 @@ extern "C" int32_t vl2_attn_fwd(const void* q, const void* k, const void* v, voi
         return fail(VL2_E_SHAPE, "vl2_attn_fwd: strides must keep 16-byte row alignment");
     if (causal && causal_off < 0) return fail(VL2_E_SHAPE, "vl2_attn_fwd: causal_off must be >= 0");
     if (variant < 0 || variant > 5) return fail(VL2_E_BADARG, "vl2_attn_fwd: unknown variant %d", variant);
-    if (variant == 5 && (!kLab || D != 128 || !causal)) return fail(VL2_E_UNSUPP, "vl2_attn_fwd: variant 5 (variant 3 without the hidden-tile skip) is a lab form of the causal head_dim 128 kernel: libvl2hip_lab.so only");
+    const bool cls_shape = D == 64 && !causal && nq == nk && nk > 64 && (nk - 1) % 64 == 0 && group == 1;
+    if (variant == 5 && (!kLab || !((D == 128 && causal) || cls_shape)))
+        return fail(VL2_E_UNSUPP, "vl2_attn_fwd: variant 5 (the default kernels without round 6's scheduling changes) is a lab form of the causal head_dim 128 and class-token kernels: libvl2hip_lab.so only");
     // auto: the LDS-DMA / transpose-read structure wherever it is built (measured on MI355X, profiles/r02_attn_ab_*.jsonl:
     // causal D=128 S=945 / 1621 / 2973: 23.3 / 38.1 / 97.7 us vs 26.3 / 43.8 / 106.1 us; ViT D=64 T=8 / 16 / 32: 25.4 / 43.0 / 78.5 vs
     // 26.9 / 43.8 / 78.1 us); head_dim 96 (SigLIP's padded 72) stays on the register-staged kernel
@@ -1037,12 +1039,13 @@ extern "C" int32_t vl2_attn_fwd(const void* q, const void* k, const void* v, voi
     }
 #ifdef VL2_LAB
     if (variant == 5) {
-        hipLaunchKernelGGL((attn2_fwd_kernel<128, true, false, 1, false>), g, b, 0, s, a);
+        if (cls_shape) hipLaunchKernelGGL((attn2_fwd_kernel<64, false, true, 1, false>), dim3((nq - 1 + 127) / 128 + ((((nq - 1) & 127) == 0 || ((nq - 1) & 127) > 96) ? 1 : 0), H, B), b, 0, s, a);
+        else hipLaunchKernelGGL((attn2_fwd_kernel<128, true, false, 1, false>), g, b, 0, s, a);
         return launched("vl2_attn_fwd");
     }
 #endif
     if (variant == 3) {                                   // second structure (k_attn2.h): LDS-DMA ring + transpose reads
-        if (cls_peel) hipLaunchKernelGGL((attn2_fwd_kernel<64, false, true>), dim3((nq - 1 + 127) / 128 + ((((nq - 1) & 127) == 0 || ((nq - 1) & 127) > 96) ? 1 : 0), H, B), b, 0, s, a);
+        if (cls_peel) hipLaunchKernelGGL((attn2_fwd_kernel<64, false, true>), dim3(H, B, (nq - 1 + 127) / 128 + ((((nq - 1) & 127) == 0 || ((nq - 1) & 127) > 96) ? 1 : 0)), b, 0, s, a);      // (query block = the slowest index: k_attn2.h)
         else if (D == 64 && !causal) hipLaunchKernelGGL((attn2_fwd_kernel<64, false>), g, b, 0, s, a);
         else if (D == 64 && causal) hipLaunchKernelGGL((attn2_fwd_kernel<64, true>), g, b, 0, s, a);
         else if (D == 128 && !causal) hipLaunchKernelGGL((attn2_fwd_kernel<128, false>), g, b, 0, s, a);
