@@ -61,7 +61,8 @@ def skip_ab():
     from videollama2_amd import _lib
     _lib.set_lab(True)
     D, smax = 128, 4096
-    for name, S, nh, nkv in (("T16 7B", 1621, 32, 8), ("T32 7B", 2973, 32, 8), ("T16 72B", 1621, 64, 8), ("S=1792", 1792, 32, 8)):
+    for name, S, nh, nkv in (("T16 7B", 1621, 32, 8), ("T32 7B", 2973, 32, 8), ("T16 72B", 1621, 64, 8), ("S=1792", 1792, 32, 8), ("S=2048", 2048, 32, 8),
+                             ("S=2304", 2304, 32, 8), ("S=4096", 4096, 32, 8), ("T16 v21", 1452, 28, 4)):
         q, kc, vc = rnd(S, nh * D), rnd(nkv, smax, D), rnd(nkv, smax, D)
         outs = {}
         for v in (3, 5):
