@@ -109,6 +109,13 @@ __global__ __launch_bounds__(256 * NS, (NS == 2 && D == 64) ? 4 : 2) void attn2_
         // more workgroups than the chip holds at once (2 per CU): plain longest-first -- the cheap blocks make up the last, partially filled round (round 6:
         // S = 2973 92.9 -> 82.5 us, 64 heads at S = 1621 68.9 -> 55.3); all resident: the first 256 longest, then ascending, so that a CU pairs a long block with a short one
         qb = (SKIP && nqb * G > (NS == 2 ? 256 : 512)) ? nqb - 1 - r : (r < nfirst ? nqb - 1 - r : r - nfirst);
+        if (SKIP && NS == 1 && nqb * G <= 512 && nqb > nfirst) {
+            // all resident, two per CU at most: the (nfirst - n2) longest blocks should keep their CU to themselves, so the n2 blocks that will get a
+            // partner go first (the dispatcher fills every CU's first slot before any second one: workgroup 256 + i joins workgroup i).  Round 6, on top of the
+            // hidden-tile skip: S = 1621 39.6 -> 37.8 us, S = 1792 40.5 -> 39.7, 28 heads at S = 1452 32.4 -> 31.5 (profiles/r06_attn_alone_ab.jsonl)
+            const int n2 = nqb - nfirst, alone = nfirst - n2;
+            qb = r < n2 ? nqb - 1 - alone - r : r < nfirst ? nqb - 1 - (r - n2) : r - nfirst;
+        }
         h = g % p.heads;
         b = g / p.heads;
     }
